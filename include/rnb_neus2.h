@@ -1,0 +1,234 @@
+/*
+ * rnb_neus2.h — C-ABI of the MI355X-native RNb-NeuS2 training hot path.
+ *
+ * The reference (RobinBruneau/RNb-NeuS2) has no FFI for this path: the hot
+ * path sits behind the in-process C++ interface tcnn::Network<float, half>
+ * (dependencies/neus2_tcnn/include/tiny-cuda-nn/object.h:96-295) and the
+ * Testbed member functions that drive it (src/testbed_nerf.cu). This header
+ * is the plain-C boundary a maintainer would bind in their place. Every entry
+ * point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative rnb_status otherwise;
+ *    no exception crosses the boundary; rnb_last_error() gives the message.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *    device work is enqueued on it; functions documented "syncs" block.
+ *  - pointers named *_dev are device pointers, *_host host pointers.
+ *  - a context is not thread-safe; use one context per GPU / per process.
+ *
+ * The same signatures, with the prefix orc_ instead of rnb_ and host
+ * pointers everywhere, are exported by oracle/liborc.so (the CPU checker).
+ */
+#ifndef RNB_NEUS2_H
+#define RNB_NEUS2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNB_ABI_VERSION 1
+
+typedef enum rnb_status {
+	RNB_OK = 0,
+	RNB_ERR_INVALID = -1,   /* bad argument / bad state */
+	RNB_ERR_DEVICE = -2,    /* HIP runtime error */
+	RNB_ERR_NOMEM = -3,
+	RNB_ERR_NO_SAMPLES = -4 /* "Nerf training generated 0 samples" (src/testbed_nerf.cu:3662-3668) */
+} rnb_status;
+
+/* Fixed architecture of the reference (configs/nerf/base.json, nerf_network.h:40-83). */
+#define RNB_N_POS_DIMS 3
+#define RNB_COORD_FLOATS 7          /* NerfCoordinate: pos3, dt, dir3 (nerf.h:76-102) */
+#define RNB_OUT_WIDTH 16            /* padded network output width */
+#define RNB_SDF_IN 32
+#define RNB_SDF_HID 64
+#define RNB_SDF_OUT 16
+#define RNB_RGB_IN 48
+#define RNB_RGB_HID 64
+#define RNB_RGB_OUT 16
+#define RNB_N_SDF_MLP_PARAMS (RNB_SDF_HID * RNB_SDF_IN + RNB_SDF_OUT * RNB_SDF_HID)                       /* 3072 */
+#define RNB_N_RGB_MLP_PARAMS (RNB_RGB_HID * RNB_RGB_IN + RNB_RGB_HID * RNB_RGB_HID + RNB_RGB_OUT * RNB_RGB_HID) /* 8192 */
+#define RNB_N_VARIANCE_PARAMS 4
+#define RNB_GRIDSIZE 128            /* NERF_GRIDSIZE (nerf.h:24-26) */
+#define RNB_CASCADES 8              /* NERF_CASCADES (testbed_nerf.cu:50) */
+#define RNB_MAX_STEPS 1024          /* NERF_STEPS (testbed_nerf.cu:49) */
+#define RNB_MAX_LEVELS 16
+
+/* Mirrors the values the reference reads from configs/nerf/base.json, the CLI
+ * flags of src/main.cu:83-258 that reach the loss kernel, and testbed.h defaults. */
+typedef struct rnb_config {
+	uint32_t abi_version;             /* = RNB_ABI_VERSION */
+	/* hash grid — base.json:30-40, grid.h:946-1027 */
+	uint32_t n_levels;                /* 14 */
+	uint32_t log2_hashmap_size;       /* 19 */
+	uint32_t base_resolution;         /* 16 */
+	float    per_level_scale;         /* exp(log(top_resolution*aabb_scale/base)/(L-1)), testbed.cu:2320-2323 */
+	float    valid_level_scale;       /* 0.02 */
+	float    base_valid_level_scale;  /* 0.2 */
+	uint32_t base_training_step;      /* 100 */
+	float    sdf_bias;                /* -0.1, nerf_network.h:74 */
+	/* batch geometry — testbed.h:908, testbed.cu:2229, testbed_nerf.cu:3554-3555 */
+	uint32_t target_batch_size;       /* 1<<18 */
+	uint32_t initial_rays_per_batch;  /* 1<<12 */
+	uint32_t max_rays_per_batch;      /* 1<<18 */
+	uint32_t aabb_scale;              /* 1 (power of two) */
+	uint32_t seed;                    /* 1337, testbed.h:550 */
+	/* loss — testbed.h:490-521, main.cu:349-410 */
+	float    mask_loss_weight;        /* --mask-weight */
+	float    ek_loss_weight;          /* 0.01 */
+	uint32_t apply_L2;                /* !--lone */
+	uint32_t apply_rgbplus;           /* !--no-rgbplus */
+	uint32_t apply_no_albedo;         /* --no-albedo */
+	uint32_t apply_light_opti;        /* --opti-lights */
+	uint32_t apply_supernormal;       /* --supernormal */
+	uint32_t apply_relu;              /* --relu */
+	uint32_t apply_bce;               /* --bce */
+	uint32_t snap_to_pixel_centers;   /* 1 unless --disable-snap-to-center */
+	/* optimizer — base.json:5-28 */
+	float    learning_rate;           /* 1e-3 */
+	float    beta1, beta2, epsilon;   /* 0.9, 0.99, 1e-15 */
+	float    l2_reg;                  /* 1e-6 */
+	float    ema_decay;               /* 0.95 */
+	uint32_t lr_decay_start;          /* 20000 */
+	uint32_t lr_decay_interval;       /* 10000 */
+	float    lr_decay_base;           /* 0.33 */
+	float    density_grid_decay;      /* 0.95, testbed.h:671 */
+	/* data parallel: this process is `rank` of `world_size`; see DESIGN.md §multi-GPU */
+	uint32_t world_size;              /* 1 */
+	uint32_t rank;                    /* 0 */
+	uint32_t reserved[8];
+} rnb_config;
+
+/* One training view — TrainingImageMetadata + TrainingXForm (nerf_loader.h:33-49). */
+typedef struct rnb_view {
+	uint32_t width, height;
+	float focal_length[2];     /* pixels */
+	float principal_point[2];  /* normalised to [0,1] */
+	float xform[12];           /* camera-to-world 3x4, row-major: xform[r*4+c] */
+} rnb_view;
+
+typedef struct rnb_step_stats {
+	uint32_t training_step;            /* value after the step */
+	uint32_t rays_per_batch;           /* rays generated by this step (per rank) */
+	uint32_t next_rays_per_batch;      /* controller output, testbed_nerf.cu:3554-3555 */
+	uint32_t measured_batch_size;      /* compacted samples */
+	uint32_t measured_batch_size_before_compaction;
+	uint32_t n_rays_kept;              /* rays that survived marching (ray_counter) */
+	uint32_t density_grid_updated;     /* 1 when training_prep_nerf ran this step */
+	float loss, ek_loss, mask_loss;    /* Counters::update_after_training scalars */
+	float prep_ms, step_ms;            /* the two ScopeGuard timers, testbed.cu:2807-2810, 2853-2856 */
+} rnb_step_stats;
+
+typedef struct rnb_ctx rnb_ctx;
+
+/* Buffers reachable through rnb_buffer(). Device pointers for librnb_neus2_hip, host for liborc. */
+typedef enum rnb_buffer_id {
+	RNB_BUF_PARAMS_FP32 = 0,   /* float[n_params]  master weights (trainer.h:78-84) */
+	RNB_BUF_PARAMS_FP16 = 1,   /* half[n_params]   training weights */
+	RNB_BUF_PARAMS_EMA = 2,    /* half[n_params]   EMA = inference weights (ema.h:63-78) */
+	RNB_BUF_GRADS_FP32 = 3,    /* float[n_params]  gradient accumulators (x loss_scale 128) */
+	RNB_BUF_ADAM_M = 4,        /* float[n_params] */
+	RNB_BUF_ADAM_V = 5,        /* float[n_params] */
+	RNB_BUF_ADAM_STEPS = 6,    /* uint32[n_params] */
+	RNB_BUF_DENSITY_GRID = 7,  /* float[128^3 * (max_cascade+1)] */
+	RNB_BUF_DENSITY_BITFIELD = 8, /* uint8[128^3/8 * 8 mips] */
+	RNB_BUF_DENSITY_MEAN = 9,  /* float[1] */
+	RNB_BUF_RAY_INDICES = 10,  /* uint32[rays] */
+	RNB_BUF_RAYS = 11,         /* float[rays*6] origin, unnormalised dir */
+	RNB_BUF_NUMSTEPS = 12,     /* uint32[rays*2] (numsteps, base) */
+	RNB_BUF_COORDS = 13,       /* float[16*B*7] */
+	RNB_BUF_MLP_OUT = 14,      /* half[16*B*16] */
+	RNB_BUF_DLOSS_DOUT = 15,   /* half[B*16] */
+	RNB_BUF_COORDS_COMPACTED = 16, /* float[B*7] */
+	RNB_BUF_LOSS = 17,         /* float[rays] */
+	RNB_BUF_EK_LOSS = 18,
+	RNB_BUF_MASK_LOSS = 19,
+	RNB_BUF_COUNTERS = 20,     /* uint32[4]: numsteps_counter, numsteps_counter_compacted, ray_counter, samples_written */
+	RNB_BUF_DENSITY_GRID_TMP = 21, /* float[128^3 * (max_cascade+1)] */
+	RNB_BUF_GRID_SAMPLE_POS = 22,  /* float[n*3] positions of the last density-grid update */
+	RNB_BUF_GRID_SAMPLE_IDX = 23,  /* uint32[n] */
+	RNB_BUF_COUNT
+} rnb_buffer_id;
+
+typedef enum rnb_memcpy_kind { RNB_H2D = 0, RNB_D2H = 1, RNB_D2D = 2 } rnb_memcpy_kind;
+
+/* ---- lifecycle -------------------------------------------------------- */
+const char* rnb_last_error(void);
+uint32_t rnb_abi_version(void);
+/* Fills *cfg with the defaults of configs/nerf/base.json + testbed.h + main.cu (no CLI flags given). */
+int rnb_default_config(rnb_config* cfg);
+/* Testbed::reset_network (src/testbed.cu:2220-2485): allocates parameters, optimizer state,
+ * occupancy grid and step scratch on the current HIP device. */
+int rnb_create(const rnb_config* cfg, rnb_ctx** out);
+int rnb_destroy(rnb_ctx* ctx);
+
+/* ---- parameters ------------------------------------------------------- */
+/* NerfNetwork::n_params (nerf_network.h:722-724): 3072 + 8192 + grid + 4. */
+uint64_t rnb_n_params(const rnb_ctx* ctx);
+/* Offsets (in elements) of [sdf mlp | rgb mlp | hash grid | variance] (nerf_network.h:539-583). */
+int rnb_param_layout(const rnb_ctx* ctx, uint64_t offsets[5]);
+/* Per-level tables (grid.h:977-1012): hashmap offsets (n_levels+1, in entries), resolution, scale. */
+int rnb_grid_tables(const rnb_ctx* ctx, uint32_t* offsets, uint32_t* resolution, float* scale);
+/* Trainer::initialize_params + NerfNetwork::initialize_params (trainer.h:72-109, nerf_network.h:625-696):
+ * PCG32 streams identical to the reference; sdf_mlp_weights_host = the 3072 floats of
+ * utils/mlp_weights_hidden_layer_num_1_hidden_size_32.txt. Syncs. */
+int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
+/* Trainer::deserialize-like: overwrite fp32 master weights from host, re-derive fp16/EMA copies,
+ * reset Adam state (trainer.h:263-275). Syncs. */
+int rnb_set_params(rnb_ctx* ctx, const float* params_host);
+int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
+int rnb_memcpy(rnb_ctx* ctx, void* dst, const void* src, uint64_t n_bytes, int kind); /* syncs */
+
+/* ---- dataset ---------------------------------------------------------- */
+/* NerfDataset as uploaded by Testbed::load_nerf (src/testbed_nerf.cu:3078-3218): per view one RGBA16
+ * normal map and one RGBA16 albedo map (8 bytes/pixel, row-major, alpha = mask). Host pointers; copies. Syncs. */
+int rnb_set_dataset(rnb_ctx* ctx, uint32_t n_views, const rnb_view* views,
+                    const uint16_t* const* normals_host, const uint16_t* const* albedos_host);
+
+/* ---- hot-path stages (each replaces the cited reference function) ------ */
+/* GridEncoding::set_training_step + NerfNetwork::m_training_step (grid.h:1430-1437, testbed.cu:2787-2793). */
+int rnb_set_training_step(rnb_ctx* ctx, uint32_t step);
+uint32_t rnb_valid_level(const rnb_ctx* ctx);
+/* Testbed::training_prep_nerf -> update_density_grid_nerf (testbed_nerf.cu:4125-4138, 3424-3495), K1-K5. */
+int rnb_update_density_grid(rnb_ctx* ctx, void* stream);
+/* Testbed::update_density_grid_mean_and_bitfield (testbed_nerf.cu:3497-3517), K5 from the current grid. */
+int rnb_update_density_bitfield(rnb_ctx* ctx, void* stream);
+/* NerfNetwork::density (nerf_network.h:522-537): xyz[n,3] f32 -> density half[n], training weights. */
+int rnb_density(rnb_ctx* ctx, void* stream, const float* xyz_dev, uint32_t n, uint16_t* out_dev, int use_inference_params);
+/* NerfNetwork::sdf (nerf_network.h:454-520): xyz[n,3] -> sdf+bias half[n] (EMA weights for meshing). */
+int rnb_sdf(rnb_ctx* ctx, void* stream, const float* xyz_dev, uint32_t n, uint16_t* out_dev, int use_inference_params);
+/* Network::inference_mixed_precision -> NerfNetwork::forward_impl (nerf_network.h:87-253):
+ * coords[n,7] f32 -> out[n,16] half. */
+int rnb_forward_infer(rnb_ctx* ctx, void* stream, const float* coords_dev, uint32_t n, uint16_t* out_dev, int use_inference_params);
+/* generate_training_samples_nerf_with_global_movement (testbed_nerf.cu:1216-1387), K6.
+ * Fills RAY_INDICES/RAYS/NUMSTEPS/COORDS/COUNTERS. Deterministic slot order. */
+int rnb_generate_training_samples(rnb_ctx* ctx, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples);
+/* compute_loss_kernel_train_nerf_with_global_movement + fill_rollover* (testbed_nerf.cu:1396-2097, 4044-4052), K8+K9.
+ * Reads MLP_OUT for COORDS; fills DLOSS_DOUT, COORDS_COMPACTED, the three LOSS buffers and COUNTERS[1]. */
+int rnb_compute_loss(rnb_ctx* ctx, void* stream, uint32_t n_rays, uint32_t n_rays_total);
+/* Network::forward + Network::backward on the compacted batch (testbed_nerf.cu:4067-4068;
+ * nerf_network.h:97-452), K10+K11. Accumulates into GRADS_FP32 (zeroed first). */
+int rnb_forward_backward(rnb_ctx* ctx, void* stream);
+/* Trainer::optimizer_step: ExponentialDecay -> Adam -> EMA (trainer.h:170-172; adam.h:52-202; ema.h:63-147), K12. */
+int rnb_optimizer_step(rnb_ctx* ctx, void* stream);
+
+/* ---- whole step ------------------------------------------------------- */
+/* Testbed::train (src/testbed.cu:2776-2872) = prep schedule + train_nerf (testbed_nerf.cu:3560-3668).
+ * rnb_train_step == begin; [all-reduce of GRADS_FP32 and rnb_step_exchange across ranks]; end. Syncs. */
+int rnb_train_step(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
+/* Everything up to and including the backward pass; leaves gradients in GRADS_FP32. */
+int rnb_train_step_begin(rnb_ctx* ctx, void* stream);
+/* Optimizer step, ++training_step, Counters::update_after_training (testbed_nerf.cu:3532-3558). Syncs. */
+int rnb_train_step_end(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
+uint32_t rnb_training_step(const rnb_ctx* ctx);
+uint32_t rnb_rays_per_batch(const rnb_ctx* ctx);
+/* Re-seat the controller state (snapshot resume, testbed.cu:3333-3390). */
+int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_batch,
+                       uint32_t measured_batch_size_before_compaction, uint32_t n_rays_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNB_NEUS2_H */

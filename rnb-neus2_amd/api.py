@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's training interface over the C-ABI of include/rnb_neus2.h.
+
+The reference drives this path through ``Testbed`` (src/testbed.cu:2776-2872, src/testbed_nerf.cu:3560-4138);
+``Context`` keeps the same verbs (reset_network/init params, load dataset, train step, per-stage calls) and hands
+everything to ``librnb_neus2_hip.so``. There is no CPU fallback: if the HIP library is missing, loading fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import Config, View, StepStats, BUF, BUF_DTYPE
+
+__all__ = ["Context", "Config", "View", "StepStats", "load_library", "default_config", "library_path",
+           "load_sdf_init_weights", "RnbError", "BUF"]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO_ROOT = os.path.dirname(_PKG_DIR)
+_LIB_NAME = "librnb_neus2_hip.so"
+
+
+class RnbError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rnb error %d: %s" % (code, message))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+_FUNCS = None
+
+
+def load_library():
+    """Load the HIP library. Fails loudly when it has not been built (no fallback path exists)."""
+    global _FUNCS
+    if _FUNCS is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the hot path." % path)
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        _FUNCS = _abi.declare(lib, "rnb_")
+        if _FUNCS.abi_version() != _abi.ABI_VERSION:
+            raise RuntimeError("ABI version mismatch between %s and the Python host side" % path)
+    return _FUNCS
+
+
+def default_config(fns=None, **overrides):
+    fns = fns or load_library()
+    cfg = Config()
+    rc = fns.default_config(C.byref(cfg))
+    if rc != 0:
+        raise RnbError(rc, fns.last_error().decode())
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError("rnb_config has no field %r" % k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def load_sdf_init_weights(path=None):
+    """The sphere-SDF initialisation of the density MLP (nerf_network.h:585-623)."""
+    path = path or os.path.join(_REPO_ROOT, "utils", "mlp_weights_hidden_layer_num_1_hidden_size_32.txt")
+    w = np.loadtxt(path, dtype=np.float64).astype(np.float32).ravel()
+    if w.size != _abi.N_SDF_MLP_PARAMS:
+        raise ValueError("expected %d SDF-MLP weights in %s, found %d" % (_abi.N_SDF_MLP_PARAMS, path, w.size))
+    return np.ascontiguousarray(w)
+
+
+def _stream_handle(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(getattr(stream, "cuda_stream"))  # torch.cuda.Stream
+
+
+class Context:
+    """One training context on the current HIP device (``rnb_ctx``)."""
+
+    def __init__(self, cfg=None, fns=None, **overrides):
+        self.f = fns or load_library()
+        self.cfg = cfg if cfg is not None else default_config(self.f, **overrides)
+        self._h = C.c_void_p()
+        self._check(self.f.create(C.byref(self.cfg), C.byref(self._h)))
+        self._keep = []
+
+    # -- plumbing -------------------------------------------------------
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise RnbError(rc, self.f.last_error().decode(errors="replace"))
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.f.destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def n_params(self):
+        return int(self.f.n_params(self._h))
+
+    def param_layout(self):
+        off = (C.c_uint64 * 5)()
+        self._check(self.f.param_layout(self._h, off))
+        return dict(sdf=off[0], rgb=off[1], grid=off[2], variance=off[3], end=off[4])
+
+    def grid_tables(self):
+        n = self.cfg.n_levels
+        off = (C.c_uint32 * (n + 1))()
+        res = (C.c_uint32 * n)()
+        sc = (C.c_float * n)()
+        self._check(self.f.grid_tables(self._h, off, res, sc))
+        return np.array(off, dtype=np.uint32), np.array(res, dtype=np.uint32), np.array(sc, dtype=np.float32)
+
+    def buffer(self, name):
+        """(pointer, n_bytes) of a context buffer; a device pointer for the HIP library."""
+        ptr = C.c_void_p()
+        nb = C.c_uint64()
+        self._check(self.f.buffer(self._h, BUF[name], C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
+    def get(self, name, count=None, offset=0):
+        """Copy (part of) a context buffer to a numpy array; count/offset in elements."""
+        ptr, nb = self.buffer(name)
+        dt = np.dtype(BUF_DTYPE[name])
+        total = nb // dt.itemsize
+        if count is None:
+            count = total - offset
+        if offset + count > total:
+            raise ValueError("%s: range [%d, %d) exceeds %d elements" % (name, offset, offset + count, total))
+        out = np.empty(count, dtype=dt)
+        if count:
+            self._check(self.f.memcpy(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr + offset * dt.itemsize),
+                                      count * dt.itemsize, _abi.D2H))
+        return out
+
+    def put(self, name, array, offset=0):
+        ptr, nb = self.buffer(name)
+        dt = np.dtype(BUF_DTYPE[name])
+        a = np.ascontiguousarray(array, dtype=dt).ravel()
+        if (offset + a.size) * dt.itemsize > nb:
+            raise ValueError("%s: write of %d elements at %d exceeds buffer" % (name, a.size, offset))
+        if a.size:
+            self._check(self.f.memcpy(self._h, C.c_void_p(ptr + offset * dt.itemsize), a.ctypes.data_as(C.c_void_p),
+                                      a.size * dt.itemsize, _abi.H2D))
+
+    # -- parameters -----------------------------------------------------
+    def init_params(self, sdf_weights=None):
+        w = load_sdf_init_weights() if sdf_weights is None else np.ascontiguousarray(sdf_weights, dtype=np.float32)
+        self._check(self.f.init_params(self._h, w.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def set_params(self, params_fp32):
+        p = np.ascontiguousarray(params_fp32, dtype=np.float32).ravel()
+        if p.size != self.n_params:
+            raise ValueError("expected %d params, got %d" % (self.n_params, p.size))
+        self._check(self.f.set_params(self._h, p.ctypes.data_as(C.POINTER(C.c_float))))
+
+    # -- dataset --------------------------------------------------------
+    def set_dataset(self, views, normals, albedos):
+        """views: sequence of dicts(width, height, focal_length(2), principal_point(2), xform(3x4 c2w));
+        normals/albedos: per view uint16 arrays [H, W, 4] (RGBA16, alpha = mask)."""
+        n = len(views)
+        if n == 0 or len(normals) != n or len(albedos) != n:
+            raise ValueError("views / normals / albedos must be non-empty and of equal length")
+        arr = (View * n)()
+        nptr = (C.c_void_p * n)()
+        aptr = (C.c_void_p * n)()
+        keep = []
+        for i, v in enumerate(views):
+            arr[i].width = int(v["width"])
+            arr[i].height = int(v["height"])
+            arr[i].focal_length[:] = [float(x) for x in v["focal_length"]]
+            arr[i].principal_point[:] = [float(x) for x in v["principal_point"]]
+            arr[i].xform[:] = [float(x) for x in np.asarray(v["xform"], dtype=np.float32).reshape(12)]
+            nm = np.ascontiguousarray(normals[i], dtype=np.uint16)
+            al = np.ascontiguousarray(albedos[i], dtype=np.uint16)
+            if nm.size != arr[i].width * arr[i].height * 4 or al.size != nm.size:
+                raise ValueError("view %d: image size does not match width*height*4" % i)
+            keep += [nm, al]
+            nptr[i] = nm.ctypes.data
+            aptr[i] = al.ctypes.data
+        self._check(self.f.set_dataset(self._h, n, arr, nptr, aptr))
+
+    # -- stages ---------------------------------------------------------
+    def set_training_step(self, step):
+        self._check(self.f.set_training_step(self._h, int(step)))
+
+    @property
+    def valid_level(self):
+        return int(self.f.valid_level(self._h))
+
+    @property
+    def training_step(self):
+        return int(self.f.training_step(self._h))
+
+    @property
+    def rays_per_batch(self):
+        return int(self.f.rays_per_batch(self._h))
+
+    def set_controller(self, training_step, rays_per_batch, measured_before_compaction=0, n_rays_total=0):
+        self._check(self.f.set_controller(self._h, int(training_step), int(rays_per_batch), int(measured_before_compaction), int(n_rays_total)))
+
+    def update_density_grid(self, stream=None):
+        self._check(self.f.update_density_grid(self._h, _stream_handle(stream)))
+
+    def update_density_bitfield(self, stream=None):
+        self._check(self.f.update_density_bitfield(self._h, _stream_handle(stream)))
+
+    def _point_query(self, fn, xyz, inference):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        n = xyz.shape[0]
+        cptr, cb = self.buffer("COORDS")
+        optr, ob = self.buffer("MLP_OUT")
+        if n * 12 > cb or n * 2 > ob:
+            raise ValueError("too many points for the scratch buffers")
+        self.put("COORDS", xyz)
+        self._check(fn(self._h, None, C.c_void_p(cptr), n, C.c_void_p(optr), int(bool(inference))))
+        return self.get("MLP_OUT", n)
+
+    def density(self, xyz, inference=False):
+        """NerfNetwork::density on host points [n,3] -> float16[n] (staged through the context's scratch)."""
+        return self._point_query(self.f.density, xyz, inference)
+
+    def sdf(self, xyz, inference=True):
+        return self._point_query(self.f.sdf, xyz, inference)
+
+    def forward_infer(self, coords, inference=False):
+        """NerfNetwork::inference_mixed_precision on host coords [n,7] -> float16[n,16]."""
+        coords = np.ascontiguousarray(coords, dtype=np.float32).reshape(-1, 7)
+        n = coords.shape[0]
+        cptr, cb = self.buffer("COORDS")
+        optr, ob = self.buffer("MLP_OUT")
+        if n * 28 > cb or n * 32 > ob:
+            raise ValueError("too many samples for the scratch buffers")
+        self.put("COORDS", coords)
+        self._check(self.f.forward_infer(self._h, None, C.c_void_p(cptr), n, C.c_void_p(optr), int(bool(inference))))
+        return self.get("MLP_OUT", n * 16).reshape(n, 16)
+
+    def forward_infer_staged(self, n, stream=None):
+        """Evaluate the first n samples already in COORDS into MLP_OUT (what train_nerf_step does, testbed_nerf.cu:3967)."""
+        cptr, _ = self.buffer("COORDS")
+        optr, _ = self.buffer("MLP_OUT")
+        self._check(self.f.forward_infer(self._h, _stream_handle(stream), C.c_void_p(cptr), int(n), C.c_void_p(optr), 0))
+
+    def generate_training_samples(self, n_rays, n_rays_total=0, max_samples=None, stream=None):
+        if max_samples is None:
+            max_samples = self.cfg.target_batch_size * 16
+        self._check(self.f.generate_training_samples(self._h, _stream_handle(stream), int(n_rays), int(n_rays_total), int(max_samples)))
+
+    def compute_loss(self, n_rays, n_rays_total=0, stream=None):
+        self._check(self.f.compute_loss(self._h, _stream_handle(stream), int(n_rays), int(n_rays_total)))
+
+    def forward_backward(self, stream=None):
+        self._check(self.f.forward_backward(self._h, _stream_handle(stream)))
+
+    def optimizer_step(self, stream=None):
+        self._check(self.f.optimizer_step(self._h, _stream_handle(stream)))
+
+    def train_step(self, stream=None, allow_no_samples=False):
+        st = StepStats()
+        rc = self.f.train_step(self._h, _stream_handle(stream), C.byref(st))
+        self._check(rc, allow=(_abi.ERR_NO_SAMPLES,) if allow_no_samples else ())
+        return st
+
+    def train_step_begin(self, stream=None):
+        self._check(self.f.train_step_begin(self._h, _stream_handle(stream)))
+
+    def train_step_end(self, stream=None, allow_no_samples=False):
+        st = StepStats()
+        rc = self.f.train_step_end(self._h, _stream_handle(stream), C.byref(st))
+        self._check(rc, allow=(_abi.ERR_NO_SAMPLES,) if allow_no_samples else ())
+        return st

@@ -1,0 +1,41 @@
+"""Compiles csrc/ into librnb_neus2_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo)."""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG_DIR, "csrc", "rnb_neus2_hip.hip")
+OUT = os.path.join(PKG_DIR, "librnb_neus2_hip.so")
+DEPS = [os.path.join(PKG_DIR, "csrc", f) for f in ("rnb_neus2_hip.hip", "common.cuh", "mlp.cuh", "kernels_net.cuh", "kernels_ray.cuh")] + [
+    os.path.join(os.path.dirname(PKG_DIR), "include", "rnb_neus2.h")]
+
+# -ffp-contract=off: the index/ray arithmetic must match the CPU checker bit for bit (no FMA contraction).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,787 @@
+// kernels_net.cuh — network kernels of the hot path:
+//   k_point_query   NerfNetwork::sdf / ::density (+ splat, K2+K3)       nerf_network.h:454-537, testbed_nerf.cu:616-635
+//   k_forward       NerfNetwork::forward_impl, inference flavour (K7)    nerf_network.h:97-253
+//   k_fwd_bwd       forward + backward data path on the compacted batch (K10+K11)  nerf_network.h:97-452
+//   k_dw / k_dw_finish   weight-gradient GEMMs (K = samples)            fully_fused_mlp.cu:960-1014, 1120-1131
+//   k_grid_scatter  hash-grid gradient scatter, first + second order     grid.h:366-495, 556-683
+//   k_adam_ema      ExponentialDecay -> Adam -> EMA                      adam.h:52-202, ema.h:63-78
+#pragma once
+#include "mlp.cuh"
+
+namespace rnb {
+
+constexpr int WG = 256;          // 4 wavefronts per workgroup
+constexpr int WAVES_PER_WG = 4;
+
+// ---------------------------------------------------------------------------------------------
+// per-lane pieces
+// ---------------------------------------------------------------------------------------------
+
+// [x - 0.5 | 28 features | 0] as halfs into row `lane` of a 32-wide tile (nerf_network.h:149-155).
+__device__ __forceinline__ void write_sdf_in_row(half_t* __restrict__ tile, const int lane, const float x, const float y, const float z, const half_t (&feat)[28]) {
+	half_t row[32];
+	row[0] = f2h(x) - (half_t)0.5f; // fill_positions_view_with_fixed_offset: half arithmetic (common_operation.cuh:187-199)
+	row[1] = f2h(y) - (half_t)0.5f;
+	row[2] = f2h(z) - (half_t)0.5f;
+#pragma unroll
+	for (int k = 0; k < 28; ++k) row[3 + k] = feat[k];
+	row[31] = (half_t)0.f;
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		h8 v;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) v[j] = row[q * 8 + j];
+		*reinterpret_cast<h8*>(tile + lane * S32 + q * 8) = v;
+	}
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void encode_all(const GridMeta& G, const uint32_t* __restrict__ grid, const float x, const float y, const float z, half_t (&feat)[28], float (&dydx)[GRAD ? 28 : 1][3]) {
+#pragma unroll
+	for (uint32_t level = 0; level < 14; ++level) {
+		half_t f0 = (half_t)0.f, f1 = (half_t)0.f;
+		float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
+		if (level < G.n_levels && level <= G.valid_level) {
+			encode_level<GRAD>(G, grid, level, x, y, z, f0, f1, d0, d1);
+		}
+		feat[level * 2 + 0] = f0;
+		feat[level * 2 + 1] = f1;
+		if (GRAD) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { dydx[GRAD ? level * 2 + 0 : 0][d] = d0[d]; dydx[GRAD ? level * 2 + 1 : 0][d] = d1[d]; }
+		}
+	}
+}
+
+// sdf_to_density_variance_buffer (common_operation.cuh:311-328): half arithmetic throughout.
+__device__ __forceinline__ half_t sdf_to_density(half_t sdf, half_t variance) {
+	const half_t s = f2h(expf(h2f(variance * (half_t)10.0f)));
+	const half_t sig = f2h(1.0f / (1.0f + expf(-h2f(sdf * s))));
+	return (s * sig) * ((half_t)1.0f - sig);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 (+K3): point query
+// ---------------------------------------------------------------------------------------------
+struct PointArgs {
+	const float* xyz;          // [n][3]
+	uint32_t n;
+	half_t* out;               // [n] or null
+	const uint32_t* splat_idx; // [n] or null: atomicMax of the density into grid_tmp[idx]
+	float* grid_tmp;
+	int want_density;          // 0: sdf + bias, 1: density
+	float sdf_bias;
+};
+
+__global__ __launch_bounds__(WG, 1) void k_point_query(const GridMeta G, const NetW net, const PointArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	load_weights<false>(wts, net, threadIdx.x, WG);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* tA = wts + W_FWD_END + wave * 2 * ACT_TILE_HALFS;
+	half_t* tB = tA + ACT_TILE_HALFS;
+	const half_t variance = net.variance[0];
+	const half_t bias = f2h(a.sdf_bias);
+	const uint32_t n_tiles = (a.n + TILE - 1) / TILE;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		const bool valid = s < a.n;
+		float x = 0.5f, y = 0.5f, z = 0.5f;
+		if (valid) { x = a.xyz[(size_t)s * 3 + 0]; y = a.xyz[(size_t)s * 3 + 1]; z = a.xyz[(size_t)s * 3 + 2]; }
+		half_t feat[28];
+		float dummy[1][3];
+		encode_all<false>(G, net.grid, x, y, z, feat, dummy);
+		write_sdf_in_row(tA, lane, x, y, z, feat);
+		wave_lds_sync();
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, tA, S32, acc, lane);
+			store_acc<4, true>(acc, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		{
+			f4 acc[1][4];
+			zero_acc<1>(acc);
+			mfma_layer<1, 2>(wts + W_S1, S64, tB, S64, acc, lane);
+			wave_lds_sync(); // all reads of tB done before tA (free) is overwritten below
+			store_acc<1, false>(acc, tA, S32, 0, lane);
+		}
+		wave_lds_sync();
+		half_t v = tA[lane * S32 + 0] + bias; // sdf_add_bias (common_operation.cuh:299-309)
+		if (a.want_density) v = sdf_to_density(v, variance);
+		if (valid) {
+			if (a.out) a.out[s] = v;
+			if (a.splat_idx) atomicMax(reinterpret_cast<uint32_t*>(a.grid_tmp) + a.splat_idx[s], __float_as_uint(h2f(v))); // testbed_nerf.cu:634
+		}
+		wave_lds_sync();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared forward body (nerf_network.h:97-253) for one 64-sample tile. Leaves in LDS:
+//   tC[.][0..31] = compact rgb input, r in tC[.][0..15] after the last layer (if run).
+// ---------------------------------------------------------------------------------------------
+struct FwdRegs {
+	float x, y, z;
+	float dydx[28][3];
+	float grad[3];
+	half_t sdf0;        // raw sdf_out[0]
+	uint64_t m_z1, m_h1, m_h2; // relu' masks in D-fragment order
+};
+
+// ---------------------------------------------------------------------------------------------
+// K7: inference-flavoured forward
+// ---------------------------------------------------------------------------------------------
+struct FwdArgs {
+	const float* coords;       // [n][7]
+	const uint32_t* n_ptr;     // device-side sample count (null -> n_max)
+	uint32_t n_max;
+	half_t* out;               // [n][16]
+	float sdf_bias;
+};
+
+__global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW net, const FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	load_weights<false>(wts, net, threadIdx.x, WG);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* tA = wts + W_FWD_END + wave * 3 * ACT_TILE_HALFS;
+	half_t* tB = tA + ACT_TILE_HALFS;
+	half_t* tC = tB + ACT_TILE_HALFS;
+	const half_t variance = net.variance[0];
+	const half_t bias = f2h(a.sdf_bias);
+	uint32_t n = a.n_max;
+	if (a.n_ptr) n = min(*a.n_ptr, a.n_max);
+	const uint32_t n_tiles = (n + TILE - 1) / TILE;
+	const int r16 = lane & 15, hq = lane >> 4;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		const bool valid = s < n;
+		float c[7] = {0.5f, 0.5f, 0.5f, 0.f, 0.f, 0.f, 0.f};
+		if (valid) {
+#pragma unroll
+			for (int q = 0; q < 7; ++q) c[q] = a.coords[(size_t)s * 7 + q];
+		}
+		half_t feat[28];
+		float dydx[28][3];
+		encode_all<true>(G, net.grid, c[0], c[1], c[2], feat, dydx);
+		write_sdf_in_row(tA, lane, c[0], c[1], c[2], feat);
+		wave_lds_sync();
+		// z1 = relu(W0 sdf_in) -> tB ; dz1 = W1[0,:] (.) relu'(z1) -> tA   (nerf_network.h:159-176)
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, tA, S32, acc, lane);
+			const uint64_t m = store_acc<4, true>(acc, tB, S64, 0, lane);
+			wave_lds_sync(); // tA fully consumed by the MFMAs above
+#pragma unroll
+			for (int mt = 0; mt < 4; ++mt) {
+				const h4 w1 = *reinterpret_cast<const h4*>(wts + W_S1 + 0 * S64 + 16 * mt + 4 * hq);
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) {
+					h4 v;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) v[r] = ((m >> ((mt * 4 + nt) * 4 + r)) & 1ull) ? w1[r] : (half_t)0.f;
+					*reinterpret_cast<h4*>(tA + (16 * nt + r16) * S64 + 16 * mt + 4 * hq) = v;
+				}
+			}
+		}
+		wave_lds_sync();
+		// sdf_out = W1 z1 -> tC[.][0..15]
+		{
+			f4 acc[1][4];
+			zero_acc<1>(acc);
+			mfma_layer<1, 2>(wts + W_S1, S64, tB, S64, acc, lane);
+			store_acc<1, false>(acc, tC, S32, 0, lane);
+		}
+		// dsdf_din = W0^T dz1 -> tB[.][0..31] (z1 no longer needed)
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer<2, 2>(wts + W_S0T, S64, tA, S64, acc, lane);
+			wave_lds_sync(); // sdf_out MFMAs have read tB
+			store_acc<2, false>(acc, tB, S32, 0, lane);
+		}
+		wave_lds_sync();
+		// per lane: grad = sum_k dsdf_din[3+k] * dy_dx[k] + dsdf_din[0..2]  (grid.h:527-554, nerf_network.h:185-189)
+		float grad[3] = {0.f, 0.f, 0.f};
+		{
+			half_t din[32];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h8 v = *reinterpret_cast<const h8*>(tB + lane * S32 + q * 8);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) din[q * 8 + j] = v[j];
+			}
+#pragma unroll
+			for (int k = 0; k < 28; ++k) {
+				const float dl = h2f(din[3 + k]);
+#pragma unroll
+				for (int d = 0; d < 3; ++d) grad[d] += dl * dydx[k][d];
+			}
+#pragma unroll
+			for (int d = 0; d < 3; ++d) grad[d] += h2f(din[d]);
+		}
+		const half_t sdf0 = tC[lane * S32 + 0];
+		// rgb input (compact): [sdf_out(16) | x y z | grad | 0 x10]  (nerf_network.h:206-218)
+		{
+			h8 v0 = {f2h(c[0]), f2h(c[1]), f2h(c[2]), f2h(grad[0]), f2h(grad[1]), f2h(grad[2]), (half_t)0.f, (half_t)0.f};
+			h8 v1 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			*reinterpret_cast<h8*>(tC + lane * S32 + 16) = v0;
+			*reinterpret_cast<h8*>(tC + lane * S32 + 24) = v1;
+		}
+		wave_lds_sync();
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_C0, S32, tC, S32, acc, lane);
+			store_acc<4, true>(acc, tA, S64, 0, lane);
+		}
+		wave_lds_sync();
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 2>(wts + W_C1, S64, tA, S64, acc, lane);
+			store_acc<4, true>(acc, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		{
+			f4 acc[1][4];
+			zero_acc<1>(acc);
+			mfma_layer<1, 2>(wts + W_C2, S64, tB, S64, acc, lane);
+			store_acc<1, false>(acc, tC, S32, 0, lane);
+		}
+		wave_lds_sync();
+		// output packing (nerf_network.h:221-250)
+		{
+			h8 o0 = *reinterpret_cast<const h8*>(tC + lane * S32 + 0);
+			h8 o1 = *reinterpret_cast<const h8*>(tC + lane * S32 + 8);
+			o0[3] = sdf0 + bias;
+			o0[4] = f2h(grad[0]); o0[5] = f2h(grad[1]); o0[6] = f2h(grad[2]);
+			o0[7] = variance;
+			o1[0] = f2h(c[4]); o1[1] = f2h(c[5]); o1[2] = f2h(c[6]);
+			if (valid) {
+				h8* dst = reinterpret_cast<h8*>(a.out + (size_t)s * 16);
+				dst[0] = o0;
+				dst[1] = o1;
+			}
+		}
+		wave_lds_sync();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10 + K11 data path on the compacted batch
+// ---------------------------------------------------------------------------------------------
+struct TrainScratch {
+	// feature-major [feature][B] halfs: operands of the weight-gradient GEMMs
+	half_t *h2, *h1, *cin, *z1, *sdfin, *dz1; // activations (cin: 32 compact rows)
+	half_t *dr, *dh2, *dh1, *dso, *dz, *ddin, *front; // gradients (dr: 16 rows, dso: 16 rows, ddin: 32 rows)
+	// per-sample inputs of the grid scatter, level-major
+	uint32_t* g1;  // [14][B] half2: dL/dfeat, first order
+	uint32_t* g2;  // [14][B] half2: d sdf / d feat (dL_denc_output of the double backward)
+	float* dn;     // [3][B]: dL/d(grad sdf)
+	float* var_partial; // [n_waves_total] partial sums of dL_doutput[7]
+};
+
+struct TrainArgs {
+	const float* coords;   // [B][7] compacted
+	const half_t* dout;    // [B][16]
+	uint32_t B;
+	float sdf_bias;
+	TrainScratch t;
+};
+
+__device__ __forceinline__ void fm_store(const half_t* __restrict__ tile, const int stride, const int width, half_t* __restrict__ dst, const uint32_t B, const uint32_t s) {
+	const half_t* row = tile + (s & 63) * stride;
+	for (int f = 0; f < width; f += 8) {
+		const h8 v = *reinterpret_cast<const h8*>(row + f);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) dst[(size_t)(f + j) * B + s] = v[j];
+	}
+}
+
+__global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	load_weights<true>(wts, net, threadIdx.x, WG);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* tA = wts + W_TRAIN_END + wave * 3 * ACT_TILE_HALFS;
+	half_t* tB = tA + ACT_TILE_HALFS;
+	half_t* tC = tB + ACT_TILE_HALFS;
+	const int r16 = lane & 15, hq = lane >> 4;
+	const uint32_t B = a.B;
+	const uint32_t n_tiles = B / TILE;
+	const TrainScratch& T = a.t;
+	float var_sum = 0.f;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		float c[7];
+#pragma unroll
+		for (int q = 0; q < 7; ++q) c[q] = a.coords[(size_t)s * 7 + q];
+		half_t dout[16];
+		{
+			const h8* src = reinterpret_cast<const h8*>(a.dout + (size_t)s * 16);
+			const h8 d0 = src[0], d1 = src[1];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { dout[j] = d0[j]; dout[8 + j] = d1[j]; }
+		}
+		// ---------------- forward (as k_forward, activations also exported feature-major) ----------------
+		half_t feat[28];
+		float dydx[28][3];
+		encode_all<true>(G, net.grid, c[0], c[1], c[2], feat, dydx);
+		write_sdf_in_row(tA, lane, c[0], c[1], c[2], feat);
+		wave_lds_sync();
+		fm_store(tA, S32, 32, T.sdfin, B, s);
+		uint64_t m_z1;
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, tA, S32, acc, lane);
+			m_z1 = store_acc<4, true>(acc, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tB, S64, 64, T.z1, B, s);
+		// sdf_out -> tC[.][0..15]
+		{
+			f4 acc[1][4];
+			zero_acc<1>(acc);
+			mfma_layer<1, 2>(wts + W_S1, S64, tB, S64, acc, lane);
+			store_acc<1, false>(acc, tC, S32, 0, lane);
+		}
+		wave_lds_sync(); // tA (sdf_in) and tB (z1) are dead from here on
+		// dz1 -> tA (64 wide)
+#pragma unroll
+		for (int mt = 0; mt < 4; ++mt) {
+			const h4 w1 = *reinterpret_cast<const h4*>(wts + W_S1 + 0 * S64 + 16 * mt + 4 * hq);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				h4 v;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) v[r] = ((m_z1 >> ((mt * 4 + nt) * 4 + r)) & 1ull) ? w1[r] : (half_t)0.f;
+				*reinterpret_cast<h4*>(tA + (16 * nt + r16) * S64 + 16 * mt + 4 * hq) = v;
+			}
+		}
+		wave_lds_sync();
+		fm_store(tA, S64, 64, T.dz1, B, s);
+		// dsdf_din -> tB[.][0..31]
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer<2, 2>(wts + W_S0T, S64, tA, S64, acc, lane);
+			store_acc<2, false>(acc, tB, S32, 0, lane);
+		}
+		wave_lds_sync();
+		float grad[3] = {0.f, 0.f, 0.f};
+		half_t din[32];
+		{
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h8 v = *reinterpret_cast<const h8*>(tB + lane * S32 + q * 8);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) din[q * 8 + j] = v[j];
+			}
+#pragma unroll
+			for (int k = 0; k < 28; ++k) {
+				const float dl = h2f(din[3 + k]);
+#pragma unroll
+				for (int d = 0; d < 3; ++d) grad[d] += dl * dydx[k][d];
+			}
+#pragma unroll
+			for (int d = 0; d < 3; ++d) grad[d] += h2f(din[d]);
+#pragma unroll
+			for (int l = 0; l < 14; ++l) T.g2[(size_t)l * B + s] = pack_h2(din[3 + 2 * l], din[3 + 2 * l + 1]);
+		}
+		{
+			h8 v0 = {f2h(c[0]), f2h(c[1]), f2h(c[2]), f2h(grad[0]), f2h(grad[1]), f2h(grad[2]), (half_t)0.f, (half_t)0.f};
+			h8 v1 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			*reinterpret_cast<h8*>(tC + lane * S32 + 16) = v0;
+			*reinterpret_cast<h8*>(tC + lane * S32 + 24) = v1;
+		}
+		wave_lds_sync();
+		fm_store(tC, S32, 32, T.cin, B, s);
+		uint64_t m_h1, m_h2;
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_C0, S32, tC, S32, acc, lane);
+			m_h1 = store_acc<4, true>(acc, tA, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tA, S64, 64, T.h1, B, s);
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 2>(wts + W_C1, S64, tA, S64, acc, lane);
+			m_h2 = store_acc<4, true>(acc, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tB, S64, 64, T.h2, B, s);
+		// (the rgb output layer is not needed by the backward pass: no output activation, fully_fused_mlp.cu:936-940)
+
+		// ---------------- backward (nerf_network.h:257-452) ----------------
+		// dL_drgb = rows 0..2 of dL_doutput (extract_rgb); dh2 = (W2^T dr) (.) relu'(h2), 3 MACs per element
+		{
+#pragma unroll
+			for (int q = 0; q < 16; ++q) T.dr[(size_t)q * B + s] = q < 3 ? dout[q] : (half_t)0.f;
+			half_t* row = tA + lane * S64; // tA (h1) is dead: dh2 goes there, sample-major, computed per lane
+			const float d0 = h2f(dout[0]), d1 = h2f(dout[1]), d2 = h2f(dout[2]);
+			const half_t* hrow = tB + lane * S64;
+			for (int f = 0; f < 64; f += 8) {
+				const h8 hv = *reinterpret_cast<const h8*>(hrow + f);
+				h8 o;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					float acc = 0.f;
+					acc += h2f(wts[W_C2 + 0 * S64 + f + j]) * d0;
+					acc += h2f(wts[W_C2 + 1 * S64 + f + j]) * d1;
+					acc += h2f(wts[W_C2 + 2 * S64 + f + j]) * d2;
+					o[j] = (h2f(hv[j]) > 0.f) ? f2h(acc) : (half_t)0.f;
+				}
+				*reinterpret_cast<h8*>(row + f) = o;
+			}
+		}
+		wave_lds_sync();
+		fm_store(tA, S64, 64, T.dh2, B, s);
+		// dh1 = (W1^T dh2) (.) relu'(h1) -> tB
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 2>(wts + W_C1T, S64, tA, S64, acc, lane);
+			wave_lds_sync();
+			store_acc_masked<4>(acc, m_h1, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tB, S64, 64, T.dh1, B, s);
+		// dcin (compact 32) = W0c^T dh1 -> tA[.][0..31]
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer<2, 2>(wts + W_C0T, S64, tB, S64, acc, lane);
+			store_acc<2, false>(acc, tA, S32, 0, lane);
+		}
+		wave_lds_sync();
+		// dso = dcin[0:16], [0] += dL_doutput[3] (add_density_gradient); dn (nerf_network.h:343-373)
+		float dn[3];
+		{
+			const h8 a0 = *reinterpret_cast<const h8*>(tA + lane * S32 + 0);
+			const h8 a1 = *reinterpret_cast<const h8*>(tA + lane * S32 + 8);
+			const h8 a2 = *reinterpret_cast<const h8*>(tA + lane * S32 + 16);
+			h8 o0 = a0, o1 = a1;
+			o0[0] = o0[0] + dout[3];
+			const h8 zero = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			// 32-wide tile for the K = 32 MFMA: columns 16..31 zero
+			*reinterpret_cast<h8*>(tC + lane * S32 + 0) = o0;
+			*reinterpret_cast<h8*>(tC + lane * S32 + 8) = o1;
+			*reinterpret_cast<h8*>(tC + lane * S32 + 16) = zero;
+			*reinterpret_cast<h8*>(tC + lane * S32 + 24) = zero;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { T.dso[(size_t)j * B + s] = o0[j]; T.dso[(size_t)(8 + j) * B + s] = o1[j]; }
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				float v = h2f(a2[3 + d]);                  // dL_drgb_network_input rows 35..37
+				v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
+				v += h2f(dout[8 + d]);                     // add_positions_view
+				dn[d] = v;
+				T.dn[(size_t)d * B + s] = v;
+			}
+			var_sum += h2f(dout[7]);
+		}
+		wave_lds_sync();
+		// dz = (W1^T dso) (.) relu'(z1) -> tB (64 wide)
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S1T, S32, tC, S32, acc, lane);
+			store_acc_masked<4>(acc, m_z1, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tB, S64, 64, T.dz, B, s);
+		// dsin = W0^T dz -> tA[.][0..31]; its feature rows are the first-order dL/dfeat of the grid
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer<2, 2>(wts + W_S0T, S64, tB, S64, acc, lane);
+			store_acc<2, false>(acc, tA, S32, 0, lane);
+		}
+		wave_lds_sync();
+		{
+			half_t dsin[32];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h8 v = *reinterpret_cast<const h8*>(tA + lane * S32 + q * 8);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) dsin[q * 8 + j] = v[j];
+			}
+#pragma unroll
+			for (int l = 0; l < 14; ++l) T.g1[(size_t)l * B + s] = pack_h2(dsin[3 + 2 * l], dsin[3 + 2 * l + 1]);
+		}
+		// ddin = [half(dn) | dL/d(dL_dy) | 0] -> tC (32 wide)   (grid.h:858-883, nerf_network.h:423-433)
+		{
+			half_t dd[32];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) dd[d] = f2h(dn[d]);
+#pragma unroll
+			for (int k = 0; k < 28; ++k) {
+				float r = 0.f;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) r += dydx[k][d] * dn[d];
+				dd[3 + k] = f2h(r);
+			}
+			dd[31] = (half_t)0.f;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				h8 v;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) v[j] = dd[q * 8 + j];
+				*reinterpret_cast<h8*>(tC + lane * S32 + q * 8) = v;
+			}
+		}
+		wave_lds_sync();
+		fm_store(tC, S32, 32, T.ddin, B, s);
+		// front = (W0 ddin) (.) relu'(z1) -> tB   (fully_fused_mlp.cu:1097-1107)
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, tC, S32, acc, lane);
+			wave_lds_sync();
+			store_acc_masked<4>(acc, m_z1, tB, S64, 0, lane);
+		}
+		wave_lds_sync();
+		fm_store(tB, S64, 64, T.front, B, s);
+		wave_lds_sync();
+		(void)m_h2;
+	}
+	// variance gradient partial (nerf_network.h:327-340): one value per wavefront, reduced in fixed order later
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) var_sum += __shfl_down(var_sum, off, 64);
+	if (lane == 0) T.var_partial[blockIdx.x * WAVES_PER_WG + wave] = var_sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM: dW[o][i] = sum_s Y[o][s] X[i][s], operands feature-major in global memory, so both MFMA
+// fragments are 16-byte contiguous loads (no LDS). Each wavefront owns K-steps of 32 samples; per-wave partial
+// results go to `partial` and are summed in a fixed order by k_dw_finish (deterministic).
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, bool ONES>
+__global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, const half_t* __restrict__ XT, const uint32_t B, const uint32_t chunk, float* __restrict__ partial) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int r16 = lane & 15, hq = lane >> 4;
+	f4 acc[MT][NT];
+#pragma unroll
+	for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+		for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+	const uint32_t s_begin = blockIdx.x * chunk, s_end = s_begin + chunk;
+	for (uint32_t s0 = s_begin + wave * 32; s0 < s_end; s0 += WAVES_PER_WG * 32) {
+		h8 bfr[NT];
+#pragma unroll
+		for (int nt = 0; nt < NT; ++nt) bfr[nt] = *reinterpret_cast<const h8*>(XT + (size_t)(16 * nt + r16) * B + s0 + 8 * hq);
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) {
+			h8 afr;
+			if (ONES) {
+				const half_t one = (r16 == 0 && mt == 0) ? (half_t)1.f : (half_t)0.f;
+				afr = h8{one, one, one, one, one, one, one, one};
+			} else {
+				afr = *reinterpret_cast<const h8*>(YT + (size_t)(16 * mt + r16) * B + s0 + 8 * hq);
+			}
+#pragma unroll
+			for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr, bfr[nt], acc[mt][nt], 0, 0, 0);
+		}
+	}
+	float* dst = partial + (size_t)(blockIdx.x * WAVES_PER_WG + wave) * (MT * 16) * (NT * 16);
+#pragma unroll
+	for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+		for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * hq + r) * (NT * 16) + 16 * nt + r16] = acc[mt][nt][r];
+}
+
+// Offsets (floats) of the seven partial blocks inside one wave's slab are given by the host.
+struct DwFinishArgs {
+	const float* partial[7]; // rgb2[16x64], rgb1[64x64], rgb0c[64x32], sdf1[16x64], sdf0[64x32], sdf0_2nd[64x32], sdf1_2nd[16x64]
+	uint32_t n_partials;     // waves that produced a partial
+	const float* var_partial;
+	uint32_t n_var_partials;
+	float* grads;            // GRADS_FP32
+	uint32_t off_sdf, off_rgb, off_var;
+};
+
+// One thread per MLP parameter (+1 for the variance). Mirrors the reference's precision staging: each GEMM result is
+// narrowed to half (beta = 0), the second-order GEMMs accumulate onto it (beta = 1) and narrow again
+// (fully_fused_mlp.cu:948, 966, 1001, 1012, 1127).
+__global__ void k_dw_finish(const DwFinishArgs a) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t n_mlp = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
+	if (i > n_mlp) return;
+	if (i == n_mlp) {
+		float v = 0.f;
+		for (uint32_t p = 0; p < a.n_var_partials; ++p) v += a.var_partial[p];
+		a.grads[a.off_var + 0] = v;
+		a.grads[a.off_var + 1] = 0.f; a.grads[a.off_var + 2] = 0.f; a.grads[a.off_var + 3] = 0.f;
+		return;
+	}
+	auto sum = [&](const float* base, uint32_t stride, uint32_t idx) {
+		float s = 0.f;
+		for (uint32_t p = 0; p < a.n_partials; ++p) s += base[(size_t)p * stride + idx];
+		return s;
+	};
+	float g;
+	if (i < 64 * 32) { // sdf W0
+		g = rh(sum(a.partial[4], 64 * 32, i));
+		g = rh(sum(a.partial[5], 64 * 32, i) + g);
+		a.grads[a.off_sdf + i] = g;
+	} else if (i < RNB_N_SDF_MLP_PARAMS) { // sdf W1
+		const uint32_t j = i - 64 * 32;
+		g = rh(sum(a.partial[3], 16 * 64, j));
+		g = rh(sum(a.partial[6], 16 * 64, j) + g);
+		a.grads[a.off_sdf + i] = g;
+	} else {
+		const uint32_t j = i - RNB_N_SDF_MLP_PARAMS;
+		if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
+			const uint32_t o = j / 48, col = j % 48;
+			if (col < 16) g = rh(sum(a.partial[2], 64 * 32, o * 32 + col));
+			else if (col >= 32) g = rh(sum(a.partial[2], 64 * 32, o * 32 + (col - 16)));
+			else g = 0.f;
+		} else if (j < 64 * 48 + 64 * 64) {
+			g = rh(sum(a.partial[1], 64 * 64, j - 64 * 48));
+		} else {
+			g = rh(sum(a.partial[0], 16 * 64, j - 64 * 48 - 64 * 64));
+		}
+		a.grads[a.off_rgb + j] = g;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hash-grid gradient scatter, level-major (blockIdx.y = level) so one level's table stays in the XCD L2s.
+// First-order (grid.h:366-495) and second-order (grid.h:556-683) addends of a corner are summed in registers and
+// issued as one fp32 atomic per (corner, feature). Each addend is narrowed to half first, as the reference does.
+// ---------------------------------------------------------------------------------------------
+struct ScatterArgs {
+	const float* coords; // [B][7]
+	const uint32_t* g1;  // [14][B]
+	const uint32_t* g2;  // [14][B]
+	const float* dn;     // [3][B]
+	uint32_t B;
+	float* grid_grad;    // GRADS_FP32 + off_grid
+};
+
+__global__ __launch_bounds__(256) void k_grid_scatter(const GridMeta G, const ScatterArgs a) {
+	const uint32_t level = blockIdx.y;
+	if (level > G.valid_level) return;
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= a.B) return;
+	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+	float pos[3];
+	uint32_t pg[3];
+	pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
+	pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
+	pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
+	const h2 q1 = unpack_h2(a.g1[(size_t)level * a.B + s]);
+	const h2 q2 = unpack_h2(a.g2[(size_t)level * a.B + s]);
+	const float g1[2] = {h2f(q1[0]), h2f(q1[1])};
+	const float g2[2] = {h2f(q2[0]), h2f(q2[1])};
+	const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+	float add[8][2];
+#pragma unroll
+	for (uint32_t idx = 0; idx < 8; ++idx) {
+		float weight = 1;
+#pragma unroll
+		for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
+		add[idx][0] = rh(g1[0] * weight);
+		add[idx][1] = rh(g1[1] * weight);
+	}
+#pragma unroll
+	for (uint32_t gd = 0; gd < 3; ++gd) {
+		const float grad_in = scale * dn[gd] * 1.0f;
+#pragma unroll
+		for (uint32_t idx = 0; idx < 4; ++idx) {
+			float weight = grad_in;
+			uint32_t corner = 0;
+#pragma unroll
+			for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+				const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+				if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
+				else { weight *= pos[d]; corner |= (1u << d); }
+			}
+			add[corner][0] += rh(g2[0] * -weight);
+			add[corner][1] += rh(g2[1] * -weight);
+			add[corner | (1u << gd)][0] += rh(g2[0] * weight);
+			add[corner | (1u << gd)][1] += rh(g2[1] * weight);
+		}
+	}
+#pragma unroll
+	for (uint32_t idx = 0; idx < 8; ++idx) {
+		const uint32_t e = grid_entry(hashmap_size, res, pg[0] + (idx & 1u), pg[1] + ((idx >> 1) & 1u), pg[2] + ((idx >> 2) & 1u));
+		if (add[idx][0] != 0.f) atomicAdd(gg + (size_t)e * 2 + 0, add[idx][0]);
+		if (add[idx][1] != 0.f) atomicAdd(gg + (size_t)e * 2 + 1, add[idx][1]);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.
+// ---------------------------------------------------------------------------------------------
+struct AdamArgs {
+	uint64_t n;
+	uint64_t n_matrix;
+	float* w32; half_t* w16; half_t* ema;
+	float* grads; float* m; float* v; uint32_t* steps;
+	float base_lr, beta1, beta2, epsilon, l2_reg;
+	float ema_decay, ema_debias_old, ema_debias_new;
+};
+
+__global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const float graw = a.grads[i];
+		if (graw != 0.f) a.grads[i] = 0.f; // leave the accumulators clear for the next step
+		float gradient = rh(graw) / LOSS_SCALE; // the reference's gradient vector is half (trainer.h:78-84)
+		const bool is_matrix = i < a.n_matrix;
+		half_t w16 = a.w16[i];
+		if (is_matrix || gradient != 0.f) { // adam.h:111-114
+			const float weight_fp = a.w32[i];
+			if (is_matrix) gradient += a.l2_reg * weight_fp;
+			const float gradient_sq = gradient * gradient;
+			const float first_moment = a.m[i] = a.beta1 * a.m[i] + (1 - a.beta1) * gradient;
+			const float second_moment = a.v[i] = a.beta2 * a.v[i] + (1 - a.beta2) * gradient_sq;
+			float learning_rate = a.base_lr;
+			const uint32_t cs = ++a.steps[i];
+			learning_rate *= sqrtf(1 - powf(a.beta2, (float)cs)) / (1 - powf(a.beta1, (float)cs));
+			const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), 0.f), 3.402823466e+38f);
+			const float decayed_weight = (1 - 0.f * learning_rate) * weight_fp - copysignf(0.f * learning_rate, weight_fp);
+			const float new_weight = decayed_weight - effective_learning_rate * first_moment;
+			a.w32[i] = new_weight;
+			w16 = f2h(new_weight);
+			a.w16[i] = w16;
+		}
+		const float filtered = (h2f(a.ema[i]) * a.ema_decay * a.ema_debias_old + h2f(w16) * (1 - a.ema_decay)) * a.ema_debias_new;
+		a.ema[i] = f2h(filtered);
+	}
+}
+
+__global__ void k_fp32_to_half(const float* __restrict__ src, half_t* __restrict__ dst, uint64_t n) {
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = f2h(src[i]);
+}
+
+// random.h:67-93 generate_random_uniform<float>: thread i draws elements i + n_threads*j (j < 4) from stream offset 4*i.
+__global__ void k_random_uniform(Pcg32 rng, uint64_t n, uint64_t n_threads_total, float lower, float upper, float* __restrict__ out) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_threads_total) return;
+	rng.advance((int64_t)i * 4);
+	for (uint64_t j = 0; j < 4; ++j) {
+		const uint64_t idx = i + n_threads_total * j;
+		if (idx >= n) return;
+		const float val = rng.next_float();
+		out[idx] = val * (upper - lower) + lower;
+	}
+}
+
+} // namespace rnb

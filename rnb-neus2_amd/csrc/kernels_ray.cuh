@@ -1,0 +1,736 @@
+// kernels_ray.cuh — occupancy grid, ray marching and loss kernels.
+//   k_grid_samples / k_ema_grid / k_mean_* / k_grid_to_bitfield / k_bitfield_max_pool   testbed_nerf.cu:585-740, 3424-3517
+//   k_march_count / k_scan_rays / k_march_write                                         testbed_nerf.cu:1216-1387
+//   k_loss_pass1 / k_scan_compact / k_loss_pass2 / k_rollover                            testbed_nerf.cu:1396-2097, 4044-4052
+// Sample slots are assigned in ray order by prefix sums instead of the reference's atomicAdd order (any order is a
+// legal outcome of the reference's race; ray order makes the step reproducible and the sample stream coalesced).
+#pragma once
+#include "common.cuh"
+
+namespace rnb {
+
+struct SceneAabb { float mn, mx, cone_angle; uint32_t max_cascade; };
+
+__device__ __forceinline__ Vec3 warp_position(const SceneAabb& A, const Vec3& p) {
+	const float diag = A.mx - A.mn;
+	return {(p.x - A.mn) / diag, (p.y - A.mn) / diag, (p.z - A.mn) / diag};
+}
+__device__ __forceinline__ bool aabb_contains(const SceneAabb& A, const Vec3& p) {
+	return p.x >= A.mn && p.x <= A.mx && p.y >= A.mn && p.y <= A.mx && p.z >= A.mn && p.z <= A.mx;
+}
+__device__ __forceinline__ void ray_intersect(const SceneAabb& A, const Vec3& pos, const Vec3& dir, float* tmin_o, float* tmax_o) { // bounding_box.cuh:163-206
+	const float mn = A.mn, mx = A.mx;
+	const float FMAX = 3.402823466e+38f;
+	float tmin = (mn - pos.x) / dir.x, tmax = (mx - pos.x) / dir.x;
+	if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
+	float tymin = (mn - pos.y) / dir.y, tymax = (mx - pos.y) / dir.y;
+	if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
+	if (tmin > tymax || tymin > tmax) { *tmin_o = FMAX; *tmax_o = FMAX; return; }
+	if (tymin > tmin) tmin = tymin;
+	if (tymax < tmax) tmax = tymax;
+	float tzmin = (mn - pos.z) / dir.z, tzmax = (mx - pos.z) / dir.z;
+	if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
+	if (tmin > tzmax || tzmin > tmax) { *tmin_o = FMAX; *tmax_o = FMAX; return; }
+	if (tzmin > tmin) tmin = tzmin;
+	if (tzmax < tmax) tmax = tzmax;
+	*tmin_o = tmin; *tmax_o = tmax;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy grid
+// ---------------------------------------------------------------------------------------------
+// generate_grid_samples_nerf_nonuniform (testbed_nerf.cu:585-614)
+__global__ void k_grid_samples(const uint32_t n_elements, Pcg32 rng, const uint32_t step, const SceneAabb A, const float* __restrict__ grid_in,
+                               float* __restrict__ pos_out, uint32_t* __restrict__ idx_out, const float thresh) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const uint32_t n_cascades = A.max_cascade + 1;
+	rng.advance((int64_t)i * 4);
+	const uint32_t level = (uint32_t)(rng.next_float() * n_cascades) % n_cascades;
+	uint32_t idx = 0;
+	for (uint32_t j = 0; j < 10; ++j) {
+		idx = ((i + step * n_elements) * 56924617u + j * 19349663u + 96925573u) % GRID_CELLS;
+		idx += level * GRID_CELLS;
+		if (grid_in[idx] > thresh) break;
+	}
+	const uint32_t pos_idx = idx % GRID_CELLS;
+	const uint32_t x = morton3D_invert(pos_idx >> 0), y = morton3D_invert(pos_idx >> 1), z = morton3D_invert(pos_idx >> 2);
+	const float rx = rng.next_float(), ry = rng.next_float(), rz = rng.next_float();
+	const float sc = scalbnf(1.0f, (int)level);
+	const Vec3 pos = {(((float)x + rx) / GRIDSIZE - 0.5f) * sc + 0.5f, (((float)y + ry) / GRIDSIZE - 0.5f) * sc + 0.5f, (((float)z + rz) / GRIDSIZE - 0.5f) * sc + 0.5f};
+	const Vec3 w = warp_position(A, pos);
+	pos_out[(size_t)i * 3 + 0] = w.x; pos_out[(size_t)i * 3 + 1] = w.y; pos_out[(size_t)i * 3 + 2] = w.z;
+	idx_out[i] = idx;
+}
+
+// ema_grid_samples_nerf (testbed_nerf.cu:655-685)
+__global__ void k_ema_grid(const uint32_t n_elements, const float decay, float* __restrict__ grid_out, const float* __restrict__ grid_in) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const float importance = grid_in[i];
+	const float prev_val = grid_out[i];
+	grid_out[i] = (prev_val < 0.f) ? prev_val : fmaxf(prev_val * decay, importance);
+}
+
+// mean of max(v,0)/n over the first mip (testbed_nerf.cu:3509), summed in fp64 in a fixed order (2 kernels).
+__global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ grid, double* __restrict__ partial) {
+	__shared__ double sh[256];
+	const uint32_t per_block = GRID_CELLS / gridDim.x;
+	const uint32_t base = blockIdx.x * per_block;
+	double acc = 0.0;
+	for (uint32_t i = threadIdx.x; i < per_block; i += 256) acc += (double)(fmaxf(grid[base + i], 0.f) / (float)GRID_CELLS);
+	sh[threadIdx.x] = acc;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void k_mean_final(const double* __restrict__ partial, const uint32_t n, float* __restrict__ mean_out) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		double s = 0.0;
+		for (uint32_t i = 0; i < n; ++i) s += partial[i];
+		*mean_out = (float)s;
+	}
+}
+// grid_to_bitfield (testbed_nerf.cu:693-717)
+__global__ void k_grid_to_bitfield(const uint32_t n_elements, const uint32_t n_nonzero_elements, const float* __restrict__ grid, uint8_t* __restrict__ bitfield, const float* __restrict__ mean_density_ptr) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	if (i >= n_nonzero_elements) { bitfield[i] = 0; return; }
+	uint8_t bits = 0;
+	const float thresh = fminf(MIN_OPTICAL_THICKNESS, *mean_density_ptr);
+#pragma unroll
+	for (uint8_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? ((uint8_t)1 << j) : 0;
+	bitfield[i] = bits;
+}
+// bitfield_max_pool (testbed_nerf.cu:719-740)
+__global__ void k_bitfield_max_pool(const uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	uint8_t bits = 0;
+#pragma unroll
+	for (uint8_t j = 0; j < 8; ++j) bits |= prev_level[(size_t)i * 8 + j] > 0 ? ((uint8_t)1 << j) : 0;
+	const uint32_t x = morton3D_invert(i >> 0) + GRIDSIZE / 8;
+	const uint32_t y = morton3D_invert(i >> 1) + GRIDSIZE / 8;
+	const uint32_t z = morton3D_invert(i >> 2) + GRIDSIZE / 8;
+	next_level[morton3D(x, y, z)] |= bits;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dataset access (common_device.cuh:31-61, 621-700)
+// ---------------------------------------------------------------------------------------------
+struct ViewDev {
+	uint32_t width, height;
+	float focal[2], principal[2];
+	float xform[12];
+	const uint16_t* normal;
+	const uint16_t* albedo;
+};
+
+__device__ __forceinline__ float srgb_to_linear(float srgb) {
+	if (srgb <= 0.04045f) return srgb / 12.92f;
+	return powf((srgb + 0.055f) / 1.055f, 2.4f);
+}
+__device__ __forceinline__ float linear_to_srgb(float linear) {
+	if (linear < 0.0031308f) return 12.92f * linear;
+	return 1.055f * powf(linear, 0.41666f) - 0.055f;
+}
+__device__ __forceinline__ void read_rgba(const float xy[2], const ViewDev& m, const uint16_t* __restrict__ pixels, float rgba[4]) {
+	const int x = (int)(xy[0] * (float)m.width), y = (int)(xy[1] * (float)m.height);
+	const int px = max(min(x, (int)m.width - 1), 0), py = max(min(y, (int)m.height - 1), 0);
+	const uint2 raw = *reinterpret_cast<const uint2*>(pixels + ((size_t)px + (size_t)py * m.width) * 4);
+	if (raw.x == 0x00FF00FFu && raw.y == 0u) { rgba[0] = rgba[1] = rgba[2] = rgba[3] = -1.f; return; }
+	const float v0 = (float)(raw.x & 0xffffu), v1 = (float)(raw.x >> 16), v2 = (float)(raw.y & 0xffffu), v3 = (float)(raw.y >> 16);
+	const float alpha = v3 * (1.0f / 65535.0f);
+	rgba[0] = srgb_to_linear(v0 * (1.0f / 65535.0f)) * alpha;
+	rgba[1] = srgb_to_linear(v1 * (1.0f / 65535.0f)) * alpha;
+	rgba[2] = srgb_to_linear(v2 * (1.0f / 65535.0f)) * alpha;
+	rgba[3] = alpha;
+}
+// red channel test of testbed_nerf.cu:1264 without the pow(): linear*alpha <= 0  <=>  v0 == 0 || alpha == 0 (or the -1 sentinel)
+__device__ __forceinline__ bool red_is_nonpositive(const float xy[2], const ViewDev& m, const uint16_t* __restrict__ pixels) {
+	const int x = (int)(xy[0] * (float)m.width), y = (int)(xy[1] * (float)m.height);
+	const int px = max(min(x, (int)m.width - 1), 0), py = max(min(y, (int)m.height - 1), 0);
+	const uint2 raw = *reinterpret_cast<const uint2*>(pixels + ((size_t)px + (size_t)py * m.width) * 4);
+	if (raw.x == 0x00FF00FFu && raw.y == 0u) return true;
+	return (raw.x & 0xffffu) == 0u || (raw.y >> 16) == 0u;
+}
+__device__ __forceinline__ void random_image_pos(Pcg32& rng, const uint32_t w, const uint32_t h, const bool snap, float xy[2]) { // testbed_nerf.cu:1171-1192
+	xy[0] = rng.next_float(); xy[1] = rng.next_float();
+	if (snap) {
+		const float res[2] = {(float)w, (float)h};
+		const float lim[2] = {(float)((int)w - 1), (float)((int)h - 1)};
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			float p = xy[a] * res[a];
+			p = fmaxf(p, 0.0f);
+			p = fminf(p, lim[a]);
+			xy[a] = (p + 0.5f) / res[a];
+		}
+	}
+}
+__device__ __forceinline__ uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_rays_total, uint32_t n_images) { // testbed_nerf.cu:1194-1214
+	return (((base_idx + n_rays_total) * n_images) / n_rays) % n_images;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: ray generation + DDA march (testbed_nerf.cu:1216-1387)
+// ---------------------------------------------------------------------------------------------
+struct MarchArgs {
+	uint32_t n_rays;        // this rank's rays
+	uint32_t n_rays_global; // n_rays * world_size
+	uint32_t ray_offset;    // rank * n_rays
+	uint32_t n_rays_total;
+	uint32_t max_samples;
+	uint32_t n_images;
+	uint32_t snap;
+	Pcg32 rng;
+	SceneAabb A;
+	const ViewDev* views;
+	const uint8_t* bitfield;
+	// per-ray scratch
+	float* setup;       // [n_rays][8]: o(3) dir(3) startt alive
+	float* d_unnorm;    // [n_rays][3]
+	uint32_t* steps;    // [n_rays]
+	uint32_t* base;     // [n_rays]
+	uint32_t* slot;     // [n_rays] (0xffffffff = dropped)
+	// outputs
+	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
+};
+
+template <typename F>
+__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
+	const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	uint32_t j = 0;
+	float t = startt;
+	Vec3 pos;
+	while (aabb_contains(A, pos = o + t * dir) && j < max_steps) {
+		const float dt = calc_dt(t, A.cone_angle);
+		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+		if (density_grid_occupied_at(pos, bitfield, mip)) {
+			emit(j, pos, dt);
+			++j;
+			t += dt;
+		} else {
+			const uint32_t res = GRIDSIZE >> mip;
+			t = advance_to_next_voxel(t, A.cone_angle, pos, dir, idir, res);
+		}
+	}
+	return j;
+}
+
+__global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays) return;
+	const uint32_t gi = a.ray_offset + i;
+	const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+	const ViewDev m = a.views[img];
+	Pcg32 rng = a.rng;
+	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+	float xy[2];
+	random_image_pos(rng, m.width, m.height, a.snap != 0, xy);
+	uint32_t steps = 0;
+	float alive = 0.f;
+	Vec3 o = {0, 0, 0}, dir = {0, 0, 1}, du = {0, 0, 1};
+	float startt = 0.f;
+	bool dead = false;
+	if (red_is_nonpositive(xy, m, m.normal)) {
+		if (rng.next_float() >= 0.9) dead = true; // testbed_nerf.cu:1264, short-circuit draw
+	}
+	if (!dead) {
+		(void)rng.next_float(); // motionblur_time, testbed_nerf.cu:1270
+		o = v3(m.xform[3], m.xform[7], m.xform[11]);
+		const Vec3 dcam = {
+			(xy[0] - m.principal[0]) * (float)m.width / m.focal[0],
+			(xy[1] - m.principal[1]) * (float)m.height / m.focal[1],
+			1.0f,
+		};
+		du = v3(m.xform[0] * dcam.x + m.xform[1] * dcam.y + m.xform[2] * dcam.z,
+		        m.xform[4] * dcam.x + m.xform[5] * dcam.y + m.xform[6] * dcam.z,
+		        m.xform[8] * dcam.x + m.xform[9] * dcam.y + m.xform[10] * dcam.z);
+		dir = normalized(du);
+		float tmin, tmax;
+		ray_intersect(a.A, o, dir, &tmin, &tmax);
+		tmin = fmaxf(tmin, 0.0f);
+		startt = tmin;
+		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
+		alive = 1.f;
+		steps = march(a.A, a.bitfield, o, dir, startt, RNB_MAX_STEPS, [](uint32_t, const Vec3&, float) {});
+	}
+	float* st = a.setup + (size_t)i * 8;
+	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
+	a.d_unnorm[(size_t)i * 3 + 0] = du.x; a.d_unnorm[(size_t)i * 3 + 1] = du.y; a.d_unnorm[(size_t)i * 3 + 2] = du.z;
+	a.steps[i] = steps;
+}
+
+// Single-workgroup exclusive scans over the rays (n <= 2^18): base = scan(steps); survivors = base + steps <= max_samples;
+// slot = scan(survivor). counters[0] = sum(steps) (numsteps_counter), [2] = #survivors (ray_counter), [3] = samples written.
+__global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint32_t max_samples, const uint32_t* __restrict__ steps,
+                                                    uint32_t* __restrict__ base, uint32_t* __restrict__ slot, uint32_t* __restrict__ counters) {
+	__shared__ uint32_t sh[1024];
+	__shared__ uint32_t sh2[1024];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t per = (n + 1023) / 1024;
+	const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
+	uint32_t sum = 0;
+	for (uint32_t i = lo; i < hi; ++i) sum += steps[i];
+	sh[tid] = sum;
+	__syncthreads();
+	for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+		uint32_t v = tid >= off ? sh[tid - off] : 0;
+		__syncthreads();
+		sh[tid] += v;
+		__syncthreads();
+	}
+	uint32_t run = sh[tid] - sum;
+	const uint32_t total = sh[1023];
+	uint32_t n_surv = 0, written = 0;
+	for (uint32_t i = lo; i < hi; ++i) {
+		const uint32_t st = steps[i];
+		base[i] = run;
+		const bool ok = st > 0 && run + st <= max_samples; // testbed_nerf.cu:1348-1355
+		slot[i] = ok ? 1u : 0u;
+		n_surv += ok ? 1u : 0u;
+		written += ok ? st : 0u;
+		run += st;
+	}
+	__syncthreads();
+	sh[tid] = n_surv;
+	sh2[tid] = written;
+	__syncthreads();
+	for (uint32_t off = 1; off < 1024; off <<= 1) {
+		uint32_t v = tid >= off ? sh[tid - off] : 0;
+		uint32_t w = tid >= off ? sh2[tid - off] : 0;
+		__syncthreads();
+		sh[tid] += v;
+		sh2[tid] += w;
+		__syncthreads();
+	}
+	uint32_t srun = sh[tid] - n_surv;
+	for (uint32_t i = lo; i < hi; ++i) {
+		const bool ok = slot[i] != 0u;
+		slot[i] = ok ? srun : 0xffffffffu;
+		srun += ok ? 1u : 0u;
+	}
+	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; }
+}
+
+__global__ __launch_bounds__(128) void k_march_write(const MarchArgs a) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays) return;
+	const uint32_t s = a.slot[i];
+	if (s == 0xffffffffu) return;
+	const float* st = a.setup + (size_t)i * 8;
+	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
+	const float startt = st[6];
+	const uint32_t steps = a.steps[i], base = a.base[i];
+	a.ray_indices[s] = i;
+	float* ro = a.rays + (size_t)s * 6;
+	ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
+	ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
+	a.numsteps[(size_t)s * 2 + 0] = steps;
+	a.numsteps[(size_t)s * 2 + 1] = base;
+	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
+	float* co = a.coords + (size_t)base * 7;
+	const SceneAabb A = a.A;
+	march(A, a.bitfield, o, dir, startt, steps, [&](uint32_t j, const Vec3& pos, float dt) {
+		const Vec3 wp = warp_position(A, pos);
+		float* q = co + (size_t)j * 7;
+		q[0] = wp.x; q[1] = wp.y; q[2] = wp.z; q[3] = warp_dt(dt); q[4] = wd.x; q[5] = wd.y; q[6] = wd.z;
+	});
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8: loss + output gradients (testbed_nerf.cu:1396-2097)
+// ---------------------------------------------------------------------------------------------
+struct LossFlags {
+	uint32_t apply_L2, apply_rgbplus, apply_no_albedo, apply_light_opti, apply_relu, apply_bce, snap;
+	float mask_loss_weight, ek_loss_weight;
+};
+
+struct RayLoss { // pass 1 -> pass 2
+	uint32_t n_comp;
+	float rgb_ray[4];
+	float weight_sum_raw;
+	float rgbtarget[4];
+	float light[3];
+	float dir[3];
+	float mask_certainty, mask_gt;
+};
+
+struct LossArgs {
+	uint32_t n_rays, n_rays_global, ray_offset, n_rays_total, n_images, B;
+	Pcg32 rng;
+	SceneAabb A;
+	LossFlags F;
+	float light_dirs[9];
+	const ViewDev* views;
+	const uint32_t* counters;   // [2] = rays kept
+	const uint32_t* ray_indices;
+	const float* rays;
+	uint32_t* numsteps;
+	const float* coords;
+	const half_t* mlp_out;
+	RayLoss* ray_loss;
+	uint32_t* ncomp;  // [n_rays]
+	uint32_t* cbase;  // [n_rays]
+	float* coords_compacted;
+	half_t* dloss;
+	float *loss, *ek_loss, *mask_loss;
+};
+
+__device__ __forceinline__ void albedo_from_output(const LossFlags& F, const half_t* __restrict__ o, float albedo[4]) { // testbed_nerf.cu:1614-1639
+	if (F.apply_no_albedo) { albedo[0] = albedo[1] = albedo[2] = 1.f; albedo[3] = 0.f; return; }
+	float a[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) a[k] = logistic(h2f(o[k]));
+	albedo[0] = a[0]; albedo[1] = a[1]; albedo[2] = a[2];
+	if (F.apply_rgbplus) {
+		if (F.apply_L2) albedo[3] = sqrtf(fmaxf(0.0f, 3 - a[0] * a[0] - a[1] * a[1] - a[2] * a[2]));
+		else albedo[3] = 3 - fabsf(a[0]) - fabsf(a[1]) - fabsf(a[2]);
+	} else albedo[3] = 0.f;
+}
+
+struct AlphaTerms { float inv_s, sdf_value, true_cos, iter_cos, est_next, p_div_c, alpha; float g[3]; };
+
+__device__ __forceinline__ AlphaTerms alpha_terms(const half_t* __restrict__ o, const float dt, const float dir[3], const float cos_anneal_ratio) { // testbed_nerf.cu:1652-1677
+	AlphaTerms a;
+	a.inv_s = expf(h2f((half_t)10.f * o[7]));
+	a.sdf_value = h2f(o[3]);
+	a.g[0] = h2f(o[4]); a.g[1] = h2f(o[5]); a.g[2] = h2f(o[6]);
+	a.true_cos = (dir[0] * a.g[0] + dir[1] * a.g[1] + dir[2] * a.g[2]);
+	const float r1 = (float)(-a.true_cos * 0.5 + 0.5);
+	const float relu1 = r1 > 0.0f ? r1 : 0.0f;
+	const float relu2 = -a.true_cos > 0.0f ? -a.true_cos : 0.0f;
+	a.iter_cos = (float)-(relu1 * (1.0 - cos_anneal_ratio) + relu2 * cos_anneal_ratio);
+	a.est_next = (float)(a.sdf_value + a.iter_cos * dt * 0.5);
+	const float est_prev = (float)(a.sdf_value - a.iter_cos * dt * 0.5);
+	const float next_cdf = logistic(a.est_next * a.inv_s);
+	const float prev_cdf = logistic(est_prev * a.inv_s);
+	const float p = prev_cdf - next_cdf;
+	const float cc = prev_cdf;
+	a.p_div_c = (p + 1e-5f) / (cc + 1e-5f);
+	a.alpha = fminf(fmaxf(a.p_div_c, 0.0f), 1.0f);
+	return a;
+}
+
+__global__ __launch_bounds__(128) void k_loss_pass1(const LossArgs a) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays) return;
+	if (i >= a.counters[2]) { a.ncomp[i] = 0; return; }
+	const uint32_t numsteps = a.numsteps[(size_t)i * 2 + 0];
+	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+	const float* coords_in = a.coords + (size_t)base * 7;
+	const half_t* net = a.mlp_out + (size_t)base * 16;
+	const uint32_t ray_idx = a.ray_indices[i];
+	const uint32_t gi = a.ray_offset + ray_idx;
+	Pcg32 rng = a.rng;
+	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+	const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+	const ViewDev m = a.views[img];
+	const Vec3 ray_d = {a.rays[(size_t)i * 6 + 3], a.rays[(size_t)i * 6 + 4], a.rays[(size_t)i * 6 + 5]};
+	const Vec3 dir0 = normalized(ray_d);
+	float dir[3] = {dir0.x, dir0.y, dir0.z};
+	float xy[2];
+	random_image_pos(rng, m.width, m.height, a.F.snap != 0, xy);
+	float tex_albedo[4], tex_normal[4];
+	read_rgba(xy, m, m.albedo, tex_albedo);
+	read_rgba(xy, m, m.normal, tex_normal);
+	const float exposure_scale = expf(0.6931471805599453f * 0.f);
+	float nv[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) nv[k] = linear_to_srgb(exposure_scale * tex_normal[k]) * 2.0f - 1.0f;
+	nv[1] *= -1; nv[2] *= -1;
+	{ const float nn = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]); nv[0] /= nn; nv[1] /= nn; nv[2] /= nn; }
+	float albedo_value[4];
+	if (a.F.apply_no_albedo) { albedo_value[0] = albedo_value[1] = albedo_value[2] = 1.f; albedo_value[3] = 0.f; }
+	else {
+		float al[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) al[k] = linear_to_srgb(exposure_scale * tex_albedo[k]);
+		albedo_value[0] = al[0]; albedo_value[1] = al[1]; albedo_value[2] = al[2];
+		if (a.F.apply_rgbplus) {
+			if (a.F.apply_L2) albedo_value[3] = sqrtf(fmaxf(0.0f, 3 - al[0] * al[0] - al[1] * al[1] - al[2] * al[2]));
+			else albedo_value[3] = 3 - fabsf(al[0]) - fabsf(al[1]) - fabsf(al[2]);
+		} else albedo_value[3] = 0.f;
+	}
+	float Ld[9];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) Ld[k] = a.light_dirs[k];
+	Pcg32 lrng = a.rng; // deterministic light pick: draw #7 of the ray's stream (the reference seeds curand with clock64())
+	lrng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY + 7);
+	const int random_light = (int)(lrng.next_uint() % 3u);
+	if (a.F.apply_light_opti) { // testbed_nerf.cu:1563-1581
+		float k3[3] = {-nv[1], nv[0], 0.f};
+		const float kn = sqrtf(k3[0] * k3[0] + k3[1] * k3[1] + k3[2] * k3[2]);
+		k3[0] /= kn; k3[1] /= kn; k3[2] /= kn;
+		const float cos_theta = nv[2];
+		const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+		const float K[9] = {0, -k3[2], k3[1], k3[2], 0, -k3[0], -k3[1], k3[0], 0};
+		float Rm[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+			Rm[r * 3 + q] = cos_theta * (r == q ? 1.f : 0.f) + sin_theta * K[r * 3 + q] + (1 - cos_theta) * (k3[r] * k3[q]);
+		float outm[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+			float sacc = 0.f;
+			for (int t = 0; t < 3; ++t) sacc += (-Rm[r * 3 + t]) * Ld[t * 3 + q];
+			outm[r * 3 + q] = sacc;
+		}
+		for (int k = 0; k < 9; ++k) Ld[k] = outm[k];
+	}
+	const float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
+	RayLoss R;
+#pragma unroll
+	for (int r = 0; r < 3; ++r) R.light[r] = m.xform[r * 4 + 0] * light_cam[0] + m.xform[r * 4 + 1] * light_cam[1] + m.xform[r * 4 + 2] * light_cam[2];
+	float shading_target = nv[0] * light_cam[0] + nv[1] * light_cam[1] + nv[2] * light_cam[2];
+	if (a.F.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) R.rgbtarget[k] = albedo_value[k] * shading_target;
+
+	float T = 1.f;
+	const float EPSILON = 1e-4f;
+	float rgb_ray[4] = {0, 0, 0, 0};
+	float weight_sum = 0.f;
+	uint32_t n = 0;
+	for (; n < numsteps; ++n) {
+		if (T < EPSILON) break;
+		half_t o[16];
+		{
+			const h8* src = reinterpret_cast<const h8*>(net + (size_t)n * 16);
+			const h8 o0 = src[0], o1 = src[1];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { o[j] = o0[j]; o[8 + j] = o1[j]; }
+		}
+		float albedo[4];
+		albedo_from_output(a.F, o, albedo);
+		const float dt = unwarp_dt(coords_in[(size_t)n * 7 + 3]);
+		if (n == 0) { // BENT_DIR, testbed_nerf.cu:1645-1650
+			const Vec3 dv = normalized(v3(h2f(o[8]) * 2.0f - 1.0f, h2f(o[9]) * 2.0f - 1.0f, h2f(o[10]) * 2.0f - 1.0f));
+			dir[0] = dv.x; dir[1] = dv.y; dir[2] = dv.z;
+		}
+		const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
+		const float weight = at.alpha * T;
+		float shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
+		if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rgb_ray[k] += weight * albedo[k] * shading;
+		weight_sum += weight;
+		T *= (1.f - at.alpha);
+	}
+	R.n_comp = n;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
+	R.weight_sum_raw = weight_sum;
+	R.dir[0] = dir[0]; R.dir[1] = dir[1]; R.dir[2] = dir[2];
+	R.mask_certainty = (float)(tex_albedo[3] > 0.99);
+	R.mask_gt = (float)(tex_normal[3] > 0.99);
+	a.ray_loss[i] = R;
+	a.ncomp[i] = n;
+}
+
+// exclusive scan of ncomp over the kept rays; counters[1] = total (numsteps_counter_compacted)
+__global__ __launch_bounds__(1024) void k_scan_compact(const uint32_t n_max, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters) {
+	__shared__ uint32_t sh[1024];
+	const uint32_t n = min(counters[2], n_max);
+	const uint32_t tid = threadIdx.x;
+	const uint32_t per = (n + 1023) / 1024;
+	const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
+	uint32_t sum = 0;
+	for (uint32_t i = lo; i < hi; ++i) sum += ncomp[i];
+	sh[tid] = sum;
+	__syncthreads();
+	for (uint32_t off = 1; off < 1024; off <<= 1) {
+		uint32_t v = tid >= off ? sh[tid - off] : 0;
+		__syncthreads();
+		sh[tid] += v;
+		__syncthreads();
+	}
+	uint32_t run = sh[tid] - sum;
+	for (uint32_t i = lo; i < hi; ++i) { cbase[i] = run; run += ncomp[i]; }
+	if (tid == 0) counters[1] = sh[1023];
+}
+
+__global__ __launch_bounds__(128) void k_loss_pass2(const LossArgs a) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays || i >= a.counters[2]) return;
+	const RayLoss R = a.ray_loss[i];
+	const uint32_t compacted_base = a.cbase[i];
+	const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
+	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+	a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
+	a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+	if (compacted_numsteps == 0) return;
+	const float* coords_in = a.coords + (size_t)base * 7;
+	const half_t* net = a.mlp_out + (size_t)base * 16;
+	float* coords_out = a.coords_compacted + (size_t)compacted_base * 7;
+	half_t* dloss = a.dloss + (size_t)compacted_base * 16;
+	const LossFlags F = a.F;
+	const float gn = (float)a.n_rays_global;
+
+	float grad[4];
+	float loss = 0.f;
+	{
+		float diff[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) diff[k] = R.rgb_ray[k] - R.rgbtarget[k];
+		if (F.apply_L2) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) grad[k] = 2 * diff[k];
+			loss = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) grad[k] = copysignf(1.0f, diff[k]);
+			loss = fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
+		}
+	}
+	if (F.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) grad[k] /= 2; }
+	loss *= R.mask_certainty;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) grad[k] *= R.mask_certainty;
+	float weight_sum = R.weight_sum_raw;
+	float gradient_weight_sum;
+	if (weight_sum >= 1.0 - 1e-4) { weight_sum = (float)(1.0 - 1e-4); gradient_weight_sum = 0.0f; }
+	else if (weight_sum <= 1e-4) { weight_sum = 1e-4; gradient_weight_sum = 0.0f; }
+	else {
+		const float sig = 1.0f / (1.0f + expf(-weight_sum));
+		if (F.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * F.mask_loss_weight;
+		else gradient_weight_sum = (sig - R.mask_gt) * F.mask_loss_weight;
+	}
+	a.loss[i] = loss / gn;
+	{
+		const float sig = 1.0f / (1.0f + expf(-weight_sum));
+		if (F.apply_bce) a.mask_loss[i] = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
+		else a.mask_loss[i] = -(R.mask_gt * logf(sig) + (1 - R.mask_gt) * logf(1 - sig));
+	}
+
+	const float loss_scale = LOSS_SCALE / gn; // testbed_nerf.cu:1832
+	float rgb_ray2[4] = {0, 0, 0, 0};
+	float weight_sum2 = 0.f;
+	float T = 1.f;
+	const float dir[3] = {R.dir[0], R.dir[1], R.dir[2]};
+	float ek = 0.f;
+	for (uint32_t j = 0; j < compacted_numsteps; ++j) {
+#pragma unroll
+		for (int q = 0; q < 7; ++q) coords_out[(size_t)j * 7 + q] = coords_in[(size_t)j * 7 + q];
+		half_t o[16];
+		{
+			const h8* src = reinterpret_cast<const h8*>(net + (size_t)j * 16);
+			const h8 o0 = src[0], o1 = src[1];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { o[q] = o0[q]; o[8 + q] = o1[q]; }
+		}
+		const float dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
+		float albedo[4];
+		albedo_from_output(F, o, albedo);
+		const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
+		const float alpha = at.alpha;
+		const float weight = alpha * T;
+		float shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
+		if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * albedo[k] * shading;
+		weight_sum2 += weight;
+		T *= (1.f - alpha);
+		float suffix[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) suffix[k] = R.rgb_ray[k] - rgb_ray2[k];
+		const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
+		float dloss_dn[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (R.light[d] * aG);
+		float J3[3] = {0, 0, 0};
+		if (F.apply_rgbplus) {
+			if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
+			else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
+		}
+		float drgb[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
+		half_t dl[16];
+#pragma unroll
+		for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
+		const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const float sg = logistic(h2f(o[d]));
+			dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+		}
+		const float sum_weight_suffix = weight_sum - weight_sum2;
+		float dot_term = 0.f;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) dot_term += grad[k] * (T * albedo[k] * shading - suffix[k]);
+		const float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (T - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
+		float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
+		if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
+			const float plus_sigmoid_x = at.inv_s * at.iter_cos * dt;
+			const float plus_e = expf(plus_sigmoid_x);
+			const float e_minus = expf(-at.est_next * at.inv_s);
+			dE_dsdf = -at.inv_s * e_minus;
+			dE_dinvs = -at.est_next * e_minus;
+			const float aa = 1 + e_minus;
+			const float bb = 1 + plus_e * e_minus;
+			const float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
+			const float delta = aa * (bb * bb) * (cc * cc);
+			dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
+			dalpha_dEp = -e_minus / (delta);
+			dEp_dinvs = plus_e * at.iter_cos * dt;
+			dEp_ditc = plus_e * at.inv_s * dt;
+			dE_ditc = (float)(-at.inv_s * e_minus * dt * 0.5);
+		}
+		const float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
+		const float dloss_dvariance = dloss_dinvs * at.inv_s * 10;
+		const float d_iter_cos_true_cos = (at.true_cos >= 0) ? 0.0f : 1.0f;
+		const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
+		const float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
+		const float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
+		const float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
+		dl[3] = f2h(loss_scale * dloss_dsdf);
+		ek += (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
+#pragma unroll
+		for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * at.g[d]);
+		dl[7] = f2h(loss_scale * dloss_dvariance);
+#pragma unroll
+		for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
+		h8 w0, w1;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { w0[q] = dl[q]; w1[q] = dl[8 + q]; }
+		h8* dst = reinterpret_cast<h8*>(dloss + (size_t)j * 16);
+		dst[0] = w0;
+		dst[1] = w1;
+	}
+	a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
+}
+
+// fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)
+__global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords) {
+	const uint32_t n_in = counters[1];
+	if (n_in == 0 || n_in >= B) return;
+	const uint64_t n_out16 = (uint64_t)B * 16, n_in16 = (uint64_t)n_in * 16;
+	const uint64_t n_out7 = (uint64_t)B * 7, n_in7 = (uint64_t)n_in * 7;
+	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_out16; q += (uint64_t)gridDim.x * blockDim.x) {
+		if (q >= n_in16) {
+			const float v = h2f(dloss[q % n_in16]);
+			dloss[q] = f2h(v * n_in / B);
+		}
+		if (q >= n_in7 && q < n_out7) coords[q] = coords[q % n_in7];
+	}
+}
+
+// loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
+__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out) {
+	__shared__ double sh[3][1024];
+	const uint32_t n = min(counters[2], n_max);
+	double s0 = 0, s1 = 0, s2 = 0;
+	for (uint32_t i = threadIdx.x; i < n; i += 1024) { s0 += l0[i]; s1 += l1[i]; s2 += l2[i]; }
+	sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+	__syncthreads();
+	for (int off = 512; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; sh[2][threadIdx.x] += sh[2][threadIdx.x + off]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
+}
+
+} // namespace rnb

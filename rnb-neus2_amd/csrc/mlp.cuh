@@ -1,0 +1,146 @@
+// mlp.cuh — the fused SDF+color MLP of NerfNetwork (nerf_network.h:97-452) on CDNA4 matrix cores.
+//
+// Data layout. One wavefront owns a tile of 64 samples (lane = sample in the per-sample phases).
+// Activations are staged through per-wave LDS tiles, sample-major [64][stride] halfs, so that
+//   B fragment of v_mfma_f32_16x16x32_f16: lane l reads X[16*nt + (l&15)][32*ks + 8*(l>>4) .. +7]  (one ds_read_b128)
+//   A fragment: lane l reads W[16*mt + (l&15)][32*ks + 8*(l>>4) .. +7] from the weight image in LDS, which is the
+//               reference's own row-major [out][in] layout (fully_fused_mlp.cu:786-819) with padded rows
+//   D fragment: lane l, reg r = Y[out = 16*mt + 4*(l>>4) + r][sample = 16*nt + (l&15)] -> 4 consecutive outputs of
+//               one sample -> one ds_write_b64 into the next layer's sample-major tile.
+// Row strides of 40 (K=32) and 72 (K=64) halfs make every ds_read_b128 of a fragment conflict-free
+// (16 rows x {80,144} B land on 16 distinct 16-byte slots of the 64-bank LDS).
+// fp32 accumulation in the MFMA (the reference's WMMA accumulates in fp16, fully_fused_mlp.cu:68).
+#pragma once
+#include "common.cuh"
+
+namespace rnb {
+
+constexpr int S32 = 40;  // row stride (halfs) of K=32 matrices / 32-wide tiles
+constexpr int S64 = 72;  // row stride (halfs) of K=64 matrices / 64-wide tiles
+constexpr int TILE = 64; // samples per wavefront tile
+constexpr int ACT_TILE_HALFS = TILE * S64; // one activation tile (any width up to 64)
+
+// Weight image in LDS (offsets in halfs). Forward part first, training-only transposes after it.
+constexpr int W_S0 = 0;                    // [64][S32] sdf W0
+constexpr int W_S1 = W_S0 + 64 * S32;      // [16][S64] sdf W1
+constexpr int W_S0T = W_S1 + 16 * S64;     // [32][S64] sdf W0^T
+constexpr int W_C0 = W_S0T + 32 * S64;     // [64][S32] rgb W0, compact columns {0..15, 32..47}
+constexpr int W_C1 = W_C0 + 64 * S32;      // [64][S64] rgb W1
+constexpr int W_C2 = W_C1 + 64 * S64;      // [16][S64] rgb W2
+constexpr int W_FWD_END = W_C2 + 16 * S64; // 14336 halfs
+constexpr int W_C1T = W_FWD_END;           // [64][S64] rgb W1^T
+constexpr int W_C0T = W_C1T + 64 * S64;    // [32][S64] rgb W0^T, compact rows
+constexpr int W_S1T = W_C0T + 32 * S64;    // [64][S32] sdf W1^T (K = 16 padded to 32 with zeros)
+constexpr int W_TRAIN_END = W_S1T + 64 * S32; // 23808 halfs
+
+// Cooperative load of the weight image by the whole workgroup (once per kernel).
+template <bool TRAIN>
+__device__ inline void load_weights(half_t* __restrict__ w, const NetW& net, int tid, int nthreads) {
+	for (int i = tid; i < 64 * 32; i += nthreads) { int o = i >> 5, k = i & 31; w[W_S0 + o * S32 + k] = net.sdf_w0[i]; w[W_S0T + k * S64 + o] = net.sdf_w0[i]; }
+	for (int i = tid; i < 16 * 64; i += nthreads) { int o = i >> 6, k = i & 63; w[W_S1 + o * S64 + k] = net.sdf_w1[i]; }
+	for (int i = tid; i < 64 * 32; i += nthreads) { // compact input index c: 0..15 -> column c, 16..31 -> column c + 16
+		int o = i >> 5, c = i & 31;
+		int col = c < 16 ? c : c + 16;
+		half_t v = net.rgb_w0[o * 48 + col];
+		w[W_C0 + o * S32 + c] = v;
+		if (TRAIN) w[W_C0T + c * S64 + o] = v;
+	}
+	for (int i = tid; i < 64 * 64; i += nthreads) { int o = i >> 6, k = i & 63; half_t v = net.rgb_w1[i]; w[W_C1 + o * S64 + k] = v; if (TRAIN) w[W_C1T + k * S64 + o] = v; }
+	for (int i = tid; i < 16 * 64; i += nthreads) { int o = i >> 6, k = i & 63; w[W_C2 + o * S64 + k] = net.rgb_w2[i]; }
+	if (TRAIN) {
+		for (int i = tid; i < 64 * 32; i += nthreads) { int j = i >> 5, k = i & 31; w[W_S1T + j * S32 + k] = k < 16 ? net.sdf_w1[k * 64 + j] : (half_t)0.f; }
+	}
+}
+
+// acc[mt][nt] += W[16mt.., :] * X[16nt.., :]^T over K = 32*K_STEPS.
+template <int M_TILES, int K_STEPS>
+__device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const int w_stride, const half_t* __restrict__ X, const int x_stride, f4 (&acc)[M_TILES][4], const int lane) {
+	const int r16 = lane & 15, hq = lane >> 4;
+	h8 b[4][K_STEPS];
+#pragma unroll
+	for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+		for (int ks = 0; ks < K_STEPS; ++ks) b[nt][ks] = *reinterpret_cast<const h8*>(X + (16 * nt + r16) * x_stride + 32 * ks + 8 * hq);
+#pragma unroll
+	for (int mt = 0; mt < M_TILES; ++mt) {
+#pragma unroll
+		for (int ks = 0; ks < K_STEPS; ++ks) {
+			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+		}
+	}
+}
+
+template <int M_TILES>
+__device__ __forceinline__ void zero_acc(f4 (&acc)[M_TILES][4]) {
+#pragma unroll
+	for (int mt = 0; mt < M_TILES; ++mt)
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
+}
+
+// D fragments -> sample-major LDS tile Y[64][y_stride] at column col0. RELU applies the forward activation
+// (warp_activation, common_device.h:69-115) and returns the relu' bit mask of this lane's 16*M_TILES elements.
+template <int M_TILES, bool RELU>
+__device__ __forceinline__ uint64_t store_acc(const f4 (&acc)[M_TILES][4], half_t* __restrict__ Y, const int y_stride, const int col0, const int lane) {
+	const int r16 = lane & 15, hq = lane >> 4;
+	uint64_t mask = 0;
+#pragma unroll
+	for (int mt = 0; mt < M_TILES; ++mt) {
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) {
+			h4 v;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				float a = acc[mt][nt][r];
+				if (RELU) {
+					const bool on = a > 0.f;
+					if (!on) a = 0.f;
+					const half_t hv = f2h(a);
+					// the backward transfer tests the stored half activation (common_device.h:182 ff.)
+					if (h2f(hv) > 0.f) mask |= (1ull << ((mt * 4 + nt) * 4 + r));
+					v[r] = hv;
+				} else {
+					v[r] = f2h(a);
+				}
+			}
+			*reinterpret_cast<h4*>(Y + (16 * nt + r16) * y_stride + col0 + 16 * mt + 4 * hq) = v;
+		}
+	}
+	return mask;
+}
+
+// D fragments gated by a relu' mask (warp_activation_backward) -> sample-major tile.
+template <int M_TILES>
+__device__ __forceinline__ void store_acc_masked(const f4 (&acc)[M_TILES][4], const uint64_t mask, half_t* __restrict__ Y, const int y_stride, const int col0, const int lane) {
+	const int r16 = lane & 15, hq = lane >> 4;
+#pragma unroll
+	for (int mt = 0; mt < M_TILES; ++mt) {
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) {
+			h4 v;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const bool on = (mask >> ((mt * 4 + nt) * 4 + r)) & 1ull;
+				v[r] = f2h(on ? acc[mt][nt][r] : 0.f);
+			}
+			*reinterpret_cast<h4*>(Y + (16 * nt + r16) * y_stride + col0 + 16 * mt + 4 * hq) = v;
+		}
+	}
+}
+
+// Also writes the fragments feature-major to global memory: dst[feature][n_total] at sample column s0 + ...
+// (operands of the weight-gradient GEMMs, whose K dimension is the sample index).
+template <int M_TILES>
+__device__ __forceinline__ void store_tile_feature_major(const half_t* __restrict__ Y, const int y_stride, const int width, half_t* __restrict__ dst, const uint32_t n_total, const uint32_t s0, const int lane) {
+	// lane = sample: read the row from LDS, scatter one half per feature row (64 lanes -> 128 contiguous bytes per feature)
+	const half_t* row = Y + lane * y_stride;
+	for (int f = 0; f < width; f += 8) {
+		const h8 v = *reinterpret_cast<const h8*>(row + f);
+#pragma unroll
+		for (int j = 0; j < 8; ++j) dst[(size_t)(f + j) * n_total + s0 + lane] = v[j];
+	}
+}
+
+} // namespace rnb

@@ -1,0 +1,812 @@
+// rnb_neus2_hip.hip — C-ABI of include/rnb_neus2.h over the gfx950 kernels (host driver).
+// Host-side sequencing follows Testbed::train / train_nerf / train_nerf_step (src/testbed.cu:2776-2872,
+// src/testbed_nerf.cu:3560-4123). No CPU fallback: every entry point runs HIP kernels or fails.
+#include "kernels_net.cuh"
+#include "kernels_ray.cuh"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace rnb;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                         \
+	do {                                                                                                      \
+		hipError_t e_ = (expr);                                                                               \
+		if (e_ != hipSuccess) return fail(RNB_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+template <typename T>
+struct DevBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	hipError_t alloc(size_t count) {
+		n = count;
+		if (count == 0) { p = nullptr; return hipSuccess; }
+		return hipMalloc((void**)&p, count * sizeof(T));
+	}
+	void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+	size_t bytes() const { return n * sizeof(T); }
+};
+
+uint32_t next_multiple_u32(uint32_t v, uint32_t m) { return ((v + m - 1) / m) * m; }
+
+uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid.h:1430-1437
+	if (training_step <= 0) return cfg.n_levels;
+	float v = cfg.base_valid_level_scale * cfg.n_levels + cfg.valid_level_scale * std::max(0, (int)(training_step - (int)cfg.base_training_step));
+	return std::min(cfg.n_levels, (uint32_t)ceilf(v));
+}
+
+} // namespace
+
+struct rnb_ctx {
+	rnb_config cfg;
+	GridMeta grid;
+	uint64_t n_grid_params = 0, n_params = 0;
+	uint64_t off_sdf = 0, off_rgb = 0, off_grid = 0, off_var = 0;
+	SceneAabb aabb;
+	int n_cus = 256;
+
+	DevBuf<float> params_fp32, grads, adam_m, adam_v;
+	DevBuf<half_t> params_fp16, params_ema;
+	DevBuf<uint32_t> adam_steps;
+	DevBuf<float> density_grid, density_grid_tmp, density_mean;
+	DevBuf<double> mean_partial, loss_sums;
+	DevBuf<uint8_t> bitfield;
+	DevBuf<float> grid_sample_pos;
+	DevBuf<uint32_t> grid_sample_idx;
+	uint32_t n_grid_samples = 0;
+
+	// dataset
+	uint32_t n_views = 0;
+	DevBuf<ViewDev> views;
+	DevBuf<uint16_t> pixels;
+	float light_dirs[9];
+
+	// step scratch
+	DevBuf<uint32_t> ray_indices, numsteps, counters;
+	DevBuf<float> rays, coords, coords_compacted, loss, ek_loss, mask_loss;
+	DevBuf<half_t> mlp_out, dloss_dout;
+	DevBuf<float> ray_setup, ray_dunnorm;
+	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
+	DevBuf<RayLoss> ray_loss;
+	// training scratch
+	DevBuf<half_t> fm;       // feature-major operand arrays
+	DevBuf<uint32_t> g1, g2;
+	DevBuf<float> dn, var_partial, dw_partial;
+	TrainScratch ts;
+	uint32_t dw_nwg = 0, dw_chunk = 0;
+	uint32_t fwd_grid = 0;
+	bool grads_clean = true;
+
+	Pcg32 rng, density_grid_rng, trainer_rng;
+	uint32_t density_grid_ema_step = 0;
+	uint32_t training_step = 0, valid_level = 0, rays_per_batch = 0;
+	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0, n_rays_total = 0;
+	uint32_t optimizer_step_count = 0;
+	float lr_factor = 1.f;
+	uint32_t cur_n_rays = 0, cur_n_rays_total = 0;
+	bool grid_updated = false;
+	float prep_ms = 0.f;
+	std::chrono::steady_clock::time_point step_start;
+
+	NetW net(bool inference) const {
+		const half_t* p = inference ? params_ema.p : params_fp16.p;
+		NetW n;
+		n.sdf_w0 = p + off_sdf;
+		n.sdf_w1 = n.sdf_w0 + 64 * 32;
+		n.rgb_w0 = p + off_rgb;
+		n.rgb_w1 = n.rgb_w0 + 64 * 48;
+		n.rgb_w2 = n.rgb_w1 + 64 * 64;
+		n.grid = reinterpret_cast<const uint32_t*>(p + off_grid);
+		n.variance = p + off_var;
+		return n;
+	}
+	GridMeta meta() const { GridMeta g = grid; g.valid_level = valid_level; return g; }
+};
+
+namespace {
+
+constexpr size_t LDS_POINT = (size_t)(W_FWD_END + WAVES_PER_WG * 2 * ACT_TILE_HALFS) * sizeof(half_t);
+constexpr size_t LDS_FWD = (size_t)(W_FWD_END + WAVES_PER_WG * 3 * ACT_TILE_HALFS) * sizeof(half_t);
+constexpr size_t LDS_TRAIN = (size_t)(W_TRAIN_END + WAVES_PER_WG * 3 * ACT_TILE_HALFS) * sizeof(half_t);
+static_assert(LDS_TRAIN <= 160 * 1024, "training kernel LDS exceeds 160 KiB");
+
+void build_grid_tables(rnb_ctx* c) { // grid.h:977-1012
+	const rnb_config& cfg = c->cfg;
+	std::memset(&c->grid, 0, sizeof(c->grid));
+	c->grid.n_levels = cfg.n_levels;
+	uint32_t offset = 0;
+	for (uint32_t i = 0; i < cfg.n_levels; ++i) {
+		const float scale = exp2f(i * std::log2(cfg.per_level_scale)) * cfg.base_resolution - 1.0f;
+		const uint32_t resolution = (uint32_t)(ceilf(scale)) + 1;
+		c->grid.scale[i] = (float)(resolution - 1);
+		c->grid.resolution[i] = resolution;
+		uint32_t max_params = std::numeric_limits<uint32_t>::max() / 2;
+		uint32_t params_in_level = std::pow((float)resolution, 3) > (float)max_params ? max_params : resolution * resolution * resolution;
+		params_in_level = next_multiple_u32(params_in_level, 8u);
+		params_in_level = std::min(params_in_level, (1u << cfg.log2_hashmap_size));
+		c->grid.offsets[i] = offset;
+		offset += params_in_level;
+	}
+	for (uint32_t i = cfg.n_levels; i <= RNB_MAX_LEVELS; ++i) c->grid.offsets[i] = offset;
+	c->n_grid_params = (uint64_t)offset * 2;
+}
+
+void build_light_dirs(rnb_ctx* c) { // testbed_nerf.cu:1537-1554
+	auto radians = [](float deg) { return deg * M_PI / 180.0f; };
+	float tilt[3] = {(float)radians(0.0f), (float)radians(120.0f), (float)radians(240.0f)};
+	float slant[3] = {(float)radians(54.74f), (float)radians(54.74f), (float)radians(54.74f)};
+	for (int k = 0; k < 3; ++k) {
+		c->light_dirs[0 * 3 + k] = -(sinf(slant[k]) * cosf(tilt[k]));
+		c->light_dirs[1 * 3 + k] = -(sinf(slant[k]) * sinf(tilt[k]));
+		c->light_dirs[2 * 3 + k] = -cosf(slant[k]);
+	}
+	if (c->cfg.apply_supernormal) {
+		for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) c->light_dirs[r * 3 + k] = (r == k) ? 1.f : 0.f;
+	}
+}
+
+int derive_half_params(rnb_ctx* c, hipStream_t s) { // trainer.h:103-107
+	hipLaunchKernelGGL(k_fp32_to_half, dim3(2048), dim3(256), 0, s, c->params_fp32.p, c->params_fp16.p, c->n_params);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int reset_optimizer_state(rnb_ctx* c) {
+	HIP_TRY(hipMemset(c->adam_m.p, 0, c->adam_m.bytes()));
+	HIP_TRY(hipMemset(c->adam_v.p, 0, c->adam_v.bytes()));
+	HIP_TRY(hipMemset(c->adam_steps.p, 0, c->adam_steps.bytes()));
+	HIP_TRY(hipMemset(c->grads.p, 0, c->grads.bytes()));
+	c->grads_clean = true;
+	c->optimizer_step_count = 0;
+	return RNB_OK;
+}
+
+// ---- K5 ----
+int update_bitfield(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3497-3517
+	const uint32_t n_blocks = 1024;
+	hipLaunchKernelGGL(k_mean_partial, dim3(n_blocks), dim3(256), 0, s, c->density_grid.p, c->mean_partial.p);
+	hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, c->mean_partial.p, n_blocks, c->density_mean.p);
+	const uint32_t n_bytes_per_mip = GRID_CELLS / 8;
+	const uint32_t n_el = n_bytes_per_mip * N_CASCADES;
+	hipLaunchKernelGGL(k_grid_to_bitfield, dim3((n_el + 127) / 128), dim3(128), 0, s, n_el, n_bytes_per_mip * (c->aabb.max_cascade + 1), c->density_grid.p, c->bitfield.p, c->density_mean.p);
+	for (uint32_t level = 1; level < N_CASCADES; ++level) {
+		hipLaunchKernelGGL(k_bitfield_max_pool, dim3((GRID_CELLS / 64 + 127) / 128), dim3(128), 0, s, GRID_CELLS / 64,
+		                   c->bitfield.p + (size_t)n_bytes_per_mip * (level - 1), c->bitfield.p + (size_t)n_bytes_per_mip * level);
+	}
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference) {
+	if (n == 0) return RNB_OK;
+	PointArgs a;
+	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias;
+	const uint32_t n_tiles = (n + TILE - 1) / TILE;
+	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
+	hipLaunchKernelGGL(k_point_query, dim3(grid), dim3(WG), LDS_POINT, s, c->meta(), c->net(inference), a);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+// ---- K1-K5 ----
+int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t n_nonuniform) { // testbed_nerf.cu:3424-3495
+	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
+	const uint32_t n_samples = n_uniform + n_nonuniform;
+	if (c->training_step == 0) {
+		c->density_grid_ema_step = 0;
+		HIP_TRY(hipMemsetAsync(c->density_grid.p, 0, sizeof(float) * n_elements, s));
+	}
+	HIP_TRY(hipMemsetAsync(c->density_grid_tmp.p, 0, sizeof(float) * n_elements, s));
+	if (n_uniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_uniform + 127) / 128), dim3(128), 0, s, n_uniform, c->density_grid_rng, c->density_grid_ema_step, c->aabb, c->density_grid.p,
+	                                  c->grid_sample_pos.p, c->grid_sample_idx.p, -0.01f);
+	c->density_grid_rng.advance();
+	if (n_nonuniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_nonuniform + 127) / 128), dim3(128), 0, s, n_nonuniform, c->density_grid_rng, c->density_grid_ema_step, c->aabb, c->density_grid.p,
+	                                     c->grid_sample_pos.p + (size_t)n_uniform * 3, c->grid_sample_idx.p + n_uniform, MIN_OPTICAL_THICKNESS);
+	c->density_grid_rng.advance();
+	HIP_TRY(hipGetLastError());
+	c->n_grid_samples = n_samples;
+	int rc = launch_point_query(c, s, c->grid_sample_pos.p, n_samples, nullptr, c->grid_sample_idx.p, c->density_grid_tmp.p, 1, false);
+	if (rc != RNB_OK) return rc;
+	hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
+	HIP_TRY(hipGetLastError());
+	++c->density_grid_ema_step;
+	return update_bitfield(c, s);
+}
+
+int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
+	const uint32_t n_cascades = c->aabb.max_cascade + 1;
+	if (c->training_step < 256) return update_density_grid(c, s, GRID_CELLS * n_cascades, 0);
+	return update_density_grid(c, s, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
+}
+
+int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference) {
+	if (n_max == 0) return RNB_OK;
+	FwdArgs a;
+	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias;
+	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
+	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
+	hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
+	MarchArgs a;
+	a.n_rays = n_rays;
+	a.n_rays_global = n_rays * c->cfg.world_size;
+	a.ray_offset = c->cfg.rank * n_rays;
+	a.n_rays_total = n_rays_total;
+	a.max_samples = max_samples;
+	a.n_images = c->n_views;
+	a.snap = c->cfg.snap_to_pixel_centers;
+	a.rng = c->rng;
+	a.A = c->aabb;
+	a.views = c->views.p;
+	a.bitfield = c->bitfield.p;
+	a.setup = c->ray_setup.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
+	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
+	return a;
+}
+
+int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
+	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
+	const uint32_t blocks = (n_rays + 127) / 128;
+	hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p);
+	hipLaunchKernelGGL(k_march_write, dim3(blocks), dim3(128), 0, s, a);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total) {
+	LossArgs a;
+	a.n_rays = n_rays; a.n_rays_global = n_rays * c->cfg.world_size; a.ray_offset = c->cfg.rank * n_rays; a.n_rays_total = n_rays_total;
+	a.n_images = c->n_views; a.B = c->cfg.target_batch_size;
+	a.rng = c->rng; a.A = c->aabb;
+	a.F.apply_L2 = c->cfg.apply_L2; a.F.apply_rgbplus = c->cfg.apply_rgbplus; a.F.apply_no_albedo = c->cfg.apply_no_albedo; a.F.apply_light_opti = c->cfg.apply_light_opti;
+	a.F.apply_relu = c->cfg.apply_relu; a.F.apply_bce = c->cfg.apply_bce; a.F.snap = c->cfg.snap_to_pixel_centers;
+	a.F.mask_loss_weight = c->cfg.mask_loss_weight; a.F.ek_loss_weight = c->cfg.ek_loss_weight;
+	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
+	a.views = c->views.p; a.counters = c->counters.p; a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p;
+	a.coords = c->coords.p; a.mlp_out = c->mlp_out.p; a.ray_loss = c->ray_loss.p; a.ncomp = c->ncomp.p; a.cbase = c->cbase.p;
+	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss.p; a.mask_loss = c->mask_loss.p;
+	HIP_TRY(hipMemsetAsync(c->loss.p, 0, sizeof(float) * n_rays, s));
+	HIP_TRY(hipMemsetAsync(c->ek_loss.p, 0, sizeof(float) * n_rays, s));
+	HIP_TRY(hipMemsetAsync(c->mask_loss.p, 0, sizeof(float) * n_rays, s));
+	const uint32_t blocks = (n_rays + 127) / 128;
+	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
+	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int forward_backward(rnb_ctx* c, hipStream_t s) {
+	const uint32_t B = c->cfg.target_batch_size;
+	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
+	c->grads_clean = false;
+	TrainArgs a;
+	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts;
+	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
+	// weight-gradient GEMMs
+	const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
+	const size_t slab = (size_t)nwg * WAVES_PER_WG;
+	float* p = c->dw_partial.p;
+	float* p_rgb2 = p;                      p += slab * 16 * 64;
+	float* p_rgb1 = p;                      p += slab * 64 * 64;
+	float* p_rgb0 = p;                      p += slab * 64 * 32;
+	float* p_sdf1 = p;                      p += slab * 16 * 64;
+	float* p_sdf0 = p;                      p += slab * 64 * 32;
+	float* p_sdf0b = p;                     p += slab * 64 * 32;
+	float* p_sdf1b = p;                     p += slab * 16 * 64;
+	const TrainScratch& T = c->ts;
+	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dr, T.h2, B, chunk, p_rgb2);
+	hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dh2, T.h1, B, chunk, p_rgb1);
+	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dh1, T.cin, B, chunk, p_rgb0);
+	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dso, T.z1, B, chunk, p_sdf1);
+	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz, T.sdfin, B, chunk, p_sdf0);
+	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz1, T.ddin, B, chunk, p_sdf0b);
+	hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, s, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
+	DwFinishArgs f;
+	f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
+	f.n_partials = (uint32_t)slab;
+	f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
+	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var;
+	const uint32_t n_fin = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS + 1;
+	hipLaunchKernelGGL(k_dw_finish, dim3((n_fin + 127) / 128), dim3(128), 0, s, f);
+	ScatterArgs sa;
+	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
+	hipLaunchKernelGGL(k_grid_scatter, dim3((B + 255) / 256, c->cfg.n_levels), dim3(256), 0, s, c->meta(), sa);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int optimizer_step(rnb_ctx* c, hipStream_t s) {
+	const rnb_config& cfg = c->cfg;
+	const uint32_t step0 = c->optimizer_step_count; // exponential_decay.h:61-72
+	if (step0 == 0) c->lr_factor = 1.0f;
+	if (step0 >= cfg.lr_decay_start && (step0 - cfg.lr_decay_start) % cfg.lr_decay_interval == 0 && step0 <= 10000000u) c->lr_factor *= cfg.lr_decay_base;
+	const uint32_t current_step = ++c->optimizer_step_count;
+	AdamArgs a;
+	a.n = c->n_params; a.n_matrix = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
+	a.w32 = c->params_fp32.p; a.w16 = c->params_fp16.p; a.ema = c->params_ema.p;
+	a.grads = c->grads.p; a.m = c->adam_m.p; a.v = c->adam_v.p; a.steps = c->adam_steps.p;
+	a.base_lr = cfg.learning_rate * c->lr_factor; a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.epsilon = cfg.epsilon; a.l2_reg = cfg.l2_reg;
+	a.ema_decay = cfg.ema_decay;
+	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1); // ema.h:116-117
+	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
+	hipLaunchKernelGGL(k_adam_ema, dim3(4096), dim3(256), 0, s, a);
+	HIP_TRY(hipGetLastError());
+	c->grads_clean = true;
+	return RNB_OK;
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+} // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* rnb_last_error(void) { return g_err.c_str(); }
+uint32_t rnb_abi_version(void) { return RNB_ABI_VERSION; }
+
+int rnb_default_config(rnb_config* cfg) {
+	if (!cfg) return fail(RNB_ERR_INVALID, "cfg is null");
+	std::memset(cfg, 0, sizeof(*cfg));
+	cfg->abi_version = RNB_ABI_VERSION;
+	cfg->n_levels = 14; cfg->log2_hashmap_size = 19; cfg->base_resolution = 16;
+	cfg->per_level_scale = std::exp(std::log(2048.0f * 1.0f / 16.0f) / (14 - 1)); // testbed.cu:2320-2323
+	cfg->valid_level_scale = 0.02f; cfg->base_valid_level_scale = 0.2f; cfg->base_training_step = 100;
+	cfg->sdf_bias = -0.1f;
+	cfg->target_batch_size = 1u << 18; cfg->initial_rays_per_batch = 1u << 12; cfg->max_rays_per_batch = 1u << 18;
+	cfg->aabb_scale = 1; cfg->seed = 1337;
+	cfg->mask_loss_weight = 1.0f; cfg->ek_loss_weight = 0.01f;
+	cfg->apply_L2 = 1; cfg->apply_rgbplus = 1; cfg->apply_no_albedo = 0; cfg->apply_light_opti = 0;
+	cfg->apply_supernormal = 0; cfg->apply_relu = 0; cfg->apply_bce = 0; cfg->snap_to_pixel_centers = 1;
+	cfg->learning_rate = 1e-3f; cfg->beta1 = 0.9f; cfg->beta2 = 0.99f; cfg->epsilon = 1e-15f; cfg->l2_reg = 1e-6f;
+	cfg->ema_decay = 0.95f; cfg->lr_decay_start = 20000; cfg->lr_decay_interval = 10000; cfg->lr_decay_base = 0.33f;
+	cfg->density_grid_decay = 0.95f;
+	cfg->world_size = 1; cfg->rank = 0;
+	return RNB_OK;
+}
+
+int rnb_destroy(rnb_ctx* c) {
+	if (!c) return RNB_OK;
+	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free();
+	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free();
+	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
+	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
+	c->loss.free(); c->ek_loss.free(); c->mask_loss.free(); c->mlp_out.free(); c->dloss_dout.free();
+	c->ray_setup.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
+	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
+	delete c;
+	return RNB_OK;
+}
+
+int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
+	if (!cfg || !out) return fail(RNB_ERR_INVALID, "null argument");
+	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
+	if (cfg->n_levels == 0 || cfg->n_levels > 14) return fail(RNB_ERR_INVALID, "n_levels must be in [1,14]");
+	if (cfg->base_resolution < 2) return fail(RNB_ERR_INVALID, "base_resolution must be >= 2");
+	if (cfg->aabb_scale == 0 || (cfg->aabb_scale & (cfg->aabb_scale - 1)) != 0 || cfg->aabb_scale > 128) return fail(RNB_ERR_INVALID, "aabb_scale must be a power of two <= 128");
+	if (cfg->target_batch_size == 0 || cfg->target_batch_size % 128 != 0) return fail(RNB_ERR_INVALID, "target_batch_size must be a positive multiple of 128");
+	if (cfg->max_rays_per_batch == 0 || cfg->max_rays_per_batch > (1u << 18)) return fail(RNB_ERR_INVALID, "max_rays_per_batch must be in [1, 2^18]");
+	if (cfg->world_size == 0 || cfg->rank >= cfg->world_size) return fail(RNB_ERR_INVALID, "bad rank/world_size");
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, dev));
+	if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) return fail(RNB_ERR_DEVICE, std::string("librnb_neus2_hip targets gfx950 (MI355X); found ") + prop.gcnArchName);
+	rnb_ctx* c = new rnb_ctx();
+	c->cfg = *cfg;
+	c->n_cus = prop.multiProcessorCount;
+	build_grid_tables(c);
+	c->off_sdf = 0;
+	c->off_rgb = RNB_N_SDF_MLP_PARAMS;
+	c->off_grid = c->off_rgb + RNB_N_RGB_MLP_PARAMS;
+	c->off_var = c->off_grid + c->n_grid_params;
+	c->n_params = c->off_var + RNB_N_VARIANCE_PARAMS;
+	c->aabb.mn = 0.5f - 0.5f * std::min(1u << (N_CASCADES - 1), cfg->aabb_scale); // testbed_nerf.cu:3198-3214
+	c->aabb.mx = 0.5f + 0.5f * std::min(1u << (N_CASCADES - 1), cfg->aabb_scale);
+	c->aabb.max_cascade = 0;
+	while ((1u << c->aabb.max_cascade) < cfg->aabb_scale) ++c->aabb.max_cascade;
+	c->aabb.cone_angle = cfg->aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
+	const uint32_t B = cfg->target_batch_size, maxr = cfg->max_rays_per_batch;
+	const uint32_t n_grid = GRID_CELLS * (c->aabb.max_cascade + 1);
+#define ALLOC(buf, count)                                                                                              \
+	do {                                                                                                               \
+		if ((buf).alloc(count) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
+	} while (0)
+	ALLOC(c->params_fp32, c->n_params); ALLOC(c->grads, c->n_params); ALLOC(c->adam_m, c->n_params); ALLOC(c->adam_v, c->n_params);
+	ALLOC(c->params_fp16, c->n_params); ALLOC(c->params_ema, c->n_params); ALLOC(c->adam_steps, c->n_params);
+	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 4);
+	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
+	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
+	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
+	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
+	ALLOC(c->loss, maxr); ALLOC(c->ek_loss, maxr); ALLOC(c->mask_loss, maxr);
+	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
+	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
+	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
+	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
+	ALLOC(c->g1, (size_t)B * 14); ALLOC(c->g2, (size_t)B * 14); ALLOC(c->dn, (size_t)B * 3);
+	{
+		half_t* q = c->fm.p;
+		TrainScratch& T = c->ts;
+		T.h2 = q; q += (size_t)B * 64; T.h1 = q; q += (size_t)B * 64; T.z1 = q; q += (size_t)B * 64; T.dz1 = q; q += (size_t)B * 64;
+		T.dh2 = q; q += (size_t)B * 64; T.dh1 = q; q += (size_t)B * 64; T.dz = q; q += (size_t)B * 64; T.front = q; q += (size_t)B * 64;
+		T.cin = q; q += (size_t)B * 32; T.sdfin = q; q += (size_t)B * 32; T.ddin = q; q += (size_t)B * 32;
+		T.dr = q; q += (size_t)B * 16; T.dso = q; q += (size_t)B * 16;
+		T.g1 = c->g1.p; T.g2 = c->g2.p; T.dn = c->dn.p;
+	}
+	c->fwd_grid = std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
+	ALLOC(c->var_partial, (size_t)c->fwd_grid * WAVES_PER_WG);
+	c->ts.var_partial = c->var_partial.p;
+	{ // split-K geometry of the weight-gradient GEMMs: chunk = B / nwg, a multiple of 128 samples
+		const uint32_t units = B / 128;
+		uint32_t nwg = 1;
+		for (uint32_t d = 1; d <= std::min<uint32_t>(units, 256u); ++d) if (units % d == 0) nwg = d;
+		c->dw_nwg = nwg;
+		c->dw_chunk = B / nwg;
+		const size_t per_wave = (size_t)16 * 64 * 3 + 64 * 64 + (size_t)64 * 32 * 3;
+		ALLOC(c->dw_partial, (size_t)nwg * WAVES_PER_WG * per_wave);
+	}
+#undef ALLOC
+	HIP_TRY(hipMemset(c->params_fp32.p, 0, c->params_fp32.bytes()));
+	HIP_TRY(hipMemset(c->params_fp16.p, 0, c->params_fp16.bytes()));
+	HIP_TRY(hipMemset(c->params_ema.p, 0, c->params_ema.bytes()));
+	HIP_TRY(hipMemset(c->density_grid.p, 0, c->density_grid.bytes()));
+	HIP_TRY(hipMemset(c->density_grid_tmp.p, 0, c->density_grid_tmp.bytes()));
+	HIP_TRY(hipMemset(c->bitfield.p, 0, c->bitfield.bytes()));
+	HIP_TRY(hipMemset(c->counters.p, 0, c->counters.bytes()));
+	HIP_TRY(hipMemset(c->density_mean.p, 0, 4));
+	HIP_TRY(hipMemset(c->coords.p, 0, c->coords.bytes()));
+	HIP_TRY(hipMemset(c->coords_compacted.p, 0, c->coords_compacted.bytes()));
+	HIP_TRY(hipMemset(c->dloss_dout.p, 0, c->dloss_dout.bytes()));
+	HIP_TRY(hipMemset(c->mlp_out.p, 0, c->mlp_out.bytes()));
+	int rc = reset_optimizer_state(c);
+	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
+	// Testbed::reset_network (testbed.cu:2223-2237)
+	c->rng = Pcg32{cfg->seed};
+	c->density_grid_rng = Pcg32{c->rng.next_uint()};
+	(void)c->rng.next_uint(); // tv_loss_rng
+	c->rays_per_batch = std::min(cfg->initial_rays_per_batch, cfg->max_rays_per_batch);
+	c->training_step = 0;
+	c->valid_level = compute_valid_level(c->cfg, 0);
+	build_light_dirs(c);
+	*out = c;
+	return RNB_OK;
+}
+
+uint64_t rnb_n_params(const rnb_ctx* c) { return c ? c->n_params : 0; }
+
+int rnb_param_layout(const rnb_ctx* c, uint64_t offsets[5]) {
+	if (!c || !offsets) return fail(RNB_ERR_INVALID, "null argument");
+	offsets[0] = c->off_sdf; offsets[1] = c->off_rgb; offsets[2] = c->off_grid; offsets[3] = c->off_var; offsets[4] = c->n_params;
+	return RNB_OK;
+}
+
+int rnb_grid_tables(const rnb_ctx* c, uint32_t* offsets, uint32_t* resolution, float* scale) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	for (uint32_t i = 0; i <= c->cfg.n_levels; ++i) if (offsets) offsets[i] = c->grid.offsets[i];
+	for (uint32_t i = 0; i < c->cfg.n_levels; ++i) { if (resolution) resolution[i] = c->grid.resolution[i]; if (scale) scale[i] = c->grid.scale[i]; }
+	return RNB_OK;
+}
+
+int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
+	if (!c || !sdf_w) return fail(RNB_ERR_INVALID, "null argument");
+	std::seed_seq seq{c->cfg.seed}; // Trainer ctor, trainer.h:54-61
+	std::vector<uint32_t> seeds(2);
+	seq.generate(std::begin(seeds), std::end(seeds));
+	Pcg32 rnd{seeds.front()};
+	std::vector<float> mlp(RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS, 0.f);
+	auto xavier = [&](float* dst, int rows, int cols) { // gpu_matrix.h:292-306
+		float scale = 1.f;
+		scale *= std::sqrt(6.0f / (float)(cols + rows));
+		for (int i = 0; i < rows * cols; ++i) dst[i] = (float)(rnd.next_float() * 2.0f * scale - scale);
+	};
+	xavier(mlp.data(), 64, 32);            // density network: draws consumed, then overwritten (nerf_network.h:629-643)
+	xavier(mlp.data() + 64 * 32, 16, 64);
+	std::memcpy(mlp.data(), sdf_w, sizeof(float) * RNB_N_SDF_MLP_PARAMS);
+	float* rgb = mlp.data() + RNB_N_SDF_MLP_PARAMS;
+	xavier(rgb, 64, 48);
+	xavier(rgb + 64 * 48, 64, 64);
+	xavier(rgb + 64 * 48 + 64 * 64, 16, 64);
+	HIP_TRY(hipMemset(c->params_fp32.p, 0, c->params_fp32.bytes()));
+	HIP_TRY(hipMemcpy(c->params_fp32.p + c->off_sdf, mlp.data(), mlp.size() * sizeof(float), hipMemcpyHostToDevice));
+	{ // hash grid U(-1e-4, 1e-4) on the device (grid.h:1379-1384; random.h:67-93)
+		const uint64_t n = c->n_grid_params;
+		const uint64_t n_thr = (n + 3) / 4;
+		const uint64_t n_threads_total = ((n_thr + 127) / 128) * 128;
+		hipLaunchKernelGGL(k_random_uniform, dim3((uint32_t)(n_threads_total / 128)), dim3(128), 0, 0, rnd, n, n_threads_total, -1e-4f, 1e-4f, c->params_fp32.p + c->off_grid);
+		HIP_TRY(hipGetLastError());
+		rnd.advance((int64_t)n);
+	}
+	float var[RNB_N_VARIANCE_PARAMS];
+	for (int q = 0; q < RNB_N_VARIANCE_PARAMS; ++q) { // nerf_network.h:691-692: pcg32{1337}, U(0.3, 0.3)
+		Pcg32 vr{1337};
+		vr.advance(q);
+		const float val = vr.next_float();
+		var[q] = val * (0.300f - 0.300f) + 0.300f;
+	}
+	HIP_TRY(hipMemcpy(c->params_fp32.p + c->off_var, var, sizeof(var), hipMemcpyHostToDevice));
+	c->trainer_rng = rnd;
+	int rc = derive_half_params(c, 0);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipMemset(c->params_ema.p, 0, c->params_ema.bytes()));
+	rc = reset_optimizer_state(c);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	return RNB_OK;
+}
+
+int rnb_set_params(rnb_ctx* c, const float* params) {
+	if (!c || !params) return fail(RNB_ERR_INVALID, "null argument");
+	HIP_TRY(hipMemcpy(c->params_fp32.p, params, c->params_fp32.bytes(), hipMemcpyHostToDevice));
+	int rc = derive_half_params(c, 0);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipMemcpy(c->params_ema.p, c->params_fp16.p, c->params_fp16.bytes(), hipMemcpyDeviceToDevice));
+	rc = reset_optimizer_state(c);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	return RNB_OK;
+}
+
+int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
+	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
+#define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
+	switch (id) {
+		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
+		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16);
+		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
+		case RNB_BUF_GRADS_FP32: BUF(c->grads);
+		case RNB_BUF_ADAM_M: BUF(c->adam_m);
+		case RNB_BUF_ADAM_V: BUF(c->adam_v);
+		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
+		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
+		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield);
+		case RNB_BUF_DENSITY_MEAN: BUF(c->density_mean);
+		case RNB_BUF_RAY_INDICES: BUF(c->ray_indices);
+		case RNB_BUF_RAYS: BUF(c->rays);
+		case RNB_BUF_NUMSTEPS: BUF(c->numsteps);
+		case RNB_BUF_COORDS: BUF(c->coords);
+		case RNB_BUF_MLP_OUT: BUF(c->mlp_out);
+		case RNB_BUF_DLOSS_DOUT: BUF(c->dloss_dout);
+		case RNB_BUF_COORDS_COMPACTED: BUF(c->coords_compacted);
+		case RNB_BUF_LOSS: BUF(c->loss);
+		case RNB_BUF_EK_LOSS: BUF(c->ek_loss);
+		case RNB_BUF_MASK_LOSS: BUF(c->mask_loss);
+		case RNB_BUF_COUNTERS: BUF(c->counters);
+		case RNB_BUF_DENSITY_GRID_TMP: BUF(c->density_grid_tmp);
+		case RNB_BUF_GRID_SAMPLE_POS: *ptr = c->grid_sample_pos.p; *n_bytes = (uint64_t)c->n_grid_samples * 12; return RNB_OK;
+		case RNB_BUF_GRID_SAMPLE_IDX: *ptr = c->grid_sample_idx.p; *n_bytes = (uint64_t)c->n_grid_samples * 4; return RNB_OK;
+		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
+	}
+#undef BUF
+}
+
+int rnb_memcpy(rnb_ctx*, void* dst, const void* src, uint64_t n_bytes, int kind) {
+	if (!dst || !src) return fail(RNB_ERR_INVALID, "null argument");
+	hipMemcpyKind k = kind == RNB_H2D ? hipMemcpyHostToDevice : kind == RNB_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(dst, src, n_bytes, k));
+	return RNB_OK;
+}
+
+int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const uint16_t* const* normals, const uint16_t* const* albedos) {
+	if (!c || !views || !normals || !albedos || n_views == 0) return fail(RNB_ERR_INVALID, "bad dataset");
+	size_t total = 0;
+	for (uint32_t v = 0; v < n_views; ++v) {
+		if (views[v].width == 0 || views[v].height == 0 || !normals[v] || !albedos[v]) return fail(RNB_ERR_INVALID, "empty view");
+		total += (size_t)views[v].width * views[v].height * 4 * 2;
+	}
+	c->pixels.free(); c->views.free();
+	if (c->pixels.alloc(total) != hipSuccess) return fail(RNB_ERR_NOMEM, "hipMalloc failed for the dataset");
+	if (c->views.alloc(n_views) != hipSuccess) return fail(RNB_ERR_NOMEM, "hipMalloc failed for view metadata");
+	std::vector<ViewDev> vd(n_views);
+	size_t off = 0;
+	for (uint32_t v = 0; v < n_views; ++v) {
+		const size_t n = (size_t)views[v].width * views[v].height * 4;
+		vd[v].width = views[v].width; vd[v].height = views[v].height;
+		for (int k = 0; k < 2; ++k) { vd[v].focal[k] = views[v].focal_length[k]; vd[v].principal[k] = views[v].principal_point[k]; }
+		for (int k = 0; k < 12; ++k) vd[v].xform[k] = views[v].xform[k];
+		vd[v].normal = c->pixels.p + off;
+		HIP_TRY(hipMemcpy(c->pixels.p + off, normals[v], n * 2, hipMemcpyHostToDevice));
+		off += n;
+		vd[v].albedo = c->pixels.p + off;
+		HIP_TRY(hipMemcpy(c->pixels.p + off, albedos[v], n * 2, hipMemcpyHostToDevice));
+		off += n;
+	}
+	HIP_TRY(hipMemcpy(c->views.p, vd.data(), sizeof(ViewDev) * n_views, hipMemcpyHostToDevice));
+	c->n_views = n_views;
+	return RNB_OK;
+}
+
+int rnb_set_training_step(rnb_ctx* c, uint32_t step) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->training_step = step;
+	c->valid_level = compute_valid_level(c->cfg, (int)step);
+	return RNB_OK;
+}
+uint32_t rnb_valid_level(const rnb_ctx* c) { return c ? c->valid_level : 0; }
+
+int rnb_update_density_grid(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return training_prep(c, as_stream(stream));
+}
+int rnb_update_density_bitfield(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return update_bitfield(c, as_stream(stream));
+}
+
+int rnb_sdf(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) {
+	if (!c || (!xyz && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
+	return launch_point_query(c, as_stream(stream), xyz, n, reinterpret_cast<half_t*>(out), nullptr, nullptr, 0, inference != 0);
+}
+int rnb_density(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) {
+	if (!c || (!xyz && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
+	return launch_point_query(c, as_stream(stream), xyz, n, reinterpret_cast<half_t*>(out), nullptr, nullptr, 1, inference != 0);
+}
+int rnb_forward_infer(rnb_ctx* c, void* stream, const float* coords, uint32_t n, uint16_t* out, int inference) {
+	if (!c || (!coords && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
+	return launch_forward(c, as_stream(stream), coords, nullptr, n, reinterpret_cast<half_t*>(out), inference != 0);
+}
+
+int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
+	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
+	if (max_samples > c->cfg.target_batch_size * 16) return fail(RNB_ERR_INVALID, "max_samples exceeds 16*target_batch_size");
+	return generate_training_samples(c, as_stream(stream), n_rays, n_rays_total, max_samples);
+}
+
+int rnb_compute_loss(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
+	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
+	return compute_loss(c, as_stream(stream), n_rays, n_rays_total);
+}
+
+int rnb_forward_backward(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return forward_backward(c, as_stream(stream));
+}
+
+int rnb_optimizer_step(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return optimizer_step(c, as_stream(stream));
+}
+
+int rnb_train_step_begin(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
+	hipStream_t s = as_stream(stream);
+	c->valid_level = compute_valid_level(c->cfg, (int)c->training_step); // testbed.cu:2792
+	c->grid_updated = false;
+	c->prep_ms = 0.f;
+	int rc;
+	const uint32_t n_prep_to_skip = std::min(std::max(c->training_step / 16u, 1u), 16u); // testbed.cu:2805
+	if (c->training_step % n_prep_to_skip == 0) {
+		auto t0 = std::chrono::steady_clock::now();
+		rc = training_prep(c, s);
+		if (rc != RNB_OK) return rc;
+		HIP_TRY(hipStreamSynchronize(s)); // testbed.cu:2820
+		c->grid_updated = true;
+		c->prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_prep_to_skip;
+	}
+	c->step_start = std::chrono::steady_clock::now();
+	const uint32_t B = c->cfg.target_batch_size;
+	const uint32_t max_samples = B * 16;
+	uint32_t max_inference;
+	if (c->measured_batch_size_before_compaction == 0) { // testbed_nerf.cu:3891-3896
+		c->measured_batch_size_before_compaction = max_inference = max_samples;
+	} else {
+		max_inference = next_multiple_u32(std::min(c->measured_batch_size_before_compaction, max_samples), 128u);
+	}
+	if (c->training_step == 0) c->n_rays_total = 0; // testbed_nerf.cu:3906-3908
+	const uint32_t n_rays_total = c->n_rays_total;
+	const uint32_t n_rays = c->rays_per_batch;
+	c->n_rays_total += n_rays * c->cfg.world_size;
+	c->cur_n_rays = n_rays;
+	c->cur_n_rays_total = n_rays_total;
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
+	rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
+	if (rc != RNB_OK) return rc;
+	rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
+	if (rc != RNB_OK) return rc;
+	rc = compute_loss(c, s, n_rays, n_rays_total);
+	if (rc != RNB_OK) return rc;
+	rc = forward_backward(c, s);
+	if (rc != RNB_OK) return rc;
+	c->rng.advance(); // testbed_nerf.cu:4118
+	return RNB_OK;
+}
+
+int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	hipStream_t s = as_stream(stream);
+	int rc = optimizer_step(c, s);
+	if (rc != RNB_OK) return rc;
+	++c->training_step;
+	const uint32_t B = c->cfg.target_batch_size;
+	const uint32_t n_rays = c->cur_n_rays;
+	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
+	HIP_TRY(hipGetLastError());
+	uint32_t counters[4];
+	double sums[4];
+	HIP_TRY(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(sums, c->loss_sums.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s)); // testbed.cu:2866
+	// Counters::update_after_training (testbed_nerf.cu:3532-3558)
+	c->measured_batch_size = 0;
+	c->measured_batch_size_before_compaction = 0;
+	float loss_scalar = 0.f, ek_scalar = 0.f, mask_scalar = 0.f;
+	uint32_t next_rays = c->rays_per_batch;
+	rc = RNB_OK;
+	if (counters[0] == 0 || counters[1] == 0) {
+		rc = RNB_ERR_NO_SAMPLES;
+		g_err = "Nerf training generated 0 samples.";
+	} else {
+		c->measured_batch_size_before_compaction = counters[0];
+		c->measured_batch_size = counters[1];
+		loss_scalar = (float)sums[0] * (float)c->measured_batch_size / (float)B;
+		ek_scalar = (float)sums[1] * (float)c->measured_batch_size / (float)B;
+		mask_scalar = (float)sums[2] * (float)c->measured_batch_size / (float)B;
+		next_rays = (uint32_t)((float)c->rays_per_batch * (float)B / (float)c->measured_batch_size);
+		next_rays = std::min(next_multiple_u32(next_rays, 128u), c->cfg.max_rays_per_batch);
+	}
+	if (stats) {
+		stats->training_step = c->training_step;
+		stats->rays_per_batch = n_rays;
+		stats->next_rays_per_batch = next_rays;
+		stats->measured_batch_size = c->measured_batch_size;
+		stats->measured_batch_size_before_compaction = c->measured_batch_size_before_compaction;
+		stats->n_rays_kept = counters[2];
+		stats->density_grid_updated = c->grid_updated ? 1 : 0;
+		stats->loss = loss_scalar; stats->ek_loss = ek_scalar; stats->mask_loss = mask_scalar;
+		stats->prep_ms = c->prep_ms;
+		stats->step_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->step_start).count();
+	}
+	c->rays_per_batch = next_rays;
+	return rc;
+}
+
+int rnb_train_step(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+	int rc = rnb_train_step_begin(c, stream);
+	if (rc != RNB_OK) return rc;
+	return rnb_train_step_end(c, stream, stats);
+}
+
+uint32_t rnb_training_step(const rnb_ctx* c) { return c ? c->training_step : 0; }
+uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0; }
+
+int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (rays_per_batch == 0 || rays_per_batch > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "rays_per_batch out of range");
+	c->training_step = training_step;
+	c->valid_level = compute_valid_level(c->cfg, (int)training_step);
+	c->rays_per_batch = rays_per_batch;
+	c->measured_batch_size_before_compaction = measured_before;
+	c->n_rays_total = n_rays_total;
+	return RNB_OK;
+}
+
+} // extern "C"

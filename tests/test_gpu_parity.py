@@ -1,0 +1,270 @@
+"""GPU parity tests: every stage of the hot path, HIP (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Bit-exact for integer / index / RNG work (parameter init streams, occupancy sample indices, bitfield, ray marching);
+floating-point stages within the tolerances written next to each assert (north star: fp32 losses within 1e-4 relative).
+Later stages are always fed the ORACLE's outputs of the earlier stage, so each test isolates one kernel group.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(target_batch_size=1 << 13, max_rays_per_batch=1 << 13, initial_rays_per_batch=512, apply_no_albedo=1)
+
+
+def _pair(**over):
+    import rnb_neus2_amd as rnb
+    from rnb_neus2_amd import synthetic
+    from tests import oracle_lib
+    kw = dict(KW)
+    kw.update(over)
+    views, normals, albedos = synthetic.make_scene(4, 96, 168.0)
+    gpu = rnb.Context(**kw)
+    cpu = oracle_lib.context(**kw)
+    for c in (gpu, cpu):
+        c.init_params()
+        c.set_dataset(views, normals, albedos)
+    return gpu, cpu
+
+
+def _randomize(gpu, cpu, seed=0):
+    """Geometric init + noise on every weight and O(0.05) hash-grid entries, so that every path carries signal
+    (at the reference's initialisation the SDF-MLP columns fed by the hash features are exactly zero)."""
+    rng = np.random.default_rng(seed)
+    p = cpu.get("PARAMS_FP32").copy()
+    lay = cpu.param_layout()
+    p[lay["sdf"]:lay["rgb"]] += rng.standard_normal(lay["rgb"] - lay["sdf"]).astype(np.float32) * 0.03
+    p[lay["rgb"]:lay["grid"]] += rng.standard_normal(lay["grid"] - lay["rgb"]).astype(np.float32) * 0.03
+    p[lay["grid"]:lay["variance"]] = (rng.random(lay["variance"] - lay["grid"], dtype=np.float32) - 0.5) * 0.1
+    for c in (gpu, cpu):
+        c.set_params(p)
+
+
+def _half_close(a, b, rel=2e-3, abs_=2e-4, frac=0.999, name=""):
+    """Two half arrays agree up to a couple of half ulps on (almost) every element."""
+    a = a.astype(np.float32)
+    b = b.astype(np.float32)
+    ok = np.abs(a - b) <= abs_ + rel * np.abs(b)
+    assert ok.mean() >= frac, "%s: only %.5f of elements within tolerance; worst %g vs %g" % (
+        name, ok.mean(), a.ravel()[np.argmax(np.abs(a - b))], b.ravel()[np.argmax(np.abs(a - b))])
+
+
+@pytest.fixture(scope="module")
+def pair():
+    gpu, cpu = _pair()
+    yield gpu, cpu
+    gpu.close()
+    cpu.close()
+
+
+@pytest.fixture(scope="module")
+def rpair():
+    gpu, cpu = _pair(apply_no_albedo=0)
+    _randomize(gpu, cpu)
+    yield gpu, cpu
+    gpu.close()
+    cpu.close()
+
+
+def test_init_params_bit_exact(pair):
+    gpu, cpu = pair
+    for name in ("PARAMS_FP32", "PARAMS_FP16", "PARAMS_EMA"):
+        a, b = gpu.get(name), cpu.get(name)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    assert np.array_equal(gpu.grid_tables()[0], cpu.grid_tables()[0])
+
+
+def test_density_grid_update(pair):
+    gpu, cpu = pair
+    for c in pair:
+        c.set_training_step(0)
+        c.update_density_grid()
+    # K1: sample positions and cell indices are integer/RNG work: bit exact
+    assert np.array_equal(gpu.get("GRID_SAMPLE_IDX"), cpu.get("GRID_SAMPLE_IDX"))
+    assert np.array_equal(gpu.get("GRID_SAMPLE_POS").view(np.uint32), cpu.get("GRID_SAMPLE_POS").view(np.uint32))
+    # K2-K4: densities go through the MLP (fp32-accumulate MFMA vs sequential fp32): a few half ulps
+    _half_close(gpu.get("DENSITY_GRID"), cpu.get("DENSITY_GRID"), rel=4e-3, abs_=1e-3, name="density grid")
+    # K5 from a SHARED fp32 grid: mean and bitfield bit exact
+    gpu.put("DENSITY_GRID", cpu.get("DENSITY_GRID"))
+    gpu.update_density_bitfield()
+    assert gpu.get("DENSITY_MEAN")[0] == cpu.get("DENSITY_MEAN")[0]
+    assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
+
+
+def test_point_queries(rpair):
+    gpu, cpu = pair = rpair
+    rng = np.random.default_rng(0)
+    xyz = rng.random((1000, 3), dtype=np.float32)
+    for c in pair:
+        c.set_training_step(700)  # all 14 levels live
+    _half_close(gpu.sdf(xyz, inference=False), cpu.sdf(xyz, inference=False), name="sdf")
+    _half_close(gpu.density(xyz), cpu.density(xyz), rel=4e-3, abs_=1e-3, name="density")
+    # ragged / tiny / empty batches
+    for n in (0, 1, 63, 65):
+        a, b = gpu.sdf(xyz[:n], inference=False), cpu.sdf(xyz[:n], inference=False)
+        assert a.shape == b.shape == (n,)
+        if n:
+            _half_close(a, b, frac=1.0 if n < 10 else 0.98, name="sdf n=%d" % n)
+
+
+@pytest.mark.parametrize("step", [0, 50, 700])
+def test_forward_infer(rpair, step):
+    gpu, cpu = pair = rpair
+    rng = np.random.default_rng(step)
+    n = 3000 + step % 7
+    coords = rng.random((n, 7), dtype=np.float32)
+    for c in pair:
+        c.set_training_step(step)
+    assert gpu.valid_level == cpu.valid_level
+    a, b = gpu.forward_infer(coords), cpu.forward_infer(coords)
+    # channels 3 (sdf), 4-6 (grad sdf), 7 (variance), 8-10 (dir) feed the loss; 0-2, 11-15 are raw rgb-MLP outputs
+    assert np.array_equal(a[:, 7].view(np.uint16), b[:, 7].view(np.uint16))
+    assert np.array_equal(a[:, 8:11].view(np.uint16), b[:, 8:11].view(np.uint16))
+    _half_close(a[:, 3], b[:, 3], name="sdf channel")
+    _half_close(a[:, 4:7], b[:, 4:7], rel=4e-3, abs_=2e-3, name="gradient channels")
+    _half_close(a[:, [0, 1, 2, 11, 12, 13, 14, 15]], b[:, [0, 1, 2, 11, 12, 13, 14, 15]], rel=4e-3, abs_=2e-3, frac=0.995, name="rgb channels")
+
+
+def _sync_occupancy(gpu, cpu, step=0):
+    for c in (gpu, cpu):
+        c.set_training_step(step)
+    cpu.update_density_grid()
+    gpu.put("DENSITY_GRID", cpu.get("DENSITY_GRID"))
+    gpu.update_density_bitfield()
+    assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
+
+
+def test_generate_training_samples_bit_exact(pair):
+    gpu, cpu = pair
+    _sync_occupancy(gpu, cpu)
+    for n_rays, n_rays_total, max_samples in ((512, 0, 8192 * 16), (1000, 4096, 8192 * 16), (2048, 77, 20000)):
+        for c in pair:
+            c.generate_training_samples(n_rays, n_rays_total, max_samples)
+        cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+        assert np.array_equal(cg[[0, 2, 3]], cc[[0, 2, 3]]), (cg, cc)
+        kept, written = int(cc[2]), int(cc[3])
+        assert kept > 0 and written > 0
+        assert np.array_equal(gpu.get("RAY_INDICES", kept), cpu.get("RAY_INDICES", kept))
+        assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+        assert np.array_equal(gpu.get("RAYS", kept * 6).view(np.uint32), cpu.get("RAYS", kept * 6).view(np.uint32))
+        assert np.array_equal(gpu.get("COORDS", written * 7).view(np.uint32), cpu.get("COORDS", written * 7).view(np.uint32))
+    # the overflow case dropped rays (max_samples = 20000 < total)
+    assert cc[0] > 20000 and cc[3] <= 20000
+
+
+def _stage_samples(gpu, cpu, n_rays=512, step=0):
+    _sync_occupancy(gpu, cpu, step)
+    for c in (gpu, cpu):
+        c.generate_training_samples(n_rays, 0)
+    written = int(cpu.get("COUNTERS")[3])
+    cpu.forward_infer_staged(written)
+    gpu.put("MLP_OUT", cpu.get("MLP_OUT", written * 16))
+    return written
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(apply_no_albedo=0), dict(apply_no_albedo=0, apply_light_opti=1, apply_L2=0), dict(apply_bce=1, apply_relu=1, mask_loss_weight=0.3)])
+def test_compute_loss(flags):
+    gpu, cpu = _pair(**flags)
+    try:
+        n_rays = 512
+        _stage_samples(gpu, cpu, n_rays)
+        for c in (gpu, cpu):
+            c.compute_loss(n_rays, 0)
+        cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+        assert np.array_equal(cg, cc)  # compaction decisions identical (T < 1e-4 cut, overflow clamp)
+        kept = int(cc[2])
+        B = KW["target_batch_size"]
+        assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+        assert np.array_equal(gpu.get("COORDS_COMPACTED").view(np.uint32), cpu.get("COORDS_COMPACTED").view(np.uint32))
+        for name in ("LOSS", "EK_LOSS", "MASK_LOSS"):
+            a, b = gpu.get(name, n_rays).astype(np.float64), cpu.get(name, n_rays).astype(np.float64)
+            # north star: fp32 losses within 1e-4 relative (sum over the batch) — per ray a little looser for expf ulps
+            assert abs(a.sum() - b.sum()) <= 1e-4 * abs(b.sum()) + 1e-12, (name, a.sum(), b.sum())
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-9, err_msg=name)
+        a = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        b = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        used = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+        _half_close(a[:, used], b[:, used], rel=3e-3, abs_=1e-6, frac=0.998, name="dL/doutput")
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_forward_backward_gradients(rpair):
+    gpu, cpu = pair = rpair
+    n_rays = 512
+    _stage_samples(gpu, cpu, n_rays, step=700)
+    cpu.compute_loss(n_rays, 0)
+    gpu.put("DLOSS_DOUT", cpu.get("DLOSS_DOUT"))
+    gpu.put("COORDS_COMPACTED", cpu.get("COORDS_COMPACTED"))
+    for c in pair:
+        c.forward_backward()
+    g, r = gpu.get("GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
+    lay = cpu.param_layout()
+    # dense MLP weights (half-rounded like the reference's gradient matrices): relative to the matrix scale
+    for lo, hi, name in ((lay["sdf"], lay["rgb"], "sdf mlp"), (lay["rgb"], lay["grid"], "rgb mlp")):
+        scale = np.abs(r[lo:hi]).max() + 1e-30
+        err = np.abs(g[lo:hi] - r[lo:hi]).max() / scale
+        assert err < 5e-3, (name, err)
+    # hash grid: fp32 accumulators of half-rounded addends; identical sparsity pattern and values to fp32 summation noise
+    gg, rg = g[lay["grid"]:lay["variance"]], r[lay["grid"]:lay["variance"]]
+    assert np.array_equal(gg != 0, rg != 0) or (np.mean((gg != 0) != (rg != 0)) < 1e-4)
+    scale = np.abs(rg).max() + 1e-30
+    assert np.abs(gg - rg).max() / scale < 2e-3
+    nz = rg != 0
+    rel = np.abs(gg[nz] - rg[nz]) / (np.abs(rg[nz]) + 1e-3 * scale)
+    assert np.quantile(rel, 0.999) < 2e-2
+    # variance
+    assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2e-3 * abs(r[lay["variance"]]) + 1e-6
+
+
+def test_optimizer_step(pair):
+    gpu, cpu = pair
+    rng = np.random.default_rng(3)
+    n = cpu.n_params
+    grads = np.zeros(n, dtype=np.float32)
+    idx = rng.choice(n, size=200000, replace=False)
+    grads[idx] = rng.standard_normal(idx.size).astype(np.float32) * 0.05
+    grads[:11264] = rng.standard_normal(11264).astype(np.float32) * 0.01
+    for _ in range(3):
+        for c in pair:
+            c.put("GRADS_FP32", grads)
+            c.optimizer_step()
+    for name, tol in (("PARAMS_FP32", 2e-6), ("ADAM_M", 1e-6), ("ADAM_V", 1e-6)):
+        a, b = gpu.get(name), cpu.get(name)
+        np.testing.assert_allclose(a, b, rtol=tol, atol=1e-9, err_msg=name)
+    assert np.array_equal(gpu.get("ADAM_STEPS"), cpu.get("ADAM_STEPS"))
+    _half_close(gpu.get("PARAMS_EMA"), cpu.get("PARAMS_EMA"), rel=1.1e-3, abs_=1e-7, frac=0.9999, name="ema")
+    # the step consumed the accumulators
+    assert not gpu.get("GRADS_FP32").any()
+
+
+def test_train_steps_track_oracle():
+    gpu, cpu = _pair()
+    try:
+        for i in range(6):
+            sg, sc = gpu.train_step(), cpu.train_step()
+            assert sg.training_step == sc.training_step == i + 1
+            assert sg.rays_per_batch == sc.rays_per_batch
+            # the occupancy grids agree to half ulps, so sample counts may differ by a few cells' worth
+            assert abs(int(sg.measured_batch_size_before_compaction) - int(sc.measured_batch_size_before_compaction)) <= 0.02 * sc.measured_batch_size_before_compaction
+            for k in ("loss", "ek_loss", "mask_loss"):
+                a, b = getattr(sg, k), getattr(sc, k)
+                assert abs(a - b) <= 0.05 * abs(b) + 1e-6, (i, k, a, b)
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_error_behaviour():
+    import rnb_neus2_amd as rnb
+    with pytest.raises(rnb.RnbError):
+        rnb.Context(target_batch_size=100)  # not a multiple of 128
+    c = rnb.Context(**KW)
+    try:
+        with pytest.raises(rnb.RnbError):
+            c.train_step()  # no dataset
+        with pytest.raises(rnb.RnbError):
+            c.generate_training_samples(0)
+    finally:
+        c.close()
