@@ -220,8 +220,22 @@ int rnb_optimizer_step(rnb_ctx* ctx, void* stream);
 int rnb_train_step(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
 /* Everything up to and including the backward pass; leaves gradients in GRADS_FP32. */
 int rnb_train_step_begin(rnb_ctx* ctx, void* stream);
-/* Optimizer step, ++training_step, Counters::update_after_training (testbed_nerf.cu:3532-3558). Syncs. */
+/* Optimizer step, ++training_step, Counters::update_after_training (testbed_nerf.cu:3532-3558). Syncs.
+ * == apply; local; finish(local values). Data-parallel hosts call the three pieces and sum the local counters /
+ * loss sums over the ranks before finish, so every rank draws the same rays_per_batch for the next step. */
 int rnb_train_step_end(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
+int rnb_train_step_apply(rnb_ctx* ctx, void* stream);
+/* counters = {numsteps_counter, numsteps_counter_compacted, ray_counter, samples_written}; loss_sums = sums of the LOSS,
+ * EK_LOSS, MASK_LOSS arrays. Syncs the stream. */
+int rnb_train_step_local(rnb_ctx* ctx, void* stream, uint64_t counters[4], double loss_sums[3]);
+int rnb_train_step_finish(rnb_ctx* ctx, const uint64_t counters[4], const double loss_sums[3], rnb_step_stats* stats);
+/* Per-kernel timing with HIP events on the step's stream (the reference only keeps the two wall-clock EMAs
+ * m_training_prep_ms / m_training_ms, testbed.h:863-867). enable(1) also clears the accumulators. Entry idx of
+ * [0, rnb_profile_count): kernel-group name, accumulated milliseconds, timed launches, units processed
+ * (samples / rays / parameters). */
+int rnb_profile_enable(rnb_ctx* ctx, int on);
+int rnb_profile_count(const rnb_ctx* ctx);
+int rnb_profile_get(const rnb_ctx* ctx, int idx, const char** name, double* total_ms, uint64_t* launches, double* units);
 uint32_t rnb_training_step(const rnb_ctx* ctx);
 uint32_t rnb_rays_per_batch(const rnb_ctx* ctx);
 /* Re-seat the controller state (snapshot resume, testbed.cu:3333-3390). */

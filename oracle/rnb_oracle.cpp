@@ -55,7 +55,13 @@
 #define rnb_train_step orc_train_step
 #define rnb_train_step_begin orc_train_step_begin
 #define rnb_train_step_end orc_train_step_end
+#define rnb_train_step_apply orc_train_step_apply
+#define rnb_train_step_local orc_train_step_local
+#define rnb_train_step_finish orc_train_step_finish
 #define rnb_training_step orc_training_step
+#define rnb_profile_enable orc_profile_enable
+#define rnb_profile_count orc_profile_count
+#define rnb_profile_get orc_profile_get
 #define rnb_rays_per_batch orc_rays_per_batch
 #define rnb_set_controller orc_set_controller
 #define rnb_ctx orc_ctx_s
@@ -169,7 +175,7 @@ struct orc_ctx_s {
 	uint32_t optimizer_step_count = 0;
 	float lr_factor = 1.f;
 	// begin/end hand-off
-	uint32_t cur_n_rays = 0;
+	uint32_t cur_n_rays = 0, local_measured_before = 0;
 	bool grid_updated = false;
 	float prep_ms = 0.f;
 	std::chrono::steady_clock::time_point step_start;
@@ -1651,39 +1657,54 @@ int rnb_train_step_begin(orc_ctx_s* c, void*) {
 	return RNB_OK;
 }
 
-int rnb_train_step_end(orc_ctx_s* c, void*, rnb_step_stats* stats) {
+int rnb_train_step_apply(orc_ctx_s* c, void*) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	optimizer_step(c);
 	++c->training_step;
-	// Counters::update_after_training (testbed_nerf.cu:3532-3558)
-	const uint32_t B = c->cfg.target_batch_size;
+	return RNB_OK;
+}
+
+int rnb_train_step_local(orc_ctx_s* c, void*, uint64_t counters[4], double sums[3]) {
+	if (!c || !counters || !sums) return fail(RNB_ERR_INVALID, "null argument");
+	for (int k = 0; k < 4; ++k) counters[k] = c->counters[k];
+	double s0 = 0, s1 = 0, s2 = 0;
+	const uint32_t n = std::min(c->counters[2], c->cur_n_rays);
+	for (uint32_t i = 0; i < n; ++i) { s0 += c->loss[i]; s1 += c->ek_loss[i]; s2 += c->mask_loss[i]; }
+	sums[0] = s0; sums[1] = s1; sums[2] = s2;
+	c->local_measured_before = c->counters[0];
+	return RNB_OK;
+}
+
+// Counters::update_after_training (testbed_nerf.cu:3532-3558) on counters summed over the data-parallel ranks.
+int rnb_train_step_finish(orc_ctx_s* c, const uint64_t counters[4], const double sums[3], rnb_step_stats* stats) {
+	if (!c || !counters || !sums) return fail(RNB_ERR_INVALID, "null argument");
+	const uint64_t Bg = (uint64_t)c->cfg.target_batch_size * c->cfg.world_size;
 	const uint32_t n_rays = c->cur_n_rays;
 	c->measured_batch_size = 0;
 	c->measured_batch_size_before_compaction = 0;
 	float loss_scalar = 0.f, ek_scalar = 0.f, mask_scalar = 0.f;
 	uint32_t next_rays = c->rays_per_batch;
 	int rc = RNB_OK;
-	if (c->counters[0] == 0 || c->counters[1] == 0) {
+	if (counters[0] == 0 || counters[1] == 0) {
 		rc = RNB_ERR_NO_SAMPLES;
 		g_err = "Nerf training generated 0 samples.";
 	} else {
-		c->measured_batch_size_before_compaction = c->counters[0];
-		c->measured_batch_size = c->counters[1];
-		double s0 = 0, s1 = 0, s2 = 0;
-		for (uint32_t i = 0; i < n_rays; ++i) { s0 += c->loss[i]; s1 += c->ek_loss[i]; s2 += c->mask_loss[i]; }
-		loss_scalar = (float)s0 * (float)c->measured_batch_size / (float)B;
-		ek_scalar = (float)s1 * (float)c->measured_batch_size / (float)B;
-		mask_scalar = (float)s2 * (float)c->measured_batch_size / (float)B;
-		next_rays = (uint32_t)((float)c->rays_per_batch * (float)B / (float)c->measured_batch_size);
+		c->measured_batch_size_before_compaction = c->local_measured_before;
+		c->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);
+		const float measured = (float)counters[1], target = (float)Bg;
+		loss_scalar = (float)sums[0] * measured / target;
+		ek_scalar = (float)sums[1] * measured / target;
+		mask_scalar = (float)sums[2] * measured / target;
+		next_rays = (uint32_t)((float)c->rays_per_batch * target / measured);
 		next_rays = std::min(next_multiple(next_rays, 128u), c->cfg.max_rays_per_batch);
 	}
 	if (stats) {
 		stats->training_step = c->training_step;
 		stats->rays_per_batch = n_rays;
 		stats->next_rays_per_batch = next_rays;
-		stats->measured_batch_size = c->measured_batch_size;
-		stats->measured_batch_size_before_compaction = c->measured_batch_size_before_compaction;
-		stats->n_rays_kept = c->counters[2];
+		stats->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);
+		stats->measured_batch_size_before_compaction = (uint32_t)(counters[0] / c->cfg.world_size);
+		stats->n_rays_kept = (uint32_t)(counters[2] / c->cfg.world_size);
 		stats->density_grid_updated = c->grid_updated ? 1 : 0;
 		stats->loss = loss_scalar; stats->ek_loss = ek_scalar; stats->mask_loss = mask_scalar;
 		stats->prep_ms = c->prep_ms;
@@ -1693,11 +1714,26 @@ int rnb_train_step_end(orc_ctx_s* c, void*, rnb_step_stats* stats) {
 	return rc;
 }
 
+int rnb_train_step_end(orc_ctx_s* c, void* stream, rnb_step_stats* stats) {
+	int rc = rnb_train_step_apply(c, stream);
+	if (rc != RNB_OK) return rc;
+	uint64_t counters[4];
+	double sums[3];
+	rc = rnb_train_step_local(c, stream, counters, sums);
+	if (rc != RNB_OK) return rc;
+	return rnb_train_step_finish(c, counters, sums, stats);
+}
+
 int rnb_train_step(orc_ctx_s* c, void* stream, rnb_step_stats* stats) {
 	int rc = rnb_train_step_begin(c, stream);
 	if (rc != RNB_OK) return rc;
 	return rnb_train_step_end(c, stream, stats);
 }
+
+// The checker keeps no per-kernel timers: the entry points exist so both libraries export the same ABI.
+int rnb_profile_enable(orc_ctx_s* c, int) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); }
+int rnb_profile_count(const orc_ctx_s*) { return 0; }
+int rnb_profile_get(const orc_ctx_s*, int, const char**, double*, uint64_t*, double*) { return fail(RNB_ERR_INVALID, "the CPU checker has no profile entries"); }
 
 uint32_t rnb_training_step(const orc_ctx_s* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch : 0; }

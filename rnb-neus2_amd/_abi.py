@@ -137,6 +137,12 @@ PROTOTYPES = {
     "train_step": (_i, [_ctx, _stream, C.POINTER(StepStats)]),
     "train_step_begin": (_i, [_ctx, _stream]),
     "train_step_end": (_i, [_ctx, _stream, C.POINTER(StepStats)]),
+    "profile_enable": (_i, [_ctx, _i]),
+    "profile_count": (_i, [_ctx]),
+    "profile_get": (_i, [_ctx, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "train_step_apply": (_i, [_ctx, _stream]),
+    "train_step_local": (_i, [_ctx, _stream, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "train_step_finish": (_i, [_ctx, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(StepStats)]),
     "training_step": (_u32, [_ctx]),
     "rays_per_batch": (_u32, [_ctx]),
     "set_controller": (_i, [_ctx, _u32, _u32, _u32, _u32]),

@@ -217,6 +217,18 @@ class Context:
     def set_controller(self, training_step, rays_per_batch, measured_before_compaction=0, n_rays_total=0):
         self._check(self.f.set_controller(self._h, int(training_step), int(rays_per_batch), int(measured_before_compaction), int(n_rays_total)))
 
+    def profile_enable(self, on=True):
+        self._check(self.f.profile_enable(self._h, int(bool(on))))
+
+    def profile(self):
+        """Per-kernel-group HIP-event timings accumulated since profile_enable(True)."""
+        out = []
+        for i in range(self.f.profile_count(self._h)):
+            name, ms, n, units = C.c_char_p(), C.c_double(), C.c_uint64(), C.c_double()
+            self._check(self.f.profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(n), C.byref(units)))
+            out.append(dict(kernel=name.value.decode(), total_ms=ms.value, launches=n.value, units=units.value))
+        return out
+
     def update_density_grid(self, stream=None):
         self._check(self.f.update_density_grid(self._h, _stream_handle(stream)))
 
@@ -281,6 +293,24 @@ class Context:
 
     def train_step_begin(self, stream=None):
         self._check(self.f.train_step_begin(self._h, _stream_handle(stream)))
+
+    def train_step_apply(self, stream=None):
+        self._check(self.f.train_step_apply(self._h, _stream_handle(stream)))
+
+    def train_step_local(self, stream=None):
+        """(counters uint64[4], loss_sums float64[3]) of this rank for the step just applied."""
+        cnt = (C.c_uint64 * 4)()
+        sums = (C.c_double * 3)()
+        self._check(self.f.train_step_local(self._h, _stream_handle(stream), cnt, sums))
+        return np.array(cnt, dtype=np.uint64), np.array(sums, dtype=np.float64)
+
+    def train_step_finish(self, counters, loss_sums, allow_no_samples=False):
+        cnt = (C.c_uint64 * 4)(*[int(x) for x in counters])
+        sums = (C.c_double * 3)(*[float(x) for x in loss_sums])
+        st = StepStats()
+        rc = self.f.train_step_finish(self._h, cnt, sums, C.byref(st))
+        self._check(rc, allow=(_abi.ERR_NO_SAMPLES,) if allow_no_samples else ())
+        return st
 
     def train_step_end(self, stream=None, allow_no_samples=False):
         st = StepStats()

@@ -50,8 +50,41 @@ uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid
 
 } // namespace
 
+// Per-kernel-group timing with HIP events on the caller's stream (bench.py's roofline leg).
+enum ProfId { P_NONE = -1, P_GRID_SAMPLES = 0, P_POINT_QUERY, P_EMA_BITFIELD, P_MARCH_COUNT, P_SCAN_RAYS, P_MARCH_WRITE, P_FORWARD, P_LOSS_PASS1,
+              P_SCAN_COMPACT, P_LOSS_PASS2, P_FWD_BWD, P_DW, P_SCATTER, P_ADAM, P_REDUCE, P_COUNT };
+static const char* const PROF_NAMES[P_COUNT] = {"k_grid_samples", "k_point_query", "k_ema_grid+bitfield", "k_march_count", "k_scan_rays", "k_march_write", "k_forward",
+                                                "k_loss_pass1", "k_scan_compact", "k_loss_pass2+k_rollover", "k_fwd_bwd", "k_dw*7+k_dw_finish", "k_grid_scatter", "k_adam_ema", "k_reduce_losses"};
+struct Profiler {
+	bool on = false;
+	std::vector<hipEvent_t> ev;
+	std::vector<int> ids;
+	size_t n = 0;
+	double total_ms[P_COUNT] = {0};
+	uint64_t launches[P_COUNT] = {0};
+	double units[P_COUNT] = {0};
+	void mark(hipStream_t s, int id) {
+		if (!on) return;
+		if (n == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); ids.push_back(0); }
+		ids[n] = id;
+		(void)hipEventRecord(ev[n], s);
+		++n;
+	}
+	void collect() { // after a stream sync
+		for (size_t i = 1; i < n; ++i) {
+			if (ids[i] < 0) continue;
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { total_ms[ids[i]] += ms; ++launches[ids[i]]; }
+		}
+		n = 0;
+	}
+	void reset() { for (int i = 0; i < P_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; units[i] = 0; } n = 0; }
+	void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); ids.clear(); n = 0; }
+};
+
 struct rnb_ctx {
 	rnb_config cfg;
+	Profiler prof;
 	GridMeta grid;
 	uint64_t n_grid_params = 0, n_params = 0;
 	uint64_t off_sdf = 0, off_rgb = 0, off_grid = 0, off_var = 0;
@@ -96,7 +129,7 @@ struct rnb_ctx {
 	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0, n_rays_total = 0;
 	uint32_t optimizer_step_count = 0;
 	float lr_factor = 1.f;
-	uint32_t cur_n_rays = 0, cur_n_rays_total = 0;
+	uint32_t cur_n_rays = 0, cur_n_rays_total = 0, local_measured_before = 0;
 	bool grid_updated = false;
 	float prep_ms = 0.f;
 	std::chrono::steady_clock::time_point step_start;
@@ -205,6 +238,7 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t n_nonuniform) { // testbed_nerf.cu:3424-3495
 	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
+	c->prof.mark(s, P_NONE);
 	if (c->training_step == 0) {
 		c->density_grid_ema_step = 0;
 		HIP_TRY(hipMemsetAsync(c->density_grid.p, 0, sizeof(float) * n_elements, s));
@@ -217,13 +251,18 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	                                     c->grid_sample_pos.p + (size_t)n_uniform * 3, c->grid_sample_idx.p + n_uniform, MIN_OPTICAL_THICKNESS);
 	c->density_grid_rng.advance();
 	HIP_TRY(hipGetLastError());
+	c->prof.mark(s, P_GRID_SAMPLES);
 	c->n_grid_samples = n_samples;
 	int rc = launch_point_query(c, s, c->grid_sample_pos.p, n_samples, nullptr, c->grid_sample_idx.p, c->density_grid_tmp.p, 1, false);
 	if (rc != RNB_OK) return rc;
+	c->prof.mark(s, P_POINT_QUERY);
+	c->prof.units[P_POINT_QUERY] += n_samples;
 	hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
 	HIP_TRY(hipGetLastError());
 	++c->density_grid_ema_step;
-	return update_bitfield(c, s);
+	rc = update_bitfield(c, s);
+	c->prof.mark(s, P_EMA_BITFIELD);
+	return rc;
 }
 
 int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
@@ -264,9 +303,14 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	const uint32_t blocks = (n_rays + 127) / 128;
+	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p);
+	c->prof.mark(s, P_SCAN_RAYS);
 	hipLaunchKernelGGL(k_march_write, dim3(blocks), dim3(128), 0, s, a);
+	c->prof.mark(s, P_MARCH_WRITE);
+	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -287,10 +331,14 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	HIP_TRY(hipMemsetAsync(c->ek_loss.p, 0, sizeof(float) * n_rays, s));
 	HIP_TRY(hipMemsetAsync(c->mask_loss.p, 0, sizeof(float) * n_rays, s));
 	const uint32_t blocks = (n_rays + 127) / 128;
+	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(128), 0, s, a);
+	c->prof.mark(s, P_LOSS_PASS1);
 	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
+	c->prof.mark(s, P_SCAN_COMPACT);
 	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(128), 0, s, a);
 	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
+	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -301,7 +349,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	c->grads_clean = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts;
+	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
+	c->prof.mark(s, P_FWD_BWD);
+	c->prof.units[P_FWD_BWD] += B;
 	// weight-gradient GEMMs
 	const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
 	const size_t slab = (size_t)nwg * WAVES_PER_WG;
@@ -328,9 +379,13 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var;
 	const uint32_t n_fin = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS + 1;
 	hipLaunchKernelGGL(k_dw_finish, dim3((n_fin + 127) / 128), dim3(128), 0, s, f);
+	c->prof.mark(s, P_DW);
+	c->prof.units[P_DW] += B;
 	ScatterArgs sa;
 	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	hipLaunchKernelGGL(k_grid_scatter, dim3((B + 255) / 256, c->cfg.n_levels), dim3(256), 0, s, c->meta(), sa);
+	c->prof.mark(s, P_SCATTER);
+	c->prof.units[P_SCATTER] += B;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -349,7 +404,10 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	a.ema_decay = cfg.ema_decay;
 	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1); // ema.h:116-117
 	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
+	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_adam_ema, dim3(4096), dim3(256), 0, s, a);
+	c->prof.mark(s, P_ADAM);
+	c->prof.units[P_ADAM] += (double)c->n_params;
 	HIP_TRY(hipGetLastError());
 	c->grads_clean = true;
 	return RNB_OK;
@@ -394,6 +452,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->loss.free(); c->ek_loss.free(); c->mask_loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->ray_setup.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
+	c->prof.destroy();
 	delete c;
 	return RNB_OK;
 }
@@ -730,8 +789,10 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
 	rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
 	if (rc != RNB_OK) return rc;
+	c->prof.mark(s, P_NONE);
 	rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
+	c->prof.mark(s, P_FORWARD);
 	rc = compute_loss(c, s, n_rays, n_rays_total);
 	if (rc != RNB_OK) return rc;
 	rc = forward_backward(c, s);
@@ -740,46 +801,64 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	return RNB_OK;
 }
 
-int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+int rnb_train_step_apply(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	hipStream_t s = as_stream(stream);
 	int rc = optimizer_step(c, s);
 	if (rc != RNB_OK) return rc;
 	++c->training_step;
-	const uint32_t B = c->cfg.target_batch_size;
-	const uint32_t n_rays = c->cur_n_rays;
-	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
+	c->prof.mark(s, P_NONE);
+	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
+	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], double loss_sums_out[3]) {
+	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
+	hipStream_t s = as_stream(stream);
 	uint32_t counters[4];
 	double sums[4];
 	HIP_TRY(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipMemcpyAsync(sums, c->loss_sums.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s)); // testbed.cu:2866
-	// Counters::update_after_training (testbed_nerf.cu:3532-3558)
+	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += counters[3]; }
+	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
+	for (int k = 0; k < 3; ++k) loss_sums_out[k] = sums[k];
+	c->local_measured_before = counters[0];
+	return RNB_OK;
+}
+
+// Counters::update_after_training (testbed_nerf.cu:3532-3558) on counters summed over the data-parallel ranks.
+int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double sums[3], rnb_step_stats* stats) {
+	if (!c || !counters || !sums) return fail(RNB_ERR_INVALID, "null argument");
+	const uint64_t Bg = (uint64_t)c->cfg.target_batch_size * c->cfg.world_size;
+	const uint32_t n_rays = c->cur_n_rays;
 	c->measured_batch_size = 0;
 	c->measured_batch_size_before_compaction = 0;
 	float loss_scalar = 0.f, ek_scalar = 0.f, mask_scalar = 0.f;
 	uint32_t next_rays = c->rays_per_batch;
-	rc = RNB_OK;
+	int rc = RNB_OK;
 	if (counters[0] == 0 || counters[1] == 0) {
 		rc = RNB_ERR_NO_SAMPLES;
 		g_err = "Nerf training generated 0 samples.";
 	} else {
-		c->measured_batch_size_before_compaction = counters[0];
-		c->measured_batch_size = counters[1];
-		loss_scalar = (float)sums[0] * (float)c->measured_batch_size / (float)B;
-		ek_scalar = (float)sums[1] * (float)c->measured_batch_size / (float)B;
-		mask_scalar = (float)sums[2] * (float)c->measured_batch_size / (float)B;
-		next_rays = (uint32_t)((float)c->rays_per_batch * (float)B / (float)c->measured_batch_size);
+		c->measured_batch_size_before_compaction = c->local_measured_before; // bounds this rank's next inference launch
+		c->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);
+		const float measured = (float)counters[1], target = (float)Bg;
+		loss_scalar = (float)sums[0] * measured / target;
+		ek_scalar = (float)sums[1] * measured / target;
+		mask_scalar = (float)sums[2] * measured / target;
+		next_rays = (uint32_t)((float)c->rays_per_batch * target / measured);
 		next_rays = std::min(next_multiple_u32(next_rays, 128u), c->cfg.max_rays_per_batch);
 	}
 	if (stats) {
 		stats->training_step = c->training_step;
 		stats->rays_per_batch = n_rays;
 		stats->next_rays_per_batch = next_rays;
-		stats->measured_batch_size = c->measured_batch_size;
-		stats->measured_batch_size_before_compaction = c->measured_batch_size_before_compaction;
-		stats->n_rays_kept = counters[2];
+		stats->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);
+		stats->measured_batch_size_before_compaction = (uint32_t)(counters[0] / c->cfg.world_size);
+		stats->n_rays_kept = (uint32_t)(counters[2] / c->cfg.world_size);
 		stats->density_grid_updated = c->grid_updated ? 1 : 0;
 		stats->loss = loss_scalar; stats->ek_loss = ek_scalar; stats->mask_loss = mask_scalar;
 		stats->prep_ms = c->prep_ms;
@@ -789,10 +868,36 @@ int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
 	return rc;
 }
 
+int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+	int rc = rnb_train_step_apply(c, stream);
+	if (rc != RNB_OK) return rc;
+	uint64_t counters[4];
+	double sums[3];
+	rc = rnb_train_step_local(c, stream, counters, sums);
+	if (rc != RNB_OK) return rc;
+	return rnb_train_step_finish(c, counters, sums, stats);
+}
+
 int rnb_train_step(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
 	int rc = rnb_train_step_begin(c, stream);
 	if (rc != RNB_OK) return rc;
 	return rnb_train_step_end(c, stream, stats);
+}
+
+int rnb_profile_enable(rnb_ctx* c, int on) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->prof.on = on != 0;
+	c->prof.reset();
+	return RNB_OK;
+}
+int rnb_profile_count(const rnb_ctx*) { return P_COUNT; }
+int rnb_profile_get(const rnb_ctx* c, int idx, const char** name, double* total_ms, uint64_t* launches, double* units) {
+	if (!c || idx < 0 || idx >= P_COUNT) return fail(RNB_ERR_INVALID, "bad profile index");
+	if (name) *name = PROF_NAMES[idx];
+	if (total_ms) *total_ms = c->prof.total_ms[idx];
+	if (launches) *launches = c->prof.launches[idx];
+	if (units) *units = c->prof.units[idx];
+	return RNB_OK;
 }
 
 uint32_t rnb_training_step(const rnb_ctx* c) { return c ? c->training_step : 0; }

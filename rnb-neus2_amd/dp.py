@@ -1,0 +1,67 @@
+"""Data-parallel training step over torch.distributed (RCCL on MI355X, gloo in the CPU tests).
+
+The reference is single-GPU (no collective call sites). Sharding: every rank holds the full
+parameter block, occupancy grid and dataset; rank r generates the global rays [r*R, (r+1)*R) of a step of W*R rays
+(same PCG32 stream positions and image assignment as a single process running W*R rays), compacts its own
+``target_batch_size`` samples, and the ranks exchange
+  * ONE all-reduce (sum) of the fp32 gradient accumulators (10.56 M floats = 42 MB) before the optimizer, and
+  * one 7-value all-reduce of the step counters / loss sums so all ranks draw the same rays_per_batch next step.
+The occupancy update is replicated: identical parameters + identical RNG => identical grids, no communication.
+"""
+import numpy as np
+
+
+class _DeviceArray:
+    """Minimal __cuda_array_interface__ view of a device buffer owned by the HIP library."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def grads_tensor(ctx):
+    """torch view (no copy) of the context's fp32 gradient accumulators, for dist.all_reduce."""
+    import torch
+    ptr, nbytes = ctx.buffer("GRADS_FP32")
+    return torch.as_tensor(_DeviceArray(ptr, nbytes // 4, "<f4"), device="cuda")
+
+
+class DataParallelTrainer:
+    """Drives ``ctx`` (created with world_size/rank in its config) through begin -> all-reduce -> apply -> finish.
+
+    ``all_reduce_grads(ctx)`` sums the gradient accumulators in place over the ranks; ``all_reduce_small(vec)``
+    sums a float64 numpy vector. The defaults use torch.distributed; the CPU tests inject gloo/numpy versions.
+    """
+
+    def __init__(self, ctx, all_reduce_grads=None, all_reduce_small=None, stream=None):
+        self.ctx = ctx
+        self.stream = stream
+        self._grads = None
+        self._reduce_grads = all_reduce_grads or self._torch_reduce_grads
+        self._reduce_small = all_reduce_small or self._torch_reduce_small
+
+    def _torch_reduce_grads(self, ctx):
+        import torch.distributed as dist
+        if self._grads is None:
+            self._grads = grads_tensor(ctx)
+        dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
+
+    def _torch_reduce_small(self, vec):
+        import torch
+        import torch.distributed as dist
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.from_numpy(vec.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def step(self, allow_no_samples=False):
+        ctx = self.ctx
+        ctx.train_step_begin(self.stream)
+        if ctx.cfg.world_size > 1:
+            self._reduce_grads(ctx)
+        ctx.train_step_apply(self.stream)
+        counters, sums = ctx.train_step_local(self.stream)
+        if ctx.cfg.world_size > 1:
+            vec = np.concatenate([counters.astype(np.float64), sums])
+            vec = self._reduce_small(vec)
+            counters, sums = np.rint(vec[:4]).astype(np.uint64), vec[4:]
+        return ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
