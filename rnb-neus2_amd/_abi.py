@@ -1,7 +1,8 @@
 """ctypes declarations of include/rnb_neus2.h (structs, enums, prototypes).
 
 ``declare(lib, prefix)`` attaches argtypes/restypes to an already loaded CDLL. The product always uses the
-prefix ``rnb_`` (librnb_neus2_hip.so); the tests apply the same declarations to the CPU checker with ``orc_``.
+prefix ``rnb_`` (librnb_neus2_hip.so); the test suite applies the same declarations to its CPU checker, which exports
+the identical signatures under its own prefix.
 """
 import ctypes as C
 

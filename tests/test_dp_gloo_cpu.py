@@ -1,0 +1,121 @@
+"""World-size-2 data-parallel path on CPU (gloo): the sharding of the ray index space, the gradient all-reduce and the
+counter exchange of rnb-neus2_amd/dp.py, exercised with the CPU checker as the compute engine (test infrastructure)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+KW = dict(target_batch_size=1 << 12, max_rays_per_batch=1 << 12, initial_rays_per_batch=256, apply_no_albedo=1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene():
+    from rnb_neus2_amd import synthetic
+    return synthetic.make_scene(4, 48, 84.0)
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_lib
+    from rnb_neus2_amd import dp
+    views, nm, al = _scene()
+    c = oracle_lib.context(world_size=world, rank=rank, **KW)
+    c.init_params()
+    c.set_dataset(views, nm, al)
+
+    def reduce_grads(ctx):  # host buffers: stage through a torch tensor
+        t = torch.from_numpy(ctx.get("GRADS_FP32"))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ctx.put("GRADS_FP32", t.numpy())
+
+    tr = dp.DataParallelTrainer(c, all_reduce_grads=reduce_grads)
+    out = {"rank": rank, "steps": []}
+    for i in range(3):
+        st = tr.step()
+        if i == 0:
+            kept = int(c.get("COUNTERS")[2])
+            out["ray_indices"] = c.get("RAY_INDICES", kept)
+            out["rays"] = c.get("RAYS", kept * 6)
+        out["steps"].append(st.as_dict())
+    out["params"] = c.get("PARAMS_FP32")[:20000].copy()
+    out["params_tail"] = c.get("PARAMS_FP32")[-4:].copy()
+    out["grid"] = c.get("DENSITY_BITFIELD").copy()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_step():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    # replicas stay identical: same parameters, same occupancy grid, same controller decisions
+    assert np.array_equal(r0["params"], r1["params"]) and np.array_equal(r0["params_tail"], r1["params_tail"])
+    assert np.array_equal(r0["grid"], r1["grid"])
+    for a, b in zip(r0["steps"], r1["steps"]):
+        for k in ("training_step", "rays_per_batch", "next_rays_per_batch", "measured_batch_size", "loss", "mask_loss", "ek_loss"):
+            assert a[k] == b[k], k
+    # the union of the two ranks' rays at step 0 is the ray set of ONE process marching world*R rays (same RNG positions)
+    from tests import oracle_lib
+    views, nm, al = _scene()
+    big = dict(KW)
+    big["target_batch_size"] = 2 * KW["target_batch_size"]  # one process needs the sample budget of both ranks
+    single = oracle_lib.context(**big)
+    single.init_params()
+    single.set_dataset(views, nm, al)
+    single.set_training_step(0)
+    single.update_density_grid()
+    R = r0["steps"][0]["rays_per_batch"]
+    single.generate_training_samples(2 * R, 0)
+    kept = int(single.get("COUNTERS")[2])
+    idx = single.get("RAY_INDICES", kept)
+    rays = single.get("RAYS", kept * 6).reshape(kept, 6)
+    union_idx = np.concatenate([r0["ray_indices"], r1["ray_indices"] + R])
+    union_rays = np.concatenate([r0["rays"].reshape(-1, 6), r1["rays"].reshape(-1, 6)])
+    assert np.array_equal(union_idx, idx)
+    assert np.array_equal(union_rays.view(np.uint32), rays.view(np.uint32))
+    single.close()
+
+
+def test_single_rank_trainer_equals_train_step():
+    from tests import oracle_lib
+    from rnb_neus2_amd import dp
+    views, nm, al = _scene()
+    a = oracle_lib.context(**KW)
+    b = oracle_lib.context(**KW)
+    for c in (a, b):
+        c.init_params()
+        c.set_dataset(views, nm, al)
+    tr = dp.DataParallelTrainer(a)
+    for _ in range(2):
+        sa, sb = tr.step(), b.train_step()
+        da, db = sa.as_dict(), sb.as_dict()
+        for k in da:
+            if k not in ("prep_ms", "step_ms"):
+                assert da[k] == db[k], k
+    assert np.array_equal(a.get("PARAMS_FP32"), b.get("PARAMS_FP32"))
+    a.close()
+    b.close()
