@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -377,13 +378,26 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	f.n_partials = (uint32_t)slab;
 	f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
 	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var;
-	const uint32_t n_fin = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS + 1;
-	hipLaunchKernelGGL(k_dw_finish, dim3((n_fin + 127) / 128), dim3(128), 0, s, f);
+	const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
+	hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, s, f);
 	c->prof.mark(s, P_DW);
 	c->prof.units[P_DW] += B;
 	ScatterArgs sa;
 	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
-	hipLaunchKernelGGL(k_grid_scatter, dim3((B + 255) / 256, c->cfg.n_levels), dim3(256), 0, s, c->meta(), sa);
+	{ // cell runs per level: cell size / march step ~ 590 / resolution samples; pick K accordingly
+		uint32_t l = 0;
+		const uint32_t L = c->cfg.n_levels;
+		auto launch = [&](auto kern, uint32_t k, uint32_t l_begin, uint32_t l_end) {
+			if (l_end <= l_begin) return;
+			const uint32_t threads = (B + k - 1) / k;
+			hipLaunchKernelGGL(kern, dim3((threads + 255) / 256, l_end - l_begin), dim3(256), 0, s, c->meta(), sa, l_begin);
+		};
+		uint32_t e16 = 0, e4 = 0;
+		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= 128) e16 = l + 1; if (c->grid.resolution[l] <= 400) e4 = l + 1; }
+		launch(k_grid_scatter<16>, 16, 0, e16);
+		launch(k_grid_scatter<4>, 4, e16, e4);
+		launch(k_grid_scatter<1>, 1, e4, L);
+	}
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
 	HIP_TRY(hipGetLastError());
