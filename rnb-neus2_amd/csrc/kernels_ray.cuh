@@ -192,6 +192,7 @@ struct MarchArgs {
 	const uint8_t* bitfield;
 	// per-ray scratch
 	float* setup;       // [n_rays][8]: o(3) dir(3) startt alive
+	float* ray_t;       // [n_rays][RNB_MAX_STEPS]: t of every sample found by the counting pass
 	float* d_unnorm;    // [n_rays][3]
 	uint32_t* steps;    // [n_rays]
 	uint32_t* base;     // [n_rays]
@@ -210,7 +211,7 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 		const float dt = calc_dt(t, A.cone_angle);
 		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		if (density_grid_occupied_at(pos, bitfield, mip)) {
-			emit(j, pos, dt);
+			emit(j, pos, dt, t);
 			++j;
 			t += dt;
 		} else {
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 		startt = tmin;
 		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
 		alive = 1.f;
-		steps = march(a.A, a.bitfield, o, dir, startt, RNB_MAX_STEPS, [](uint32_t, const Vec3&, float) {});
+		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
+		steps = march(a.A, a.bitfield, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
 	}
 	float* st = a.setup + (size_t)i * 8;
 	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
@@ -317,29 +319,36 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; }
 }
 
-__global__ __launch_bounds__(128) void k_march_write(const MarchArgs a) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+// Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
+// t values recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
+__global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
 	if (i >= a.n_rays) return;
 	const uint32_t s = a.slot[i];
 	if (s == 0xffffffffu) return;
 	const float* st = a.setup + (size_t)i * 8;
 	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
-	const float startt = st[6];
 	const uint32_t steps = a.steps[i], base = a.base[i];
-	a.ray_indices[s] = i;
-	float* ro = a.rays + (size_t)s * 6;
-	ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
-	ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
-	a.numsteps[(size_t)s * 2 + 0] = steps;
-	a.numsteps[(size_t)s * 2 + 1] = base;
+	if (lane == 0) {
+		a.ray_indices[s] = i;
+		float* ro = a.rays + (size_t)s * 6;
+		ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
+		ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
+		a.numsteps[(size_t)s * 2 + 0] = steps;
+		a.numsteps[(size_t)s * 2 + 1] = base;
+	}
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
+	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
 	float* co = a.coords + (size_t)base * 7;
-	const SceneAabb A = a.A;
-	march(A, a.bitfield, o, dir, startt, steps, [&](uint32_t j, const Vec3& pos, float dt) {
-		const Vec3 wp = warp_position(A, pos);
+	for (uint32_t j = lane; j < steps; j += 64) {
+		const float t = tt[j];
+		const Vec3 pos = o + t * dir;
+		const float dt = calc_dt(t, a.A.cone_angle);
+		const Vec3 wp = warp_position(a.A, pos);
 		float* q = co + (size_t)j * 7;
 		q[0] = wp.x; q[1] = wp.y; q[2] = wp.z; q[3] = warp_dt(dt); q[4] = wd.x; q[5] = wd.y; q[6] = wd.z;
-	});
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,23 +425,23 @@ __device__ __forceinline__ AlphaTerms alpha_terms(const half_t* __restrict__ o, 
 	return a;
 }
 
-__global__ __launch_bounds__(128) void k_loss_pass1(const LossArgs a) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= a.n_rays) return;
-	if (i >= a.counters[2]) { a.ncomp[i] = 0; return; }
-	const uint32_t numsteps = a.numsteps[(size_t)i * 2 + 0];
-	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
-	const float* coords_in = a.coords + (size_t)base * 7;
-	const half_t* net = a.mlp_out + (size_t)base * 16;
+__device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+
+__device__ __forceinline__ void load_out16(const half_t* __restrict__ p, half_t o[16]) {
+	const h8* src = reinterpret_cast<const h8*>(p);
+	const h8 o0 = src[0], o1 = src[1];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) { o[j] = o0[j]; o[8 + j] = o1[j]; }
+}
+
+// Per-ray constants of the loss kernel (testbed_nerf.cu:1485-1593): pixel, target normal, light triplet, shading target.
+__device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t i, RayLoss& R) {
 	const uint32_t ray_idx = a.ray_indices[i];
 	const uint32_t gi = a.ray_offset + ray_idx;
 	Pcg32 rng = a.rng;
 	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
 	const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
 	const ViewDev m = a.views[img];
-	const Vec3 ray_d = {a.rays[(size_t)i * 6 + 3], a.rays[(size_t)i * 6 + 4], a.rays[(size_t)i * 6 + 5]};
-	const Vec3 dir0 = normalized(ray_d);
-	float dir[3] = {dir0.x, dir0.y, dir0.z};
 	float xy[2];
 	random_image_pos(rng, m.width, m.height, a.F.snap != 0, xy);
 	float tex_albedo[4], tex_normal[4];
@@ -481,53 +490,81 @@ __global__ __launch_bounds__(128) void k_loss_pass1(const LossArgs a) {
 		for (int k = 0; k < 9; ++k) Ld[k] = outm[k];
 	}
 	const float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
-	RayLoss R;
 #pragma unroll
 	for (int r = 0; r < 3; ++r) R.light[r] = m.xform[r * 4 + 0] * light_cam[0] + m.xform[r * 4 + 1] * light_cam[1] + m.xform[r * 4 + 2] * light_cam[2];
 	float shading_target = nv[0] * light_cam[0] + nv[1] * light_cam[1] + nv[2] * light_cam[2];
 	if (a.F.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) R.rgbtarget[k] = albedo_value[k] * shading_target;
+	R.mask_certainty = (float)(tex_albedo[3] > 0.99);
+	R.mask_gt = (float)(tex_normal[3] > 0.99);
+}
 
+// Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), one wavefront per ray: the per-sample terms (alpha, shading)
+// are evaluated by 64 lanes at once; the transmittance recurrence and the early stop at T < 1e-4 are then replayed in the
+// reference's sequential order (identical fp32 rounding) from lane broadcasts.
+__global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	if (i >= a.n_rays) return;
+	if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; return; }
+	const uint32_t numsteps = a.numsteps[(size_t)i * 2 + 0];
+	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+	const float* coords_in = a.coords + (size_t)base * 7;
+	const half_t* net = a.mlp_out + (size_t)base * 16;
+	RayLoss R;
+	ray_constants(a, i, R);
+	float dir[3];
+	{ // BENT_DIR (testbed_nerf.cu:1645-1650): the direction the network echoed for the ray's first sample
+		half_t o0[16];
+		load_out16(net, o0);
+		const Vec3 dv = normalized(v3(h2f(o0[8]) * 2.0f - 1.0f, h2f(o0[9]) * 2.0f - 1.0f, h2f(o0[10]) * 2.0f - 1.0f));
+		dir[0] = dv.x; dir[1] = dv.y; dir[2] = dv.z;
+	}
 	float T = 1.f;
 	const float EPSILON = 1e-4f;
 	float rgb_ray[4] = {0, 0, 0, 0};
 	float weight_sum = 0.f;
 	uint32_t n = 0;
-	for (; n < numsteps; ++n) {
-		if (T < EPSILON) break;
-		half_t o[16];
-		{
-			const h8* src = reinterpret_cast<const h8*>(net + (size_t)n * 16);
-			const h8 o0 = src[0], o1 = src[1];
-#pragma unroll
-			for (int j = 0; j < 8; ++j) { o[j] = o0[j]; o[8 + j] = o1[j]; }
+	bool done = false;
+	for (uint32_t c0 = 0; c0 < numsteps && !done; c0 += 64) {
+		const uint32_t j = c0 + lane;
+		float alpha = 0.f, shading = 0.f, albedo[4] = {1.f, 1.f, 1.f, 0.f};
+		if (j < numsteps) {
+			half_t o[16];
+			load_out16(net + (size_t)j * 16, o);
+			albedo_from_output(a.F, o, albedo);
+			const float dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
+			const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
+			alpha = at.alpha;
+			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
+			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		}
-		float albedo[4];
-		albedo_from_output(a.F, o, albedo);
-		const float dt = unwarp_dt(coords_in[(size_t)n * 7 + 3]);
-		if (n == 0) { // BENT_DIR, testbed_nerf.cu:1645-1650
-			const Vec3 dv = normalized(v3(h2f(o[8]) * 2.0f - 1.0f, h2f(o[9]) * 2.0f - 1.0f, h2f(o[10]) * 2.0f - 1.0f));
-			dir[0] = dv.x; dir[1] = dv.y; dir[2] = dv.z;
-		}
-		const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
-		const float weight = at.alpha * T;
-		float shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
-		if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+		const int cnt = (int)min(64u, numsteps - c0);
+		for (int q = 0; q < cnt; ++q) {
+			if (T < EPSILON) { done = true; break; }
+			const float al = bcast(alpha, q), sh = bcast(shading, q);
+			const float weight = al * T;
+			if (a.F.apply_no_albedo) {
+				rgb_ray[0] += weight * 1.f * sh; rgb_ray[1] += weight * 1.f * sh; rgb_ray[2] += weight * 1.f * sh; rgb_ray[3] += weight * 0.f * sh;
+			} else {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) rgb_ray[k] += weight * albedo[k] * shading;
-		weight_sum += weight;
-		T *= (1.f - at.alpha);
+				for (int k = 0; k < 4; ++k) rgb_ray[k] += weight * bcast(albedo[k], q) * sh;
+			}
+			weight_sum += weight;
+			T *= (1.f - al);
+			++n;
+		}
 	}
-	R.n_comp = n;
+	if (lane == 0) {
+		R.n_comp = n;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
-	R.weight_sum_raw = weight_sum;
-	R.dir[0] = dir[0]; R.dir[1] = dir[1]; R.dir[2] = dir[2];
-	R.mask_certainty = (float)(tex_albedo[3] > 0.99);
-	R.mask_gt = (float)(tex_normal[3] > 0.99);
-	a.ray_loss[i] = R;
-	a.ncomp[i] = n;
+		for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
+		R.weight_sum_raw = weight_sum;
+		R.dir[0] = dir[0]; R.dir[1] = dir[1]; R.dir[2] = dir[2];
+		a.ray_loss[i] = R;
+		a.ncomp[i] = n;
+	}
 }
 
 // exclusive scan of ncomp over the kept rays; counters[1] = total (numsteps_counter_compacted)
@@ -552,15 +589,21 @@ __global__ __launch_bounds__(1024) void k_scan_compact(const uint32_t n_max, con
 	if (tid == 0) counters[1] = sh[1023];
 }
 
-__global__ __launch_bounds__(128) void k_loss_pass2(const LossArgs a) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+// Pass 2 (testbed_nerf.cu:1836-2095), one wavefront per ray: lanes own samples; the running sums of the reference's
+// sequential loop are replayed from broadcasts and captured by the lane that owns each sample.
+__global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
 	if (i >= a.n_rays || i >= a.counters[2]) return;
 	const RayLoss R = a.ray_loss[i];
 	const uint32_t compacted_base = a.cbase[i];
 	const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
 	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
-	a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
-	a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
+		a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+	}
 	if (compacted_numsteps == 0) return;
 	const float* coords_in = a.coords + (size_t)base * 7;
 	const half_t* net = a.mlp_out + (size_t)base * 16;
@@ -598,8 +641,8 @@ __global__ __launch_bounds__(128) void k_loss_pass2(const LossArgs a) {
 		if (F.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * F.mask_loss_weight;
 		else gradient_weight_sum = (sig - R.mask_gt) * F.mask_loss_weight;
 	}
-	a.loss[i] = loss / gn;
-	{
+	if (lane == 0) {
+		a.loss[i] = loss / gn;
 		const float sig = 1.0f / (1.0f + expf(-weight_sum));
 		if (F.apply_bce) a.mask_loss[i] = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
 		else a.mask_loss[i] = -(R.mask_gt * logf(sig) + (1 - R.mask_gt) * logf(1 - sig));
@@ -611,96 +654,121 @@ __global__ __launch_bounds__(128) void k_loss_pass2(const LossArgs a) {
 	float T = 1.f;
 	const float dir[3] = {R.dir[0], R.dir[1], R.dir[2]};
 	float ek = 0.f;
-	for (uint32_t j = 0; j < compacted_numsteps; ++j) {
-#pragma unroll
-		for (int q = 0; q < 7; ++q) coords_out[(size_t)j * 7 + q] = coords_in[(size_t)j * 7 + q];
+	for (uint32_t c0 = 0; c0 < compacted_numsteps; c0 += 64) {
+		const uint32_t j = c0 + lane;
+		const bool valid = j < compacted_numsteps;
 		half_t o[16];
-		{
-			const h8* src = reinterpret_cast<const h8*>(net + (size_t)j * 16);
-			const h8 o0 = src[0], o1 = src[1];
 #pragma unroll
-			for (int q = 0; q < 8; ++q) { o[q] = o0[q]; o[8 + q] = o1[q]; }
+		for (int q = 0; q < 16; ++q) o[q] = (half_t)0.f;
+		float dt = MIN_CONE_STEPSIZE;
+		float albedo[4] = {1.f, 1.f, 1.f, 0.f};
+		AlphaTerms at;
+		at.alpha = 0.f; at.inv_s = 1.f; at.sdf_value = 0.f; at.true_cos = 0.f; at.iter_cos = 0.f; at.est_next = 0.f; at.p_div_c = 0.f; at.g[0] = at.g[1] = at.g[2] = 0.f;
+		float shading = 0.f, gradient_norm = 1.f;
+		if (valid) {
+#pragma unroll
+			for (int q = 0; q < 7; ++q) coords_out[(size_t)j * 7 + q] = coords_in[(size_t)j * 7 + q];
+			load_out16(net + (size_t)j * 16, o);
+			dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
+			albedo_from_output(F, o, albedo);
+			at = alpha_terms(o, dt, dir, 1.0f);
+			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
+			if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+			gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
 		}
-		const float dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
-		float albedo[4];
-		albedo_from_output(F, o, albedo);
-		const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
-		const float alpha = at.alpha;
-		const float weight = alpha * T;
-		float shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
-		if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+		const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
+		// replay of the sequential recurrences; lane q keeps its own weight and the running values right after sample q
+		float my_weight = 0.f, my_T = 1.f, my_w2 = 0.f, my_rgb2[4] = {0, 0, 0, 0};
+		const int cnt = (int)min(64u, compacted_numsteps - c0);
+		for (int q = 0; q < cnt; ++q) {
+			const float al = bcast(at.alpha, q), sh = bcast(shading, q);
+			const float weight = al * T;
+			if (F.apply_no_albedo) {
+				rgb_ray2[0] += weight * 1.f * sh; rgb_ray2[1] += weight * 1.f * sh; rgb_ray2[2] += weight * 1.f * sh; rgb_ray2[3] += weight * 0.f * sh;
+			} else {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * albedo[k] * shading;
-		weight_sum2 += weight;
-		T *= (1.f - alpha);
-		float suffix[4];
+				for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * bcast(albedo[k], q) * sh;
+			}
+			weight_sum2 += weight;
+			T *= (1.f - al);
+			ek += bcast(ekterm, q);
+			if (q == lane) {
+				my_weight = weight; my_T = T; my_w2 = weight_sum2;
 #pragma unroll
-		for (int k = 0; k < 4; ++k) suffix[k] = R.rgb_ray[k] - rgb_ray2[k];
-		const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
-		float dloss_dn[3];
-#pragma unroll
-		for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (R.light[d] * aG);
-		float J3[3] = {0, 0, 0};
-		if (F.apply_rgbplus) {
-			if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
-			else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
+				for (int k = 0; k < 4; ++k) my_rgb2[k] = rgb_ray2[k];
+			}
 		}
-		float drgb[3];
+		if (valid) {
+			const float alpha = at.alpha;
+			const float weight = my_weight;
+			const float Tj = my_T;
+			float suffix[4];
 #pragma unroll
-		for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
-		half_t dl[16];
+			for (int k = 0; k < 4; ++k) suffix[k] = R.rgb_ray[k] - my_rgb2[k];
+			const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
+			float dloss_dn[3];
 #pragma unroll
-		for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
-		const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+			for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (R.light[d] * aG);
+			float J3[3] = {0, 0, 0};
+			if (F.apply_rgbplus) {
+				if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
+				else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
+			}
+			float drgb[3];
 #pragma unroll
-		for (int d = 0; d < 3; ++d) {
-			const float sg = logistic(h2f(o[d]));
-			dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+			for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
+			half_t dl[16];
+#pragma unroll
+			for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
+			const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const float sg = logistic(h2f(o[d]));
+				dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+			}
+			const float sum_weight_suffix = weight_sum - my_w2;
+			float dot_term = 0.f;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) dot_term += grad[k] * (Tj * albedo[k] * shading - suffix[k]);
+			const float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (Tj - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
+			float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
+			if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
+				const float plus_sigmoid_x = at.inv_s * at.iter_cos * dt;
+				const float plus_e = expf(plus_sigmoid_x);
+				const float e_minus = expf(-at.est_next * at.inv_s);
+				dE_dsdf = -at.inv_s * e_minus;
+				dE_dinvs = -at.est_next * e_minus;
+				const float aa = 1 + e_minus;
+				const float bb = 1 + plus_e * e_minus;
+				const float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
+				const float delta = aa * (bb * bb) * (cc * cc);
+				dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
+				dalpha_dEp = -e_minus / (delta);
+				dEp_dinvs = plus_e * at.iter_cos * dt;
+				dEp_ditc = plus_e * at.inv_s * dt;
+				dE_ditc = (float)(-at.inv_s * e_minus * dt * 0.5);
+			}
+			const float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
+			const float dloss_dvariance = dloss_dinvs * at.inv_s * 10;
+			const float d_iter_cos_true_cos = (at.true_cos >= 0) ? 0.0f : 1.0f;
+			const float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
+			const float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
+			const float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
+			dl[3] = f2h(loss_scale * dloss_dsdf);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * at.g[d]);
+			dl[7] = f2h(loss_scale * dloss_dvariance);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
+			h8 w0, w1;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { w0[q] = dl[q]; w1[q] = dl[8 + q]; }
+			h8* dst = reinterpret_cast<h8*>(dloss + (size_t)j * 16);
+			dst[0] = w0;
+			dst[1] = w1;
 		}
-		const float sum_weight_suffix = weight_sum - weight_sum2;
-		float dot_term = 0.f;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) dot_term += grad[k] * (T * albedo[k] * shading - suffix[k]);
-		const float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (T - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
-		float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
-		if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
-			const float plus_sigmoid_x = at.inv_s * at.iter_cos * dt;
-			const float plus_e = expf(plus_sigmoid_x);
-			const float e_minus = expf(-at.est_next * at.inv_s);
-			dE_dsdf = -at.inv_s * e_minus;
-			dE_dinvs = -at.est_next * e_minus;
-			const float aa = 1 + e_minus;
-			const float bb = 1 + plus_e * e_minus;
-			const float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
-			const float delta = aa * (bb * bb) * (cc * cc);
-			dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
-			dalpha_dEp = -e_minus / (delta);
-			dEp_dinvs = plus_e * at.iter_cos * dt;
-			dEp_ditc = plus_e * at.inv_s * dt;
-			dE_ditc = (float)(-at.inv_s * e_minus * dt * 0.5);
-		}
-		const float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
-		const float dloss_dvariance = dloss_dinvs * at.inv_s * 10;
-		const float d_iter_cos_true_cos = (at.true_cos >= 0) ? 0.0f : 1.0f;
-		const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
-		const float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
-		const float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
-		const float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
-		dl[3] = f2h(loss_scale * dloss_dsdf);
-		ek += (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
-#pragma unroll
-		for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * at.g[d]);
-		dl[7] = f2h(loss_scale * dloss_dvariance);
-#pragma unroll
-		for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
-		h8 w0, w1;
-#pragma unroll
-		for (int q = 0; q < 8; ++q) { w0[q] = dl[q]; w1[q] = dl[8 + q]; }
-		h8* dst = reinterpret_cast<h8*>(dloss + (size_t)j * 16);
-		dst[0] = w0;
-		dst[1] = w1;
 	}
-	a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
+	if (lane == 0) a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)

@@ -112,7 +112,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_indices, numsteps, counters;
 	DevBuf<float> rays, coords, coords_compacted, loss, ek_loss, mask_loss;
 	DevBuf<half_t> mlp_out, dloss_dout;
-	DevBuf<float> ray_setup, ray_dunnorm;
+	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
 	DevBuf<RayLoss> ray_loss;
 	// training scratch
@@ -296,7 +296,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.A = c->aabb;
 	a.views = c->views.p;
 	a.bitfield = c->bitfield.p;
-	a.setup = c->ray_setup.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
+	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
 	return a;
 }
@@ -309,7 +309,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_RAYS);
-	hipLaunchKernelGGL(k_march_write, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_march_write, dim3((n_rays + 3) / 4), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -331,13 +331,13 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	HIP_TRY(hipMemsetAsync(c->loss.p, 0, sizeof(float) * n_rays, s));
 	HIP_TRY(hipMemsetAsync(c->ek_loss.p, 0, sizeof(float) * n_rays, s));
 	HIP_TRY(hipMemsetAsync(c->mask_loss.p, 0, sizeof(float) * n_rays, s));
-	const uint32_t blocks = (n_rays + 127) / 128;
+	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
 	c->prof.mark(s, P_LOSS_PASS1);
 	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
-	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(128), 0, s, a);
+	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
 	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
@@ -464,7 +464,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->ek_loss.free(); c->mask_loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->ray_setup.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
+	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
 	delete c;
@@ -513,7 +513,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
 	ALLOC(c->loss, maxr); ALLOC(c->ek_loss, maxr); ALLOC(c->mask_loss, maxr);
-	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
+	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
