@@ -292,6 +292,8 @@ struct TrainArgs {
 	const half_t* dout;    // [B][16]
 	uint32_t B;
 	float sdf_bias;
+	uint32_t skip_rgb; // --no-albedo: dL/d(rgb logits) is identically 0 (opti_rgb = 0, testbed_nerf.cu:1954-1962), so the
+	                   // colour MLP receives and propagates exact zeros: its forward/backward are skipped, not approximated
 	TrainScratch t;
 };
 
@@ -403,8 +405,10 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 			*reinterpret_cast<h8*>(tC + lane * S32 + 24) = v1;
 		}
 		wave_lds_sync();
+		uint64_t m_h1 = 0, m_h2 = 0;
+		float dn[3];
+		if (!a.skip_rgb) {
 		fm_store(tC, S32, 32, T.cin, B, s);
-		uint64_t m_h1, m_h2;
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
@@ -464,9 +468,14 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 			mfma_layer<2, 2>(wts + W_C0T, S64, tB, S64, acc, lane);
 			store_acc<2, false>(acc, tA, S32, 0, lane);
 		}
+		} else {
+			// dcin == 0
+			const h8 zero = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+			for (int q = 0; q < 4; ++q) *reinterpret_cast<h8*>(tA + lane * S32 + q * 8) = zero;
+		}
 		wave_lds_sync();
 		// dso = dcin[0:16], [0] += dL_doutput[3] (add_density_gradient); dn (nerf_network.h:343-373)
-		float dn[3];
 		{
 			const h8 a0 = *reinterpret_cast<const h8*>(tA + lane * S32 + 0);
 			const h8 a1 = *reinterpret_cast<const h8*>(tA + lane * S32 + 8);
@@ -611,6 +620,7 @@ struct DwFinishArgs {
 	uint32_t n_var_partials;
 	float* grads;            // GRADS_FP32
 	uint32_t off_sdf, off_rgb, off_var;
+	uint32_t skip_rgb;       // colour-MLP gradients are exactly zero (see TrainArgs::skip_rgb)
 };
 
 // 64 parameters per workgroup x 16 slices of the partial list (fixed summation order -> deterministic). Mirrors the
@@ -659,7 +669,9 @@ __global__ __launch_bounds__(1024) void k_dw_finish(const DwFinishArgs a) {
 		if (slice == 0) a.grads[a.off_sdf + i] = g;
 	} else {
 		const uint32_t j = i - RNB_N_SDF_MLP_PARAMS;
-		if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
+		if (a.skip_rgb) {
+			g = 0.f;
+		} else if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
 			const uint32_t o = j / 48, col = j % 48;
 			const uint32_t cc = col < 16 ? col : (col >= 32 ? col - 16 : 0);
 			const float v = rh(dw_sum(a.partial[2], 64 * 32, o * 32 + cc, a.n_partials, slice, sh, e));
@@ -764,6 +776,57 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridMeta G, const Sc
 	if (K > 1) flush();
 }
 
+// Fine (hashed) levels: every sample touches its own cells, so the cost is the number of atomic lane-operations. Four
+// adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a cell is the next table entry
+// (hash prime 1 / dense stride 1), so the four lanes' atomics fall on 16 contiguous bytes of one cache line and travel as
+// one request; each lane issues the 4 (dy, dz) corners.
+__global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, const ScatterArgs a, const uint32_t level0) {
+	const uint32_t level = blockIdx.y + level0;
+	if (level > G.valid_level) return;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t s = t >> 2;
+	if (s >= a.B) return;
+	const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+	float pos[3];
+	uint32_t pg[3];
+	pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
+	pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
+	pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
+	const float g1 = h2f(unpack_h2(a.g1[(size_t)level * a.B + s])[f]);
+	const float g2 = h2f(unpack_h2(a.g2[(size_t)level * a.B + s])[f]);
+	const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+#pragma unroll
+	for (uint32_t yz = 0; yz < 4; ++yz) {
+		const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+		float w[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
+		// first order: weight = 1 * wx * wy * wz in the reference's multiplication order (grid.h:478-490)
+		float weight = 1;
+		weight *= w[0]; weight *= w[1]; weight *= w[2];
+		float add = rh(g1 * weight);
+		// second order (grid.h:655-681): for each gradient dimension the corner is a 'left' (-) or 'right' (+) end
+#pragma unroll
+		for (uint32_t gd = 0; gd < 3; ++gd) {
+			float w2 = scale * dn[gd] * 1.0f;
+#pragma unroll
+			for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+				const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+				w2 *= w[d];
+			}
+			add += rh(g2 * (c[gd] ? w2 : -w2));
+		}
+		if (add != 0.f) {
+			const uint32_t e = grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]);
+			atomicAdd(gg + (size_t)e * 2 + f, add);
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.
 // ---------------------------------------------------------------------------------------------
@@ -776,31 +839,55 @@ struct AdamArgs {
 	float ema_decay, ema_debias_old, ema_debias_new;
 };
 
+// Four parameters per thread (n_params, n_matrix are multiples of 4): 16-byte fp32 / 8-byte fp16 accesses. Entries of
+// the hash grid whose gradient is zero only take the EMA path (adam.h:111-114), i.e. 10 B of traffic per parameter.
 __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * blockDim.x) {
-		const float graw = a.grads[i];
-		if (graw != 0.f) a.grads[i] = 0.f; // leave the accumulators clear for the next step
-		float gradient = rh(graw) / LOSS_SCALE; // the reference's gradient vector is half (trainer.h:78-84)
-		const bool is_matrix = i < a.n_matrix;
-		half_t w16 = a.w16[i];
-		if (is_matrix || gradient != 0.f) { // adam.h:111-114
-			const float weight_fp = a.w32[i];
-			if (is_matrix) gradient += a.l2_reg * weight_fp;
-			const float gradient_sq = gradient * gradient;
-			const float first_moment = a.m[i] = a.beta1 * a.m[i] + (1 - a.beta1) * gradient;
-			const float second_moment = a.v[i] = a.beta2 * a.v[i] + (1 - a.beta2) * gradient_sq;
-			float learning_rate = a.base_lr;
-			const uint32_t cs = ++a.steps[i];
-			learning_rate *= sqrtf(1 - powf(a.beta2, (float)cs)) / (1 - powf(a.beta1, (float)cs));
-			const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), 0.f), 3.402823466e+38f);
-			const float decayed_weight = (1 - 0.f * learning_rate) * weight_fp - copysignf(0.f * learning_rate, weight_fp);
-			const float new_weight = decayed_weight - effective_learning_rate * first_moment;
-			a.w32[i] = new_weight;
-			w16 = f2h(new_weight);
-			a.w16[i] = w16;
+	const uint64_t n4 = a.n / 4;
+	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t i0 = q * 4;
+		f4 graw = reinterpret_cast<const f4*>(a.grads)[q];
+		if (graw[0] != 0.f || graw[1] != 0.f || graw[2] != 0.f || graw[3] != 0.f) reinterpret_cast<f4*>(a.grads)[q] = f4{0.f, 0.f, 0.f, 0.f}; // leave the accumulators clear
+		h4 w16 = reinterpret_cast<const h4*>(a.w16)[q];
+		const h4 ema = reinterpret_cast<const h4*>(a.ema)[q];
+		const bool is_matrix = i0 < a.n_matrix;
+		bool any = is_matrix;
+		float gradient[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { gradient[k] = rh(graw[k]) / LOSS_SCALE; any = any || gradient[k] != 0.f; } // the reference's gradient vector is half (trainer.h:78-84)
+		if (any) {
+			f4 w32 = reinterpret_cast<const f4*>(a.w32)[q];
+			f4 m = reinterpret_cast<const f4*>(a.m)[q];
+			f4 v = reinterpret_cast<const f4*>(a.v)[q];
+			uint4 st = reinterpret_cast<const uint4*>(a.steps)[q];
+			uint32_t stp[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				if (!(is_matrix || gradient[k] != 0.f)) continue; // adam.h:111-114
+				const float weight_fp = w32[k];
+				float g = gradient[k];
+				if (is_matrix) g += a.l2_reg * weight_fp;
+				const float gradient_sq = g * g;
+				const float first_moment = m[k] = a.beta1 * m[k] + (1 - a.beta1) * g;
+				const float second_moment = v[k] = a.beta2 * v[k] + (1 - a.beta2) * gradient_sq;
+				float learning_rate = a.base_lr;
+				const uint32_t cs = ++stp[k];
+				learning_rate *= sqrtf(1 - powf(a.beta2, (float)cs)) / (1 - powf(a.beta1, (float)cs));
+				const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), 0.f), 3.402823466e+38f);
+				const float decayed_weight = (1 - 0.f * learning_rate) * weight_fp - copysignf(0.f * learning_rate, weight_fp);
+				const float new_weight = decayed_weight - effective_learning_rate * first_moment;
+				w32[k] = new_weight;
+				w16[k] = f2h(new_weight);
+			}
+			reinterpret_cast<f4*>(a.w32)[q] = w32;
+			reinterpret_cast<f4*>(a.m)[q] = m;
+			reinterpret_cast<f4*>(a.v)[q] = v;
+			reinterpret_cast<uint4*>(a.steps)[q] = make_uint4(stp[0], stp[1], stp[2], stp[3]);
+			reinterpret_cast<h4*>(a.w16)[q] = w16;
 		}
-		const float filtered = (h2f(a.ema[i]) * a.ema_decay * a.ema_debias_old + h2f(w16) * (1 - a.ema_decay)) * a.ema_debias_new;
-		a.ema[i] = f2h(filtered);
+		h4 e;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) e[k] = f2h((h2f(ema[k]) * a.ema_decay * a.ema_debias_old + h2f(w16[k]) * (1 - a.ema_decay)) * a.ema_debias_new);
+		reinterpret_cast<h4*>(a.ema)[q] = e;
 	}
 }
 

@@ -349,7 +349,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
 	TrainArgs a;
-	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts;
+	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
@@ -366,9 +366,11 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	float* p_sdf0b = p;                     p += slab * 64 * 32;
 	float* p_sdf1b = p;                     p += slab * 16 * 64;
 	const TrainScratch& T = c->ts;
-	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dr, T.h2, B, chunk, p_rgb2);
-	hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dh2, T.h1, B, chunk, p_rgb1);
-	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dh1, T.cin, B, chunk, p_rgb0);
+	if (!a.skip_rgb) {
+		hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dr, T.h2, B, chunk, p_rgb2);
+		hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dh2, T.h1, B, chunk, p_rgb1);
+		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dh1, T.cin, B, chunk, p_rgb0);
+	}
 	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dso, T.z1, B, chunk, p_sdf1);
 	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz, T.sdfin, B, chunk, p_sdf0);
 	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz1, T.ddin, B, chunk, p_sdf0b);
@@ -377,7 +379,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 	f.n_partials = (uint32_t)slab;
 	f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
-	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var;
+	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 	const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
 	hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, s, f);
 	c->prof.mark(s, P_DW);
@@ -393,10 +395,13 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 			hipLaunchKernelGGL(kern, dim3((threads + 255) / 256, l_end - l_begin), dim3(256), 0, s, c->meta(), sa, l_begin);
 		};
 		uint32_t e16 = 0, e4 = 0;
-		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= 128) e16 = l + 1; if (c->grid.resolution[l] <= 400) e4 = l + 1; }
+		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 128u;
+		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 128u;
+		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
 		launch(k_grid_scatter<16>, 16, 0, e16);
 		launch(k_grid_scatter<4>, 4, e16, e4);
-		launch(k_grid_scatter<1>, 1, e4, L);
+		if (getenv("RNB_SCATTER_NOQUAD")) launch(k_grid_scatter<1>, 1, e4, L);
+		else if (L > e4) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - e4), dim3(256), 0, s, c->meta(), sa, e4);
 	}
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
