@@ -267,6 +267,141 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 	a.steps[i] = steps;
 }
 
+// Same result as k_march_count, 16 lanes per ray. The sequence of march positions t_0 = startt, t_{k+1} = t_k + dt(t_k)
+// does not depend on the occupancy (the reference's advance_to_next_voxel steps by the same dt, testbed_nerf.cu:311-323),
+// only WHICH positions are visited does. Each round the 16 lanes of a ray test 16 consecutive positions at once (one
+// round of dependent bitfield loads instead of 16), exchange the outcomes with ballots, and every lane replays the
+// reference's sequential visit order over those outcomes with integer bit operations: occupied -> sample, next
+// position; empty -> jump to the first position at or beyond the voxel exit. Visited set and t values are identical.
+constexpr int MG = 16; // lanes per ray
+
+__global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
+	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
+	const int lane = threadIdx.x & 63;
+	const int g = lane & (MG - 1);
+	const int gb = lane & ~(MG - 1); // first lane of the group inside the wavefront
+	const bool ray_exists = i < a.n_rays;
+	Vec3 o = {0, 0, 0}, dir = {0, 0, 1}, du = {0, 0, 1}, idir = {0, 0, 1};
+	float t_cur = 0.f, startt = 0.f, alive = 0.f;
+	bool term = true;
+	if (ray_exists) {
+		const uint32_t gi = a.ray_offset + i;
+		const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+		const ViewDev m = a.views[img];
+		Pcg32 rng = a.rng;
+		rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+		float xy[2];
+		random_image_pos(rng, m.width, m.height, a.snap != 0, xy);
+		bool dead = false;
+		if (red_is_nonpositive(xy, m, m.normal)) {
+			if (rng.next_float() >= 0.9) dead = true; // testbed_nerf.cu:1264
+		}
+		if (!dead) {
+			(void)rng.next_float(); // motionblur_time
+			o = v3(m.xform[3], m.xform[7], m.xform[11]);
+			const Vec3 dcam = {
+				(xy[0] - m.principal[0]) * (float)m.width / m.focal[0],
+				(xy[1] - m.principal[1]) * (float)m.height / m.focal[1],
+				1.0f,
+			};
+			du = v3(m.xform[0] * dcam.x + m.xform[1] * dcam.y + m.xform[2] * dcam.z,
+			        m.xform[4] * dcam.x + m.xform[5] * dcam.y + m.xform[6] * dcam.z,
+			        m.xform[8] * dcam.x + m.xform[9] * dcam.y + m.xform[10] * dcam.z);
+			dir = normalized(du);
+			idir = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+			float tmin, tmax;
+			ray_intersect(a.A, o, dir, &tmin, &tmax);
+			tmin = fmaxf(tmin, 0.0f);
+			startt = tmin;
+			startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
+			t_cur = startt;
+			alive = 1.f;
+			term = false;
+		}
+	}
+	uint32_t j = 0;
+	bool have_pending = false;
+	float pending_target = 0.f;
+	float* tt = a.ray_t + (size_t)(ray_exists ? i : 0) * RNB_MAX_STEPS;
+	const float cone = a.A.cone_angle;
+	while (__any(!term)) {
+		// the next MG positions of the ray (every lane of the group computes the same values)
+		float T[MG + 1];
+		T[0] = t_cur;
+		float my_t = t_cur;
+#pragma unroll
+		for (int m = 0; m < MG; ++m) {
+			T[m + 1] = T[m] + calc_dt(T[m], cone);
+			if (m + 1 == g) my_t = T[m + 1];
+		}
+		// my position
+		const Vec3 pos = o + my_t * dir;
+		const bool inside = !term && aabb_contains(a.A, pos);
+		bool occ = false;
+		float t_target = 0.f;
+		uint32_t nxt = MG; // absolute index of the next visited position if mine is visited and empty
+		if (inside) {
+			const float dt = calc_dt(my_t, cone);
+			const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+			occ = density_grid_occupied_at(pos, a.bitfield, mip);
+			if (!occ) {
+				const uint32_t res = GRIDSIZE >> mip;
+				t_target = my_t + distance_to_next_voxel(pos, dir, idir, res);
+#pragma unroll
+				for (int m = MG - 1; m >= 1; --m) {
+					if (m > g && T[m] >= t_target) nxt = (uint32_t)m;
+				}
+			}
+		}
+		const unsigned long long occ_w = __ballot(occ), in_w = __ballot(inside);
+		const uint32_t nm1 = nxt - 1u; // 0..15
+		const unsigned long long p0 = __ballot(nm1 & 1u), p1 = __ballot(nm1 & 2u), p2 = __ballot(nm1 & 4u), p3 = __ballot(nm1 & 8u);
+		const uint32_t occ16 = (uint32_t)(occ_w >> gb) & 0xffffu, in16 = (uint32_t)(in_w >> gb) & 0xffffu;
+		const uint32_t q0 = (uint32_t)(p0 >> gb) & 0xffffu, q1 = (uint32_t)(p1 >> gb) & 0xffffu, q2 = (uint32_t)(p2 >> gb) & 0xffffu, q3 = (uint32_t)(p3 >> gb) & 0xffffu;
+		// replay of the sequential visit order over this round's outcomes
+		uint32_t vis = 0;
+		const uint32_t j0 = j;
+		int pend_src = -1;
+		if (!term) {
+			int cur = 0;
+			if (have_pending) { // continue the reference's do { t += dt } while (t < t_target) across the round boundary
+				cur = MG;
+#pragma unroll
+				for (int m = MG - 1; m >= 0; --m) if (T[m] >= pending_target) cur = m;
+				if (cur < MG) have_pending = false;
+			}
+			while (cur < MG) {
+				if (!((in16 >> cur) & 1u)) { term = true; break; } // left the box (testbed_nerf.cu:1337)
+				if ((occ16 >> cur) & 1u) {
+					const uint32_t run_mask = (occ16 & in16) >> cur;
+					int run = __builtin_ctz(~run_mask);
+					run = min(run, MG - cur);
+					const int allowed = min(run, (int)(RNB_MAX_STEPS - j));
+					vis |= ((1u << allowed) - 1u) << cur;
+					j += (uint32_t)allowed;
+					cur += allowed;
+					if (j >= RNB_MAX_STEPS) { term = true; break; }
+				} else {
+					const int nx = 1 + (int)(((q0 >> cur) & 1u) | (((q1 >> cur) & 1u) << 1) | (((q2 >> cur) & 1u) << 2) | (((q3 >> cur) & 1u) << 3));
+					if (nx >= MG) { have_pending = true; pend_src = cur; }
+					cur = nx;
+				}
+			}
+		}
+		// the empty lane that jumped beyond the round hands its voxel-exit target to the whole group
+		const float tgt = __shfl(t_target, gb + (pend_src < 0 ? 0 : pend_src), 64);
+		if (pend_src >= 0) pending_target = tgt;
+		if ((vis >> g) & 1u) tt[j0 + __popc(vis & ((1u << g) - 1u))] = my_t;
+		t_cur = T[MG];
+	}
+	if (ray_exists && g == 0) {
+		float* st = a.setup + (size_t)i * 8;
+		st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
+		a.d_unnorm[(size_t)i * 3 + 0] = du.x; a.d_unnorm[(size_t)i * 3 + 1] = du.y; a.d_unnorm[(size_t)i * 3 + 2] = du.z;
+		a.steps[i] = j;
+	}
+}
+
 // Single-workgroup exclusive scans over the rays (n <= 2^18): base = scan(steps); survivors = base + steps <= max_samples;
 // slot = scan(survivor). counters[0] = sum(steps) (numsteps_counter), [2] = #survivors (ray_counter), [3] = samples written.
 __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint32_t max_samples, const uint32_t* __restrict__ steps,

@@ -305,7 +305,8 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	if (getenv("RNB_MARCH_NARROW")) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	else hipLaunchKernelGGL(k_march_count_wide, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_RAYS);
