@@ -123,6 +123,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+struct __attribute__((packed, aligned(4))) U2 { uint32_t x, y; }; // 8-byte gather at 4-byte alignment (global_load_dwordx2)
+
 // ---- hash-grid indexing (grid.h:113-148; N_DIMS = 3, F = 2, GridType::Hash) ----
 __device__ __forceinline__ uint32_t grid_entry(uint32_t hashmap_size, uint32_t res, uint32_t px, uint32_t py, uint32_t pz) {
 	// The stride loop of grid.h:137-141, unrolled; all conditions are wave-uniform (per level).
@@ -168,11 +170,20 @@ __device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* 
 	pos_fract(x, scale, &pos[0], &pg[0]);
 	pos_fract(y, scale, &pos[1], &pg[1]);
 	pos_fract(z, scale, &pos[2], &pg[2]);
+	// The x-neighbour of a cell is the next table entry on dense levels and, on hashed levels, whenever x is even
+	// (hash prime 1): one 8-byte gather then serves both corners. Random gathers are bound by the number of lane
+	// accesses the L1 processes, not by bytes, so this removes ~1/3 of the cost. (Entry `size` is readable: the
+	// parameter block continues past every level.)
 	uint32_t v[8];
 #pragma unroll
-	for (uint32_t idx = 0; idx < 8; ++idx) {
-		const uint32_t e = grid_entry(hashmap_size, res, pg[0] + (idx & 1u), pg[1] + ((idx >> 1) & 1u), pg[2] + ((idx >> 2) & 1u));
-		v[idx] = g[e];
+	for (uint32_t yz = 0; yz < 4; ++yz) {
+		const uint32_t e0 = grid_entry(hashmap_size, res, pg[0], pg[1] + (yz & 1u), pg[2] + (yz >> 1));
+		const uint32_t e1 = grid_entry(hashmap_size, res, pg[0] + 1u, pg[1] + (yz & 1u), pg[2] + (yz >> 1));
+		const U2 p = *reinterpret_cast<const U2*>(g + e0);
+		uint32_t v1 = p.y;
+		if (e1 != e0 + 1u) v1 = g[e1];
+		v[yz * 2 + 0] = p.x;
+		v[yz * 2 + 1] = v1;
 	}
 	half_t r0 = (half_t)0.f, r1 = (half_t)0.f;
 #pragma unroll
