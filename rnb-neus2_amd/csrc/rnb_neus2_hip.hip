@@ -399,10 +399,18 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 128u;
 		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 128u;
 		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
+		if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: one launch per level
+			for (l = 0; l < L; ++l) {
+				if (l < e16) launch(k_grid_scatter<16>, 16, l, l + 1);
+				else if (l < e4) launch(k_grid_scatter<4>, 4, l, l + 1);
+				else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+			}
+		} else {
 		launch(k_grid_scatter<16>, 16, 0, e16);
 		launch(k_grid_scatter<4>, 4, e16, e4);
 		if (getenv("RNB_SCATTER_NOQUAD")) launch(k_grid_scatter<1>, 1, e4, L);
 		else if (L > e4) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - e4), dim3(256), 0, s, c->meta(), sa, e4);
+		}
 	}
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
