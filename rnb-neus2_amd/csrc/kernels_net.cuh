@@ -776,6 +776,98 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridMeta G, const Sc
 	if (K > 1) flush();
 }
 
+// Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
+// global atomics pile up on a handful of addresses. Each workgroup accumulates its slice of the batch into a private copy
+// of the level's gradient table in LDS (ds_add_f32), with the same run-length merge in registers, then flushes the
+// non-zero entries once.
+struct ScatterLdsArgs { ScatterArgs a; uint32_t level; uint32_t samples_per_wg; };
+
+__global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	float* tab = reinterpret_cast<float*>(smem_raw);
+	const ScatterArgs& a = p.a;
+	const uint32_t level = p.level;
+	if (level > G.valid_level) return;
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const uint32_t n_tab = hashmap_size * 2;
+	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) tab[q] = 0.f;
+	__syncthreads();
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+	constexpr int K = 8;
+	const uint32_t wg_begin = blockIdx.x * p.samples_per_wg;
+	const uint32_t wg_end = min(wg_begin + p.samples_per_wg, a.B);
+	for (uint32_t s0 = wg_begin + threadIdx.x * K; s0 < wg_end; s0 += blockDim.x * K) {
+		float acc[8][2];
+		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+		for (int q = 0; q < 8; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
+		auto flush = [&]() {
+#pragma unroll
+			for (uint32_t idx = 0; idx < 8; ++idx) {
+				if (acc[idx][0] == 0.f && acc[idx][1] == 0.f) continue;
+				const uint32_t e = grid_entry(hashmap_size, res, cur[0] + (idx & 1u), cur[1] + ((idx >> 1) & 1u), cur[2] + ((idx >> 2) & 1u));
+				if (acc[idx][0] != 0.f) atomicAdd(tab + e * 2 + 0, acc[idx][0]);
+				if (acc[idx][1] != 0.f) atomicAdd(tab + e * 2 + 1, acc[idx][1]);
+				acc[idx][0] = 0.f; acc[idx][1] = 0.f;
+			}
+		};
+#pragma unroll 1
+		for (int j = 0; j < K; ++j) {
+			const uint32_t s = s0 + j;
+			if (s >= wg_end) break;
+			float pos[3];
+			uint32_t pg[3];
+			pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
+			pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
+			pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
+			if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+				if (cur[0] != 0xffffffffu) flush();
+			}
+			cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+			const h2 q1 = unpack_h2(a.g1[(size_t)level * a.B + s]);
+			const h2 q2 = unpack_h2(a.g2[(size_t)level * a.B + s]);
+			const float g1[2] = {h2f(q1[0]), h2f(q1[1])};
+			const float g2[2] = {h2f(q2[0]), h2f(q2[1])};
+			const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+#pragma unroll
+			for (uint32_t idx = 0; idx < 8; ++idx) {
+				float weight = 1;
+#pragma unroll
+				for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
+				acc[idx][0] += rh(g1[0] * weight);
+				acc[idx][1] += rh(g1[1] * weight);
+			}
+#pragma unroll
+			for (uint32_t gd = 0; gd < 3; ++gd) {
+				const float grad_in = scale * dn[gd] * 1.0f;
+#pragma unroll
+				for (uint32_t idx = 0; idx < 4; ++idx) {
+					float weight = grad_in;
+					uint32_t corner = 0;
+#pragma unroll
+					for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+						const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+						if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
+						else { weight *= pos[d]; corner |= (1u << d); }
+					}
+					acc[corner][0] += rh(g2[0] * -weight);
+					acc[corner][1] += rh(g2[1] * -weight);
+					acc[corner | (1u << gd)][0] += rh(g2[0] * weight);
+					acc[corner | (1u << gd)][1] += rh(g2[1] * weight);
+				}
+			}
+		}
+		flush();
+	}
+	__syncthreads();
+	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) {
+		const float v = tab[q];
+		if (v != 0.f) atomicAdd(gg + q, v);
+	}
+}
+
 // Fine (hashed) levels: every sample touches its own cells, so the cost is the number of atomic lane-operations. Four
 // adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a cell is the next table entry
 // (hash prime 1 / dense stride 1), so the four lanes' atomics fall on 16 contiguous bytes of one cache line and travel as

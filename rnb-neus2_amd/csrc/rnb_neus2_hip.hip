@@ -396,8 +396,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 			hipLaunchKernelGGL(kern, dim3((threads + 255) / 256, l_end - l_begin), dim3(256), 0, s, c->meta(), sa, l_begin);
 		};
 		uint32_t e16 = 0, e4 = 0;
-		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 128u;
-		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 128u;
+		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 24u;
+		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 24u;
 		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
 		if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: one launch per level
 			for (l = 0; l < L; ++l) {
@@ -406,7 +406,23 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 				else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
 			}
 		} else {
-		launch(k_grid_scatter<16>, 16, 0, e16);
+		// levels whose gradient table fits in LDS (fp32 x 2 features): private per-workgroup accumulation
+		uint32_t e_lds = 0;
+		if (!getenv("RNB_SCATTER_NOLDS")) {
+			for (l = 0; l < L; ++l) {
+				const size_t bytes = (size_t)(c->grid.offsets[l + 1] - c->grid.offsets[l]) * 8;
+				if (l == e_lds && bytes <= 120 * 1024) {
+					ScatterLdsArgs la; la.a = sa; la.level = l;
+					const uint32_t n_wg = std::min<uint32_t>(128u, (B + 2047) / 2048);
+					la.samples_per_wg = ((B + n_wg - 1) / n_wg + 7) / 8 * 8;
+					hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), bytes, s, c->meta(), la);
+					e_lds = l + 1;
+				}
+			}
+		}
+		if (e16 < e_lds) e16 = e_lds;
+		if (e4 < e_lds) e4 = e_lds;
+		launch(k_grid_scatter<16>, 16, e_lds, e16);
 		launch(k_grid_scatter<4>, 4, e16, e4);
 		if (getenv("RNB_SCATTER_NOQUAD")) launch(k_grid_scatter<1>, 1, e4, L);
 		else if (L > e4) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - e4), dim3(256), 0, s, c->meta(), sa, e4);
@@ -571,6 +587,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
 	c->density_grid_rng = Pcg32{c->rng.next_uint()};
