@@ -98,7 +98,8 @@ typedef struct rnb_config {
 	/* data parallel: this process is `rank` of `world_size`; see DESIGN.md §multi-GPU */
 	uint32_t world_size;              /* 1 */
 	uint32_t rank;                    /* 0 */
-	uint32_t reserved[8];
+	uint32_t only_sdf_training;       /* 0; Adam skips the colour MLP (adam.h:121-165), set by --fractional-training (testbed.cu:1886-1895) */
+	uint32_t reserved[7];
 } rnb_config;
 
 /* One training view — TrainingImageMetadata + TrainingXForm (nerf_loader.h:33-49). */
@@ -163,6 +164,10 @@ int rnb_default_config(rnb_config* cfg);
  * occupancy grid and step scratch on the current HIP device. */
 int rnb_create(const rnb_config* cfg, rnb_ctx** out);
 int rnb_destroy(rnb_ctx* ctx);
+/* Re-reads the run-time switches from cfg — the Testbed setters of src/testbed.cu:255-323 (apply_L2, apply_no_albedo,
+ * set_mask_weight, ...), the optimizer hyper-parameters re-applied every step (testbed.cu:2823-2835) and
+ * only_sdf_training. Geometry fields (levels, batch size, seed, ranks) must be unchanged. */
+int rnb_update_config(rnb_ctx* ctx, const rnb_config* cfg);
 
 /* ---- parameters ------------------------------------------------------- */
 /* NerfNetwork::n_params (nerf_network.h:722-724): 3072 + 8192 + grid + 4. */
@@ -179,6 +184,10 @@ int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
  * reset Adam state (trainer.h:263-275). Syncs. */
 int rnb_set_params(rnb_ctx* ctx, const float* params_host);
 int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
+/* Caller-owned device scratch (GPUMemory<T> in the reference, e.g. the lattice of get_density_on_grid,
+ * src/testbed_nerf.cu:4218-4269). Host memory in the CPU checker. */
+int rnb_device_malloc(rnb_ctx* ctx, uint64_t n_bytes, void** ptr);
+int rnb_device_free(rnb_ctx* ctx, void* ptr);
 int rnb_memcpy(rnb_ctx* ctx, void* dst, const void* src, uint64_t n_bytes, int kind); /* syncs */
 
 /* ---- dataset ---------------------------------------------------------- */

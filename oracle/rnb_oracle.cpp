@@ -28,43 +28,7 @@
 #include "orc_common.h"
 
 // Export the rnb_neus2.h signatures under the orc_ prefix.
-#define rnb_last_error orc_last_error
-#define rnb_abi_version orc_abi_version
-#define rnb_default_config orc_default_config
-#define rnb_create orc_create
-#define rnb_destroy orc_destroy
-#define rnb_n_params orc_n_params
-#define rnb_param_layout orc_param_layout
-#define rnb_grid_tables orc_grid_tables
-#define rnb_init_params orc_init_params
-#define rnb_set_params orc_set_params
-#define rnb_buffer orc_buffer
-#define rnb_memcpy orc_memcpy
-#define rnb_set_dataset orc_set_dataset
-#define rnb_set_training_step orc_set_training_step
-#define rnb_valid_level orc_valid_level
-#define rnb_update_density_grid orc_update_density_grid
-#define rnb_update_density_bitfield orc_update_density_bitfield
-#define rnb_density orc_density
-#define rnb_sdf orc_sdf
-#define rnb_forward_infer orc_forward_infer
-#define rnb_generate_training_samples orc_generate_training_samples
-#define rnb_compute_loss orc_compute_loss
-#define rnb_forward_backward orc_forward_backward
-#define rnb_optimizer_step orc_optimizer_step
-#define rnb_train_step orc_train_step
-#define rnb_train_step_begin orc_train_step_begin
-#define rnb_train_step_end orc_train_step_end
-#define rnb_train_step_apply orc_train_step_apply
-#define rnb_train_step_local orc_train_step_local
-#define rnb_train_step_finish orc_train_step_finish
-#define rnb_training_step orc_training_step
-#define rnb_profile_enable orc_profile_enable
-#define rnb_profile_count orc_profile_count
-#define rnb_profile_get orc_profile_get
-#define rnb_rays_per_batch orc_rays_per_batch
-#define rnb_set_controller orc_set_controller
-#define rnb_ctx orc_ctx_s
+#include "orc_prefix.h"
 #include "../include/rnb_neus2.h"
 
 #include <algorithm>
@@ -1293,6 +1257,7 @@ void optimizer_step(orc_ctx_s* c) {
 		float gradient = h2f(f2h(c->grads[i])) / LOSS_SCALE;
 		const bool is_matrix = i < n_matrix;
 		if (!is_matrix && gradient == 0) continue;
+		if (cfg.only_sdf_training && i >= c->off_rgb && i < c->off_grid) continue; // found_reflectance && only_sdf_training (adam.h:121-165)
 		const float weight_fp = w32[i];
 		if (is_matrix) gradient += cfg.l2_reg * weight_fp;
 		const float gradient_sq = gradient * gradient;
@@ -1412,6 +1377,19 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 }
 
 int rnb_destroy(orc_ctx_s* c) { delete c; return RNB_OK; }
+int rnb_update_config(orc_ctx_s* c, const rnb_config* cfg) {
+	if (!c || !cfg) return fail(RNB_ERR_INVALID, "null argument");
+	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
+	rnb_config& dst = c->cfg;
+	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
+	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank)
+		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
+	dst = *cfg;
+	build_light_dirs(c);
+	return RNB_OK;
+}
+
 uint64_t rnb_n_params(const orc_ctx_s* c) { return c ? c->n_params : 0; }
 
 int rnb_param_layout(const orc_ctx_s* c, uint64_t offsets[5]) {
@@ -1532,6 +1510,18 @@ int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
+}
+
+int rnb_device_malloc(orc_ctx_s* c, uint64_t n_bytes, void** ptr) {
+	if (!c || !ptr) return fail(RNB_ERR_INVALID, "null argument");
+	*ptr = n_bytes ? std::malloc(n_bytes) : nullptr;
+	if (n_bytes && !*ptr) return fail(RNB_ERR_NOMEM, "malloc failed");
+	return RNB_OK;
+}
+int rnb_device_free(orc_ctx_s* c, void* ptr) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	std::free(ptr);
+	return RNB_OK;
 }
 
 int rnb_memcpy(orc_ctx_s*, void* dst, const void* src, uint64_t n_bytes, int) {

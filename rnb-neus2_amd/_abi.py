@@ -56,7 +56,8 @@ class Config(C.Structure):
         ("density_grid_decay", C.c_float),
         ("world_size", C.c_uint32),
         ("rank", C.c_uint32),
-        ("reserved", C.c_uint32 * 8),
+        ("only_sdf_training", C.c_uint32),
+        ("reserved", C.c_uint32 * 7),
     ]
 
 
@@ -116,6 +117,7 @@ PROTOTYPES = {
     "default_config": (_i, [C.POINTER(Config)]),
     "create": (_i, [C.POINTER(Config), C.POINTER(_ctx)]),
     "destroy": (_i, [_ctx]),
+    "update_config": (_i, [_ctx, C.POINTER(Config)]),
     "n_params": (_u64, [_ctx]),
     "param_layout": (_i, [_ctx, C.POINTER(_u64)]),
     "grid_tables": (_i, [_ctx, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_float)]),
@@ -123,6 +125,8 @@ PROTOTYPES = {
     "set_params": (_i, [_ctx, C.POINTER(C.c_float)]),
     "buffer": (_i, [_ctx, _i, C.POINTER(C.c_void_p), C.POINTER(_u64)]),
     "memcpy": (_i, [_ctx, C.c_void_p, C.c_void_p, _u64, _i]),
+    "device_malloc": (_i, [_ctx, _u64, C.POINTER(C.c_void_p)]),
+    "device_free": (_i, [_ctx, C.c_void_p]),
     "set_dataset": (_i, [_ctx, _u32, C.POINTER(View), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "set_training_step": (_i, [_ctx, _u32]),
     "valid_level": (_u32, [_ctx]),

@@ -112,6 +112,14 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def update_config(self, **overrides):
+        """Run-time switches (loss flags, weights, optimizer hyper-parameters, only_sdf_training)."""
+        for k, v in overrides.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError("rnb_config has no field %r" % k)
+            setattr(self.cfg, k, v)
+        self._check(self.f.update_config(self._h, C.byref(self.cfg)))
+
     @property
     def n_params(self):
         return int(self.f.n_params(self._h))

@@ -37,5 +37,28 @@ def build(force=False, verbose=False):
     return OUT
 
 
+ROOT = os.path.dirname(PKG_DIR)
+TESTBED_SRC = os.path.join(PKG_DIR, "host", "testbed_main.cpp")
+TESTBED_OUT = os.path.join(ROOT, "build", "testbed")
+TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp")] + [
+    os.path.join(ROOT, "include", "rnb_neus2.h")]
+
+
+def build_testbed(force=False, verbose=False):
+    """`build/testbed`: the reference's command line (src/main.cu) over the C-ABI; plain g++, links the HIP library + zlib."""
+    if not force and os.path.exists(TESTBED_OUT):
+        t = os.path.getmtime(TESTBED_OUT)
+        if not any(os.path.getmtime(d) > t for d in TESTBED_DEPS):
+            return TESTBED_OUT
+    os.makedirs(os.path.dirname(TESTBED_OUT), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
+           "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TESTBED_OUT
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_testbed(force=True, verbose=True))

@@ -929,6 +929,7 @@ struct AdamArgs {
 	float* grads; float* m; float* v; uint32_t* steps;
 	float base_lr, beta1, beta2, epsilon, l2_reg;
 	float ema_decay, ema_debias_old, ema_debias_new;
+	uint64_t skip_lo, skip_hi; // only_sdf_training: parameters [skip_lo, skip_hi) (the colour MLP) get no Adam update (adam.h:121-165)
 };
 
 // Four parameters per thread (n_params, n_matrix are multiples of 4): 16-byte fp32 / 8-byte fp16 accesses. Entries of
@@ -946,6 +947,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 		float gradient[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) { gradient[k] = rh(graw[k]) / LOSS_SCALE; any = any || gradient[k] != 0.f; } // the reference's gradient vector is half (trainer.h:78-84)
+		if (i0 >= a.skip_lo && i0 < a.skip_hi) any = false;
 		if (any) {
 			f4 w32 = reinterpret_cast<const f4*>(a.w32)[q];
 			f4 m = reinterpret_cast<const f4*>(a.m)[q];

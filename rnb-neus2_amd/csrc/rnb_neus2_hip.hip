@@ -446,6 +446,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	a.grads = c->grads.p; a.m = c->adam_m.p; a.v = c->adam_v.p; a.steps = c->adam_steps.p;
 	a.base_lr = cfg.learning_rate * c->lr_factor; a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.epsilon = cfg.epsilon; a.l2_reg = cfg.l2_reg;
 	a.ema_decay = cfg.ema_decay;
+	a.skip_lo = cfg.only_sdf_training ? (uint64_t)c->off_rgb : 0; a.skip_hi = cfg.only_sdf_training ? (uint64_t)c->off_grid : 0;
 	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1); // ema.h:116-117
 	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
 	c->prof.mark(s, P_NONE);
@@ -458,6 +459,17 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 }
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int update_config_common(rnb_config& dst, const rnb_config* cfg) {
+	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
+	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
+	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank)
+		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
+	dst = *cfg;
+	return RNB_OK;
+}
+
 
 } // namespace
 
@@ -600,6 +612,14 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	return RNB_OK;
 }
 
+int rnb_update_config(rnb_ctx* c, const rnb_config* cfg) {
+	if (!c || !cfg) return fail(RNB_ERR_INVALID, "null argument");
+	int rc = update_config_common(c->cfg, cfg);
+	if (rc != RNB_OK) return rc;
+	build_light_dirs(c);
+	return RNB_OK;
+}
+
 uint64_t rnb_n_params(const rnb_ctx* c) { return c ? c->n_params : 0; }
 
 int rnb_param_layout(const rnb_ctx* c, uint64_t offsets[5]) {
@@ -705,6 +725,19 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
+}
+
+int rnb_device_malloc(rnb_ctx* c, uint64_t n_bytes, void** ptr) {
+	if (!c || !ptr) return fail(RNB_ERR_INVALID, "null argument");
+	*ptr = nullptr;
+	if (n_bytes == 0) return RNB_OK;
+	if (hipMalloc(ptr, n_bytes) != hipSuccess) return fail(RNB_ERR_NOMEM, "hipMalloc failed");
+	return RNB_OK;
+}
+int rnb_device_free(rnb_ctx* c, void* ptr) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (ptr) HIP_TRY(hipFree(ptr));
+	return RNB_OK;
 }
 
 int rnb_memcpy(rnb_ctx*, void* dst, const void* src, uint64_t n_bytes, int kind) {

@@ -1,0 +1,151 @@
+// mesh.hpp — iso-surface extraction and OBJ output for `--save-mesh` (src/marching_cubes.cu:276-430, 794-982;
+// src/testbed_nerf.cu:4218-4350). Vertices sit on lattice edges exactly where the reference's gen_vertices puts them
+// (linear interpolation of the SDF lattice, one shared vertex per crossing edge). The cell triangulation table is
+// generated here from first principles (face-by-face contour tracing with the "separate the inside corners" rule) rather
+// than taken from the published Bourke table: same vertex set, watertight, possibly different diagonals in ambiguous
+// cells. Faces are wound counter-clockwise around the outward (sdf > threshold side) normal.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mesh {
+
+struct Vec3 { float x, y, z; };
+
+// corner c -> (x, y, z) offsets; edges e -> (corner a, corner b). Numbering as in src/marching_cubes.cu:261-275.
+static const int CORNER[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+static const int EDGE[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+
+struct Tables {
+	// tri[mask] = list of edge ids, 3 per triangle, -1 terminated (at most 12 triangles)
+	std::array<std::array<int8_t, 40>, 256> tri;
+	Tables() {
+		// faces with corners in counter-clockwise order seen from OUTSIDE the cube
+		static const int FACE[6][4] = {{0, 3, 2, 1} /* z=0 */, {4, 5, 6, 7} /* z=1 */, {0, 1, 5, 4} /* y=0 */, {2, 3, 7, 6} /* y=1 */, {0, 4, 7, 3} /* x=0 */, {1, 2, 6, 5} /* x=1 */};
+		auto edge_between = [](int a, int b) {
+			for (int e = 0; e < 12; ++e) if ((EDGE[e][0] == a && EDGE[e][1] == b) || (EDGE[e][0] == b && EDGE[e][1] == a)) return e;
+			return -1;
+		};
+		for (int mask = 0; mask < 256; ++mask) {
+			int next[12];
+			for (int e = 0; e < 12; ++e) next[e] = -1;
+			for (int f = 0; f < 6; ++f) {
+				bool in[4];
+				int n_in = 0;
+				for (int k = 0; k < 4; ++k) { in[k] = (mask >> FACE[f][k]) & 1; n_in += in[k]; }
+				if (n_in == 0 || n_in == 4) continue;
+				// every maximal run of inside corners along the CCW cycle contributes one segment: from the edge where the
+				// run is left (inside -> outside) to the edge where it was entered (outside -> inside); inside lies on its left.
+				for (int k = 0; k < 4; ++k) {
+					if (in[k] && !in[(k + 1) & 3]) { // run ends at corner k
+						int s = k;
+						while (in[(s + 3) & 3]) s = (s + 3) & 3; // first corner of the run
+						const int exit_edge = edge_between(FACE[f][k], FACE[f][(k + 1) & 3]);
+						const int entry_edge = edge_between(FACE[f][(s + 3) & 3], FACE[f][s]);
+						next[exit_edge] = entry_edge;
+					}
+				}
+			}
+			int n = 0;
+			bool used[12] = {false};
+			for (int e0 = 0; e0 < 12; ++e0) {
+				if (next[e0] < 0 || used[e0]) continue;
+				int loop[12], len = 0;
+				for (int e = e0; !used[e]; e = next[e]) { used[e] = true; loop[len++] = e; if (next[e] < 0) { len = 0; break; } }
+				for (int k = 1; k + 1 < len; ++k) { tri[mask][n++] = (int8_t)loop[0]; tri[mask][n++] = (int8_t)loop[k]; tri[mask][n++] = (int8_t)loop[k + 1]; }
+			}
+			tri[mask][n] = -1;
+		}
+	}
+};
+
+struct Mesh {
+	std::vector<Vec3> verts, normals, colors;
+	std::vector<uint32_t> indices;
+};
+
+// density[x + y*rx + z*rx*ry]; lattice point (x,y,z) sits at aabb_min + (x,y,z) * (aabb_max - aabb_min) / res
+inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const float aabb_min[3], const float aabb_max[3], float thresh) {
+	static const Tables T;
+	Mesh m;
+	const size_t res2 = (size_t)rx * ry, res3 = res2 * rz;
+	std::vector<int32_t> vidx(res3 * 3, -1);
+	const float sc[3] = {(aabb_max[0] - aabb_min[0]) / rx, (aabb_max[1] - aabb_min[1]) / ry, (aabb_max[2] - aabb_min[2]) / rz};
+	auto inside = [&](size_t i) { return density[i] > thresh; };
+	for (int z = 0; z < rz; ++z) for (int y = 0; y < ry; ++y) for (int x = 0; x < rx; ++x) { // gen_vertices (marching_cubes.cu:276-327)
+		const size_t idx = (size_t)x + (size_t)y * rx + (size_t)z * res2;
+		const float f0 = density[idx];
+		const bool in0 = f0 > thresh;
+		const int lim[3] = {rx - 1, ry - 1, rz - 1};
+		const int p[3] = {x, y, z};
+		const size_t step[3] = {1, (size_t)rx, res2};
+		for (int a = 0; a < 3; ++a) {
+			if (p[a] >= lim[a]) continue;
+			const float f1 = density[idx + step[a]];
+			if (in0 != (f1 > thresh)) {
+				const float dt = (thresh - f0) / (f1 - f0);
+				float q[3] = {(float)x, (float)y, (float)z};
+				q[a] += dt;
+				vidx[idx + res3 * a] = (int32_t)m.verts.size();
+				m.verts.push_back({q[0] * sc[0] + aabb_min[0], q[1] * sc[1] + aabb_min[1], q[2] * sc[2] + aabb_min[2]});
+			}
+		}
+	}
+	for (int z = 0; z + 1 < rz; ++z) for (int y = 0; y + 1 < ry; ++y) for (int x = 0; x + 1 < rx; ++x) { // gen_faces
+		const size_t idx = (size_t)x + (size_t)y * rx + (size_t)z * res2;
+		int mask = 0;
+		for (int c = 0; c < 8; ++c) if (inside(idx + CORNER[c][0] + (size_t)CORNER[c][1] * rx + (size_t)CORNER[c][2] * res2)) mask |= 1 << c;
+		if (mask == 0 || mask == 255) continue;
+		const int8_t* t = T.tri[mask].data();
+		for (int k = 0; t[k] >= 0; ++k) {
+			const int e = t[k];
+			const int a = EDGE[e][0], b = EDGE[e][1];
+			int axis = 0;
+			for (int d = 0; d < 3; ++d) if (CORNER[a][d] != CORNER[b][d]) axis = d;
+			const int lo = (CORNER[a][0] + CORNER[a][1] + CORNER[a][2] <= CORNER[b][0] + CORNER[b][1] + CORNER[b][2]) ? a : b;
+			const size_t cidx = idx + CORNER[lo][0] + (size_t)CORNER[lo][1] * rx + (size_t)CORNER[lo][2] * res2;
+			const int32_t v = vidx[cidx + res3 * axis];
+			if (v < 0) throw std::runtime_error("marching cubes: missing edge vertex");
+			m.indices.push_back((uint32_t)v);
+		}
+	}
+	// area-weighted vertex normals (compute_mesh_1ring, marching_cubes.cu:330-365), outward orientation
+	m.normals.assign(m.verts.size(), {0, 0, 0});
+	for (size_t i = 0; i + 2 < m.indices.size(); i += 3) {
+		const uint32_t ia = m.indices[i], ib = m.indices[i + 1], ic = m.indices[i + 2];
+		const Vec3 a = m.verts[ia], b = m.verts[ib], c = m.verts[ic];
+		const Vec3 u = {b.x - a.x, b.y - a.y, b.z - a.z}, v = {c.x - a.x, c.y - a.y, c.z - a.z};
+		const Vec3 n = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+		for (uint32_t q : {ia, ib, ic}) { m.normals[q].x += n.x; m.normals[q].y += n.y; m.normals[q].z += n.z; }
+	}
+	return m;
+}
+
+// OBJ with per-vertex colours and normals (save_mesh, marching_cubes.cu:922-981): v = n2w_s * ((p - offset) / scale) + n2w_t
+inline void save_obj(const std::string& path, const Mesh& m, float nerf_scale, const float nerf_offset[3], float n2w_s, const float n2w_t[3]) {
+	FILE* f = std::fopen(path.c_str(), "wb");
+	if (!f) throw std::runtime_error("cannot write " + path);
+	for (size_t i = 0; i < m.verts.size(); ++i) {
+		const Vec3 v = m.verts[i];
+		const float p[3] = {n2w_s * ((v.x - nerf_offset[0]) / nerf_scale) + n2w_t[0], n2w_s * ((v.y - nerf_offset[1]) / nerf_scale) + n2w_t[1], n2w_s * ((v.z - nerf_offset[2]) / nerf_scale) + n2w_t[2]};
+		const Vec3 c = i < m.colors.size() ? m.colors[i] : Vec3{1.f, 1.f, 1.f};
+		auto cl = [](float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); };
+		std::fprintf(f, "v %0.5f %0.5f %0.5f %0.3f %0.3f %0.3f\n", p[0], p[1], p[2], cl(c.x), cl(c.y), cl(c.z));
+	}
+	for (const Vec3& n0 : m.normals) {
+		Vec3 n = {n2w_s * n0.x, n2w_s * n0.y, n2w_s * n0.z};
+		const float l = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+		if (l > 0.f) { n.x /= l; n.y /= l; n.z /= l; }
+		std::fprintf(f, "vn %0.5f %0.5f %0.5f\n", n.x, n.y, n.z);
+	}
+	for (size_t i = 0; i + 2 < m.indices.size(); i += 3)
+		std::fprintf(f, "f %u//%u %u//%u %u//%u\n", m.indices[i] + 1, m.indices[i] + 1, m.indices[i + 1] + 1, m.indices[i + 1] + 1, m.indices[i + 2] + 1, m.indices[i + 2] + 1);
+	std::fclose(f);
+}
+
+} // namespace mesh

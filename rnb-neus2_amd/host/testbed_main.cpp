@@ -1,0 +1,556 @@
+// testbed_main.cpp — the `./build/testbed` command line of the reference (src/main.cu:73-472), host side in C++ over the
+// C-ABI of include/rnb_neus2.h. Same flags, defaults, exit codes, output paths and stdout progress line; the training hot
+// path runs in librnb_neus2_hip.so. No GUI (the pipeline always passes --no-gui, rnb_neus2/pipeline.py:37).
+//
+//   testbed --scene <dir>/ --maxiter N --no-gui --mask-weight F [--save-snapshot] [--save-mesh --resolution R]
+//           [--snapshot PATH] [--opti-lights] [--no-albedo] [--free-memory] [--lone] [--supernormal] [--no-rgbplus]
+//           [--relu] [--bce] [--disable-snap-to-center] [-n/-c/--network/--config CFG] [--no-train] [--save-each N]
+//           [--fractional-training N] [--width W] [--height H] [-v/--version] [-h/--help]
+#include "../../include/rnb_neus2.h"
+#include "dataset.hpp"
+#include "json_min.hpp"
+#include "mesh.hpp"
+#include "msgpack_min.hpp"
+#include "png16.hpp"
+
+#include <sys/stat.h>
+#include <dirent.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define NGP_VERSION "rnb-neus2-mi355x 0.1"
+
+namespace {
+
+using namespace hostio;
+std::string exe_dir() {
+	char buf[4096];
+	ssize_t n = ::readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+	if (n <= 0) return ".";
+	buf[n] = 0;
+	return parent_path(buf);
+}
+
+// ---- args (dependencies/args semantics as used by src/main.cu:83-258) ----
+struct FlagSpec { std::vector<std::string> names; bool has_value; const char* meta; const char* help; };
+const std::vector<FlagSpec> FLAGS = {
+	{{"h", "help"}, false, "HELP", "Display this help menu."},
+	{{"lone"}, false, "L_ONE", "Activate l_one between colors !"},
+	{{"supernormal"}, false, "SUPERNORMAL", "Activate Supernormal loss function"},
+	{{"no-rgbplus"}, false, "NO_RGB_PLUS", "Deactivate rgb normalisation"},
+	{{"disable-snap-to-center"}, false, "DISABLE_SNAP_TO_CENTER", "Disable snap to center for the camera !"},
+	{{"relu"}, false, "RELU", "Activate ReLU for shading !"},
+	{{"bce"}, false, "BCE", "Apply BCE mask loss instead of Sigmoid BCE !"},
+	{{"n", "c", "network", "config"}, true, "CONFIG", "Path to the network config. Uses the scene's default if unspecified."},
+	{{"no-gui"}, false, "NO_GUI", "Disables the GUI and instead reports training progress on the command line."},
+	{{"save-mesh"}, false, "SAVE_MESH", "Save as a mesh when it's done."},
+	{{"save-snapshot"}, false, "SAVE_SNAPSHOT", "Save as a snapshot when it's done."},
+	{{"opti-lights"}, false, "OPTI-LIGHTS", "Use optimal lights per pixels"},
+	{{"no-albedo"}, false, "no-albedo", "To use when you don't want to optimize the albedo"},
+	{{"no-train"}, false, "NO_TRAIN", "Disables training on startup."},
+	{{"free-memory"}, false, "FREE-MEMORY", "Free images from GPU memory"},
+	{{"s", "scene"}, true, "SCENE", "The scene to load (directory with transform*.json)."},
+	{{"snapshot"}, true, "SNAPSHOT", "Optional snapshot to load upon startup."},
+	{{"width"}, true, "WIDTH", "Resolution width of the GUI."},
+	{{"save-each"}, true, "SAVE_EACH", "Save mesh each X number of iterations"},
+	{{"resolution"}, true, "RESOLUTION", "Resolution used for marching cube"},
+	{{"height"}, true, "HEIGHT", "Resolution height of the GUI."},
+	{{"maxiter"}, true, "MAXITER", "Maximum number of iterations."},
+	{{"v", "version"}, false, "VERSION", "Display the version of neural graphics primitives."},
+	{{"mask-weight"}, true, "MASK_WEIGHT", "Mask weight."},
+	{{"fractional-training"}, true, "FRACTIONAL_TRAINING", "Step for fractional training"},
+};
+
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ValidationError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct Args {
+	std::map<std::string, std::string> values; // canonical (last) name -> value ("" for plain flags)
+	bool has(const std::string& k) const { return values.count(k) > 0; }
+	const std::string& get(const std::string& k) const { return values.at(k); }
+	uint32_t get_u32(const std::string& k) const {
+		const std::string& s = get(k);
+		char* e = nullptr;
+		unsigned long long v = std::strtoull(s.c_str(), &e, 10);
+		if (s.empty() || *e || s[0] == '-') throw ParseError("Argument '" + k + "' received invalid value type '" + s + "'");
+		return (uint32_t)v;
+	}
+	float get_f32(const std::string& k) const {
+		const std::string& s = get(k);
+		char* e = nullptr;
+		float v = std::strtof(s.c_str(), &e);
+		if (s.empty() || *e) throw ParseError("Argument '" + k + "' received invalid value type '" + s + "'");
+		return v;
+	}
+};
+
+void print_help(std::ostream& os, const char* prog) {
+	os << "  " << prog << " {OPTIONS}\n\n    neural graphics primitives\n    version " NGP_VERSION "\n\n  OPTIONS:\n\n";
+	for (const auto& f : FLAGS) {
+		os << "      ";
+		for (size_t i = 0; i < f.names.size(); ++i) { os << (i ? ", " : "") << (f.names[i].size() == 1 ? "-" : "--") << f.names[i]; if (f.has_value) os << (f.names[i].size() == 1 ? "[" : "=[") << f.meta << "]"; }
+		os << "\n                                        " << f.help << "\n";
+	}
+}
+
+Args parse_cli(int argc, char** argv) {
+	Args a;
+	auto find = [&](const std::string& name) -> const FlagSpec* {
+		for (const auto& f : FLAGS) for (const auto& n : f.names) if (n == name) return &f;
+		return nullptr;
+	};
+	for (int i = 1; i < argc; ++i) {
+		std::string tok = argv[i];
+		std::string name, value;
+		bool inline_value = false;
+		if (tok.rfind("--", 0) == 0) {
+			name = tok.substr(2);
+			size_t eq = name.find('=');
+			if (eq != std::string::npos) { value = name.substr(eq + 1); name = name.substr(0, eq); inline_value = true; }
+		} else if (tok.size() >= 2 && tok[0] == '-') {
+			name = tok.substr(1, 1);
+			if (tok.size() > 2) { value = tok.substr(2); inline_value = true; }
+		} else {
+			throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + tok);
+		}
+		const FlagSpec* f = find(name);
+		if (!f) throw ParseError("Flag could not be matched: " + name);
+		if (f->has_value) {
+			if (!inline_value) {
+				if (i + 1 >= argc) throw ParseError("Flag '" + name + "' requires an argument but received none");
+				value = argv[++i];
+			}
+		} else if (inline_value) {
+			throw ParseError("Passed an argument into a non-argument flag: " + tok);
+		}
+		a.values[f->names.back()] = value;
+	}
+	return a;
+}
+
+#define RNB_CHECK(expr)                                                                          \
+	do {                                                                                         \
+		int rc_ = (expr);                                                                        \
+		if (rc_ != RNB_OK) throw std::runtime_error(std::string(#expr) + ": " + rnb_last_error()); \
+	} while (0)
+
+struct Testbed {
+	rnb_config cfg;
+	rnb_ctx* ctx = nullptr;
+	Dataset ds;
+	std::string scene, output_path;
+	uint32_t max_iter = 15000; // testbed.h:503
+	float loss_scalar = 0.f;
+	bool train = true;
+	bool fractional_training = false;
+	uint32_t fractional = 0;
+	uint32_t save_each = 0;
+	uint32_t res_mesh = 512;
+	std::string mesh_prefix;
+	jsonmin::Value network_config;
+
+	~Testbed() { if (ctx) rnb_destroy(ctx); }
+
+	void apply_network_config(const jsonmin::Value& c) { // Testbed::reset_network, src/testbed.cu:2245-2335
+		const auto& enc = c["encoding"];
+		cfg.n_levels = enc.value("n_levels", 16u);
+		cfg.log2_hashmap_size = enc.value("log2_hashmap_size", 15u);
+		cfg.base_resolution = enc.value("base_resolution", 0u);
+		if (!cfg.base_resolution) cfg.base_resolution = 1u << (cfg.log2_hashmap_size / 3);
+		const float desired_resolution = enc.value("top_resolution", 2048.0f);
+		float pls = enc.value("per_level_scale", 0.0f);
+		if (pls <= 0.0f && cfg.n_levels > 1) pls = std::exp(std::log(desired_resolution * (float)ds.aabb_scale / (float)cfg.base_resolution) / (cfg.n_levels - 1));
+		cfg.per_level_scale = pls;
+		cfg.valid_level_scale = enc.value("valid_level_scale", 0.01f);
+		cfg.base_valid_level_scale = enc.value("base_valid_level_scale", 0.5f);
+		cfg.base_training_step = enc.value("base_training_step", 200u);
+		cfg.sdf_bias = c["network"].value("sdf_bias", -0.1f);
+		const auto& hp = c["hyperparams"];
+		cfg.target_batch_size = hp.value("batch_size", 1u << 18);
+		cfg.mask_loss_weight = hp.value("mask_loss_weight", 0.f);
+		cfg.ek_loss_weight = hp.value("ek_loss_weight", 0.01f);
+		const jsonmin::Value* opt = &c["optimizer"]; // Ema -> ExponentialDecay -> Adam
+		if (opt->contains("decay")) cfg.ema_decay = (*opt)["decay"].as_float();
+		if (opt->contains("nested")) {
+			opt = &(*opt)["nested"];
+			cfg.lr_decay_start = opt->value("decay_start", cfg.lr_decay_start);
+			cfg.lr_decay_interval = opt->value("decay_interval", cfg.lr_decay_interval);
+			cfg.lr_decay_base = opt->value("decay_base", cfg.lr_decay_base);
+			if (opt->contains("nested")) {
+				opt = &(*opt)["nested"];
+				cfg.learning_rate = opt->value("learning_rate", cfg.learning_rate);
+				cfg.beta1 = opt->value("beta1", cfg.beta1); cfg.beta2 = opt->value("beta2", cfg.beta2);
+				cfg.epsilon = opt->value("epsilon", cfg.epsilon); cfg.l2_reg = opt->value("l2_reg", cfg.l2_reg);
+			}
+		}
+		cfg.aabb_scale = (uint32_t)ds.aabb_scale;
+	}
+
+	void create_context() {
+		if (ctx) { rnb_destroy(ctx); ctx = nullptr; }
+		RNB_CHECK(rnb_create(&cfg, &ctx));
+		// geometric initialisation of the SDF MLP (nerf_network.h:585-623): <exe_dir>/../utils/...
+		const std::string wpath = parent_path(exe_dir()) + "/utils/mlp_weights_hidden_layer_num_1_hidden_size_32.txt";
+		std::FILE* fp = std::fopen(wpath.c_str(), "r");
+		std::printf("network_params_elements: %d\n", RNB_N_SDF_MLP_PARAMS);
+		if (!fp) {
+			std::printf("[ERROR] Load SDF MLP weight failed!\n[ERROR] Tried to load from: %s\n[ERROR] Please ensure the utils directory exists in the project root!\n", wpath.c_str());
+			std::exit(1);
+		}
+		std::vector<float> w(RNB_N_SDF_MLP_PARAMS, 0.f);
+		for (auto& v : w) if (std::fscanf(fp, "%f", &v) != 1) break;
+		std::fclose(fp);
+		RNB_CHECK(rnb_init_params(ctx, w.data()));
+		std::vector<const uint16_t*> nm(ds.views.size()), al(ds.views.size());
+		for (size_t i = 0; i < ds.views.size(); ++i) { nm[i] = ds.normals[i].rgba.data(); al[i] = ds.albedos[i].rgba.data(); }
+		RNB_CHECK(rnb_set_dataset(ctx, (uint32_t)ds.views.size(), ds.views.data(), nm.data(), al.data()));
+	}
+
+	void load_training_data(const std::string& data_path) { // Testbed::load_training_data, src/testbed.cu:83-122
+		scene = data_path;
+		output_path = data_path + "/output";
+		make_dir(output_path);
+		if (std::FILE* lf = std::fopen((output_path + "/log.txt").c_str(), "wb")) std::fclose(lf);
+		make_dir(output_path + "/mesh");
+		make_dir(output_path + "/images");
+		const auto t0 = std::chrono::steady_clock::now();
+		ds = load_dataset(data_path);
+		std::printf("Loaded %zu images after %.1fs\n", ds.views.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+	}
+
+	// ---- snapshot (src/testbed.cu:3280-3390; tiny-cuda-nn/trainer.h:263-305) ----
+	template <typename T> std::vector<T> download(int buf) {
+		void* p; uint64_t nb;
+		RNB_CHECK(rnb_buffer(ctx, buf, &p, &nb));
+		std::vector<T> h(nb / sizeof(T));
+		if (nb) RNB_CHECK(rnb_memcpy(ctx, h.data(), p, nb, RNB_D2H));
+		return h;
+	}
+	static uint16_t f32_to_f16(float f) {
+		uint32_t x; std::memcpy(&x, &f, 4);
+		const uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+		if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u : 0));
+		if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+		if (ax < 0x33000001u) return (uint16_t)sign;
+		const int e = (int)(ax >> 23) - 127;
+		const uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+		const int shift = e < -14 ? 13 + (-14 - e) : 13;
+		const uint32_t hexp = e < -14 ? 0 : (uint32_t)(e + 15);
+		uint32_t hm = m >> shift;
+		const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+		if (rem > half || (rem == half && (hm & 1u))) ++hm;
+		return (uint16_t)(sign | (hexp == 0 ? hm : ((hexp - 1) << 10) + hm));
+	}
+	static float f16_to_f32(uint16_t h) {
+		const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu;
+		uint32_t man = h & 0x3ffu, bits;
+		if (exp == 0) {
+			if (man == 0) bits = sign;
+			else { int e = -1; do { ++e; man <<= 1; } while ((man & 0x400u) == 0); bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3ffu) << 13; }
+		} else if (exp == 31) bits = sign | 0x7f800000u | man << 13;
+		else bits = sign | (exp + 127 - 15) << 23 | man << 13;
+		float f; std::memcpy(&f, &bits, 4); return f;
+	}
+
+	void save_snapshot(const std::string& path, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured, uint32_t measured_before) {
+		mpk::Value root = mpk::Value::object();
+		mpk::Value snap = mpk::Value::object();
+		const auto ema = download<uint16_t>(RNB_BUF_PARAMS_EMA); // Trainer::serialize: the inference (EMA) weights, fp16
+		snap.set("n_params", mpk::Value::uint(ema.size()));
+		snap.set("params_binary", mpk::Value::binary(ema.data(), ema.size() * 2));
+		snap.set("density_grid_size", mpk::Value::uint(RNB_GRIDSIZE));
+		const auto grid = download<float>(RNB_BUF_DENSITY_GRID);
+		std::vector<uint16_t> g16(grid.size());
+		for (size_t i = 0; i < grid.size(); ++i) g16[i] = f32_to_f16(grid[i]);
+		snap.set("density_grid_binary", mpk::Value::binary(g16.data(), g16.size() * 2));
+		mpk::Value nerf = mpk::Value::object();
+		nerf.set("aabb_scale", mpk::Value::uint((uint64_t)ds.aabb_scale));
+		mpk::Value rgb = mpk::Value::object();
+		rgb.set("rays_per_batch", mpk::Value::uint(rays_per_batch));
+		rgb.set("measured_batch_size", mpk::Value::uint(measured));
+		rgb.set("measured_batch_size_before_compaction", mpk::Value::uint(measured_before));
+		nerf.set("rgb", rgb);
+		snap.set("nerf", nerf);
+		snap.set("training_step", mpk::Value::uint(training_step));
+		snap.set("loss", mpk::Value::real(loss_scalar));
+		root.set("snapshot", snap);
+		// the network configuration travels with the snapshot (m_network_config, src/testbed.cu:3282-3313)
+		mpk::Value enc = mpk::Value::object();
+		enc.set("otype", mpk::Value::str("HashGrid"));
+		enc.set("n_levels", mpk::Value::uint(cfg.n_levels)); enc.set("n_features_per_level", mpk::Value::uint(2));
+		enc.set("log2_hashmap_size", mpk::Value::uint(cfg.log2_hashmap_size)); enc.set("base_resolution", mpk::Value::uint(cfg.base_resolution));
+		enc.set("per_level_scale", mpk::Value::real(cfg.per_level_scale));
+		enc.set("valid_level_scale", mpk::Value::real(cfg.valid_level_scale)); enc.set("base_valid_level_scale", mpk::Value::real(cfg.base_valid_level_scale));
+		enc.set("base_training_step", mpk::Value::uint(cfg.base_training_step));
+		root.set("encoding", enc);
+		mpk::Value hp = mpk::Value::object();
+		hp.set("batch_size", mpk::Value::uint(cfg.target_batch_size));
+		hp.set("mask_loss_weight", mpk::Value::real(cfg.mask_loss_weight)); hp.set("ek_loss_weight", mpk::Value::real(cfg.ek_loss_weight));
+		root.set("hyperparams", hp);
+		mpk::Value net = mpk::Value::object();
+		net.set("otype", mpk::Value::str("FullyFusedMLP")); net.set("sdf_bias", mpk::Value::real(cfg.sdf_bias));
+		root.set("network", net);
+		mpk::save(path, root);
+	}
+
+	struct Resume { uint32_t training_step = 0, rays_per_batch = 0, measured_before = 0; };
+	Resume load_snapshot(const std::string& path) { // Testbed::load_snapshot, src/testbed.cu:3333-3390
+		const mpk::Value root = mpk::load(path);
+		if (!root.find("snapshot")) throw std::runtime_error("File '" + path + "' does not contain a snapshot.");
+		const mpk::Value& snap = root.at("snapshot");
+		if ((uint32_t)snap.at("density_grid_size").number() != RNB_GRIDSIZE) throw std::runtime_error("Incompatible grid size.");
+		if (const mpk::Value* enc = root.find("encoding")) { // reset_network from the snapshot's own config
+			cfg.n_levels = (uint32_t)enc->at("n_levels").number(); cfg.log2_hashmap_size = (uint32_t)enc->at("log2_hashmap_size").number();
+			cfg.base_resolution = (uint32_t)enc->at("base_resolution").number(); cfg.per_level_scale = (float)enc->at("per_level_scale").number();
+			if (const mpk::Value* v = enc->find("valid_level_scale")) cfg.valid_level_scale = (float)v->number();
+			if (const mpk::Value* v = enc->find("base_valid_level_scale")) cfg.base_valid_level_scale = (float)v->number();
+			if (const mpk::Value* v = enc->find("base_training_step")) cfg.base_training_step = (uint32_t)v->number();
+		}
+		if (const mpk::Value* hp = root.find("hyperparams")) {
+			if (const mpk::Value* v = hp->find("batch_size")) cfg.target_batch_size = (uint32_t)v->number();
+			if (const mpk::Value* v = hp->find("mask_loss_weight")) cfg.mask_loss_weight = (float)v->number();
+			if (const mpk::Value* v = hp->find("ek_loss_weight")) cfg.ek_loss_weight = (float)v->number();
+		}
+		if (const mpk::Value* v = snap.at("nerf").find("aabb_scale")) cfg.aabb_scale = (uint32_t)v->number();
+		create_context();
+		const auto& pb = snap.at("params_binary").bin;
+		const uint64_t n = rnb_n_params(ctx);
+		if (pb.size() != n * 2) throw std::runtime_error("Can't set params because CPU buffer has the wrong size.");
+		std::vector<float> p32(n);
+		const uint16_t* ph = reinterpret_cast<const uint16_t*>(pb.data());
+		for (uint64_t i = 0; i < n; ++i) p32[i] = f16_to_f32(ph[i]); // Trainer::set_params: master = float(half)
+		RNB_CHECK(rnb_set_params(ctx, p32.data()));
+		const auto& gb = snap.at("density_grid_binary").bin;
+		void* gp; uint64_t gnb;
+		RNB_CHECK(rnb_buffer(ctx, RNB_BUF_DENSITY_GRID, &gp, &gnb));
+		if (gb.size() / 2 == gnb / 4) {
+			std::vector<float> g32(gb.size() / 2);
+			const uint16_t* gh = reinterpret_cast<const uint16_t*>(gb.data());
+			for (size_t i = 0; i < g32.size(); ++i) g32[i] = f16_to_f32(gh[i]);
+			RNB_CHECK(rnb_memcpy(ctx, gp, g32.data(), gnb, RNB_H2D));
+			RNB_CHECK(rnb_update_density_bitfield(ctx, nullptr));
+		} else if (!gb.empty()) throw std::runtime_error("Incompatible number of grid cascades.");
+		Resume r;
+		r.training_step = (uint32_t)snap.at("training_step").number();
+		loss_scalar = (float)snap.at("loss").number();
+		const mpk::Value& rgb = snap.at("nerf").at("rgb");
+		r.rays_per_batch = (uint32_t)rgb.at("rays_per_batch").number();
+		r.measured_before = (uint32_t)rgb.at("measured_batch_size_before_compaction").number();
+		RNB_CHECK(rnb_set_controller(ctx, r.training_step, std::max(1u, std::min(r.rays_per_batch, cfg.max_rays_per_batch)), r.measured_before, 0));
+		return r;
+	}
+
+	// ---- mesh (src/testbed_nerf.cu:4218-4350, src/marching_cubes.cu) ----
+	void compute_and_save_marching_cubes_mesh(const std::string& filename, uint32_t res_in) {
+		const uint32_t res = (res_in + 15u) / 16u * 16u; // next_multiple(res, 16)
+		std::printf("unwrap_it:0\n%u%u%u\n", res, res, res);
+		const float amin = 0.5f - 0.5f * (float)cfg.aabb_scale, amax = 0.5f + 0.5f * (float)cfg.aabb_scale;
+		const float mn[3] = {amin, amin, amin}, mx[3] = {amax, amax, amax};
+		const size_t n = (size_t)res * res * res;
+		std::vector<float> sdf(n);
+		const uint32_t batch = 1u << 20; // get_density_on_grid: 2^20 lattice points per network call, EMA weights
+		void *dpos = nullptr, *dout = nullptr;
+		RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)batch * 12, &dpos));
+		RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)batch * 2, &dout));
+		std::vector<float> hpos((size_t)batch * 3);
+		std::vector<uint16_t> hout(batch);
+		const float inv = 1.f / (float)res, size = amax - amin, diag = amax - amin;
+		for (size_t off = 0; off < n; off += batch) {
+			const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - off);
+			for (uint32_t q = 0; q < nb; ++q) { // generate_grid_samples_nerf_uniform (src/testbed_nerf.cu:541-553)
+				const size_t i = off + q;
+				const uint32_t x = (uint32_t)(i % res), y = (uint32_t)((i / res) % res), z = (uint32_t)(i / ((size_t)res * res));
+				const float p[3] = {(float)x * inv * size + amin, (float)y * inv * size + amin, (float)z * inv * size + amin};
+				for (int k = 0; k < 3; ++k) hpos[(size_t)q * 3 + k] = (p[k] - amin) / diag; // warp_position
+			}
+			RNB_CHECK(rnb_memcpy(ctx, dpos, hpos.data(), (uint64_t)nb * 12, RNB_H2D));
+			RNB_CHECK(rnb_sdf(ctx, nullptr, (const float*)dpos, nb, (uint16_t*)dout, 1));
+			RNB_CHECK(rnb_memcpy(ctx, hout.data(), dout, (uint64_t)nb * 2, RNB_D2H));
+			for (uint32_t q = 0; q < nb; ++q) sdf[off + q] = f16_to_f32(hout[q]);
+		}
+		mesh::Mesh m = mesh::marching_cubes(sdf.data(), (int)res, (int)res, (int)res, mn, mx, 0.0f);
+		std::printf("#vertices=%zu #triangles=%zu\n", m.verts.size(), m.indices.size() / 3);
+		sdf.clear(); sdf.shrink_to_fit();
+		// vertex colours: full network at the vertices, outward view direction (src/testbed_nerf.cu:793-799, 4193-4216)
+		m.colors.assign(m.verts.size(), {0, 0, 0});
+		if (!m.verts.empty()) {
+			void *dc = nullptr, *dq = nullptr;
+			const uint32_t cb = 1u << 18;
+			RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)cb * 28, &dc));
+			RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)cb * 32, &dq));
+			std::vector<float> hc((size_t)cb * 7);
+			std::vector<uint16_t> ho((size_t)cb * 16);
+			for (size_t off = 0; off < m.verts.size(); off += cb) {
+				const uint32_t nb = (uint32_t)std::min<size_t>(cb, m.verts.size() - off);
+				for (uint32_t q = 0; q < nb; ++q) {
+					const mesh::Vec3 v = m.verts[off + q];
+					float d[3] = {v.x - 0.5f, v.y - 0.5f, v.z - 0.5f};
+					const float l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+					float* c = &hc[(size_t)q * 7];
+					c[0] = (v.x - amin) / diag; c[1] = (v.y - amin) / diag; c[2] = (v.z - amin) / diag; c[3] = 0.f;
+					for (int k = 0; k < 3; ++k) c[4 + k] = (d[k] / l + 1.f) * 0.5f;
+				}
+				RNB_CHECK(rnb_memcpy(ctx, dc, hc.data(), (uint64_t)nb * 28, RNB_H2D));
+				RNB_CHECK(rnb_forward_infer(ctx, nullptr, (const float*)dc, nb, (uint16_t*)dq, 1));
+				RNB_CHECK(rnb_memcpy(ctx, ho.data(), dq, (uint64_t)nb * 32, RNB_D2H));
+				for (uint32_t q = 0; q < nb; ++q) {
+					auto sig = [&](int k) { return 1.f / (1.f + std::exp(-f16_to_f32(ho[(size_t)q * 16 + k]))); }; // rgb_activation = Logistic
+					m.colors[off + q] = {sig(0), sig(1), sig(2)};
+				}
+			}
+			rnb_device_free(ctx, dc); rnb_device_free(ctx, dq);
+		}
+		rnb_device_free(ctx, dpos); rnb_device_free(ctx, dout);
+		mesh::save_obj(filename, m, ds.scale, ds.offset, ds.n2w_s, ds.n2w_t);
+	}
+};
+
+} // namespace
+
+int main(int argc, char** argv) {
+	Args args;
+	try {
+		args = parse_cli(argc, argv);
+	} catch (const ParseError& e) {
+		std::cerr << e.what() << std::endl;
+		print_help(std::cerr, argv[0]);
+		return -1;
+	} catch (const ValidationError& e) {
+		std::cerr << e.what() << std::endl;
+		print_help(std::cerr, argv[0]);
+		return -2;
+	}
+	if (args.has("help")) { print_help(std::cout, argv[0]); return 0; }
+	if (args.has("version")) { std::cout << "neural graphics primitives version " NGP_VERSION << std::endl; return 0; }
+	try {
+		Testbed tb;
+		rnb_default_config(&tb.cfg);
+		try {
+			if (args.has("maxiter")) tb.max_iter = args.get_u32("maxiter");
+			if (args.has("resolution")) tb.res_mesh = args.get_u32("resolution");
+			if (args.has("save-each")) tb.save_each = args.get_u32("save-each");
+			if (args.has("fractional-training")) (void)args.get_u32("fractional-training");
+			if (args.has("mask-weight")) (void)args.get_f32("mask-weight");
+			if (args.has("width")) (void)args.get_u32("width");
+			if (args.has("height")) (void)args.get_u32("height");
+		} catch (const ParseError& e) {
+			std::cerr << e.what() << std::endl;
+			print_help(std::cerr, argv[0]);
+			return -1;
+		}
+		std::cout << "Number of iterations : " << tb.max_iter << std::endl;
+		if (args.has("scene")) {
+			std::string scene_path = args.get("scene");
+			if (!path_exists(scene_path)) { std::cerr << "Scene path " << scene_path << " does not exist." << std::endl; return 1; }
+			while (scene_path.size() > 1 && scene_path.back() == '/') scene_path.pop_back();
+			tb.load_training_data(scene_path);
+		} else {
+			std::cerr << "No scene given (--scene)." << std::endl; // the reference dereferences the missing flag (src/main.cu:413)
+			return 1;
+		}
+		Testbed::Resume resume;
+		if (args.has("snapshot")) {
+			const std::string sp = args.get("snapshot");
+			if (!path_exists(sp)) { std::cerr << "Snapshot path " << sp << " does not exist." << std::endl; return 1; }
+			resume = tb.load_snapshot(sp);
+			tb.train = true;
+			std::printf("*******Loaded snapshot succeed!\n");
+		} else {
+			std::string cfg_path = parent_path(exe_dir()) + "/configs/nerf";
+			if (args.has("config")) {
+				const std::string c = args.get("config");
+				cfg_path = path_exists(cfg_path + "/" + c) ? cfg_path + "/" + c : c;
+			} else cfg_path += "/base.json";
+			if (!path_exists(cfg_path)) { std::cerr << "Network config path " << cfg_path << " does not exist." << std::endl; return 1; }
+			std::cout << "Network config path " << cfg_path << " found!" << std::endl;
+			tb.network_config = jsonmin::parse_file(cfg_path);
+			tb.apply_network_config(tb.network_config);
+			tb.create_context();
+			tb.train = !args.has("no-train");
+		}
+		// flag setters (src/main.cu:349-410)
+		if (args.has("mask-weight")) tb.cfg.mask_loss_weight = args.get_f32("mask-weight");
+		if (args.has("fractional-training")) {
+			if (args.has("maxiter")) {
+				const uint32_t v = args.get_u32("fractional-training");
+				if (v < tb.max_iter) { tb.fractional = v; tb.fractional_training = true; }
+				else { std::cerr << "The integer must be lower than max-iter!" << std::endl; return 1; }
+			} else { std::cerr << "fractional-training works with max-iter." << std::endl; return 1; }
+		}
+		tb.cfg.apply_L2 = args.has("lone") ? 0 : 1;
+		tb.cfg.apply_supernormal = args.has("supernormal") ? 1 : 0;
+		tb.cfg.apply_rgbplus = args.has("no-rgbplus") ? 0 : 1;
+		if (args.has("disable-snap-to-center")) tb.cfg.snap_to_pixel_centers = 0;
+		tb.cfg.apply_bce = args.has("bce") ? 1 : 0;
+		tb.cfg.apply_relu = args.has("relu") ? 1 : 0;
+		tb.cfg.apply_light_opti = args.has("opti-lights") ? 1 : 0;
+		tb.cfg.apply_no_albedo = args.has("no-albedo") ? 1 : 0;
+		RNB_CHECK(rnb_update_config(tb.ctx, &tb.cfg));
+		const std::string obj_filename = tb.output_path + "/mesh_" + std::to_string(tb.max_iter) + ".obj";
+		tb.mesh_prefix = tb.output_path + "/mesh_";
+
+		// training loop (src/main.cu:444-453, Testbed::frame src/testbed.cu:1826-1919)
+		uint32_t step = rnb_training_step(tb.ctx);
+		uint32_t rays_per_batch = rnb_rays_per_batch(tb.ctx), measured = 0, measured_before = resume.measured_before;
+		double train_ms = 0.0; uint64_t rays_total = 0;
+		const bool no_train = args.has("no-train");
+		if (!no_train) {
+			bool running = true;
+			while (running) {
+				if (tb.train) {
+					rnb_step_stats st;
+					const int rc = rnb_train_step(tb.ctx, nullptr, &st);
+					if (rc == RNB_ERR_NO_SAMPLES) { std::cout << "Nerf training generated 0 samples. Aborting training." << std::endl; tb.train = false; tb.loss_scalar = 0.f; }
+					else if (rc != RNB_OK) throw std::runtime_error(rnb_last_error());
+					else {
+						tb.loss_scalar = st.loss; // m_loss_scalar.val() is the latest step's loss (common.h:264-281)
+						train_ms += st.prep_ms + st.step_ms; rays_total += st.rays_per_batch;
+						rays_per_batch = st.next_rays_per_batch; measured = st.measured_batch_size; measured_before = st.measured_batch_size_before_compaction;
+					}
+					step = rnb_training_step(tb.ctx);
+				}
+				if (tb.fractional_training) { // src/testbed.cu:1886-1895
+					const bool sdf_only = step < tb.fractional;
+					if ((tb.cfg.apply_no_albedo != 0) != sdf_only || (tb.cfg.only_sdf_training != 0) != sdf_only) {
+						tb.cfg.apply_no_albedo = sdf_only; tb.cfg.only_sdf_training = sdf_only;
+						RNB_CHECK(rnb_update_config(tb.ctx, &tb.cfg));
+					}
+				}
+				if (tb.save_each > 0 && step % tb.save_each == 0) {
+					const std::string name = tb.mesh_prefix + std::to_string(step) + ".obj";
+					std::printf("%s\n", name.c_str());
+					tb.compute_and_save_marching_cubes_mesh(name, tb.res_mesh);
+				}
+				running = step < tb.max_iter; // Testbed::frame's return value
+				if (running && step % 100 == 0) std::cout << "iteration=" << step << " loss=" << tb.loss_scalar << std::endl; // src/main.cu:444-451
+				if (!tb.train) running = false; // the reference would spin here forever once training aborted; stop instead
+			}
+			if (train_ms > 0) std::cout << "throughput: " << (double)rays_total / (train_ms * 1e-3) << " rays/s, " << train_ms / std::max(1u, step - resume.training_step) << " ms/step" << std::endl;
+		}
+		if (args.has("save-mesh")) {
+			// --free-memory releases the dataset before meshing in the reference (src/main.cu:455-459; 10 s sleep not reproduced)
+			tb.compute_and_save_marching_cubes_mesh(obj_filename, tb.res_mesh);
+		}
+		const std::string snapshot_filename = tb.output_path + "/snapshot_" + std::to_string(tb.max_iter) + ".msgpack";
+		if (args.has("save-snapshot")) {
+			std::cout << "Saving Snapshot !" << std::endl << snapshot_filename << std::endl;
+			tb.save_snapshot(snapshot_filename, step, rays_per_batch, measured, measured_before);
+		}
+	} catch (const std::exception& e) {
+		std::cerr << "Uncaught exception: " << e.what() << std::endl;
+		return 1;
+	}
+	return 0;
+}

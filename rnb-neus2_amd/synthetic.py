@@ -84,3 +84,50 @@ def make_scene(n_views=64, res=800, fx=None, cam_radius=1.5, radius=0.25, bump=0
         normals.append(nm)
         albedos.append(al)
     return views, normals, albedos
+
+
+def write_png16(path, rgba16):
+    """RGBA 16-bit PNG (colour type 6, depth 16, no interlace) — the format of the scenes' normal/albedo maps."""
+    import struct
+    import zlib
+
+    h, w, c = rgba16.shape
+    assert c == 4 and rgba16.dtype == np.uint16
+    raw = np.empty((h, 1 + w * 8), np.uint8)
+    raw[:, 0] = 0
+    raw[:, 1:] = rgba16.astype(">u2").view(np.uint8).reshape(h, w * 8)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 6, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw.tobytes(), 1)) + chunk(b"IEND", b""))
+
+
+def write_scene(path, views, normals, albedos, scale=1.0, offset=(0.0, 0.0, 0.0), n2w=None):
+    """Write the on-disk scene format the loader reads (src/nerf_loader.cu:225-764): transform.json with `from_na`,
+    per-frame transform_matrix / intrinsic_matrix / normal_path / albedo_path, plus the PNG16 maps. With `from_na` the
+    loader keeps the rotation and maps the position to pos*scale+offset, so the inverse is applied here."""
+    import json
+    import os
+
+    os.makedirs(os.path.join(path, "normal"), exist_ok=True)
+    os.makedirs(os.path.join(path, "albedo"), exist_ok=True)
+    frames = []
+    for i, (v, nm, al) in enumerate(zip(views, normals, albedos)):
+        m = np.eye(4)
+        m[:3, :4] = np.asarray(v["xform"], np.float64).reshape(3, 4)
+        m[:3, 3] = (m[:3, 3] - np.asarray(offset, np.float64)) / scale
+        k = np.eye(4)
+        k[0, 0], k[1, 1] = v["focal_length"]
+        k[0, 2] = v["principal_point"][0] * v["width"]
+        k[1, 2] = v["principal_point"][1] * v["height"]
+        write_png16(os.path.join(path, "normal", f"{i:03d}.png"), np.ascontiguousarray(nm).reshape(v["height"], v["width"], 4))
+        write_png16(os.path.join(path, "albedo", f"{i:03d}.png"), np.ascontiguousarray(al).reshape(v["height"], v["width"], 4))
+        frames.append(dict(normal_path=f"normal/{i:03d}.png", albedo_path=f"albedo/{i:03d}.png", transform_matrix=m.tolist(), intrinsic_matrix=k.tolist()))
+    meta = dict(from_na=True, w=views[0]["width"], h=views[0]["height"], aabb_scale=1.0, scale=scale, offset=list(offset), frames=frames)
+    if n2w is not None:
+        meta["n2w"] = np.asarray(n2w).tolist()
+    with open(os.path.join(path, "transform.json"), "w") as f:
+        json.dump(meta, f)
