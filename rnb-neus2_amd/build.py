@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
 ROOT = os.path.dirname(PKG_DIR)
 TESTBED_SRC = os.path.join(PKG_DIR, "host", "testbed_main.cpp")
 TESTBED_OUT = os.path.join(ROOT, "build", "testbed")
-TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp")] + [
+TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "dataset.hpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp")] + [
     os.path.join(ROOT, "include", "rnb_neus2.h")]
 
 
@@ -59,6 +59,25 @@ def build_testbed(force=False, verbose=False):
     return TESTBED_OUT
 
 
+HOSTLIB_SRC = os.path.join(PKG_DIR, "host", "hostlib.cpp")
+HOSTLIB_OUT = os.path.join(PKG_DIR, "librnb_host.so")
+HOSTLIB_DEPS = [HOSTLIB_SRC, os.path.join(PKG_DIR, "host", "png16.hpp"), os.path.join(ROOT, "include", "rnb_host.h")]
+
+
+def build_hostlib(force=False, verbose=False):
+    """librnb_host.so: CPU helpers of the Python preparation stages (PNG codec, mesh ray casting); g++ + zlib + OpenMP."""
+    if not force and os.path.exists(HOSTLIB_OUT):
+        t = os.path.getmtime(HOSTLIB_OUT)
+        if not any(os.path.getmtime(d) > t for d in HOSTLIB_DEPS):
+            return HOSTLIB_OUT
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wall", HOSTLIB_SRC, "-o", HOSTLIB_OUT, "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOSTLIB_OUT
+
+
 if __name__ == "__main__":
+    print(build_hostlib(force=True, verbose=True))
     print(build(force=True, verbose=True))
     print(build_testbed(force=True, verbose=True))

@@ -143,4 +143,58 @@ inline Image load(const std::string& path) {
 	return img;
 }
 
+// IHDR only: dimensions plus the channel count / bit depth an "unchanged" decode would report
+// (grey 1, grey+alpha 2, RGB / palette 3, RGBA / palette+tRNS 4; depth 8 for everything below 16 bits).
+struct Info { uint32_t width = 0, height = 0; int channels = 0, depth = 0; };
+inline Info probe(const std::string& path) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f) throw std::runtime_error("image not found: " + path);
+	std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	if (file.size() < 33 || std::memcmp(&file[1], "PNG", 3) != 0 || std::memcmp(&file[12], "IHDR", 4) != 0) throw std::runtime_error("not a PNG file: " + path);
+	Info i; i.width = detail::be32(&file[16]); i.height = detail::be32(&file[20]);
+	i.depth = file[24] == 16 ? 16 : 8;
+	bool has_trns = false;
+	for (size_t p = 8; p + 12 <= file.size();) {
+		const uint32_t len = detail::be32(&file[p]);
+		if (std::memcmp(&file[p + 4], "tRNS", 4) == 0) has_trns = true;
+		if (std::memcmp(&file[p + 4], "IDAT", 4) == 0) break;
+		p += 12 + (size_t)len;
+	}
+	switch (file[25]) { case 0: i.channels = has_trns ? 2 : 1; break; case 2: i.channels = has_trns ? 4 : 3; break; case 3: i.channels = has_trns ? 4 : 3; break; case 4: i.channels = 2; break; default: i.channels = 4; }
+	return i;
+}
+
+// Writer: non-interlaced, filter 0 on every row, `channels` in {1,2,3,4} (grey, grey+alpha, RGB, RGBA), depth 8 or 16.
+// `data` is row-major, interleaved, host-endian uint8 / uint16.
+inline void save(const std::string& path, const void* data, uint32_t w, uint32_t h, int channels, int depth, int level = 1) {
+	if ((depth != 8 && depth != 16) || channels < 1 || channels > 4) throw std::runtime_error("png: unsupported layout");
+	static const int CT[5] = {0, 0, 4, 2, 6};
+	const size_t row = (size_t)w * channels * (depth / 8);
+	std::vector<uint8_t> raw((row + 1) * h);
+	for (uint32_t y = 0; y < h; ++y) {
+		uint8_t* o = &raw[(row + 1) * y];
+		*o++ = 0;
+		if (depth == 8) std::memcpy(o, (const uint8_t*)data + row * y, row);
+		else { const uint16_t* s = (const uint16_t*)data + (size_t)w * channels * y; for (size_t k = 0; k < (size_t)w * channels; ++k) { o[2 * k] = (uint8_t)(s[k] >> 8); o[2 * k + 1] = (uint8_t)s[k]; } }
+	}
+	uLongf zl = compressBound((uLong)raw.size());
+	std::vector<uint8_t> z(zl);
+	if (compress2(z.data(), &zl, raw.data(), (uLong)raw.size(), level) != Z_OK) throw std::runtime_error("png: deflate failed");
+	std::ofstream f(path, std::ios::binary);
+	if (!f) throw std::runtime_error("cannot write " + path);
+	auto chunk = [&](const char* tag, const uint8_t* d, size_t n) {
+		uint8_t hd[8] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n, (uint8_t)tag[0], (uint8_t)tag[1], (uint8_t)tag[2], (uint8_t)tag[3]};
+		uLong c = crc32(0L, hd + 4, 4);
+		if (n) c = crc32(c, d, (uInt)n);
+		const uint8_t cr[4] = {(uint8_t)(c >> 24), (uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c};
+		f.write((const char*)hd, 8); if (n) f.write((const char*)d, (std::streamsize)n); f.write((const char*)cr, 4);
+	};
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+	f.write((const char*)sig, 8);
+	const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, (uint8_t)depth, (uint8_t)CT[channels], 0, 0, 0};
+	chunk("IHDR", ihdr, 13);
+	chunk("IDAT", z.data(), zl);
+	chunk("IEND", nullptr, 0);
+}
+
 } // namespace png16

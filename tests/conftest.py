@@ -1,4 +1,7 @@
+import json
 import os
+import shutil
+import subprocess
 import sys
 
 import pytest
@@ -22,3 +25,48 @@ def oracle():
 def hip():
     from rnb_neus2_amd import api
     return api.load_library()
+
+
+# a network small enough for the CPU checker to train in seconds (passed to the testbed as --config small.json)
+SMALL_CFG = {
+    "encoding": {"n_levels": 4, "log2_hashmap_size": 12, "base_resolution": 16, "top_resolution": 64, "valid_level_scale": 0.02,
+                 "base_valid_level_scale": 0.2, "base_training_step": 100},
+    "network": {"sdf_bias": -0.1},
+    "optimizer": {"decay": 0.95, "nested": {"decay_start": 20000, "decay_interval": 10000, "decay_base": 0.33,
+                                            "nested": {"learning_rate": 0.001, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}}},
+    "hyperparams": {"batch_size": 4096, "mask_loss_weight": 1.0, "ek_loss_weight": 0.01},
+}
+
+
+def make_install(root, base_cfg=None):
+    """<root>/build/testbed built from the product's testbed_main.cpp but linked against the CPU checker
+    (`-include oracle/orc_prefix.h`), plus <root>/utils and <root>/configs/nerf — the layout the binary expects."""
+    from tests import oracle_lib
+    oracle_lib.functions()
+    host = os.path.join(ROOT, "rnb-neus2_amd", "host")
+    os.makedirs(os.path.join(root, "build"))
+    os.makedirs(os.path.join(root, "configs", "nerf"))
+    shutil.copytree(os.path.join(ROOT, "utils"), os.path.join(root, "utils"))
+    if base_cfg is None:
+        shutil.copy(os.path.join(ROOT, "configs", "nerf", "base.json"), os.path.join(root, "configs", "nerf", "base.json"))
+    else:
+        with open(os.path.join(root, "configs", "nerf", "base.json"), "w") as f:
+            json.dump(base_cfg, f)
+    with open(os.path.join(root, "configs", "nerf", "small.json"), "w") as f:
+        json.dump(SMALL_CFG, f)
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-include", os.path.join(odir, "orc_prefix.h"),
+                           os.path.join(host, "testbed_main.cpp"), "-o", os.path.join(root, "build", "testbed"), "-L" + odir, "-lorc", "-lz", "-Wl,-rpath," + odir])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(host, "dump_dataset.cpp"), "-o", os.path.join(root, "build", "dump_dataset"), "-lz"])
+    return root
+
+
+@pytest.fixture(scope="session")
+def install(tmp_path_factory):
+    return make_install(tmp_path_factory.mktemp("install"))
+
+
+@pytest.fixture(scope="session")
+def small_install(tmp_path_factory):
+    """Same, but the default config (configs/nerf/base.json) is the small network — for pipeline tests, which cannot pass --config."""
+    return make_install(tmp_path_factory.mktemp("small_install"), base_cfg=SMALL_CFG)

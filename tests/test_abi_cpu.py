@@ -39,6 +39,18 @@ def test_hip_library_exports_every_declared_symbol():
     assert abs(cfg.per_level_scale - 1.45242) < 1e-4  # exp(ln(2048/16)/13), testbed.cu:2320-2323
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/rnb_host.h (PNG I/O + mesh ray casting for the preparation stages) vs librnb_host.so."""
+    import __graft_entry__ as g
+    g.build()
+    from rnb_neus2_amd import hostlib
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rnb_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(rnb_[a-z_0-9]+)\s*\(", src)))
+    assert len(names) == 8, names
+    lib = C.CDLL(hostlib.library_path())
+    assert not [n for n in names if not hasattr(lib, n)]
+
+
 def test_oracle_exports_the_same_abi():
     from tests import oracle_lib
     oracle_lib.functions()

@@ -328,3 +328,46 @@ def test_testbed_cli_gpu(tmp_path):
     assert snap2["training_step"] == 700 and np.isfinite(snap2["loss"]) and snap2["loss"] < 2 * max(snap["loss"], 1e-3)
     print(r.stdout[-400:])
     print(json.dumps({k: snap2["nerf"]["rgb"][k] for k in snap2["nerf"]["rgb"]}))
+
+
+def test_full_pipeline_gpu(tmp_path):
+    """run_full_pipeline (Python boundary, rnb_neus2/pipeline.py:222-305) driving build/testbed on the GPU: cameras.npz
+    input -> prepared scene -> stage 1 -> snapshot -> stage 2 with --opti-lights -> post-processed mesh. The normal maps
+    are the analytic sphere's, so the final mesh (world frame) must be that sphere."""
+    import os
+    from rnb_neus2_amd import hostlib, meshproc, pipeline, synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, res, fx, radius, cam_r = 16, 200, 350.0, 0.5, 3.0
+    views, normals, _ = synthetic.make_scene(n, res, fx)  # ngp frame: centre 0.5, radius 0.25, cameras at 1.5 == world/2 + 0.5
+    src = tmp_path / "in"
+    for sub in ("normal", "mask"):
+        os.makedirs(src / sub)
+    mats = {}
+    for i, (v, nm) in enumerate(zip(views, normals)):
+        c2w = np.asarray(v["xform"], np.float64).reshape(3, 4)
+        R, c = c2w[:, :3], (c2w[:, 3] - 0.5) / 0.5  # back to the world frame (scale 0.5, offset 0.5)
+        K = np.array([[fx, 0, res / 2], [0, fx, res / 2], [0, 0, 1.0]])
+        P = np.eye(4)
+        P[:3, :4] = K @ np.concatenate([R.T, (-R.T @ c)[:, None]], axis=1)
+        mats["world_mat_%d" % i] = P
+        mats["scale_mat_%d" % i] = np.eye(4)
+        nm = np.asarray(nm).reshape(res, res, 4)
+        hostlib.png_write(src / "normal" / ("%03d.png" % i), np.ascontiguousarray(nm[:, :, :3]))
+        hostlib.png_write(src / "mask" / ("%03d.png" % i), (nm[:, :, 3] // 257).astype(np.uint8))
+    np.savez(src / "cameras.npz", **mats)
+
+    class Log:
+        lines = []
+
+        def info(self, m):
+            self.lines.append(str(m))
+
+        warning = error = info
+
+    mesh_path = pipeline.run_full_pipeline(str(src), os.path.join(root, "build", "testbed"), str(tmp_path / "out"), max_steps=900, mesh_resolution=128,
+                                           scaling_mode="none", logger=Log())
+    m = meshproc.load_obj(mesh_path)
+    rad = np.linalg.norm(m.vertices, axis=1)
+    print("\n".join(l for l in Log.lines if "iteration=" in l or "throughput" in l))
+    assert len(m.vertices) > 1000 and abs(np.median(rad) - radius) < 0.015 and rad.std() < 0.02, (np.median(rad), rad.std())
+    assert m.signed_volume == pytest.approx(4 / 3 * np.pi * radius ** 3, rel=0.08)

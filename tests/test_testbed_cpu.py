@@ -4,7 +4,6 @@ loader, the training loop, the snapshot writer/reader and the mesh export are ex
 The GPU build of the same file is covered by tests/test_gpu_parity.py::test_testbed_cli_gpu."""
 import json
 import os
-import shutil
 import subprocess
 
 import msgpack
@@ -17,35 +16,11 @@ from tests import oracle_lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "rnb-neus2_amd", "host")
 
-SMALL_CFG = {
-    "encoding": {"n_levels": 4, "log2_hashmap_size": 12, "base_resolution": 16, "top_resolution": 64, "valid_level_scale": 0.02,
-                 "base_valid_level_scale": 0.2, "base_training_step": 100},
-    "network": {"sdf_bias": -0.1},
-    "optimizer": {"decay": 0.95, "nested": {"decay_start": 20000, "decay_interval": 10000, "decay_base": 0.33,
-                                            "nested": {"learning_rate": 0.001, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}}},
-    "hyperparams": {"batch_size": 4096, "mask_loss_weight": 1.0, "ek_loss_weight": 0.01},
-}
+from tests.conftest import SMALL_CFG  # noqa: E402
+
 # what SMALL_CFG means for rnb_config (per_level_scale as Testbed::reset_network derives it, src/testbed.cu:2296-2305)
 SMALL_KW = dict(n_levels=4, log2_hashmap_size=12, base_resolution=16, per_level_scale=float(np.exp(np.float32(np.log(np.float32(64.0 / 16.0))) / np.float32(3))),
                 target_batch_size=4096, mask_loss_weight=1.0, apply_no_albedo=1)
-
-
-@pytest.fixture(scope="session")
-def install(tmp_path_factory):
-    """<root>/build/testbed (oracle-linked), <root>/utils, <root>/configs/nerf — the install layout the binary expects."""
-    oracle_lib.functions()
-    root = tmp_path_factory.mktemp("install")
-    os.makedirs(root / "build")
-    os.makedirs(root / "configs" / "nerf")
-    shutil.copytree(os.path.join(ROOT, "utils"), root / "utils")
-    shutil.copy(os.path.join(ROOT, "configs", "nerf", "base.json"), root / "configs" / "nerf" / "base.json")
-    with open(root / "configs" / "nerf" / "small.json", "w") as f:
-        json.dump(SMALL_CFG, f)
-    odir = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-include", os.path.join(odir, "orc_prefix.h"),
-                           os.path.join(HOST, "testbed_main.cpp"), "-o", str(root / "build" / "testbed"), "-L" + odir, "-lorc", "-lz", "-Wl,-rpath," + odir])
-    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(HOST, "dump_dataset.cpp"), "-o", str(root / "build" / "dump_dataset"), "-lz"])
-    return root
 
 
 def run(install, *args, **kw):
