@@ -99,7 +99,8 @@ typedef struct rnb_config {
 	uint32_t world_size;              /* 1 */
 	uint32_t rank;                    /* 0 */
 	uint32_t only_sdf_training;       /* 0; Adam skips the colour MLP (adam.h:121-165), set by --fractional-training (testbed.cu:1886-1895) */
-	uint32_t reserved[7];
+	uint32_t overlap;                 /* 1; run independent stages of consecutive steps on side streams (same results); 0 = strictly serial */
+	uint32_t reserved[6];
 } rnb_config;
 
 /* One training view — TrainingImageMetadata + TrainingXForm (nerf_loader.h:33-49). */

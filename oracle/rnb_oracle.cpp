@@ -130,7 +130,7 @@ struct orc_ctx_s {
 	uint32_t density_grid_ema_step = 0;
 
 	// controller (Counters, testbed.h:627-640)
-	uint32_t training_step = 0;
+	uint32_t training_step = 0, cur_step = 0;
 	uint32_t valid_level = 0;
 	uint32_t rays_per_batch = 0;
 	uint32_t measured_batch_size = 0;
@@ -1318,6 +1318,7 @@ int rnb_default_config(rnb_config* cfg) {
 	cfg->ema_decay = 0.95f; cfg->lr_decay_start = 20000; cfg->lr_decay_interval = 10000; cfg->lr_decay_base = 0.33f;
 	cfg->density_grid_decay = 0.95f;
 	cfg->world_size = 1; cfg->rank = 0;
+	cfg->overlap = 1; // scheduling hint of the HIP library; the oracle is serial
 	return RNB_OK;
 }
 
@@ -1615,6 +1616,7 @@ int rnb_optimizer_step(orc_ctx_s* c, void*) {
 int rnb_train_step_begin(orc_ctx_s* c, void*) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (c->views.empty()) return fail(RNB_ERR_INVALID, "no dataset");
+	c->cur_step = c->training_step;
 	c->valid_level = compute_valid_level(c->cfg, (int)c->training_step); // testbed.cu:2792
 	c->grid_updated = false;
 	c->prep_ms = 0.f;
@@ -1689,7 +1691,7 @@ int rnb_train_step_finish(orc_ctx_s* c, const uint64_t counters[4], const double
 		next_rays = std::min(next_multiple(next_rays, 128u), c->cfg.max_rays_per_batch);
 	}
 	if (stats) {
-		stats->training_step = c->training_step;
+		stats->training_step = c->cur_step + 1; // _finish may be called before _apply
 		stats->rays_per_batch = n_rays;
 		stats->next_rays_per_batch = next_rays;
 		stats->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);

@@ -57,7 +57,8 @@ class Config(C.Structure):
         ("world_size", C.c_uint32),
         ("rank", C.c_uint32),
         ("only_sdf_training", C.c_uint32),
-        ("reserved", C.c_uint32 * 7),
+        ("overlap", C.c_uint32),
+        ("reserved", C.c_uint32 * 6),
     ]
 
 

@@ -919,6 +919,75 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 	}
 }
 
+// Mid levels (cell a few march steps wide): the quad layout above, but each quad walks K consecutive samples of the
+// ray-ordered batch and keeps the four (dy, dz) corner sums of its (dx, feature) in registers while the cell does not
+// change. Same-address lanes of one atomic instruction are serialised by the memory system (one request each), so merging
+// a cell run in registers divides the request count by the run length.
+// One launch covers levels level0 + blockIdx.y; k_log2 holds log2(K) of level0 + i in bits [4i, 4i+4).
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint64_t k_log2) {
+	const uint32_t level = level0 + blockIdx.y;
+	const uint32_t K = 1u << ((k_log2 >> (4 * blockIdx.y)) & 15u);
+	if (level > G.valid_level) return;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t s0 = (t >> 2) * K;
+	if (s0 >= a.B) return;
+	const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+	float acc[4] = {0.f, 0.f, 0.f, 0.f};
+	uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+	auto flush = [&]() {
+#pragma unroll
+		for (uint32_t yz = 0; yz < 4; ++yz) {
+			if (acc[yz] != 0.f) {
+				const uint32_t e = grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1));
+				atomicAdd(gg + (size_t)e * 2 + f, acc[yz]);
+				acc[yz] = 0.f;
+			}
+		}
+	};
+	const uint32_t s_end = min(s0 + K, a.B);
+#pragma unroll 1
+	for (uint32_t s = s0; s < s_end; ++s) {
+		float pos[3];
+		uint32_t pg[3];
+		pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
+		pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
+		pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
+		if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+			if (cur[0] != 0xffffffffu) flush();
+			cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+		}
+		const float g1 = h2f(unpack_h2(a.g1[(size_t)level * a.B + s])[f]);
+		const float g2 = h2f(unpack_h2(a.g2[(size_t)level * a.B + s])[f]);
+		const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+#pragma unroll
+		for (uint32_t yz = 0; yz < 4; ++yz) {
+			const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+			float w[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
+			float weight = 1;
+			weight *= w[0]; weight *= w[1]; weight *= w[2];
+			float add = rh(g1 * weight);
+#pragma unroll
+			for (uint32_t gd = 0; gd < 3; ++gd) {
+				float w2 = scale * dn[gd] * 1.0f;
+#pragma unroll
+				for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+					const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+					w2 *= w[d];
+				}
+				add += rh(g2 * (c[gd] ? w2 : -w2));
+			}
+			acc[yz] += add;
+		}
+	}
+	flush();
+}
+
 // ---------------------------------------------------------------------------------------------
 // K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.
 // ---------------------------------------------------------------------------------------------

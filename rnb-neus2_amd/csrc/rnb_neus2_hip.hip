@@ -83,6 +83,8 @@ struct Profiler {
 	void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); ids.clear(); n = 0; }
 };
 
+static inline uint32_t ilog2(uint32_t v) { uint32_t r = 0; while (v > 1) { v >>= 1; ++r; } return r; }
+
 struct rnb_ctx {
 	rnb_config cfg;
 	Profiler prof;
@@ -130,10 +132,19 @@ struct rnb_ctx {
 	uint32_t measured_batch_size = 0, measured_batch_size_before_compaction = 0, n_rays_total = 0;
 	uint32_t optimizer_step_count = 0;
 	float lr_factor = 1.f;
-	uint32_t cur_n_rays = 0, cur_n_rays_total = 0, local_measured_before = 0;
+	uint32_t cur_n_rays = 0, cur_n_rays_total = 0, local_measured_before = 0, cur_step = 0;
 	bool grid_updated = false;
 	float prep_ms = 0.f;
 	std::chrono::steady_clock::time_point step_start;
+
+	// Overlap machinery (cfg.overlap): the weight-gradient GEMMs run beside the grid scatter (s_dw), and the NEXT step's ray
+	// generation + march — which depends on the occupancy bitfield and the RNG, not on the weights — runs beside this step's
+	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
+	hipStream_t s_march = nullptr, s_dw = nullptr;
+	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr;
+	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
+	struct Readback { uint32_t counters[4]; double sums[3]; }* host_rb = nullptr; // pinned
+	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
 
 	NetW net(bool inference) const {
 		const half_t* p = inference ? params_ema.p : params_fp16.p;
@@ -149,6 +160,8 @@ struct rnb_ctx {
 	}
 	GridMeta meta() const { GridMeta g = grid; g.valid_level = valid_level; return g; }
 };
+
+static void discard_premarch(rnb_ctx* c);
 
 namespace {
 
@@ -355,7 +368,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
-	// weight-gradient GEMMs
+	// weight-gradient GEMMs: MFMA / streaming work, independent of the (atomic-bound) grid scatter below -> side stream
+	const bool fork = c->overlap();
+	hipStream_t sd = fork ? c->s_dw : s;
+	if (fork) { HIP_TRY(hipEventRecord(c->ev_fb, s)); HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0)); }
 	const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
 	const size_t slab = (size_t)nwg * WAVES_PER_WG;
 	float* p = c->dw_partial.p;
@@ -368,21 +384,22 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	float* p_sdf1b = p;                     p += slab * 16 * 64;
 	const TrainScratch& T = c->ts;
 	if (!a.skip_rgb) {
-		hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dr, T.h2, B, chunk, p_rgb2);
-		hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dh2, T.h1, B, chunk, p_rgb1);
-		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dh1, T.cin, B, chunk, p_rgb0);
+		hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dr, T.h2, B, chunk, p_rgb2);
+		hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dh2, T.h1, B, chunk, p_rgb1);
+		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dh1, T.cin, B, chunk, p_rgb0);
 	}
-	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, s, T.dso, T.z1, B, chunk, p_sdf1);
-	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz, T.sdfin, B, chunk, p_sdf0);
-	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, s, T.dz1, T.ddin, B, chunk, p_sdf0b);
-	hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, s, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
+	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dso, T.z1, B, chunk, p_sdf1);
+	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz, T.sdfin, B, chunk, p_sdf0);
+	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz1, T.ddin, B, chunk, p_sdf0b);
+	hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, sd, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
 	DwFinishArgs f;
 	f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 	f.n_partials = (uint32_t)slab;
 	f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
 	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 	const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
-	hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, s, f);
+	hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, f);
+	if (fork) HIP_TRY(hipEventRecord(c->ev_dw, sd));
 	c->prof.mark(s, P_DW);
 	c->prof.units[P_DW] += B;
 	ScatterArgs sa;
@@ -399,11 +416,25 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 24u;
 		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 24u;
 		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
+		// run length per level for the quad kernels: a cell of resolution r spans ~590 / r march steps; finer levels take one sample per quad
+		uint32_t Ks[RNB_MAX_LEVELS];
+		{
+			const char* kenv = getenv("RNB_SCATTER_K"); // debug: comma list of K per level
+			for (l = 0; l < L; ++l) {
+				const float run = 590.f / (float)c->grid.resolution[l];
+				Ks[l] = run >= 8.f ? 16 : run >= 3.f ? 8 : run >= 1.5f ? 4 : run >= 1.0f ? 2 : 1;
+				if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
+			}
+		}
 		if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: one launch per level
 			for (l = 0; l < L; ++l) {
 				if (l < e16) launch(k_grid_scatter<16>, 16, l, l + 1);
 				else if (l < e4) launch(k_grid_scatter<4>, 4, l, l + 1);
-				else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+				else {
+					const uint32_t K = Ks[l];
+					if (K > 1) hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + K - 1) / K) * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l, (uint64_t)ilog2(K));
+					else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+				}
 			}
 		} else {
 		// levels whose gradient table fits in LDS (fp32 x 2 features): private per-workgroup accumulation
@@ -425,11 +456,23 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		launch(k_grid_scatter<16>, 16, e_lds, e16);
 		launch(k_grid_scatter<4>, 4, e16, e4);
 		if (getenv("RNB_SCATTER_NOQUAD")) launch(k_grid_scatter<1>, 1, e4, L);
-		else if (L > e4) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - e4), dim3(256), 0, s, c->meta(), sa, e4);
+		else if (L > e4) {
+			uint32_t l_plain = e4, k_min = 16;
+			uint64_t k_log2 = 0;
+			for (l = e4; l < L && Ks[l] > 1 && l - e4 < 16; ++l) {
+				k_log2 |= (uint64_t)ilog2(Ks[l]) << (4 * (l - e4));
+				k_min = std::min(k_min, Ks[l]);
+				l_plain = l + 1;
+			}
+			if (l_plain > e4) // one launch, blockIdx.y = level; rows with a larger K than k_min leave their surplus workgroups at once
+				hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + k_min - 1) / k_min) * 4 + 255) / 256, l_plain - e4), dim3(256), 0, s, c->meta(), sa, e4, k_log2);
+			if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, s, c->meta(), sa, l_plain);
+		}
 		}
 	}
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
+	if (fork) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join: the optimizer needs both halves
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -496,6 +539,7 @@ int rnb_default_config(rnb_config* cfg) {
 	cfg->ema_decay = 0.95f; cfg->lr_decay_start = 20000; cfg->lr_decay_interval = 10000; cfg->lr_decay_base = 0.33f;
 	cfg->density_grid_decay = 0.95f;
 	cfg->world_size = 1; cfg->rank = 0;
+	cfg->overlap = 1;
 	return RNB_OK;
 }
 
@@ -509,6 +553,10 @@ int rnb_destroy(rnb_ctx* c) {
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
+	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
+	if (c->s_dw) { (void)hipStreamSynchronize(c->s_dw); (void)hipStreamDestroy(c->s_dw); }
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw}) if (e) (void)hipEventDestroy(e);
+	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	delete c;
 	return RNB_OK;
 }
@@ -608,12 +656,17 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	c->training_step = 0;
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
+	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
+	for (hipEvent_t* e : {&c->ev_loss, &c->ev_march, &c->ev_fb, &c->ev_dw}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocDefault));
 	*out = c;
 	return RNB_OK;
 }
 
 int rnb_update_config(rnb_ctx* c, const rnb_config* cfg) {
 	if (!c || !cfg) return fail(RNB_ERR_INVALID, "null argument");
+	discard_premarch(c);
 	int rc = update_config_common(c->cfg, cfg);
 	if (rc != RNB_OK) return rc;
 	build_light_dirs(c);
@@ -637,6 +690,7 @@ int rnb_grid_tables(const rnb_ctx* c, uint32_t* offsets, uint32_t* resolution, f
 
 int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
 	if (!c || !sdf_w) return fail(RNB_ERR_INVALID, "null argument");
+	discard_premarch(c);
 	std::seed_seq seq{c->cfg.seed}; // Trainer ctor, trainer.h:54-61
 	std::vector<uint32_t> seeds(2);
 	seq.generate(std::begin(seeds), std::end(seeds));
@@ -684,6 +738,7 @@ int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
 
 int rnb_set_params(rnb_ctx* c, const float* params) {
 	if (!c || !params) return fail(RNB_ERR_INVALID, "null argument");
+	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
 	HIP_TRY(hipMemcpy(c->params_fp32.p, params, c->params_fp32.bytes(), hipMemcpyHostToDevice));
 	int rc = derive_half_params(c, 0);
 	if (rc != RNB_OK) return rc;
@@ -750,6 +805,7 @@ int rnb_memcpy(rnb_ctx*, void* dst, const void* src, uint64_t n_bytes, int kind)
 
 int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const uint16_t* const* normals, const uint16_t* const* albedos) {
 	if (!c || !views || !normals || !albedos || n_views == 0) return fail(RNB_ERR_INVALID, "bad dataset");
+	discard_premarch(c);
 	size_t total = 0;
 	for (uint32_t v = 0; v < n_views; ++v) {
 		if (views[v].width == 0 || views[v].height == 0 || !normals[v] || !albedos[v]) return fail(RNB_ERR_INVALID, "empty view");
@@ -779,6 +835,7 @@ int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const u
 
 int rnb_set_training_step(rnb_ctx* c, uint32_t step) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c);
 	c->training_step = step;
 	c->valid_level = compute_valid_level(c->cfg, (int)step);
 	return RNB_OK;
@@ -787,10 +844,12 @@ uint32_t rnb_valid_level(const rnb_ctx* c) { return c ? c->valid_level : 0; }
 
 int rnb_update_density_grid(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c);
 	return training_prep(c, as_stream(stream));
 }
 int rnb_update_density_bitfield(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c);
 	return update_bitfield(c, as_stream(stream));
 }
 
@@ -809,6 +868,7 @@ int rnb_forward_infer(rnb_ctx* c, void* stream, const float* coords, uint32_t n,
 
 int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c);
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
 	if (max_samples > c->cfg.target_batch_size * 16) return fail(RNB_ERR_INVALID, "max_samples exceeds 16*target_batch_size");
@@ -832,16 +892,34 @@ int rnb_optimizer_step(rnb_ctx* c, void* stream) {
 	return optimizer_step(c, as_stream(stream));
 }
 
-int rnb_train_step_begin(rnb_ctx* c, void* stream) {
-	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
-	hipStream_t s = as_stream(stream);
+// Drops samples generated ahead of time for a step whose inputs have since changed (controller, flags, bitfield ...).
+static void discard_premarch(rnb_ctx* c) {
+	if (!c->pre.valid) return;
+	(void)hipStreamSynchronize(c->s_march);
+	c->n_rays_total = c->pre.n_rays_total;
+	c->pre.valid = false;
+}
+
+static uint32_t next_max_inference(rnb_ctx* c) { // testbed_nerf.cu:3891-3896
+	const uint32_t max_samples = c->cfg.target_batch_size * 16;
+	if (c->measured_batch_size_before_compaction == 0) { c->measured_batch_size_before_compaction = max_samples; return max_samples; }
+	return next_multiple_u32(std::min(c->measured_batch_size_before_compaction, max_samples), 128u);
+}
+
+static bool prep_due(uint32_t step) { // testbed.cu:2805
+	const uint32_t n_prep_to_skip = std::min(std::max(step / 16u, 1u), 16u);
+	return step % n_prep_to_skip == 0;
+}
+
+// Occupancy update (when due), ray generation + march, network evaluation of all samples, loss + compaction.
+static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->valid_level = compute_valid_level(c->cfg, (int)c->training_step); // testbed.cu:2792
 	c->grid_updated = false;
 	c->prep_ms = 0.f;
 	int rc;
-	const uint32_t n_prep_to_skip = std::min(std::max(c->training_step / 16u, 1u), 16u); // testbed.cu:2805
-	if (c->training_step % n_prep_to_skip == 0) {
+	if (prep_due(c->training_step)) {
+		discard_premarch(c); // never generated for such a step; defensive
+		const uint32_t n_prep_to_skip = std::min(std::max(c->training_step / 16u, 1u), 16u);
 		auto t0 = std::chrono::steady_clock::now();
 		rc = training_prep(c, s);
 		if (rc != RNB_OK) return rc;
@@ -850,33 +928,76 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 		c->prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_prep_to_skip;
 	}
 	c->step_start = std::chrono::steady_clock::now();
-	const uint32_t B = c->cfg.target_batch_size;
-	const uint32_t max_samples = B * 16;
-	uint32_t max_inference;
-	if (c->measured_batch_size_before_compaction == 0) { // testbed_nerf.cu:3891-3896
-		c->measured_batch_size_before_compaction = max_inference = max_samples;
-	} else {
-		max_inference = next_multiple_u32(std::min(c->measured_batch_size_before_compaction, max_samples), 128u);
-	}
-	if (c->training_step == 0) c->n_rays_total = 0; // testbed_nerf.cu:3906-3908
-	const uint32_t n_rays_total = c->n_rays_total;
+	const uint32_t max_inference = next_max_inference(c);
+	if (c->training_step == 0) { discard_premarch(c); c->n_rays_total = 0; } // testbed_nerf.cu:3906-3908
 	const uint32_t n_rays = c->rays_per_batch;
-	c->n_rays_total += n_rays * c->cfg.world_size;
+	if (c->pre.valid && (c->pre.n_rays != n_rays || c->pre.max_inference != max_inference)) discard_premarch(c);
+	uint32_t n_rays_total;
+	if (c->pre.valid) { // generated beside the previous step's backward pass
+		n_rays_total = c->pre.n_rays_total;
+		c->pre.valid = false;
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
+	} else {
+		n_rays_total = c->n_rays_total;
+		c->n_rays_total += n_rays * c->cfg.world_size;
+		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
+		rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
+		if (rc != RNB_OK) return rc;
+	}
 	c->cur_n_rays = n_rays;
 	c->cur_n_rays_total = n_rays_total;
-	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
-	rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
-	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_NONE);
 	rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
-	rc = compute_loss(c, s, n_rays, n_rays_total);
-	if (rc != RNB_OK) return rc;
-	rc = forward_backward(c, s);
+	return compute_loss(c, s, n_rays, n_rays_total);
+}
+
+static int step_back(rnb_ctx* c, hipStream_t s) {
+	int rc = forward_backward(c, s);
 	if (rc != RNB_OK) return rc;
 	c->rng.advance(); // testbed_nerf.cu:4118
 	return RNB_OK;
+}
+
+static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
+	c->prof.mark(s, P_NONE);
+	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
+	c->prof.mark(s, P_REDUCE);
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+// Ray generation + march of the step after the current one, on the side stream, once the current step's loss pass has
+// released the sample buffers (ev_loss). Skipped when that step starts with an occupancy update (it changes the bitfield).
+static int launch_premarch(rnb_ctx* c) {
+	if (!c->overlap() || c->pre.valid || prep_due(c->cur_step + 1)) return RNB_OK; // cur_step + 1: _finish may run before _apply
+	const uint32_t n_rays = c->rays_per_batch, max_inference = next_max_inference(c), n_rays_total = c->n_rays_total;
+	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
+	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), c->s_march));
+	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipEventRecord(c->ev_march, c->s_march));
+	c->n_rays_total += n_rays * c->cfg.world_size;
+	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference;
+	return RNB_OK;
+}
+
+int rnb_train_step_begin(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
+	hipStream_t s = as_stream(stream);
+	c->cur_step = c->training_step;
+	int rc = step_front(c, s);
+	if (rc != RNB_OK) return rc;
+	// the step's counters and loss sums are final here: hand them to the host now, so that the ray controller (and the next
+	// step's march) does not have to wait for the backward pass
+	rc = launch_reduce_losses(c, s);
+	if (rc != RNB_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(c->host_rb->counters, c->counters.p, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(c->host_rb->sums, c->loss_sums.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipEventRecord(c->ev_loss, s));
+	return step_back(c, s);
 }
 
 int rnb_train_step_apply(rnb_ctx* c, void* stream) {
@@ -885,24 +1006,18 @@ int rnb_train_step_apply(rnb_ctx* c, void* stream) {
 	int rc = optimizer_step(c, s);
 	if (rc != RNB_OK) return rc;
 	++c->training_step;
-	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
-	c->prof.mark(s, P_REDUCE);
-	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
 
+// Counters + loss sums of the step started by the last rnb_train_step_begin. May be called before or after _apply.
 int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], double loss_sums_out[3]) {
 	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
-	hipStream_t s = as_stream(stream);
-	uint32_t counters[4];
-	double sums[4];
-	HIP_TRY(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(sums, c->loss_sums.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s)); // testbed.cu:2866
+	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
+	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
+	const uint32_t* counters = c->host_rb->counters;
 	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
-	for (int k = 0; k < 3; ++k) loss_sums_out[k] = sums[k];
+	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];
 	return RNB_OK;
 }
@@ -931,7 +1046,7 @@ int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double s
 		next_rays = std::min(next_multiple_u32(next_rays, 128u), c->cfg.max_rays_per_batch);
 	}
 	if (stats) {
-		stats->training_step = c->training_step;
+		stats->training_step = c->cur_step + 1;
 		stats->rays_per_batch = n_rays;
 		stats->next_rays_per_batch = next_rays;
 		stats->measured_batch_size = (uint32_t)(counters[1] / c->cfg.world_size);
@@ -943,7 +1058,8 @@ int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double s
 		stats->step_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - c->step_start).count();
 	}
 	c->rays_per_batch = next_rays;
-	return rc;
+	if (rc != RNB_OK) return rc;
+	return launch_premarch(c);
 }
 
 int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
@@ -957,6 +1073,9 @@ int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
 }
 
 int rnb_train_step(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+	// With cfg.overlap the host only waits for the loss pass (rnb_train_step_local), so the call returns once the step's
+	// statistics are known and the next step's march has been queued beside the backward pass; the optimizer may still be
+	// running. Without it (or while profiling) every wait is a full stream synchronisation, as in the reference.
 	int rc = rnb_train_step_begin(c, stream);
 	if (rc != RNB_OK) return rc;
 	return rnb_train_step_end(c, stream, stats);
@@ -984,6 +1103,7 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (rays_per_batch == 0 || rays_per_batch > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "rays_per_batch out of range");
+	discard_premarch(c);
 	c->training_step = training_step;
 	c->valid_level = compute_valid_level(c->cfg, (int)training_step);
 	c->rays_per_batch = rays_per_batch;

@@ -54,14 +54,20 @@ class DataParallelTrainer:
         return t.cpu().numpy()
 
     def step(self, allow_no_samples=False):
+        """begin (march .. loss .. backward queued) -> counters as soon as the loss pass is done -> 7-value all-reduce ->
+        finish (ray controller; queues the NEXT step's march on the side stream) -> gradient all-reduce -> apply (Adam).
+        The next step's march therefore runs beside this step's backward pass, gradient all-reduce and optimizer."""
         ctx = self.ctx
         ctx.train_step_begin(self.stream)
-        if ctx.cfg.world_size > 1:
-            self._reduce_grads(ctx)
-        ctx.train_step_apply(self.stream)
         counters, sums = ctx.train_step_local(self.stream)
         if ctx.cfg.world_size > 1:
             vec = np.concatenate([counters.astype(np.float64), sums])
             vec = self._reduce_small(vec)
             counters, sums = np.rint(vec[:4]).astype(np.uint64), vec[4:]
-        return ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
+        try:
+            stats = ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
+        finally:  # the optimizer runs even when the step produced no samples, as in the reference
+            if ctx.cfg.world_size > 1:
+                self._reduce_grads(ctx)
+            ctx.train_step_apply(self.stream)
+        return stats
