@@ -780,88 +780,102 @@ __global__ __launch_bounds__(256) void k_grid_scatter(const GridMeta G, const Sc
 // global atomics pile up on a handful of addresses. Each workgroup accumulates its slice of the batch into a private copy
 // of the level's gradient table in LDS (ds_add_f32), with the same run-length merge in registers, then flushes the
 // non-zero entries once.
-struct ScatterLdsArgs { ScatterArgs a; uint32_t level; uint32_t samples_per_wg; };
+struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_wg; }; // levels [0, n_levels)
 
+// All LDS-resident levels in one pass: the per-sample loads (coords, dn) are shared between the levels and the per-thread
+// dependent-load chain is K = 4 samples long. LDS layout: level l's table at float offset 2 * G.offsets[l].
 __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	float* tab = reinterpret_cast<float*>(smem_raw);
 	const ScatterArgs& a = p.a;
-	const uint32_t level = p.level;
-	if (level > G.valid_level) return;
-	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
-	const uint32_t n_tab = hashmap_size * 2;
+	const uint32_t NL = min(p.n_levels, G.valid_level + 1u);
+	if (NL == 0) return;
+	const uint32_t n_tab = G.offsets[NL] * 2;
 	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) tab[q] = 0.f;
 	__syncthreads();
-	const float scale = G.scale[level];
-	const uint32_t res = G.resolution[level];
-	constexpr int K = 8;
+	constexpr int K = 4;
 	const uint32_t wg_begin = blockIdx.x * p.samples_per_wg;
 	const uint32_t wg_end = min(wg_begin + p.samples_per_wg, a.B);
 	for (uint32_t s0 = wg_begin + threadIdx.x * K; s0 < wg_end; s0 += blockDim.x * K) {
-		float acc[8][2];
-		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+		float cx[K], cy[K], cz[K], dn[K][3];
 #pragma unroll
-		for (int q = 0; q < 8; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
-		auto flush = [&]() {
-#pragma unroll
-			for (uint32_t idx = 0; idx < 8; ++idx) {
-				if (acc[idx][0] == 0.f && acc[idx][1] == 0.f) continue;
-				const uint32_t e = grid_entry(hashmap_size, res, cur[0] + (idx & 1u), cur[1] + ((idx >> 1) & 1u), cur[2] + ((idx >> 2) & 1u));
-				if (acc[idx][0] != 0.f) atomicAdd(tab + e * 2 + 0, acc[idx][0]);
-				if (acc[idx][1] != 0.f) atomicAdd(tab + e * 2 + 1, acc[idx][1]);
-				acc[idx][0] = 0.f; acc[idx][1] = 0.f;
-			}
-		};
+		for (int j = 0; j < K; ++j) { // all of the thread's loads that do not depend on the level are issued up front
+			const uint32_t s = min(s0 + j, wg_end - 1);
+			cx[j] = a.coords[(size_t)s * 7 + 0]; cy[j] = a.coords[(size_t)s * 7 + 1]; cz[j] = a.coords[(size_t)s * 7 + 2];
+			dn[j][0] = a.dn[s]; dn[j][1] = a.dn[(size_t)a.B + s]; dn[j][2] = a.dn[(size_t)2 * a.B + s];
+		}
 #pragma unroll 1
-		for (int j = 0; j < K; ++j) {
-			const uint32_t s = s0 + j;
-			if (s >= wg_end) break;
-			float pos[3];
-			uint32_t pg[3];
-			pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
-			pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
-			pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
-			if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-				if (cur[0] != 0xffffffffu) flush();
-			}
-			cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-			const h2 q1 = unpack_h2(a.g1[(size_t)level * a.B + s]);
-			const h2 q2 = unpack_h2(a.g2[(size_t)level * a.B + s]);
-			const float g1[2] = {h2f(q1[0]), h2f(q1[1])};
-			const float g2[2] = {h2f(q2[0]), h2f(q2[1])};
-			const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+		for (uint32_t level = 0; level < NL; ++level) {
+			float* lt = tab + (size_t)G.offsets[level] * 2;
+			const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+			const float scale = G.scale[level];
+			const uint32_t res = G.resolution[level];
+			uint32_t q1[K], q2[K];
 #pragma unroll
-			for (uint32_t idx = 0; idx < 8; ++idx) {
-				float weight = 1;
+			for (int j = 0; j < K; ++j) { const uint32_t s = min(s0 + j, wg_end - 1); q1[j] = a.g1[(size_t)level * a.B + s]; q2[j] = a.g2[(size_t)level * a.B + s]; }
+			float acc[8][2];
+			uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
-				for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
-				acc[idx][0] += rh(g1[0] * weight);
-				acc[idx][1] += rh(g1[1] * weight);
-			}
+			for (int q = 0; q < 8; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
+			auto flush = [&]() {
 #pragma unroll
-			for (uint32_t gd = 0; gd < 3; ++gd) {
-				const float grad_in = scale * dn[gd] * 1.0f;
+				for (uint32_t idx = 0; idx < 8; ++idx) {
+					if (acc[idx][0] == 0.f && acc[idx][1] == 0.f) continue;
+					const uint32_t e = grid_entry(hashmap_size, res, cur[0] + (idx & 1u), cur[1] + ((idx >> 1) & 1u), cur[2] + ((idx >> 2) & 1u));
+					if (acc[idx][0] != 0.f) atomicAdd(lt + e * 2 + 0, acc[idx][0]);
+					if (acc[idx][1] != 0.f) atomicAdd(lt + e * 2 + 1, acc[idx][1]);
+					acc[idx][0] = 0.f; acc[idx][1] = 0.f;
+				}
+			};
 #pragma unroll
-				for (uint32_t idx = 0; idx < 4; ++idx) {
-					float weight = grad_in;
-					uint32_t corner = 0;
+			for (int j = 0; j < K; ++j) {
+				if (s0 + j >= wg_end) break;
+				float pos[3];
+				uint32_t pg[3];
+				pos_fract(cx[j], scale, &pos[0], &pg[0]);
+				pos_fract(cy[j], scale, &pos[1], &pg[1]);
+				pos_fract(cz[j], scale, &pos[2], &pg[2]);
+				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+					if (cur[0] != 0xffffffffu) flush();
+				}
+				cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+				const h2 h1 = unpack_h2(q1[j]);
+				const h2 hh2 = unpack_h2(q2[j]);
+				const float g1[2] = {h2f(h1[0]), h2f(h1[1])};
+				const float g2[2] = {h2f(hh2[0]), h2f(hh2[1])};
 #pragma unroll
-					for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-						const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-						if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
-						else { weight *= pos[d]; corner |= (1u << d); }
+				for (uint32_t idx = 0; idx < 8; ++idx) {
+					float weight = 1;
+#pragma unroll
+					for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
+					acc[idx][0] += rh(g1[0] * weight);
+					acc[idx][1] += rh(g1[1] * weight);
+				}
+#pragma unroll
+				for (uint32_t gd = 0; gd < 3; ++gd) {
+					const float grad_in = scale * dn[j][gd] * 1.0f;
+#pragma unroll
+					for (uint32_t idx = 0; idx < 4; ++idx) {
+						float weight = grad_in;
+						uint32_t corner = 0;
+#pragma unroll
+						for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+							const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+							if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
+							else { weight *= pos[d]; corner |= (1u << d); }
+						}
+						acc[corner][0] += rh(g2[0] * -weight);
+						acc[corner][1] += rh(g2[1] * -weight);
+						acc[corner | (1u << gd)][0] += rh(g2[0] * weight);
+						acc[corner | (1u << gd)][1] += rh(g2[1] * weight);
 					}
-					acc[corner][0] += rh(g2[0] * -weight);
-					acc[corner][1] += rh(g2[1] * -weight);
-					acc[corner | (1u << gd)][0] += rh(g2[0] * weight);
-					acc[corner | (1u << gd)][1] += rh(g2[1] * weight);
 				}
 			}
+			flush();
 		}
-		flush();
 	}
 	__syncthreads();
-	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+	float* gg = a.grid_grad;
 	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) {
 		const float v = tab[q];
 		if (v != 0.f) atomicAdd(gg + q, v);
@@ -998,14 +1012,15 @@ struct AdamArgs {
 	float* grads; float* m; float* v; uint32_t* steps;
 	float base_lr, beta1, beta2, epsilon, l2_reg;
 	float ema_decay, ema_debias_old, ema_debias_new;
+	uint64_t begin, end;       // parameter range of this launch (multiples of 4)
 	uint64_t skip_lo, skip_hi; // only_sdf_training: parameters [skip_lo, skip_hi) (the colour MLP) get no Adam update (adam.h:121-165)
 };
 
 // Four parameters per thread (n_params, n_matrix are multiples of 4): 16-byte fp32 / 8-byte fp16 accesses. Entries of
 // the hash grid whose gradient is zero only take the EMA path (adam.h:111-114), i.e. 10 B of traffic per parameter.
 __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
-	const uint64_t n4 = a.n / 4;
-	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * blockDim.x) {
+	const uint64_t q_end = a.end / 4;
+	for (uint64_t q = a.begin / 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_end; q += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t i0 = q * 4;
 		f4 graw = reinterpret_cast<const f4*>(a.grads)[q];
 		if (graw[0] != 0.f || graw[1] != 0.f || graw[2] != 0.f || graw[3] != 0.f) reinterpret_cast<f4*>(a.grads)[q] = f4{0.f, 0.f, 0.f, 0.f}; // leave the accumulators clear

@@ -934,6 +934,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, co
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
+	if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(out + 3)[threadIdx.x] = counters[threadIdx.x]; // one 40-byte readback: sums + counters
 }
 
 } // namespace rnb

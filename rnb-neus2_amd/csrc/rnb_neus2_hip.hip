@@ -112,7 +112,8 @@ struct rnb_ctx {
 
 	// step scratch
 	DevBuf<uint32_t> ray_indices, numsteps, counters;
-	DevBuf<float> rays, coords, coords_compacted, loss, ek_loss, mask_loss;
+	DevBuf<float> rays, coords, coords_compacted, loss; // loss: [3][max_rays] = colour, eikonal, mask terms per ray
+	float *ek_loss = nullptr, *mask_loss = nullptr;       // rows 1, 2 of `loss`
 	DevBuf<half_t> mlp_out, dloss_dout;
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
@@ -140,10 +141,11 @@ struct rnb_ctx {
 	// Overlap machinery (cfg.overlap): the weight-gradient GEMMs run beside the grid scatter (s_dw), and the NEXT step's ray
 	// generation + march — which depends on the occupancy bitfield and the RNG, not on the weights — runs beside this step's
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
-	hipStream_t s_march = nullptr, s_dw = nullptr;
-	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr;
+	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
+	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
+	struct { bool valid = false; uint64_t split[2] = {0, 0}; } sc; // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
-	struct Readback { uint32_t counters[4]; double sums[3]; }* host_rb = nullptr; // pinned
+	struct Readback { double sums[3]; uint32_t counters[4]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
 
 	NetW net(bool inference) const {
@@ -341,10 +343,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.views = c->views.p; a.counters = c->counters.p; a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p;
 	a.coords = c->coords.p; a.mlp_out = c->mlp_out.p; a.ray_loss = c->ray_loss.p; a.ncomp = c->ncomp.p; a.cbase = c->cbase.p;
-	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss.p; a.mask_loss = c->mask_loss.p;
-	HIP_TRY(hipMemsetAsync(c->loss.p, 0, sizeof(float) * n_rays, s));
-	HIP_TRY(hipMemsetAsync(c->ek_loss.p, 0, sizeof(float) * n_rays, s));
-	HIP_TRY(hipMemsetAsync(c->mask_loss.p, 0, sizeof(float) * n_rays, s));
+	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss; a.mask_loss = c->mask_loss;
+	HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
 	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
@@ -362,117 +362,132 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const uint32_t B = c->cfg.target_batch_size;
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
+	c->sc.valid = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	c->prof.mark(s, P_NONE);
 	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
-	// weight-gradient GEMMs: MFMA / streaming work, independent of the (atomic-bound) grid scatter below -> side stream
-	const bool fork = c->overlap();
-	hipStream_t sd = fork ? c->s_dw : s;
-	if (fork) { HIP_TRY(hipEventRecord(c->ev_fb, s)); HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0)); }
-	const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
-	const size_t slab = (size_t)nwg * WAVES_PER_WG;
-	float* p = c->dw_partial.p;
-	float* p_rgb2 = p;                      p += slab * 16 * 64;
-	float* p_rgb1 = p;                      p += slab * 64 * 64;
-	float* p_rgb0 = p;                      p += slab * 64 * 32;
-	float* p_sdf1 = p;                      p += slab * 16 * 64;
-	float* p_sdf0 = p;                      p += slab * 64 * 32;
-	float* p_sdf0b = p;                     p += slab * 64 * 32;
-	float* p_sdf1b = p;                     p += slab * 16 * 64;
 	const TrainScratch& T = c->ts;
-	if (!a.skip_rgb) {
-		hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dr, T.h2, B, chunk, p_rgb2);
-		hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dh2, T.h1, B, chunk, p_rgb1);
-		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dh1, T.cin, B, chunk, p_rgb0);
-	}
-	hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dso, T.z1, B, chunk, p_sdf1);
-	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz, T.sdfin, B, chunk, p_sdf0);
-	hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz1, T.ddin, B, chunk, p_sdf0b);
-	hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, sd, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
-	DwFinishArgs f;
-	f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
-	f.n_partials = (uint32_t)slab;
-	f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
-	f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
-	const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
-	hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, f);
-	if (fork) HIP_TRY(hipEventRecord(c->ev_dw, sd));
-	c->prof.mark(s, P_DW);
-	c->prof.units[P_DW] += B;
+	const uint32_t L = c->cfg.n_levels;
+
+	// ---- weight-gradient GEMMs (MFMA / streaming)
+	auto launch_dw = [&](hipStream_t sd) {
+		const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
+		const size_t slab = (size_t)nwg * WAVES_PER_WG;
+		float* p = c->dw_partial.p;
+		float* p_rgb2 = p;                      p += slab * 16 * 64;
+		float* p_rgb1 = p;                      p += slab * 64 * 64;
+		float* p_rgb0 = p;                      p += slab * 64 * 32;
+		float* p_sdf1 = p;                      p += slab * 16 * 64;
+		float* p_sdf0 = p;                      p += slab * 64 * 32;
+		float* p_sdf0b = p;                     p += slab * 64 * 32;
+		float* p_sdf1b = p;                     p += slab * 16 * 64;
+		if (!a.skip_rgb) {
+			hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dr, T.h2, B, chunk, p_rgb2);
+			hipLaunchKernelGGL((k_dw<4, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dh2, T.h1, B, chunk, p_rgb1);
+			hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dh1, T.cin, B, chunk, p_rgb0);
+		}
+		hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dso, T.z1, B, chunk, p_sdf1);
+		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz, T.sdfin, B, chunk, p_sdf0);
+		hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz1, T.ddin, B, chunk, p_sdf0b);
+		hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, sd, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
+		DwFinishArgs f;
+		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
+		f.n_partials = (uint32_t)slab;
+		f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
+		f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
+		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
+		hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, f);
+	};
+
+	// ---- hash-grid gradient scatter, in three groups of levels (the addends commute up to fp32 rounding, as with any atomic order):
+	//   A  plain quad kernel        levels [l_plain, L)   one cell per sample, bound by atomic requests
+	//   B  run-length quad kernel   levels [e_c, l_plain) a cell spans several march steps (~590 / resolution)
+	//   C  coarse levels            levels [0, e_c)       LDS-privatised tables (+ the generic run-length kernel beyond the LDS limit)
 	ScatterArgs sa;
 	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
-	{ // cell runs per level: cell size / march step ~ 590 / resolution samples; pick K accordingly
-		uint32_t l = 0;
-		const uint32_t L = c->cfg.n_levels;
-		auto launch = [&](auto kern, uint32_t k, uint32_t l_begin, uint32_t l_end) {
-			if (l_end <= l_begin) return;
-			const uint32_t threads = (B + k - 1) / k;
-			hipLaunchKernelGGL(kern, dim3((threads + 255) / 256, l_end - l_begin), dim3(256), 0, s, c->meta(), sa, l_begin);
-		};
-		uint32_t e16 = 0, e4 = 0;
-		const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 24u;
-		const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 24u;
-		for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
-		// run length per level for the quad kernels: a cell of resolution r spans ~590 / r march steps; finer levels take one sample per quad
-		uint32_t Ks[RNB_MAX_LEVELS];
-		{
-			const char* kenv = getenv("RNB_SCATTER_K"); // debug: comma list of K per level
-			for (l = 0; l < L; ++l) {
-				const float run = 590.f / (float)c->grid.resolution[l];
-				Ks[l] = run >= 8.f ? 16 : run >= 3.f ? 8 : run >= 1.5f ? 4 : run >= 1.0f ? 2 : 1;
-				if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
-			}
-		}
-		if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: one launch per level
-			for (l = 0; l < L; ++l) {
-				if (l < e16) launch(k_grid_scatter<16>, 16, l, l + 1);
-				else if (l < e4) launch(k_grid_scatter<4>, 4, l, l + 1);
-				else {
-					const uint32_t K = Ks[l];
-					if (K > 1) hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + K - 1) / K) * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l, (uint64_t)ilog2(K));
-					else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
-				}
-			}
-		} else {
-		// levels whose gradient table fits in LDS (fp32 x 2 features): private per-workgroup accumulation
-		uint32_t e_lds = 0;
-		if (!getenv("RNB_SCATTER_NOLDS")) {
-			for (l = 0; l < L; ++l) {
-				const size_t bytes = (size_t)(c->grid.offsets[l + 1] - c->grid.offsets[l]) * 8;
-				if (l == e_lds && bytes <= 120 * 1024) {
-					ScatterLdsArgs la; la.a = sa; la.level = l;
-					const uint32_t n_wg = std::min<uint32_t>(128u, (B + 2047) / 2048);
-					la.samples_per_wg = ((B + n_wg - 1) / n_wg + 7) / 8 * 8;
-					hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), bytes, s, c->meta(), la);
-					e_lds = l + 1;
-				}
-			}
-		}
-		if (e16 < e_lds) e16 = e_lds;
-		if (e4 < e_lds) e4 = e_lds;
-		launch(k_grid_scatter<16>, 16, e_lds, e16);
-		launch(k_grid_scatter<4>, 4, e16, e4);
-		if (getenv("RNB_SCATTER_NOQUAD")) launch(k_grid_scatter<1>, 1, e4, L);
-		else if (L > e4) {
-			uint32_t l_plain = e4, k_min = 16;
-			uint64_t k_log2 = 0;
-			for (l = e4; l < L && Ks[l] > 1 && l - e4 < 16; ++l) {
-				k_log2 |= (uint64_t)ilog2(Ks[l]) << (4 * (l - e4));
-				k_min = std::min(k_min, Ks[l]);
-				l_plain = l + 1;
-			}
-			if (l_plain > e4) // one launch, blockIdx.y = level; rows with a larger K than k_min leave their surplus workgroups at once
-				hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + k_min - 1) / k_min) * 4 + 255) / 256, l_plain - e4), dim3(256), 0, s, c->meta(), sa, e4, k_log2);
-			if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, s, c->meta(), sa, l_plain);
-		}
+	uint32_t l, e16 = 0, e4 = 0, e_lds = 0, Ks[RNB_MAX_LEVELS];
+	const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 24u;
+	const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 24u;
+	for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
+	{
+		const char* kenv = getenv("RNB_SCATTER_K"); // debug: comma list of K per level
+		for (l = 0; l < L; ++l) {
+			const float run = 590.f / (float)c->grid.resolution[l];
+			Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : run >= 0.55f ? 2 : 1;
+			if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
 		}
 	}
+	if (!getenv("RNB_SCATTER_NOLDS")) // the coarsest levels whose fp32 gradient tables fit in LDS together
+		for (l = 0; l < L; ++l) if (l == e_lds && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) e_lds = l + 1;
+	if (e16 < e_lds) e16 = e_lds;
+	if (e4 < e_lds) e4 = e_lds;
+	const uint32_t e_c = e4;
+	uint32_t l_plain = e_c, k_min = 16;
+	uint64_t k_log2 = 0;
+	const bool noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr;
+	if (!noquad)
+		for (l = e_c; l < L && Ks[l] > 1 && l - e_c < 16; ++l) {
+			k_log2 |= (uint64_t)ilog2(Ks[l]) << (4 * (l - e_c));
+			k_min = std::min(k_min, Ks[l]);
+			l_plain = l + 1;
+		}
+	auto launch_a = [&](hipStream_t st) {
+		if (noquad) { if (L > e_c) hipLaunchKernelGGL(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, c->meta(), sa, e_c); }
+		else if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, c->meta(), sa, l_plain);
+	};
+	auto launch_b = [&](hipStream_t st) { // one launch, blockIdx.y = level; rows with a larger K than k_min leave their surplus workgroups at once
+		if (l_plain > e_c)
+			hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + k_min - 1) / k_min) * 4 + 255) / 256, l_plain - e_c), dim3(256), 0, st, c->meta(), sa, e_c, k_log2);
+	};
+	auto launch_c = [&](hipStream_t st) {
+		if (e_lds) {
+			ScatterLdsArgs la; la.a = sa; la.n_levels = e_lds;
+			const uint32_t n_wg = std::min<uint32_t>(256u, (B + 1023) / 1024);
+			la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
+			hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_lds] * 8, st, c->meta(), la);
+		}
+		if (e16 > e_lds) hipLaunchKernelGGL(k_grid_scatter<16>, dim3(((B + 15) / 16 + 255) / 256, e16 - e_lds), dim3(256), 0, st, c->meta(), sa, e_lds);
+		if (e4 > e16) hipLaunchKernelGGL(k_grid_scatter<4>, dim3(((B + 3) / 4 + 255) / 256, e4 - e16), dim3(256), 0, st, c->meta(), sa, e16);
+	};
+
+	if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: serial, one launch per level
+		launch_dw(s);
+		c->prof.mark(s, P_DW);
+		for (l = 0; l < L; ++l) {
+			if (l < e16) hipLaunchKernelGGL(k_grid_scatter<16>, dim3(((B + 15) / 16 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+			else if (l < e4) hipLaunchKernelGGL(k_grid_scatter<4>, dim3(((B + 3) / 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+			else if (Ks[l] > 1) hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + Ks[l] - 1) / Ks[l]) * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l, (uint64_t)ilog2(Ks[l]));
+			else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
+		}
+	} else if (!c->overlap()) {
+		launch_dw(s);
+		c->prof.mark(s, P_DW);
+		launch_c(s); launch_b(s); launch_a(s);
+	} else {
+		// The caller's stream carries the scatter (C, B, then A: the optimizer's last chunk is then only A's 2 levels), the side
+		// stream the GEMMs. After B and A an event lets the optimizer step that group's levels while the rest is still being
+		// scattered (optimizer_step).
+		hipStream_t sd = c->s_dw;
+		HIP_TRY(hipEventRecord(c->ev_fb, s));
+		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
+		launch_dw(sd);
+		HIP_TRY(hipEventRecord(c->ev_dw, sd));
+		launch_c(s); // latency-bound: alone at the head (it stretches several-fold beside an atomic-bound kernel)
+		launch_b(s);
+		HIP_TRY(hipEventRecord(c->ev_sc[0], s));
+		launch_a(s);
+		HIP_TRY(hipEventRecord(c->ev_sc[1], s));
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
+		c->sc.split[0] = c->off_grid + (uint64_t)c->grid.offsets[noquad ? e_c : l_plain] * 2; // A = [split0, off_var)
+		c->sc.split[1] = c->off_grid + (uint64_t)c->grid.offsets[e_c] * 2;                      // B = [split1, split0), C = [off_grid, split1)
+	}
+	c->prof.units[P_DW] += B;
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
-	if (fork) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join: the optimizer needs both halves
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -493,7 +508,28 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1); // ema.h:116-117
 	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_adam_ema, dim3(4096), dim3(256), 0, s, a);
+	auto launch = [&](hipStream_t st, uint64_t lo, uint64_t hi) {
+		if (hi <= lo) return;
+		a.begin = lo; a.end = hi;
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
+		hipLaunchKernelGGL(k_adam_ema, dim3(blocks), dim3(256), 0, st, a);
+	};
+	if (c->overlap() && cfg.world_size == 1 && c->sc.valid) {
+		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
+		// on the side stream, beside the scatter of the next group; only the coarse levels' (small) block is left for the end.
+		hipStream_t sa = c->s_adam;
+		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
+		launch(sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
+		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
+		launch(sa, c->sc.split[0], c->off_var);      // group A's levels
+		HIP_TRY(hipEventRecord(c->ev_adam, sa));
+		launch(s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
+		launch(s, c->off_var, c->n_params);
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
+		c->sc.valid = false;
+	} else {
+		launch(s, 0, c->n_params);
+	}
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
 	HIP_TRY(hipGetLastError());
@@ -549,13 +585,13 @@ int rnb_destroy(rnb_ctx* c) {
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
-	c->loss.free(); c->ek_loss.free(); c->mask_loss.free(); c->mlp_out.free(); c->dloss_dout.free();
+	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
-	if (c->s_dw) { (void)hipStreamSynchronize(c->s_dw); (void)hipStreamDestroy(c->s_dw); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw}) if (e) (void)hipEventDestroy(e);
+	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	delete c;
 	return RNB_OK;
@@ -597,12 +633,12 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	} while (0)
 	ALLOC(c->params_fp32, c->n_params); ALLOC(c->grads, c->n_params); ALLOC(c->adam_m, c->n_params); ALLOC(c->adam_v, c->n_params);
 	ALLOC(c->params_fp16, c->n_params); ALLOC(c->params_ema, c->n_params); ALLOC(c->adam_steps, c->n_params);
-	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 4);
+	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 5);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
-	ALLOC(c->loss, maxr); ALLOC(c->ek_loss, maxr); ALLOC(c->mask_loss, maxr);
+	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
@@ -647,7 +683,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
 	c->density_grid_rng = Pcg32{c->rng.next_uint()};
@@ -658,7 +694,8 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	build_light_dirs(c);
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
-	for (hipEvent_t* e : {&c->ev_loss, &c->ev_march, &c->ev_fb, &c->ev_dw}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
+	for (hipEvent_t* e : {&c->ev_loss, &c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
 	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocDefault));
 	*out = c;
 	return RNB_OK;
@@ -770,9 +807,9 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_MLP_OUT: BUF(c->mlp_out);
 		case RNB_BUF_DLOSS_DOUT: BUF(c->dloss_dout);
 		case RNB_BUF_COORDS_COMPACTED: BUF(c->coords_compacted);
-		case RNB_BUF_LOSS: BUF(c->loss);
-		case RNB_BUF_EK_LOSS: BUF(c->ek_loss);
-		case RNB_BUF_MASK_LOSS: BUF(c->mask_loss);
+		case RNB_BUF_LOSS: *ptr = (void*)c->loss.p; *n_bytes = c->loss.bytes() / 3; return RNB_OK;
+		case RNB_BUF_EK_LOSS: *ptr = (void*)c->ek_loss; *n_bytes = c->loss.bytes() / 3; return RNB_OK;
+		case RNB_BUF_MASK_LOSS: *ptr = (void*)c->mask_loss; *n_bytes = c->loss.bytes() / 3; return RNB_OK;
 		case RNB_BUF_COUNTERS: BUF(c->counters);
 		case RNB_BUF_DENSITY_GRID_TMP: BUF(c->density_grid_tmp);
 		case RNB_BUF_GRID_SAMPLE_POS: *ptr = c->grid_sample_pos.p; *n_bytes = (uint64_t)c->n_grid_samples * 12; return RNB_OK;
@@ -962,7 +999,7 @@ static int step_back(rnb_ctx* c, hipStream_t s) {
 
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss.p, c->mask_loss.p, c->loss_sums.p);
+	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -994,8 +1031,7 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	// step's march) does not have to wait for the backward pass
 	rc = launch_reduce_losses(c, s);
 	if (rc != RNB_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(c->host_rb->counters, c->counters.p, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipMemcpyAsync(c->host_rb->sums, c->loss_sums.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(c->host_rb, c->loss_sums.p, sizeof(*c->host_rb), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipEventRecord(c->ev_loss, s));
 	return step_back(c, s);
 }
