@@ -158,13 +158,9 @@ __device__ __forceinline__ void pos_fract(float input, float scale, float* pos, 
 // One level of kernel_grid (grid.h:237-363): the 8 corners are gathered once and reused for the
 // feature (accumulated in half, grid.h:310-313) and for dy/dx (fp32, grid.h:324-363).
 template <bool GRAD>
-__device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* __restrict__ grid, const uint32_t level,
-                                             const float x, const float y, const float z,
-                                             half_t& f0, half_t& f1, float dy0[3], float dy1[3]) {
-	const uint32_t* g = grid + G.offsets[level];
-	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
-	const float scale = G.scale[level];
-	const uint32_t res = G.resolution[level];
+__device__ __forceinline__ void encode_level_core(const uint32_t* __restrict__ g, const uint32_t hashmap_size, const uint32_t res, const float scale,
+                                                  const float x, const float y, const float z,
+                                                  half_t& f0, half_t& f1, float dy0[3], float dy1[3]) {
 	float pos[3];
 	uint32_t pg[3];
 	pos_fract(x, scale, &pos[0], &pg[0]);
@@ -172,8 +168,10 @@ __device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* 
 	pos_fract(z, scale, &pos[2], &pg[2]);
 	// The x-neighbour of a cell is the next table entry on dense levels and, on hashed levels, whenever x is even
 	// (hash prime 1): one 8-byte gather then serves both corners. Random gathers are bound by the number of lane
-	// accesses the L1 processes, not by bytes, so this removes ~1/3 of the cost. (Entry `size` is readable: the
-	// parameter block continues past every level.)
+	// accesses the L1 processes AND by the bytes returned: measured alternatives that lost — 16-byte aligned block gathers
+	// (fewer accesses, +18 % time), unconditional second gathers (+10 %), a single wave-level branch around the four
+	// second gathers (+5 % on the one-wave-per-SIMD kernels). (Entry `size` is readable: the parameter block continues
+	// past every level.)
 	uint32_t v[8];
 #pragma unroll
 	for (uint32_t yz = 0; yz < 4; ++yz) {
@@ -223,6 +221,35 @@ __device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* 
 			dy1[gd] = a1;
 		}
 	}
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* __restrict__ grid, const uint32_t level,
+                                             const float x, const float y, const float z,
+                                             half_t& f0, half_t& f1, float dy0[3], float dy1[3]) {
+	encode_level_core<GRAD>(grid + G.offsets[level], G.offsets[level + 1] - G.offsets[level], G.resolution[level], G.scale[level], x, y, z, f0, f1, dy0, dy1);
+}
+
+// Per-level constants staged in LDS: 42 kernel-argument SGPRs that every unrolled level keeps alive would otherwise be
+// spilled to VGPR lanes (v_readlane / v_writelane traffic in the hot loop). One broadcast ds_read_b128 + 4 readfirstlane.
+struct __attribute__((aligned(16))) LevelMeta { uint32_t offset, size, res; float scale; };
+
+__device__ __forceinline__ void fill_level_meta(LevelMeta* __restrict__ lm, const GridMeta& G, const int tid) {
+	if (tid < RNB_MAX_LEVELS) {
+		LevelMeta m;
+		m.offset = G.offsets[tid]; m.size = G.offsets[tid + 1] - G.offsets[tid]; m.res = G.resolution[tid]; m.scale = G.scale[tid];
+		lm[tid] = m;
+	}
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void encode_level_lm(const LevelMeta* __restrict__ lm, const uint32_t* __restrict__ grid, const uint32_t level,
+                                                const float x, const float y, const float z,
+                                                half_t& f0, half_t& f1, float dy0[3], float dy1[3]) {
+	const uint4 raw = *reinterpret_cast<const uint4*>(lm + level);
+	const uint32_t off = __builtin_amdgcn_readfirstlane(raw.x), size = __builtin_amdgcn_readfirstlane(raw.y), res = __builtin_amdgcn_readfirstlane(raw.z);
+	const float scale = __uint_as_float(__builtin_amdgcn_readfirstlane(raw.w));
+	encode_level_core<GRAD>(grid + off, size, res, scale, x, y, z, f0, f1, dy0, dy1);
 }
 
 // ---- occupancy helpers (src/testbed_nerf.cu:439-475, 569-583, 153-155, 301-323, 429-437) ----

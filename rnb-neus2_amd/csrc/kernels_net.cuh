@@ -53,6 +53,25 @@ __device__ __forceinline__ void encode_all(const GridMeta& G, const uint32_t* __
 	}
 }
 
+template <bool GRAD>
+__device__ __forceinline__ void encode_all_lm(const LevelMeta* __restrict__ lm, const uint32_t n_levels, const uint32_t valid_level, const uint32_t* __restrict__ grid,
+                                              const float x, const float y, const float z, half_t (&feat)[28], float (&dydx)[GRAD ? 28 : 1][3]) {
+#pragma unroll
+	for (uint32_t level = 0; level < 14; ++level) {
+		half_t f0 = (half_t)0.f, f1 = (half_t)0.f;
+		float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
+		if (level < n_levels && level <= valid_level) {
+			encode_level_lm<GRAD>(lm, grid, level, x, y, z, f0, f1, d0, d1);
+		}
+		feat[level * 2 + 0] = f0;
+		feat[level * 2 + 1] = f1;
+		if (GRAD) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { dydx[GRAD ? level * 2 + 0 : 0][d] = d0[d]; dydx[GRAD ? level * 2 + 1 : 0][d] = d1[d]; }
+		}
+	}
+}
+
 // sdf_to_density_variance_buffer (common_operation.cuh:311-328): half arithmetic throughout.
 __device__ __forceinline__ half_t sdf_to_density(half_t sdf, half_t variance) {
 	const half_t s = f2h(expf(h2f(variance * (half_t)10.0f)));
@@ -259,6 +278,149 @@ __global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW 
 		{
 			h8 o0 = *reinterpret_cast<const h8*>(tC + lane * S32 + 0);
 			h8 o1 = *reinterpret_cast<const h8*>(tC + lane * S32 + 8);
+			o0[3] = sdf0 + bias;
+			o0[4] = f2h(grad[0]); o0[5] = f2h(grad[1]); o0[6] = f2h(grad[2]);
+			o0[7] = variance;
+			o1[0] = f2h(c[4]); o1[1] = f2h(c[5]); o1[2] = f2h(c[6]);
+			if (valid) {
+				h8* dst = reinterpret_cast<h8*>(a.out + (size_t)s * 16);
+				dst[0] = o0;
+				dst[1] = o1;
+			}
+		}
+		wave_lds_sync();
+	}
+}
+
+// K7, register-chained flavour (mlp.cuh): per wavefront one 32-wide exchange tile X (sdf_in rows -> d sdf / d in rows -> r
+// rows), 16 bytes per sample of colour-MLP side inputs (Y) and the raw sdf (Z); 6.3 KB instead of 27.6 KB, so two
+// workgroups fit a CU and the encode of one hides behind the MFMA / LDS phases of the other.
+constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
+constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
+
+__global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, const NetW net, const FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fill_level_meta(lm, G, threadIdx.x);
+	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
+	load_weights_chained(wts, net, threadIdx.x, WG);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* X = wts + W_FWD_END + wave * FWD2_WAVE_HALFS;
+	half_t* Y = X + TILE * S32;
+	half_t* Z = Y + TILE * 8;
+	const half_t variance = net.variance[0];
+	const half_t bias = f2h(a.sdf_bias);
+	uint32_t n = a.n_max;
+	if (a.n_ptr) n = min(*a.n_ptr, a.n_max);
+	const uint32_t n_tiles = (n + TILE - 1) / TILE;
+	const int r16 = lane & 15, hq = lane >> 4;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		const bool valid = s < n;
+		float c[7] = {0.5f, 0.5f, 0.5f, 0.f, 0.f, 0.f, 0.f};
+		if (valid) {
+#pragma unroll
+			for (int q = 0; q < 7; ++q) c[q] = a.coords[(size_t)s * 7 + q];
+		}
+		half_t feat[28];
+		float dydx[28][3];
+		encode_all_lm<true>(lm, n_levels, valid_level, net.grid, c[0], c[1], c[2], feat, dydx);
+		write_sdf_in_row(X, lane, c[0], c[1], c[2], feat);
+		wave_lds_sync();
+		// z1 = relu(W0 sdf_in) (registers) ; dz1 = W1[0,:] (.) relu'(z1) (registers)   (nerf_network.h:159-176)
+		h8 bz[4][2];
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, X, S32, acc, lane);
+			chain_pack<true>(acc, bz);
+		}
+		f4 acc_so[1][4];
+		zero_acc<1>(acc_so);
+		mfma_layer_regs<1, 2>(wts + W_S1, S64, bz, acc_so, lane); // sdf_out = W1 z1
+		{
+			// the backward transfer tests the stored half activation (common_device.h:182 ff.)
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks) {
+				const h8 w1 = *reinterpret_cast<const h8*>(wts + W_S1 + 0 * S64 + 32 * ks + 8 * hq);
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) bz[nt][ks][j] = (bz[nt][ks][j] > (half_t)0.f) ? w1[j] : (half_t)0.f;
+			}
+		}
+		wave_lds_sync(); // X (sdf_in) fully consumed by the first layer's MFMAs
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer_regs<2, 2>(wts + W_S0T, S64, bz, acc, lane); // d sdf / d in = W0^T dz1
+			store_acc<2, false>(acc, X, S32, 0, lane);
+		}
+		wave_lds_sync();
+		// per lane: grad = sum_k dsdf_din[3+k] * dy_dx[k] + dsdf_din[0..2]  (grid.h:527-554, nerf_network.h:185-189)
+		float grad[3] = {0.f, 0.f, 0.f};
+		{
+			half_t din[32];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const h8 v = *reinterpret_cast<const h8*>(X + lane * S32 + q * 8);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) din[q * 8 + j] = v[j];
+			}
+#pragma unroll
+			for (int k = 0; k < 28; ++k) {
+				const float dl = h2f(din[3 + k]);
+#pragma unroll
+				for (int d = 0; d < 3; ++d) grad[d] += dl * dydx[k][d];
+			}
+#pragma unroll
+			for (int d = 0; d < 3; ++d) grad[d] += h2f(din[d]);
+		}
+		// colour-MLP side inputs [x y z | grad | 0 0] per sample -> Y ; raw sdf (D layout, hq == 0, r == 0) -> Z   (nerf_network.h:206-218)
+		{
+			const h8 v = {f2h(c[0]), f2h(c[1]), f2h(c[2]), f2h(grad[0]), f2h(grad[1]), f2h(grad[2]), (half_t)0.f, (half_t)0.f};
+			*reinterpret_cast<h8*>(Y + lane * 8) = v;
+			if (hq == 0) {
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) Z[16 * nt + r16] = f2h(acc_so[0][nt][0]);
+			}
+		}
+		wave_lds_sync();
+		const half_t sdf0 = Z[lane];
+		h8 bh[4][2];
+		{
+			h8 bin[4][1];
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				h4 o = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+				if (hq < 2) o = *reinterpret_cast<const h4*>(Y + (16 * nt + r16) * 8 + 4 * hq);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) { bin[nt][0][j] = f2h(acc_so[0][nt][j]); bin[nt][0][4 + j] = o[j]; }
+			}
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 1>(wts + W_C0, S32, bin, acc, lane);
+			chain_pack<true>(acc, bh);
+		}
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 2>(wts + W_C1, S64, bh, acc, lane);
+			chain_pack<true>(acc, bh);
+		}
+		{
+			f4 acc[1][4];
+			zero_acc<1>(acc);
+			mfma_layer_regs<1, 2>(wts + W_C2, S64, bh, acc, lane);
+			store_acc<1, false>(acc, X, S32, 0, lane); // X rows were last read before the previous sync
+		}
+		wave_lds_sync();
+		// output packing (nerf_network.h:221-250)
+		{
+			h8 o0 = *reinterpret_cast<const h8*>(X + lane * S32 + 0);
+			h8 o1 = *reinterpret_cast<const h8*>(X + lane * S32 + 8);
 			o0[3] = sdf0 + bias;
 			o0[4] = f2h(grad[0]); o0[5] = f2h(grad[1]); o0[6] = f2h(grad[2]);
 			o0[7] = variance;

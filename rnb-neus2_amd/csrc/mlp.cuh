@@ -130,6 +130,64 @@ __device__ __forceinline__ void store_acc_masked(const f4 (&acc)[M_TILES][4], co
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-chained layers (k_forward). The D fragments of a layer are, up to a permutation of the K index, exactly the
+// B fragments the next layer needs: lane (r16, hq) holds outputs 16*mt + 4*hq + r of sample 16*nt + r16, and wants 8
+// K-values of that same sample for K-step ks. Taking (mt = 2ks, r = 0..3) and (mt = 2ks+1, r = 0..3) gives
+//   physical k = 32*ks + 8*hq + j   <->   logical feature 16*(2*ks + (j >> 2)) + 4*hq + (j & 3),
+// and since K is a summation index it is enough to store the next layer's weights with their columns in that order
+// (load_weights_chained). Hidden activations then never touch LDS: one 5 KB exchange tile per wavefront instead of three
+// 9 KB tiles, which is what lets two workgroups share a CU.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int chain_logical(int p) { return 16 * (2 * (p >> 5) + ((p & 7) >> 2)) + 4 * ((p >> 3) & 3) + (p & 3); }
+// K = 32 input of the colour MLP: [sdf_out (16, chained) | x y z grad 0.. (16, from the exchange tile)] in compact indexing
+__host__ __device__ constexpr int chain_logical_c0(int p) { return (p & 7) < 4 ? 4 * (p >> 3) + (p & 3) : 16 + 4 * (p >> 3) + ((p & 7) - 4); }
+
+// Weight image for the chained forward; same offsets as load_weights<false>, columns of every chained operand permuted.
+__device__ inline void load_weights_chained(half_t* __restrict__ w, const NetW& net, int tid, int nthreads) {
+	for (int i = tid; i < 64 * 32; i += nthreads) { int o = i >> 5, k = i & 31; w[W_S0 + o * S32 + k] = net.sdf_w0[i]; } // input comes from LDS: natural order
+	for (int i = tid; i < 16 * 64; i += nthreads) { int o = i >> 6, p = i & 63; w[W_S1 + o * S64 + p] = net.sdf_w1[o * 64 + chain_logical(p)]; }
+	for (int i = tid; i < 32 * 64; i += nthreads) { int k = i >> 6, p = i & 63; w[W_S0T + k * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + k]; } // W0^T[k][hidden]
+	for (int i = tid; i < 64 * 32; i += nthreads) {
+		int o = i >> 5, p = i & 31;
+		int c = chain_logical_c0(p);          // compact input index: 0..15 -> column c, 16..31 -> column c + 16
+		w[W_C0 + o * S32 + p] = net.rgb_w0[o * 48 + (c < 16 ? c : c + 16)];
+	}
+	for (int i = tid; i < 64 * 64; i += nthreads) { int o = i >> 6, p = i & 63; w[W_C1 + o * S64 + p] = net.rgb_w1[o * 64 + chain_logical(p)]; }
+	for (int i = tid; i < 16 * 64; i += nthreads) { int o = i >> 6, p = i & 63; w[W_C2 + o * S64 + p] = net.rgb_w2[o * 64 + chain_logical(p)]; }
+}
+
+// acc[mt][nt] += W[16mt.., :] * B over K = 32*K_STEPS, B fragments in registers.
+template <int M_TILES, int K_STEPS>
+__device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, const int w_stride, const h8 (&b)[4][K_STEPS], f4 (&acc)[M_TILES][4], const int lane) {
+	const int r16 = lane & 15, hq = lane >> 4;
+#pragma unroll
+	for (int mt = 0; mt < M_TILES; ++mt) {
+#pragma unroll
+		for (int ks = 0; ks < K_STEPS; ++ks) {
+			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+		}
+	}
+}
+
+// D fragments of a 64-wide layer -> B fragments of the next one (half, optional ReLU: warp_activation, common_device.h:69-115).
+template <bool RELU>
+__device__ __forceinline__ void chain_pack(const f4 (&acc)[4][4], h8 (&b)[4][2]) {
+#pragma unroll
+	for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+			for (int j = 0; j < 8; j += 2) { // convert first, ReLU on the packed halfs (v_cvt_pk_f16_f32 + v_pk_max_f16): same values, 2 instead of 5 instructions per pair
+				h2 p = {f2h(acc[2 * ks + (j >> 2)][nt][j & 3]), f2h(acc[2 * ks + (j >> 2)][nt][(j & 3) + 1])};
+				if (RELU) p = __builtin_elementwise_max(p, h2{(half_t)0.f, (half_t)0.f});
+				b[nt][ks][j] = p[0];
+				b[nt][ks][j + 1] = p[1];
+			}
+}
+
 // Also writes the fragments feature-major to global memory: dst[feature][n_total] at sample column s0 + ...
 // (operands of the weight-gradient GEMMs, whose K dimension is the sample index).
 template <int M_TILES>

@@ -292,8 +292,13 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	FwdArgs a;
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
-	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-	hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
+	if (getenv("RNB_FORWARD_V1")) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
+		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
+		hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
+	} else {
+		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
+		hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	}
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -682,6 +687,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
