@@ -159,6 +159,7 @@ struct FwdArgs {
 	uint32_t n_max;
 	half_t* out;               // [n][16]
 	float sdf_bias;
+	const uint32_t* idx;       // optional: evaluate the samples idx[0 .. n) (slots into coords / out) instead of 0 .. n
 };
 
 __global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW net, const FwdArgs a) {
@@ -317,8 +318,10 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const int r16 = lane & 15, hq = lane >> 4;
 	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
-		const uint32_t s = tile * TILE + lane;
-		const bool valid = s < n;
+		const uint32_t q_in = tile * TILE + lane;
+		const bool valid = q_in < n;
+		uint32_t s = q_in;
+		if (a.idx && valid) s = a.idx[q_in];
 		float c[7] = {0.5f, 0.5f, 0.5f, 0.f, 0.f, 0.f, 0.f};
 		if (valid) {
 #pragma unroll

@@ -197,6 +197,9 @@ struct MarchArgs {
 	uint32_t* steps;    // [n_rays]
 	uint32_t* base;     // [n_rays]
 	uint32_t* slot;     // [n_rays] (0xffffffff = dropped)
+	uint32_t* base1;    // [n_rays] offset of the ray's first-round samples in idx1 (two-round network evaluation, see k_loss_pass1)
+	uint32_t* idx1;     // sample slots of the first round: the first min(steps, k1) samples of every kept ray
+	uint32_t k1;        // 0 = single round
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
 };
@@ -405,9 +408,11 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 // Single-workgroup exclusive scans over the rays (n <= 2^18): base = scan(steps); survivors = base + steps <= max_samples;
 // slot = scan(survivor). counters[0] = sum(steps) (numsteps_counter), [2] = #survivors (ray_counter), [3] = samples written.
 __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint32_t max_samples, const uint32_t* __restrict__ steps,
-                                                    uint32_t* __restrict__ base, uint32_t* __restrict__ slot, uint32_t* __restrict__ counters) {
+                                                    uint32_t* __restrict__ base, uint32_t* __restrict__ slot, uint32_t* __restrict__ counters,
+                                                    const uint32_t k1, uint32_t* __restrict__ base1, uint32_t* __restrict__ fwd_counts) {
 	__shared__ uint32_t sh[1024];
 	__shared__ uint32_t sh2[1024];
+	__shared__ uint32_t sh3[1024];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t per = (n + 1023) / 1024;
 	const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 	}
 	uint32_t run = sh[tid] - sum;
 	const uint32_t total = sh[1023];
-	uint32_t n_surv = 0, written = 0;
+	uint32_t n_surv = 0, written = 0, first = 0;
 	for (uint32_t i = lo; i < hi; ++i) {
 		const uint32_t st = steps[i];
 		base[i] = run;
@@ -431,27 +436,32 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 		slot[i] = ok ? 1u : 0u;
 		n_surv += ok ? 1u : 0u;
 		written += ok ? st : 0u;
+		first += ok ? min(st, k1) : 0u;
 		run += st;
 	}
 	__syncthreads();
 	sh[tid] = n_surv;
 	sh2[tid] = written;
+	sh3[tid] = first;
 	__syncthreads();
 	for (uint32_t off = 1; off < 1024; off <<= 1) {
 		uint32_t v = tid >= off ? sh[tid - off] : 0;
 		uint32_t w = tid >= off ? sh2[tid - off] : 0;
+		uint32_t u = tid >= off ? sh3[tid - off] : 0;
 		__syncthreads();
 		sh[tid] += v;
 		sh2[tid] += w;
+		sh3[tid] += u;
 		__syncthreads();
 	}
-	uint32_t srun = sh[tid] - n_surv;
+	uint32_t srun = sh[tid] - n_surv, frun = sh3[tid] - first;
 	for (uint32_t i = lo; i < hi; ++i) {
 		const bool ok = slot[i] != 0u;
 		slot[i] = ok ? srun : 0xffffffffu;
 		srun += ok ? 1u : 0u;
+		if (k1) { base1[i] = frun; frun += ok ? min(steps[i], k1) : 0u; }
 	}
-	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; }
+	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; fwd_counts[0] = sh3[1023]; fwd_counts[1] = 0; }
 }
 
 // Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
@@ -472,6 +482,10 @@ __global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
 		ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
 		a.numsteps[(size_t)s * 2 + 0] = steps;
 		a.numsteps[(size_t)s * 2 + 1] = base;
+	}
+	if (a.k1) {
+		const uint32_t b1 = a.base1[i];
+		for (uint32_t j = lane; j < min(steps, a.k1); j += 64) a.idx1[b1 + j] = base + j;
 	}
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
 	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
@@ -523,6 +537,12 @@ struct LossArgs {
 	float* coords_compacted;
 	half_t* dloss;
 	float *loss, *ek_loss, *mask_loss;
+	// two-round network evaluation (cap = 0xffffffff: single round)
+	uint32_t cap;          // samples per ray evaluated in round 1
+	uint32_t phase;        // 0: all rays, at most `cap` samples each; 1: only the rays round 1 could not finish, all their samples
+	uint8_t* unfinished;   // [n_rays]
+	uint32_t* idx2;        // sample slots still to evaluate (round 2)
+	uint32_t* fwd_counts;  // [1] = entries of idx2
 };
 
 __device__ __forceinline__ void albedo_from_output(const LossFlags& F, const half_t* __restrict__ o, float albedo[4]) { // testbed_nerf.cu:1614-1639
@@ -642,8 +662,10 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
 	const int lane = threadIdx.x & 63;
 	if (i >= a.n_rays) return;
-	if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; return; }
-	const uint32_t numsteps = a.numsteps[(size_t)i * 2 + 0];
+	if (i >= a.counters[2]) { if (lane == 0 && a.phase == 0) a.ncomp[i] = 0; return; }
+	if (a.phase == 1 && !a.unfinished[i]) return;
+	const uint32_t numsteps_all = a.numsteps[(size_t)i * 2 + 0];
+	const uint32_t numsteps = a.phase == 0 ? min(numsteps_all, a.cap) : numsteps_all;
 	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
 	const float* coords_in = a.coords + (size_t)base * 7;
 	const half_t* net = a.mlp_out + (size_t)base * 16;
@@ -689,6 +711,21 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 			weight_sum += weight;
 			T *= (1.f - al);
 			++n;
+		}
+	}
+	if (a.phase == 0 && a.cap != 0xffffffffu) {
+		// The samples past the point where the transmittance falls below 1e-4 are never read again (testbed_nerf.cu:1609), so
+		// the network is first evaluated on the head of every ray only. A ray is settled if it terminated inside its head, or
+		// has no more samples, or would terminate at the very next check; the others queue their tails for round 2 and are
+		// recomputed in phase 1. Same values as a single full pass.
+		const bool settled = done || numsteps_all <= a.cap || T < EPSILON;
+		if (lane == 0) a.unfinished[i] = settled ? 0 : 1;
+		if (!settled) {
+			const uint32_t tail = numsteps_all - a.cap;
+			uint32_t off = 0;
+			if (lane == 0) off = atomicAdd(a.fwd_counts + 1, tail);
+			off = __builtin_amdgcn_readfirstlane(off);
+			for (uint32_t j = lane; j < tail; j += 64) a.idx2[off + j] = base + a.cap + j;
 		}
 	}
 	if (lane == 0) {
@@ -922,7 +959,7 @@ __global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counte
 }
 
 // loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
-__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts) {
 	__shared__ double sh[3][1024];
 	const uint32_t n = min(counters[2], n_max);
 	double s0 = 0, s1 = 0, s2 = 0;
@@ -934,7 +971,8 @@ __global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, co
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
-	if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(out + 3)[threadIdx.x] = counters[threadIdx.x]; // one 40-byte readback: sums + counters
+	if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(out + 3)[threadIdx.x] = counters[threadIdx.x]; // one 48-byte readback: sums + counters + evaluated samples
+	if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
 }
 
 } // namespace rnb

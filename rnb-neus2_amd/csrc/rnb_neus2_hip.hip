@@ -117,6 +117,10 @@ struct rnb_ctx {
 	DevBuf<half_t> mlp_out, dloss_dout;
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
+	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
+	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
+	DevBuf<uint8_t> unfinished;
+	uint32_t fwd_k1 = 48;
 	DevBuf<RayLoss> ray_loss;
 	// training scratch
 	DevBuf<half_t> fm;       // feature-major operand arrays
@@ -145,7 +149,7 @@ struct rnb_ctx {
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
 	struct { bool valid = false; uint64_t split[2] = {0, 0}; } sc; // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
-	struct Readback { double sums[3]; uint32_t counters[4]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
+	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
 
 	NetW net(bool inference) const {
@@ -287,12 +291,12 @@ int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
 	return update_density_grid(c, s, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
 }
 
-int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference) {
+int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference, const uint32_t* idx = nullptr) {
 	if (n_max == 0) return RNB_OK;
 	FwdArgs a;
-	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias;
+	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
-	if (getenv("RNB_FORWARD_V1")) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
+	if (getenv("RNB_FORWARD_V1") && !idx) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
 		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
 		hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
 	} else {
@@ -318,6 +322,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.bitfield = c->bitfield.p;
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
+	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = c->fwd_k1;
 	return a;
 }
 
@@ -328,7 +333,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	if (getenv("RNB_MARCH_NARROW")) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
 	else hipLaunchKernelGGL(k_march_count_wide, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_COUNT);
-	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p);
+	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	hipLaunchKernelGGL(k_march_write, dim3((n_rays + 3) / 4), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_WRITE);
@@ -337,7 +342,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	return RNB_OK;
 }
 
-int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total) {
+int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t two_round_n_max = 0) {
 	LossArgs a;
 	a.n_rays = n_rays; a.n_rays_global = n_rays * c->cfg.world_size; a.ray_offset = c->cfg.rank * n_rays; a.n_rays_total = n_rays_total;
 	a.n_images = c->n_views; a.B = c->cfg.target_batch_size;
@@ -351,7 +356,17 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss; a.mask_loss = c->mask_loss;
 	HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
+	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
+	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
+		a.cap = c->fwd_k1;
+		hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
+		c->prof.mark(s, P_LOSS_PASS1);
+		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 1, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
+		if (rc != RNB_OK) return rc;
+		c->prof.mark(s, P_FORWARD);
+		a.phase = 1;
+	}
 	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
 	c->prof.mark(s, P_LOSS_PASS1);
 	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
@@ -591,6 +606,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
+	c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -638,7 +654,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	} while (0)
 	ALLOC(c->params_fp32, c->n_params); ALLOC(c->grads, c->n_params); ALLOC(c->adam_m, c->n_params); ALLOC(c->adam_v, c->n_params);
 	ALLOC(c->params_fp16, c->n_params); ALLOC(c->params_ema, c->n_params); ALLOC(c->adam_steps, c->n_params);
-	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 5);
+	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 7);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
@@ -646,6 +662,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
+	ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 2); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g1, (size_t)B * 14); ALLOC(c->g2, (size_t)B * 14); ALLOC(c->dn, (size_t)B * 3);
@@ -698,6 +715,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	c->training_step = 0;
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
+	if (const char* e = getenv("RNB_FWD_K1")) c->fwd_k1 = (uint32_t)atoi(e); // head length of the two-round network evaluation; 0 = one round over all samples
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
@@ -990,10 +1008,12 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->cur_n_rays = n_rays;
 	c->cur_n_rays_total = n_rays_total;
 	c->prof.mark(s, P_NONE);
-	rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
+	const bool two_round = c->fwd_k1 != 0 && !getenv("RNB_FORWARD_V1");
+	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p);
+	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
-	return compute_loss(c, s, n_rays, n_rays_total);
+	return compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0);
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
@@ -1005,7 +1025,7 @@ static int step_back(rnb_ctx* c, hipStream_t s) {
 
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p);
+	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1057,7 +1077,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
 	const uint32_t* counters = c->host_rb->counters;
-	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += counters[3]; }
+	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += (c->fwd_k1 && !getenv("RNB_FORWARD_V1")) ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
 	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];
