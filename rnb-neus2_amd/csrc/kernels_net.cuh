@@ -474,6 +474,9 @@ __device__ __forceinline__ void fm_store(const half_t* __restrict__ tile, const 
 __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fill_level_meta(lm, G, threadIdx.x);
+	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
 	load_weights<true>(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 		// ---------------- forward (as k_forward, activations also exported feature-major) ----------------
 		half_t feat[28];
 		float dydx[28][3];
-		encode_all<true>(G, net.grid, c[0], c[1], c[2], feat, dydx);
+		encode_all_lm<true>(lm, n_levels, valid_level, net.grid, c[0], c[1], c[2], feat, dydx);
 		write_sdf_in_row(tA, lane, c[0], c[1], c[2], feat);
 		wave_lds_sync();
 		fm_store(tA, S32, 32, T.sdfin, B, s);

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 		srun += ok ? 1u : 0u;
 		if (k1) { base1[i] = frun; frun += ok ? min(steps[i], k1) : 0u; }
 	}
-	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; fwd_counts[0] = sh3[1023]; fwd_counts[1] = 0; }
+	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; fwd_counts[0] = sh3[1023]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
 }
 
 // Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
@@ -512,6 +512,7 @@ struct RayLoss { // pass 1 -> pass 2
 	uint32_t n_comp;
 	float rgb_ray[4];
 	float weight_sum_raw;
+	float T_resume; // transmittance after the samples pass 1 has consumed (two-round evaluation: phase 1 continues from it)
 	float rgbtarget[4];
 	float light[3];
 	float dir[3];
@@ -540,9 +541,9 @@ struct LossArgs {
 	// two-round network evaluation (cap = 0xffffffff: single round)
 	uint32_t cap;          // samples per ray evaluated in round 1
 	uint32_t phase;        // 0: all rays, at most `cap` samples each; 1: only the rays round 1 could not finish, all their samples
-	uint8_t* unfinished;   // [n_rays]
+	uint32_t* unfinished;  // [n_rays] list of the rays round 1 left unsettled (count in fwd_counts[2])
 	uint32_t* idx2;        // sample slots still to evaluate (round 2)
-	uint32_t* fwd_counts;  // [1] = entries of idx2
+	uint32_t* fwd_counts;  // [1] = entries of idx2, [2] = entries of `unfinished`
 };
 
 __device__ __forceinline__ void albedo_from_output(const LossFlags& F, const half_t* __restrict__ o, float albedo[4]) { // testbed_nerf.cu:1614-1639
@@ -655,15 +656,36 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 	R.mask_gt = (float)(tex_normal[3] > 0.99);
 }
 
+// The sequential part of the compositing loop (testbed_nerf.cu:1608-1697) for up to 64 samples whose per-sample terms sit
+// one per lane. Every lane carries the same running values; the operations and their order are the reference's, so the
+// rounding (and with it the early stop) is identical. Kept tight on purpose — this chain is the latency of the longest ray:
+// uniform exit test through a ballot, (1 - alpha) formed per lane beforehand, the three equal colour channels of the
+// --no-albedo case (albedo = (1,1,1,0)) accumulated once.
+template <bool NO_ALBEDO>
+__device__ __forceinline__ bool composite_replay(const int cnt, const float alpha, const float shading, const float (&albedo)[4],
+                                                 float& T, float (&rgb)[4], float& weight_sum, uint32_t& n) {
+	const float one_minus = 1.f - alpha;
+	for (int q = 0; q < cnt; ++q) {
+		if (__builtin_amdgcn_ballot_w64(T < 1e-4f) != 0ull) return true;
+		const float al = bcast(alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
+		const float weight = al * T;
+		if (NO_ALBEDO) {
+			rgb[0] += weight * 1.f * sh;
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) rgb[k] += weight * bcast(albedo[k], q) * sh;
+		}
+		weight_sum += weight;
+		T *= om;
+		++n;
+	}
+	return false;
+}
+
 // Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), one wavefront per ray: the per-sample terms (alpha, shading)
 // are evaluated by 64 lanes at once; the transmittance recurrence and the early stop at T < 1e-4 are then replayed in the
 // reference's sequential order (identical fp32 rounding) from lane broadcasts.
-__global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
-	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (i >= a.n_rays) return;
-	if (i >= a.counters[2]) { if (lane == 0 && a.phase == 0) a.ncomp[i] = 0; return; }
-	if (a.phase == 1 && !a.unfinished[i]) return;
+__device__ __forceinline__ void loss_pass1_ray(const LossArgs& a, const uint32_t i, const int lane) {
 	const uint32_t numsteps_all = a.numsteps[(size_t)i * 2 + 0];
 	const uint32_t numsteps = a.phase == 0 ? min(numsteps_all, a.cap) : numsteps_all;
 	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
@@ -684,7 +706,14 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 	float weight_sum = 0.f;
 	uint32_t n = 0;
 	bool done = false;
-	for (uint32_t c0 = 0; c0 < numsteps && !done; c0 += 64) {
+	uint32_t c_begin = 0;
+	if (a.phase == 1) { // continue where phase 0 stopped (it consumed exactly `cap` samples without terminating)
+		const RayLoss P = a.ray_loss[i];
+		T = P.T_resume; weight_sum = P.weight_sum_raw; n = P.n_comp; c_begin = a.cap;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rgb_ray[k] = P.rgb_ray[k];
+	}
+	for (uint32_t c0 = c_begin; c0 < numsteps && !done; c0 += 64) {
 		const uint32_t j = c0 + lane;
 		float alpha = 0.f, shading = 0.f, albedo[4] = {1.f, 1.f, 1.f, 0.f};
 		if (j < numsteps) {
@@ -698,32 +727,20 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		}
 		const int cnt = (int)min(64u, numsteps - c0);
-		for (int q = 0; q < cnt; ++q) {
-			if (T < EPSILON) { done = true; break; }
-			const float al = bcast(alpha, q), sh = bcast(shading, q);
-			const float weight = al * T;
-			if (a.F.apply_no_albedo) {
-				rgb_ray[0] += weight * 1.f * sh; rgb_ray[1] += weight * 1.f * sh; rgb_ray[2] += weight * 1.f * sh; rgb_ray[3] += weight * 0.f * sh;
-			} else {
-#pragma unroll
-				for (int k = 0; k < 4; ++k) rgb_ray[k] += weight * bcast(albedo[k], q) * sh;
-			}
-			weight_sum += weight;
-			T *= (1.f - al);
-			++n;
-		}
+		done = a.F.apply_no_albedo ? composite_replay<true>(cnt, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
+		                           : composite_replay<false>(cnt, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
 	}
+	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
 	if (a.phase == 0 && a.cap != 0xffffffffu) {
 		// The samples past the point where the transmittance falls below 1e-4 are never read again (testbed_nerf.cu:1609), so
 		// the network is first evaluated on the head of every ray only. A ray is settled if it terminated inside its head, or
 		// has no more samples, or would terminate at the very next check; the others queue their tails for round 2 and are
 		// recomputed in phase 1. Same values as a single full pass.
 		const bool settled = done || numsteps_all <= a.cap || T < EPSILON;
-		if (lane == 0) a.unfinished[i] = settled ? 0 : 1;
 		if (!settled) {
 			const uint32_t tail = numsteps_all - a.cap;
 			uint32_t off = 0;
-			if (lane == 0) off = atomicAdd(a.fwd_counts + 1, tail);
+			if (lane == 0) { off = atomicAdd(a.fwd_counts + 1, tail); a.unfinished[atomicAdd(a.fwd_counts + 2, 1u)] = i; }
 			off = __builtin_amdgcn_readfirstlane(off);
 			for (uint32_t j = lane; j < tail; j += 64) a.idx2[off + j] = base + a.cap + j;
 		}
@@ -733,9 +750,23 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
 		R.weight_sum_raw = weight_sum;
+		R.T_resume = T;
 		R.dir[0] = dir[0]; R.dir[1] = dir[1]; R.dir[2] = dir[2];
 		a.ray_loss[i] = R;
 		a.ncomp[i] = n;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
+	const int lane = threadIdx.x & 63;
+	if (a.phase == 0) { // one wavefront per ray
+		const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+		if (i >= a.n_rays) return;
+		if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; return; }
+		loss_pass1_ray(a, i, lane);
+	} else { // the rays round 1 left unsettled, from the list phase 0 built
+		const uint32_t n_list = a.fwd_counts[2];
+		for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_list; k += gridDim.x * 4) loss_pass1_ray(a, a.unfinished[k], lane);
 	}
 }
 
@@ -852,22 +883,33 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		// replay of the sequential recurrences; lane q keeps its own weight and the running values right after sample q
 		float my_weight = 0.f, my_T = 1.f, my_w2 = 0.f, my_rgb2[4] = {0, 0, 0, 0};
 		const int cnt = (int)min(64u, compacted_numsteps - c0);
-		for (int q = 0; q < cnt; ++q) {
-			const float al = bcast(at.alpha, q), sh = bcast(shading, q);
-			const float weight = al * T;
-			if (F.apply_no_albedo) {
-				rgb_ray2[0] += weight * 1.f * sh; rgb_ray2[1] += weight * 1.f * sh; rgb_ray2[2] += weight * 1.f * sh; rgb_ray2[3] += weight * 0.f * sh;
-			} else {
+		const float one_minus = 1.f - at.alpha;
+		if (F.apply_no_albedo) { // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
+			for (int q = 0; q < cnt; ++q) {
+				const float al = bcast(at.alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
+				const float weight = al * T;
+				rgb_ray2[0] += weight * 1.f * sh;
+				weight_sum2 += weight;
+				T *= om;
+				ek += bcast(ekterm, q);
+				if (q == lane) { my_weight = weight; my_T = T; my_w2 = weight_sum2; my_rgb2[0] = rgb_ray2[0]; }
+			}
+			rgb_ray2[1] = rgb_ray2[0]; rgb_ray2[2] = rgb_ray2[0];
+			my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3];
+		} else {
+			for (int q = 0; q < cnt; ++q) {
+				const float al = bcast(at.alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
+				const float weight = al * T;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * bcast(albedo[k], q) * sh;
-			}
-			weight_sum2 += weight;
-			T *= (1.f - al);
-			ek += bcast(ekterm, q);
-			if (q == lane) {
-				my_weight = weight; my_T = T; my_w2 = weight_sum2;
+				weight_sum2 += weight;
+				T *= om;
+				ek += bcast(ekterm, q);
+				if (q == lane) {
+					my_weight = weight; my_T = T; my_w2 = weight_sum2;
 #pragma unroll
-				for (int k = 0; k < 4; ++k) my_rgb2[k] = rgb_ray2[k];
+					for (int k = 0; k < 4; ++k) my_rgb2[k] = rgb_ray2[k];
+				}
 			}
 		}
 		if (valid) {

@@ -119,7 +119,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
-	DevBuf<uint8_t> unfinished;
+	DevBuf<uint32_t> unfinished;
 	uint32_t fwd_k1 = 48;
 	DevBuf<RayLoss> ray_loss;
 	// training scratch
@@ -367,7 +367,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		c->prof.mark(s, P_FORWARD);
 		a.phase = 1;
 	}
-	hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_loss_pass1, dim3(a.phase ? std::min(blocks, 1024u) : blocks), dim3(256), 0, s, a);
 	c->prof.mark(s, P_LOSS_PASS1);
 	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
@@ -465,7 +465,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	auto launch_c = [&](hipStream_t st) {
 		if (e_lds) {
 			ScatterLdsArgs la; la.a = sa; la.n_levels = e_lds;
-			const uint32_t n_wg = std::min<uint32_t>(256u, (B + 1023) / 1024);
+			const uint32_t wg_cap = getenv("RNB_SCATTER_LDS_WG") ? (uint32_t)atoi(getenv("RNB_SCATTER_LDS_WG")) : 128u;
+			const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 			la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
 			hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_lds] * 8, st, c->meta(), la);
 		}
@@ -662,7 +663,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
-	ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 2); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
+	ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g1, (size_t)B * 14); ALLOC(c->g2, (size_t)B * 14); ALLOC(c->dn, (size_t)B * 3);

@@ -12,11 +12,10 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rnb::", ""), r.get("Queue_Id", "?")))
 rows.sort()
-# a step starts at each k_forward
-starts = [i for i, r in enumerate(rows) if r[2].startswith("k_forward")]
+# one cycle = from one k_scan_compact (once per step) to the next
+starts = [i for i, r in enumerate(rows) if r[2].startswith("k_scan_compact")]
 i0, i1 = starts[-back - 1], starts[-back]
 t0 = rows[i0][0]
 print("step length %.1f us" % ((rows[i1][0] - t0) / 1e3))
-lo = max(0, i0 - 12)
-for r in rows[lo:i1 + 1]:
+for r in rows[i0:i1 + 1]:
     print("%9.1f %9.1f  %7.1f us  q%-3s %s" % ((r[0] - t0) / 1e3, (r[1] - t0) / 1e3, (r[1] - r[0]) / 1e3, r[3], r[2][:50]))
