@@ -63,7 +63,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
-    ctx = rnb.Context(apply_no_albedo=1, mask_loss_weight=1.0, world_size=world, rank=rank)
+    ctx = rnb.Context(apply_no_albedo=1, mask_loss_weight=1.0, world_size=world, rank=rank, overlap=0 if os.environ.get("RNB_OVERLAP_OFF") else 1)
     ctx.init_params()
     t0 = time.time()
     views, normals, albedos = synthetic.make_scene(args.views, args.res)
@@ -124,8 +124,14 @@ def main():
             if bytes_per_unit is not None and dom["units"] > 0:
                 units_per_launch = dom["units"] / dom["launches"]
                 achieved = bytes_per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
+                traffic = None  # HBM bytes per launch from the PMC passes (tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json); a PMC pass cannot run inside this process
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                        traffic = json.load(f)["per_step"][kname]["total_bytes"] / max(dom["launches"] / max(args.profile_steps, 1), 1.0)
+                except Exception:
+                    pass
                 roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                             "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit}
         kernels = {p["kernel"]: {"ms_per_step": round(p["total_ms"] / max(args.profile_steps, 1), 4), "launches": p["launches"]} for p in prof if p["launches"]}
         result = {
