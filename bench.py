@@ -58,7 +58,7 @@ def main():
             raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get("RNB_DP_FORCE_COLLECTIVES") and "MASTER_ADDR" in os.environ):  # the env var exercises the RCCL path on one rank
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 

@@ -8,6 +8,8 @@ parameter block, occupancy grid and dataset; rank r generates the global rays [r
   * one 7-value all-reduce of the step counters / loss sums so all ranks draw the same rays_per_batch next step.
 The occupancy update is replicated: identical parameters + identical RNG => identical grids, no communication.
 """
+import os
+
 import numpy as np
 
 
@@ -36,6 +38,8 @@ class DataParallelTrainer:
         self.ctx = ctx
         self.stream = stream
         self._grads = None
+        self._side = None
+        self._collectives = ctx.cfg.world_size > 1 or bool(os.environ.get("RNB_DP_FORCE_COLLECTIVES"))  # the env var exercises the collective path on one rank
         self._reduce_grads = all_reduce_grads or self._torch_reduce_grads
         self._reduce_small = all_reduce_small or self._torch_reduce_small
 
@@ -48,10 +52,19 @@ class DataParallelTrainer:
     def _torch_reduce_small(self, vec):
         import torch
         import torch.distributed as dist
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.from_numpy(vec.copy()).to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        if dist.get_backend() != "nccl":
+            t = torch.from_numpy(vec.copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.numpy()
+        # On its own (non-blocking) stream: the default stream holds this step's backward pass, and waiting for it here would
+        # delay the ray controller and with it the next step's march.
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            t = torch.from_numpy(vec.copy()).to("cuda", non_blocking=False)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out = t.cpu().numpy()
+        return out
 
     def step(self, allow_no_samples=False):
         """begin (march .. loss .. backward queued) -> counters as soon as the loss pass is done -> 7-value all-reduce ->
@@ -60,14 +73,14 @@ class DataParallelTrainer:
         ctx = self.ctx
         ctx.train_step_begin(self.stream)
         counters, sums = ctx.train_step_local(self.stream)
-        if ctx.cfg.world_size > 1:
+        if self._collectives:
             vec = np.concatenate([counters.astype(np.float64), sums])
             vec = self._reduce_small(vec)
             counters, sums = np.rint(vec[:4]).astype(np.uint64), vec[4:]
         try:
             stats = ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
         finally:  # the optimizer runs even when the step produced no samples, as in the reference
-            if ctx.cfg.world_size > 1:
+            if self._collectives:
                 self._reduce_grads(ctx)
             ctx.train_step_apply(self.stream)
         return stats
