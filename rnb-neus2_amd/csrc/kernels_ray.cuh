@@ -407,61 +407,77 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 
 // Single-workgroup exclusive scans over the rays (n <= 2^18): base = scan(steps); survivors = base + steps <= max_samples;
 // slot = scan(survivor). counters[0] = sum(steps) (numsteps_counter), [2] = #survivors (ray_counter), [3] = samples written.
+// Exclusive prefix sums over the rays, tile by tile (1024 coalesced elements per tile, wave shuffles + one LDS hop):
+//   base  = samples before the ray (numsteps prefix, testbed_nerf.cu:1344-1346)          -> counters[0] = total
+//   slot  = index among the rays that keep their samples (0xffffffff = dropped)            -> counters[2], counters[3]
+//   base1 = offset of the ray's first-round samples in idx1 (two-round network evaluation) -> fwd_counts[0]
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, const uint32_t lane) {
+#pragma unroll
+	for (uint32_t off = 1; off < 64; off <<= 1) {
+		const uint32_t t = __shfl_up(v, off, 64);
+		if (lane >= off) v += t;
+	}
+	return v;
+}
+
 __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint32_t max_samples, const uint32_t* __restrict__ steps,
                                                     uint32_t* __restrict__ base, uint32_t* __restrict__ slot, uint32_t* __restrict__ counters,
                                                     const uint32_t k1, uint32_t* __restrict__ base1, uint32_t* __restrict__ fwd_counts) {
-	__shared__ uint32_t sh[1024];
-	__shared__ uint32_t sh2[1024];
-	__shared__ uint32_t sh3[1024];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t per = (n + 1023) / 1024;
-	const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
-	uint32_t sum = 0;
-	for (uint32_t i = lo; i < hi; ++i) sum += steps[i];
-	sh[tid] = sum;
-	__syncthreads();
-	for (uint32_t off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-		uint32_t v = tid >= off ? sh[tid - off] : 0;
+	__shared__ uint32_t wsum[4][16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	constexpr uint32_t E = 4; // consecutive rays per thread: 4096 per tile, so the cross-lane scans are paid once per 4 rays
+	uint32_t carry[4] = {0, 0, 0, 0}; // steps, kept rays, kept samples, first-round samples
+	for (uint32_t t0 = 0; t0 < n; t0 += 1024 * E) {
+		const uint32_t i0 = t0 + tid * E;
+		uint32_t st[E];
+#pragma unroll
+		for (uint32_t e = 0; e < E; ++e) st[e] = i0 + e < n ? steps[i0 + e] : 0u;
+		// pass A: sample offsets
+		uint32_t mine = 0;
+#pragma unroll
+		for (uint32_t e = 0; e < E; ++e) mine += st[e];
+		const uint32_t inc = wave_inclusive_scan(mine, lane);
+		if (lane == 63) wsum[0][wave] = inc;
 		__syncthreads();
-		sh[tid] += v;
+		uint32_t wprefix = 0, ttotal = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = wsum[0][w]; wprefix += w < wave ? x : 0u; ttotal += x; }
+		uint32_t run = carry[0] + wprefix + inc - mine;
+		uint32_t runs[E];
+		bool ok[E];
+		uint32_t v[3] = {0, 0, 0};
+#pragma unroll
+		for (uint32_t e = 0; e < E; ++e) {
+			runs[e] = run;
+			ok[e] = st[e] > 0 && run + st[e] <= max_samples; // testbed_nerf.cu:1348-1355
+			run += st[e];
+			v[0] += ok[e] ? 1u : 0u; v[1] += ok[e] ? st[e] : 0u; v[2] += ok[e] ? min(st[e], k1) : 0u;
+		}
+		// pass B: the three sums that depend on `ok`
+		uint32_t vi[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { vi[k] = wave_inclusive_scan(v[k], lane); if (lane == 63) wsum[1 + k][wave] = vi[k]; }
 		__syncthreads();
+		uint32_t pre[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+#pragma unroll
+		for (uint32_t w = 0; w < 16; ++w)
+#pragma unroll
+			for (int k = 0; k < 3; ++k) { const uint32_t x = wsum[1 + k][w]; pre[k] += w < wave ? x : 0u; tot[k] += x; }
+		uint32_t srun = carry[1] + pre[0] + vi[0] - v[0], frun = carry[3] + pre[2] + vi[2] - v[2];
+#pragma unroll
+		for (uint32_t e = 0; e < E; ++e) {
+			if (i0 + e < n) {
+				base[i0 + e] = runs[e];
+				slot[i0 + e] = ok[e] ? srun : 0xffffffffu;
+				if (k1) base1[i0 + e] = frun;
+			}
+			srun += ok[e] ? 1u : 0u;
+			frun += ok[e] ? min(st[e], k1) : 0u;
+		}
+		carry[0] += ttotal; carry[1] += tot[0]; carry[2] += tot[1]; carry[3] += tot[2];
+		__syncthreads(); // wsum is rewritten by the next tile
 	}
-	uint32_t run = sh[tid] - sum;
-	const uint32_t total = sh[1023];
-	uint32_t n_surv = 0, written = 0, first = 0;
-	for (uint32_t i = lo; i < hi; ++i) {
-		const uint32_t st = steps[i];
-		base[i] = run;
-		const bool ok = st > 0 && run + st <= max_samples; // testbed_nerf.cu:1348-1355
-		slot[i] = ok ? 1u : 0u;
-		n_surv += ok ? 1u : 0u;
-		written += ok ? st : 0u;
-		first += ok ? min(st, k1) : 0u;
-		run += st;
-	}
-	__syncthreads();
-	sh[tid] = n_surv;
-	sh2[tid] = written;
-	sh3[tid] = first;
-	__syncthreads();
-	for (uint32_t off = 1; off < 1024; off <<= 1) {
-		uint32_t v = tid >= off ? sh[tid - off] : 0;
-		uint32_t w = tid >= off ? sh2[tid - off] : 0;
-		uint32_t u = tid >= off ? sh3[tid - off] : 0;
-		__syncthreads();
-		sh[tid] += v;
-		sh2[tid] += w;
-		sh3[tid] += u;
-		__syncthreads();
-	}
-	uint32_t srun = sh[tid] - n_surv, frun = sh3[tid] - first;
-	for (uint32_t i = lo; i < hi; ++i) {
-		const bool ok = slot[i] != 0u;
-		slot[i] = ok ? srun : 0xffffffffu;
-		srun += ok ? 1u : 0u;
-		if (k1) { base1[i] = frun; frun += ok ? min(steps[i], k1) : 0u; }
-	}
-	if (tid == 0) { counters[0] = total; counters[2] = sh[1023]; counters[3] = sh2[1023]; fwd_counts[0] = sh3[1023]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
+	if (tid == 0) { counters[0] = carry[0]; counters[2] = carry[1]; counters[3] = carry[2]; fwd_counts[0] = carry[3]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
 }
 
 // Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
@@ -772,24 +788,26 @@ __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 
 // exclusive scan of ncomp over the kept rays; counters[1] = total (numsteps_counter_compacted)
 __global__ __launch_bounds__(1024) void k_scan_compact(const uint32_t n_max, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters) {
-	__shared__ uint32_t sh[1024];
+	__shared__ uint32_t wsum[16];
 	const uint32_t n = min(counters[2], n_max);
-	const uint32_t tid = threadIdx.x;
-	const uint32_t per = (n + 1023) / 1024;
-	const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
-	uint32_t sum = 0;
-	for (uint32_t i = lo; i < hi; ++i) sum += ncomp[i];
-	sh[tid] = sum;
-	__syncthreads();
-	for (uint32_t off = 1; off < 1024; off <<= 1) {
-		uint32_t v = tid >= off ? sh[tid - off] : 0;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint32_t carry = 0;
+	uint32_t v_next = tid < n ? ncomp[tid] : 0u;
+	for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+		const uint32_t i = t0 + tid;
+		const uint32_t v = v_next;
+		v_next = i + 1024 < n ? ncomp[i + 1024] : 0u;
+		const uint32_t inc = wave_inclusive_scan(v, lane);
+		if (lane == 63) wsum[wave] = inc;
 		__syncthreads();
-		sh[tid] += v;
+		uint32_t pre = 0, tot = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; pre += w < wave ? x : 0u; tot += x; }
+		if (i < n) cbase[i] = carry + pre + inc - v;
+		carry += tot;
 		__syncthreads();
 	}
-	uint32_t run = sh[tid] - sum;
-	for (uint32_t i = lo; i < hi; ++i) { cbase[i] = run; run += ncomp[i]; }
-	if (tid == 0) counters[1] = sh[1023];
+	if (tid == 0) counters[1] = carry;
 }
 
 // Pass 2 (testbed_nerf.cu:1836-2095), one wavefront per ray: lanes own samples; the running sums of the reference's
