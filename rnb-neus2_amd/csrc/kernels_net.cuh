@@ -771,13 +771,17 @@ __global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, con
 			for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr, bfr[nt], acc[mt][nt], 0, 0, 0);
 		}
 	}
-	float* dst = partial + (size_t)(blockIdx.x * WAVES_PER_WG + wave) * (MT * 16) * (NT * 16);
+	// the four waves' partials are summed in LDS (fixed order) so that k_dw_finish reads one slab per workgroup, not per wave
+	__shared__ float red[WAVES_PER_WG][MT * 16 * NT * 16];
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
 		for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-			for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * hq + r) * (NT * 16) + 16 * nt + r16] = acc[mt][nt][r];
+			for (int r = 0; r < 4; ++r) red[wave][(16 * mt + 4 * hq + r) * (NT * 16) + 16 * nt + r16] = acc[mt][nt][r];
+	__syncthreads();
+	float* dst = partial + (size_t)blockIdx.x * (MT * 16) * (NT * 16);
+	for (int q = threadIdx.x; q < MT * 16 * NT * 16; q += WG) dst[q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
 }
 
 // Offsets (floats) of the seven partial blocks inside one wave's slab are given by the host.

@@ -395,7 +395,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	// ---- weight-gradient GEMMs (MFMA / streaming)
 	auto launch_dw = [&](hipStream_t sd) {
 		const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
-		const size_t slab = (size_t)nwg * WAVES_PER_WG;
+		const size_t slab = (size_t)nwg; // one partial per workgroup
 		float* p = c->dw_partial.p;
 		float* p_rgb2 = p;                      p += slab * 16 * 64;
 		float* p_rgb1 = p;                      p += slab * 64 * 64;
