@@ -496,7 +496,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
 		launch_dw(sd);
 		HIP_TRY(hipEventRecord(c->ev_dw, sd));
-		launch_c(s); // latency-bound: alone at the head (it stretches several-fold beside an atomic-bound kernel)
+		launch_c(s); // latency-bound: at the head, beside the GEMMs (starting the GEMMs after it was measured slower; beside an atomic-bound kernel it stretches several-fold)
 		launch_b(s);
 		HIP_TRY(hipEventRecord(c->ev_sc[0], s));
 		launch_a(s);
