@@ -178,6 +178,13 @@ __device__ __forceinline__ uint32_t image_idx(uint32_t base_idx, uint32_t n_rays
 // ---------------------------------------------------------------------------------------------
 // K6: ray generation + DDA march (testbed_nerf.cu:1216-1387)
 // ---------------------------------------------------------------------------------------------
+struct LossFlags {
+	uint32_t apply_L2, apply_rgbplus, apply_no_albedo, apply_light_opti, apply_relu, apply_bce, snap;
+	float mask_loss_weight, ek_loss_weight;
+};
+
+constexpr int RAY_CONST_FLOATS = 12; // rgbtarget[4], light[3], mask_certainty, mask_gt, pad[3]
+
 struct MarchArgs {
 	uint32_t n_rays;        // this rank's rays
 	uint32_t n_rays_global; // n_rays * world_size
@@ -200,6 +207,11 @@ struct MarchArgs {
 	uint32_t* base1;    // [n_rays] offset of the ray's first-round samples in idx1 (two-round network evaluation, see k_loss_pass1)
 	uint32_t* idx1;     // sample slots of the first round: the first min(steps, k1) samples of every kept ray
 	uint32_t k1;        // 0 = single round
+	// per-ray loss constants (target colour, light, masks) depend on the ray and the dataset only: worked out here, off the
+	// step's critical path, for the loss passes to pick up (k_march_write -> k_loss_pass1)
+	LossFlags F;
+	float light_dirs[9];
+	float* ray_const;   // [n_rays kept][RAY_CONST_FLOATS]
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
 };
@@ -480,49 +492,9 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 	if (tid == 0) { counters[0] = carry[0]; counters[2] = carry[1]; counters[3] = carry[2]; fwd_counts[0] = carry[3]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
 }
 
-// Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
-// t values recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
-__global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
-	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const uint32_t lane = threadIdx.x & 63;
-	if (i >= a.n_rays) return;
-	const uint32_t s = a.slot[i];
-	if (s == 0xffffffffu) return;
-	const float* st = a.setup + (size_t)i * 8;
-	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
-	const uint32_t steps = a.steps[i], base = a.base[i];
-	if (lane == 0) {
-		a.ray_indices[s] = i;
-		float* ro = a.rays + (size_t)s * 6;
-		ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
-		ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
-		a.numsteps[(size_t)s * 2 + 0] = steps;
-		a.numsteps[(size_t)s * 2 + 1] = base;
-	}
-	if (a.k1) {
-		const uint32_t b1 = a.base1[i];
-		for (uint32_t j = lane; j < min(steps, a.k1); j += 64) a.idx1[b1 + j] = base + j;
-	}
-	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
-	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
-	float* co = a.coords + (size_t)base * 7;
-	for (uint32_t j = lane; j < steps; j += 64) {
-		const float t = tt[j];
-		const Vec3 pos = o + t * dir;
-		const float dt = calc_dt(t, a.A.cone_angle);
-		const Vec3 wp = warp_position(a.A, pos);
-		float* q = co + (size_t)j * 7;
-		q[0] = wp.x; q[1] = wp.y; q[2] = wp.z; q[3] = warp_dt(dt); q[4] = wd.x; q[5] = wd.y; q[6] = wd.z;
-	}
-}
-
 // ---------------------------------------------------------------------------------------------
 // K8: loss + output gradients (testbed_nerf.cu:1396-2097)
 // ---------------------------------------------------------------------------------------------
-struct LossFlags {
-	uint32_t apply_L2, apply_rgbplus, apply_no_albedo, apply_light_opti, apply_relu, apply_bce, snap;
-	float mask_loss_weight, ek_loss_weight;
-};
 
 struct RayLoss { // pass 1 -> pass 2
 	uint32_t n_comp;
@@ -554,6 +526,7 @@ struct LossArgs {
 	float* coords_compacted;
 	half_t* dloss;
 	float *loss, *ek_loss, *mask_loss;
+	const float* ray_const; // per-ray constants precomputed by k_march_write (null: compute them here)
 	// two-round network evaluation (cap = 0xffffffff: single round)
 	uint32_t cap;          // samples per ray evaluated in round 1
 	uint32_t phase;        // 0: all rays, at most `cap` samples each; 1: only the rays round 1 could not finish, all their samples
@@ -607,8 +580,10 @@ __device__ __forceinline__ void load_out16(const half_t* __restrict__ p, half_t 
 }
 
 // Per-ray constants of the loss kernel (testbed_nerf.cu:1485-1593): pixel, target normal, light triplet, shading target.
-__device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t i, RayLoss& R) {
-	const uint32_t ray_idx = a.ray_indices[i];
+struct RayConstIn { Pcg32 rng; uint32_t ray_offset, n_rays_global, n_rays_total, n_images; const ViewDev* views; LossFlags F; const float* light_dirs; };
+
+template <typename RayOut>
+__device__ __forceinline__ void ray_constants_core(const RayConstIn& a, const uint32_t ray_idx, RayOut& R) {
 	const uint32_t gi = a.ray_offset + ray_idx;
 	Pcg32 rng = a.rng;
 	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
@@ -671,6 +646,74 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 	R.mask_certainty = (float)(tex_albedo[3] > 0.99);
 	R.mask_gt = (float)(tex_normal[3] > 0.99);
 }
+
+__device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t i, RayLoss& R) {
+	if (a.ray_const) { // precomputed beside the march
+		const float* q = a.ray_const + (size_t)i * RAY_CONST_FLOATS;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) R.rgbtarget[k] = q[k];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) R.light[k] = q[4 + k];
+		R.mask_certainty = q[7]; R.mask_gt = q[8];
+		return;
+	}
+	RayConstIn in;
+	in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
+	in.views = a.views; in.F = a.F; in.light_dirs = a.light_dirs;
+	ray_constants_core(in, a.ray_indices[i], R);
+}
+
+// Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
+// t values recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
+__global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	if (i >= a.n_rays) return;
+	const uint32_t s = a.slot[i];
+	if (s == 0xffffffffu) return;
+	const float* st = a.setup + (size_t)i * 8;
+	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
+	const uint32_t steps = a.steps[i], base = a.base[i];
+	if (lane == 0) {
+		a.ray_indices[s] = i;
+		float* ro = a.rays + (size_t)s * 6;
+		ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
+		ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
+		a.numsteps[(size_t)s * 2 + 0] = steps;
+		a.numsteps[(size_t)s * 2 + 1] = base;
+	}
+	if (a.ray_const) {
+		RayConstIn in;
+		in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
+		in.views = a.views; in.F = a.F; in.light_dirs = a.light_dirs;
+		struct { float rgbtarget[4], light[3], mask_certainty, mask_gt; } rc;
+		ray_constants_core(in, i, rc);
+		if (lane == 0) {
+			float* q = a.ray_const + (size_t)s * RAY_CONST_FLOATS;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) q[k] = rc.rgbtarget[k];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) q[4 + k] = rc.light[k];
+			q[7] = rc.mask_certainty; q[8] = rc.mask_gt;
+		}
+	}
+	if (a.k1) {
+		const uint32_t b1 = a.base1[i];
+		for (uint32_t j = lane; j < min(steps, a.k1); j += 64) a.idx1[b1 + j] = base + j;
+	}
+	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
+	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
+	float* co = a.coords + (size_t)base * 7;
+	for (uint32_t j = lane; j < steps; j += 64) {
+		const float t = tt[j];
+		const Vec3 pos = o + t * dir;
+		const float dt = calc_dt(t, a.A.cone_angle);
+		const Vec3 wp = warp_position(a.A, pos);
+		float* q = co + (size_t)j * 7;
+		q[0] = wp.x; q[1] = wp.y; q[2] = wp.z; q[3] = warp_dt(dt); q[4] = wd.x; q[5] = wd.y; q[6] = wd.z;
+	}
+}
+
 
 // The sequential part of the compositing loop (testbed_nerf.cu:1608-1697) for up to 64 samples whose per-sample terms sit
 // one per lane. Every lane carries the same running values; the operations and their order are the reference's, so the

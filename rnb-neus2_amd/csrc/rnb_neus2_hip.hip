@@ -119,6 +119,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
+	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
 	uint32_t fwd_k1 = 48;
 	DevBuf<RayLoss> ray_loss;
@@ -307,6 +308,14 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	return RNB_OK;
 }
 
+static LossFlags loss_flags(const rnb_ctx* c) {
+	LossFlags F;
+	F.apply_L2 = c->cfg.apply_L2; F.apply_rgbplus = c->cfg.apply_rgbplus; F.apply_no_albedo = c->cfg.apply_no_albedo; F.apply_light_opti = c->cfg.apply_light_opti;
+	F.apply_relu = c->cfg.apply_relu; F.apply_bce = c->cfg.apply_bce; F.snap = c->cfg.snap_to_pixel_centers;
+	F.mask_loss_weight = c->cfg.mask_loss_weight; F.ek_loss_weight = c->cfg.ek_loss_weight;
+	return F;
+}
+
 MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
 	MarchArgs a;
 	a.n_rays = n_rays;
@@ -323,6 +332,9 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
 	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = c->fwd_k1;
+	a.F = loss_flags(c);
+	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
+	a.ray_const = c->ray_const.p;
 	return a;
 }
 
@@ -347,9 +359,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.n_rays = n_rays; a.n_rays_global = n_rays * c->cfg.world_size; a.ray_offset = c->cfg.rank * n_rays; a.n_rays_total = n_rays_total;
 	a.n_images = c->n_views; a.B = c->cfg.target_batch_size;
 	a.rng = c->rng; a.A = c->aabb;
-	a.F.apply_L2 = c->cfg.apply_L2; a.F.apply_rgbplus = c->cfg.apply_rgbplus; a.F.apply_no_albedo = c->cfg.apply_no_albedo; a.F.apply_light_opti = c->cfg.apply_light_opti;
-	a.F.apply_relu = c->cfg.apply_relu; a.F.apply_bce = c->cfg.apply_bce; a.F.snap = c->cfg.snap_to_pixel_centers;
-	a.F.mask_loss_weight = c->cfg.mask_loss_weight; a.F.ek_loss_weight = c->cfg.ek_loss_weight;
+	a.F = loss_flags(c);
+	a.ray_const = two_round_n_max ? c->ray_const.p : nullptr; // stage API: flags may have changed since the samples were generated
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.views = c->views.p; a.counters = c->counters.p; a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p;
 	a.coords = c->coords.p; a.mlp_out = c->mlp_out.p; a.ray_loss = c->ray_loss.p; a.ncomp = c->ncomp.p; a.cbase = c->cbase.p;
@@ -607,7 +618,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
+	c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -663,7 +674,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
-	ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
+	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g1, (size_t)B * 14); ALLOC(c->g2, (size_t)B * 14); ALLOC(c->dn, (size_t)B * 3);
