@@ -38,7 +38,7 @@ def parse():
                     "regime the metric is quoted on (steps >= 1000: all 14 levels live, occupancy converged; SURVEY.md §8d)")
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=8, help="steps of the CPU checker timed as the baseline (≈1.4 s each on the GPU box host)")
     ap.add_argument("--profile-steps", type=int, default=100, help="serialized steps after the timed region for the per-kernel HIP-event table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
