@@ -252,6 +252,15 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* ctx);
 int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_batch,
                        uint32_t measured_batch_size_before_compaction, uint32_t n_rays_total);
 
+/* Data parallel only: gradient blocks in the order they become final during the backward pass queued by
+ * rnb_train_step_begin, so that a caller can exchange the early block while the rest is still being accumulated.
+ * ranges[k] = {first, last+1} parameter indices into RNB_BUF_GRADS_FP32, k = 0 .. *n_parts-1 (at most 3); the blocks
+ * partition [0, n_params). rnb_gradient_part_wait makes `stream` wait (device side) until block k is final.
+ * Without side-stream overlap there is one block, final when the stream given to _begin is. No reference counterpart
+ * (the reference is single-GPU). */
+int rnb_gradient_parts(rnb_ctx* ctx, uint64_t ranges[3][2], uint32_t* n_parts);
+int rnb_gradient_part_wait(rnb_ctx* ctx, uint32_t part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1741,4 +1741,12 @@ int rnb_set_controller(orc_ctx_s* c, uint32_t training_step, uint32_t rays_per_b
 	return RNB_OK;
 }
 
+// The checker computes gradients in one piece.
+int rnb_gradient_parts(orc_ctx_s* c, uint64_t ranges[3][2], uint32_t* n_parts) {
+	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
+	ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
+	return RNB_OK;
+}
+int rnb_gradient_part_wait(orc_ctx_s* c, uint32_t part, void*) { return (c && part == 0) ? RNB_OK : fail(RNB_ERR_INVALID, "bad part"); }
+
 } // extern "C"

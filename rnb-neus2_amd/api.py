@@ -225,6 +225,16 @@ class Context:
     def set_controller(self, training_step, rays_per_batch, measured_before_compaction=0, n_rays_total=0):
         self._check(self.f.set_controller(self._h, int(training_step), int(rays_per_batch), int(measured_before_compaction), int(n_rays_total)))
 
+    def gradient_parts(self):
+        """[(first, last+1), ...] blocks of GRADS_FP32 in the order they become final during the queued backward pass."""
+        arr = (C.c_uint64 * 2 * 3)()
+        n = C.c_uint32()
+        self._check(self.f.gradient_parts(self._h, C.byref(arr), C.byref(n)))
+        return [(int(arr[k][0]), int(arr[k][1])) for k in range(n.value)]
+
+    def gradient_part_wait(self, part, stream_handle):
+        self._check(self.f.gradient_part_wait(self._h, int(part), C.c_void_p(stream_handle)))
+
     def profile_enable(self, on=True):
         self._check(self.f.profile_enable(self._h, int(bool(on))))
 

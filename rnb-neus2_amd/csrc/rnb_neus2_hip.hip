@@ -148,7 +148,7 @@ struct rnb_ctx {
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
-	struct { bool valid = false; uint64_t split[2] = {0, 0}; } sc; // scatter groups of the current backward pass (see forward_backward)
+	struct { bool valid = false, exchanged = false; uint64_t split[2] = {0, 0}; } sc; // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
@@ -393,7 +393,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const uint32_t B = c->cfg.target_batch_size;
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
-	c->sc.valid = false;
+	c->sc.valid = false; c->sc.exchanged = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	c->prof.mark(s, P_NONE);
@@ -546,7 +546,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
 		hipLaunchKernelGGL(k_adam_ema, dim3(blocks), dim3(256), 0, st, a);
 	};
-	if (c->overlap() && cfg.world_size == 1 && c->sc.valid) {
+	if (c->overlap() && cfg.world_size == 1 && c->sc.valid && !c->sc.exchanged) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
 		// on the side stream, beside the scatter of the next group; only the coarse levels' (small) block is left for the end.
 		hipStream_t sa = c->s_adam;
@@ -1183,6 +1183,27 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 	c->rays_per_batch = rays_per_batch;
 	c->measured_batch_size_before_compaction = measured_before;
 	c->n_rays_total = n_rays_total;
+	return RNB_OK;
+}
+
+int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
+	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
+	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
+	if (c->sc.valid && c->sc.split[1] < c->sc.split[0]) { // scatter order B, A, C: B's levels are final first (ev_sc[0])
+		ranges[0][0] = c->sc.split[1]; ranges[0][1] = c->sc.split[0];
+		ranges[1][0] = 0;              ranges[1][1] = c->sc.split[1];
+		ranges[2][0] = c->sc.split[0]; ranges[2][1] = c->n_params;
+		*n_parts = 3;
+	} else {
+		ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
+	}
+	return RNB_OK;
+}
+
+int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (part == 0 && c->sc.valid) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_sc[0], 0));
+	// the other blocks are final when the stream given to rnb_train_step_begin is (it has joined the side streams)
 	return RNB_OK;
 }
 

@@ -39,15 +39,31 @@ class DataParallelTrainer:
         self.stream = stream
         self._grads = None
         self._side = None
+        self._early = None
         self._collectives = ctx.cfg.world_size > 1 or bool(os.environ.get("RNB_DP_FORCE_COLLECTIVES"))  # the env var exercises the collective path on one rank
         self._reduce_grads = all_reduce_grads or self._torch_reduce_grads
         self._reduce_small = all_reduce_small or self._torch_reduce_small
 
     def _torch_reduce_grads(self, ctx):
+        """Sum of the fp32 gradient accumulators over the ranks. The block of levels whose scatter finishes first is exchanged
+        on a side stream while the remaining levels are still being scattered; the rest follows on the default stream."""
+        import torch
         import torch.distributed as dist
         if self._grads is None:
             self._grads = grads_tensor(ctx)
-        dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
+        parts = ctx.gradient_parts()
+        if len(parts) > 1 and dist.get_backend() == "nccl":
+            if self._early is None:
+                self._early = torch.cuda.Stream()
+            lo, hi = parts[0]
+            with torch.cuda.stream(self._early):
+                ctx.gradient_part_wait(0, self._early.cuda_stream)
+                dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+            for lo, hi in parts[1:]:
+                dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+            torch.cuda.current_stream().wait_stream(self._early)
+        else:
+            dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
 
     def _torch_reduce_small(self, vec):
         import torch
