@@ -13,6 +13,9 @@ import os
 import sys
 import time
 
+# more hardware queues than HIP's default 4: the library's side streams, torch's and RCCL's must not be multiplexed onto the
+# queue that carries the step's critical path (set before the HIP runtime starts)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -260,6 +260,9 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  * (the reference is single-GPU). */
 int rnb_gradient_parts(rnb_ctx* ctx, uint64_t ranges[3][2], uint32_t* n_parts);
 int rnb_gradient_part_wait(rnb_ctx* ctx, uint32_t part, void* stream);
+/* Optimizer on block 0 only, queued on `stream` (after the caller's exchange of that block on the same stream);
+ * rnb_train_step_apply then covers the remaining blocks and joins. Optional. */
+int rnb_train_step_apply_early(rnb_ctx* ctx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,5 +44,6 @@
 #define rnb_set_controller orc_set_controller
 #define rnb_gradient_parts orc_gradient_parts
 #define rnb_gradient_part_wait orc_gradient_part_wait
+#define rnb_train_step_apply_early orc_train_step_apply_early
 #define rnb_ctx orc_ctx_s
 #endif

@@ -1747,6 +1747,7 @@ int rnb_gradient_parts(orc_ctx_s* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
 	return RNB_OK;
 }
+int rnb_train_step_apply_early(orc_ctx_s* c, void*) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); } // one block: nothing to do early
 int rnb_gradient_part_wait(orc_ctx_s* c, uint32_t part, void*) { return (c && part == 0) ? RNB_OK : fail(RNB_ERR_INVALID, "bad part"); }
 
 } // extern "C"

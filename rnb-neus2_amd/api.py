@@ -232,6 +232,9 @@ class Context:
         self._check(self.f.gradient_parts(self._h, C.byref(arr), C.byref(n)))
         return [(int(arr[k][0]), int(arr[k][1])) for k in range(n.value)]
 
+    def train_step_apply_early(self, stream_handle):
+        self._check(self.f.train_step_apply_early(self._h, C.c_void_p(stream_handle)))
+
     def gradient_part_wait(self, part, stream_handle):
         self._check(self.f.gradient_part_wait(self._h, int(part), C.c_void_p(stream_handle)))
 

@@ -148,7 +148,8 @@ struct rnb_ctx {
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
-	struct { bool valid = false, exchanged = false; uint64_t split[2] = {0, 0}; } sc; // scatter groups of the current backward pass (see forward_backward)
+	struct { bool valid = false, exchanged = false; uint64_t split[2] = {0, 0}; } sc;
+	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
@@ -524,44 +525,74 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	return RNB_OK;
 }
 
-int optimizer_step(rnb_ctx* c, hipStream_t s) {
+// Once per step: learning-rate schedule, step count, EMA debias terms (exponential_decay.h:61-72, ema.h:116-117).
+static void optimizer_begin(rnb_ctx* c) {
+	if (c->opt.begun) return;
 	const rnb_config& cfg = c->cfg;
-	const uint32_t step0 = c->optimizer_step_count; // exponential_decay.h:61-72
+	const uint32_t step0 = c->optimizer_step_count;
 	if (step0 == 0) c->lr_factor = 1.0f;
 	if (step0 >= cfg.lr_decay_start && (step0 - cfg.lr_decay_start) % cfg.lr_decay_interval == 0 && step0 <= 10000000u) c->lr_factor *= cfg.lr_decay_base;
 	const uint32_t current_step = ++c->optimizer_step_count;
-	AdamArgs a;
+	AdamArgs& a = c->opt.args;
 	a.n = c->n_params; a.n_matrix = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
 	a.w32 = c->params_fp32.p; a.w16 = c->params_fp16.p; a.ema = c->params_ema.p;
 	a.grads = c->grads.p; a.m = c->adam_m.p; a.v = c->adam_v.p; a.steps = c->adam_steps.p;
 	a.base_lr = cfg.learning_rate * c->lr_factor; a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.epsilon = cfg.epsilon; a.l2_reg = cfg.l2_reg;
 	a.ema_decay = cfg.ema_decay;
 	a.skip_lo = cfg.only_sdf_training ? (uint64_t)c->off_rgb : 0; a.skip_hi = cfg.only_sdf_training ? (uint64_t)c->off_grid : 0;
-	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1); // ema.h:116-117
+	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1);
 	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
+	c->opt.begun = true;
+	c->opt.early_done = false;
+}
+
+static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi) {
+	if (hi <= lo) return;
+	AdamArgs a = c->opt.args;
+	a.begin = lo; a.end = hi;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
+	hipLaunchKernelGGL(k_adam_ema, dim3(blocks), dim3(256), 0, st, a);
+}
+
+// Optimizer on the early gradient block only (rnb_gradient_parts block 0), on the caller's stream.
+int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
+	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
+	optimizer_begin(c);
+	adam_launch(c, st, c->sc.split[1], c->sc.split[0]);
+	HIP_TRY(hipEventRecord(c->ev_adam, st));
+	c->opt.early_done = true;
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+int optimizer_step(rnb_ctx* c, hipStream_t s) {
+	const rnb_config& cfg = c->cfg;
+	optimizer_begin(c);
 	c->prof.mark(s, P_NONE);
-	auto launch = [&](hipStream_t st, uint64_t lo, uint64_t hi) {
-		if (hi <= lo) return;
-		a.begin = lo; a.end = hi;
-		const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
-		hipLaunchKernelGGL(k_adam_ema, dim3(blocks), dim3(256), 0, st, a);
-	};
-	if (c->overlap() && cfg.world_size == 1 && c->sc.valid && !c->sc.exchanged) {
+	if (c->opt.early_done) {
+		// the caller has already stepped the early block (after exchanging it): the rest, then join
+		adam_launch(c, s, 0, c->sc.split[1]);
+		adam_launch(c, s, c->sc.split[0], c->n_params);
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
+		c->sc.valid = false;
+	} else if (c->overlap() && cfg.world_size == 1 && c->sc.valid && !c->sc.exchanged) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
 		// on the side stream, beside the scatter of the next group; only the coarse levels' (small) block is left for the end.
 		hipStream_t sa = c->s_adam;
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
-		launch(sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
+		adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
-		launch(sa, c->sc.split[0], c->off_var);      // group A's levels
+		adam_launch(c, sa, c->sc.split[0], c->off_var);      // group A's levels
 		HIP_TRY(hipEventRecord(c->ev_adam, sa));
-		launch(s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
-		launch(s, c->off_var, c->n_params);
+		adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
+		adam_launch(c, s, c->off_var, c->n_params);
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
 		c->sc.valid = false;
 	} else {
-		launch(s, 0, c->n_params);
+		adam_launch(c, s, 0, c->n_params);
 	}
+	c->opt.begun = false;
+	c->opt.early_done = false;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
 	HIP_TRY(hipGetLastError());
@@ -1198,6 +1229,11 @@ int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 		ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
 	}
 	return RNB_OK;
+}
+
+int rnb_train_step_apply_early(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return optimizer_step_early(c, as_stream(stream));
 }
 
 int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {

@@ -59,9 +59,9 @@ class DataParallelTrainer:
             with torch.cuda.stream(self._early):
                 ctx.gradient_part_wait(0, self._early.cuda_stream)
                 dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+                ctx.train_step_apply_early(self._early.cuda_stream)  # Adam on that block, beside the rest of the exchange
             for lo, hi in parts[1:]:
                 dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
-            torch.cuda.current_stream().wait_stream(self._early)
         else:
             dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
 
