@@ -151,6 +151,8 @@ typedef enum rnb_buffer_id {
 	RNB_BUF_DENSITY_GRID_TMP = 21, /* float[128^3 * (max_cascade+1)] */
 	RNB_BUF_GRID_SAMPLE_POS = 22,  /* float[n*3] positions of the last density-grid update */
 	RNB_BUF_GRID_SAMPLE_IDX = 23,  /* uint32[n] */
+	RNB_BUF_STEP_VECTOR = 24,  /* double[7]: this rank's {counters[0..3], loss sums[0..2]} of the running step, final once the loss pass is
+	                              (rnb_train_step_local has returned); data-parallel callers all-reduce it in place */
 	RNB_BUF_COUNT
 } rnb_buffer_id;
 

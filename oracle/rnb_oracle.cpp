@@ -131,6 +131,7 @@ struct orc_ctx_s {
 
 	// controller (Counters, testbed.h:627-640)
 	uint32_t training_step = 0, cur_step = 0;
+	double step_vector[7] = {0, 0, 0, 0, 0, 0, 0}; // {counters[0..3], loss sums[0..2]} of the last rnb_train_step_local
 	uint32_t valid_level = 0;
 	uint32_t rays_per_batch = 0;
 	uint32_t measured_batch_size = 0;
@@ -1508,6 +1509,7 @@ int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_DENSITY_GRID_TMP: BUF(c->density_grid_tmp);
 		case RNB_BUF_GRID_SAMPLE_POS: BUF(c->grid_sample_pos);
 		case RNB_BUF_GRID_SAMPLE_IDX: BUF(c->grid_sample_idx);
+		case RNB_BUF_STEP_VECTOR: *ptr = c->step_vector; *n_bytes = sizeof(c->step_vector); return RNB_OK;
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
@@ -1663,6 +1665,8 @@ int rnb_train_step_local(orc_ctx_s* c, void*, uint64_t counters[4], double sums[
 	const uint32_t n = std::min(c->counters[2], c->cur_n_rays);
 	for (uint32_t i = 0; i < n; ++i) { s0 += c->loss[i]; s1 += c->ek_loss[i]; s2 += c->mask_loss[i]; }
 	sums[0] = s0; sums[1] = s1; sums[2] = s2;
+	for (int k = 0; k < 4; ++k) c->step_vector[k] = (double)c->counters[k];
+	c->step_vector[4] = s0; c->step_vector[5] = s1; c->step_vector[6] = s2;
 	c->local_measured_before = c->counters[0];
 	return RNB_OK;
 }

@@ -1076,6 +1076,9 @@ __global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, co
 	if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
 	if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(out + 3)[threadIdx.x] = counters[threadIdx.x]; // one 48-byte readback: sums + counters + evaluated samples
 	if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
+	// the same numbers as one double[7] {counters, sums}: what data-parallel ranks all-reduce (RNB_BUF_STEP_VECTOR)
+	if (threadIdx.x < 4) out[8 + threadIdx.x] = (double)counters[threadIdx.x];
+	if (threadIdx.x == 0) { out[12] = sh[0][0]; out[13] = sh[1][0]; out[14] = sh[2][0]; }
 }
 
 } // namespace rnb

@@ -697,7 +697,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	} while (0)
 	ALLOC(c->params_fp32, c->n_params); ALLOC(c->grads, c->n_params); ALLOC(c->adam_m, c->n_params); ALLOC(c->adam_v, c->n_params);
 	ALLOC(c->params_fp16, c->n_params); ALLOC(c->params_ema, c->n_params); ALLOC(c->adam_steps, c->n_params);
-	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 7);
+	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
@@ -878,6 +878,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_EK_LOSS: *ptr = (void*)c->ek_loss; *n_bytes = c->loss.bytes() / 3; return RNB_OK;
 		case RNB_BUF_MASK_LOSS: *ptr = (void*)c->mask_loss; *n_bytes = c->loss.bytes() / 3; return RNB_OK;
 		case RNB_BUF_COUNTERS: BUF(c->counters);
+		case RNB_BUF_STEP_VECTOR: *ptr = (void*)(c->loss_sums.p + 8); *n_bytes = 7 * sizeof(double); return RNB_OK;
 		case RNB_BUF_DENSITY_GRID_TMP: BUF(c->density_grid_tmp);
 		case RNB_BUF_GRID_SAMPLE_POS: *ptr = c->grid_sample_pos.p; *n_bytes = (uint64_t)c->n_grid_samples * 12; return RNB_OK;
 		case RNB_BUF_GRID_SAMPLE_IDX: *ptr = c->grid_sample_idx.p; *n_bytes = (uint64_t)c->n_grid_samples * 4; return RNB_OK;

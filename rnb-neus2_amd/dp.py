@@ -39,10 +39,12 @@ class DataParallelTrainer:
         self.stream = stream
         self._grads = None
         self._side = None
+        self._vec = None
+        self._vec_host = None
         self._early = None
         self._collectives = ctx.cfg.world_size > 1 or bool(os.environ.get("RNB_DP_FORCE_COLLECTIVES"))  # the env var exercises the collective path on one rank
         self._reduce_grads = all_reduce_grads or self._torch_reduce_grads
-        self._reduce_small = all_reduce_small or self._torch_reduce_small
+        self._reduce_small = all_reduce_small  # None: all-reduce the library's device block in place
 
     def _torch_reduce_grads(self, ctx):
         """Sum of the fp32 gradient accumulators over the ranks. The block of levels whose scatter finishes first is exchanged
@@ -65,22 +67,27 @@ class DataParallelTrainer:
         else:
             dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
 
-    def _torch_reduce_small(self, vec):
+    def _torch_reduce_step_vector(self, ctx):
+        """All-reduce of the step's 7 counters / loss sums, in place on the library's device block (RNB_BUF_STEP_VECTOR): no
+        host-to-device copy, one small device-to-host copy. On its own (non-blocking) stream: the default stream holds this
+        step's backward pass, and waiting for it here would delay the ray controller and with it the next step's march."""
         import torch
         import torch.distributed as dist
         if dist.get_backend() != "nccl":
-            t = torch.from_numpy(vec.copy())
+            counters, sums = ctx.train_step_local(self.stream)
+            t = torch.from_numpy(np.concatenate([counters.astype(np.float64), sums]))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return t.numpy()
-        # On its own (non-blocking) stream: the default stream holds this step's backward pass, and waiting for it here would
-        # delay the ray controller and with it the next step's march.
-        if self._side is None:
+        if self._vec is None:
+            ptr, _ = ctx.buffer("STEP_VECTOR")
+            self._vec = torch.as_tensor(_DeviceArray(ptr, 7, "<f8"), device="cuda")
             self._side = torch.cuda.Stream()
+            self._vec_host = torch.empty(7, dtype=torch.float64, pin_memory=True)
         with torch.cuda.stream(self._side):
-            t = torch.from_numpy(vec.copy()).to("cuda", non_blocking=False)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            out = t.cpu().numpy()
-        return out
+            dist.all_reduce(self._vec, op=dist.ReduceOp.SUM)
+            self._vec_host.copy_(self._vec, non_blocking=True)
+            self._side.synchronize()
+        return self._vec_host.numpy().copy()
 
     def step(self, allow_no_samples=False):
         """begin (march .. loss .. backward queued) -> counters as soon as the loss pass is done -> 7-value all-reduce ->
@@ -90,8 +97,10 @@ class DataParallelTrainer:
         ctx.train_step_begin(self.stream)
         counters, sums = ctx.train_step_local(self.stream)
         if self._collectives:
-            vec = np.concatenate([counters.astype(np.float64), sums])
-            vec = self._reduce_small(vec)
+            if self._reduce_small is not None:
+                vec = self._reduce_small(np.concatenate([counters.astype(np.float64), sums]))
+            else:
+                vec = self._torch_reduce_step_vector(ctx)
             counters, sums = np.rint(vec[:4]).astype(np.uint64), vec[4:]
         try:
             stats = ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
