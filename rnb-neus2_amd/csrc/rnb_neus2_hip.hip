@@ -122,6 +122,12 @@ struct rnb_ctx {
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
 	uint32_t fwd_k1 = 48;
+	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
+	struct Knobs {
+		bool forward_v1 = false, march_narrow = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
+		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
+		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
+	} knobs;
 	DevBuf<RayLoss> ray_loss;
 	// training scratch
 	DevBuf<half_t> fm;       // feature-major operand arrays
@@ -298,7 +304,7 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	FwdArgs a;
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
-	if (getenv("RNB_FORWARD_V1") && !idx) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
+	if (c->knobs.forward_v1 && !idx) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
 		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
 		hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
 	} else {
@@ -343,7 +349,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
-	if (getenv("RNB_MARCH_NARROW")) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	if (c->knobs.march_narrow) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
 	else hipLaunchKernelGGL(k_march_count_wide, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
@@ -441,25 +447,24 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	ScatterArgs sa;
 	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	uint32_t l, e16 = 0, e4 = 0, e_lds = 0, Ks[RNB_MAX_LEVELS];
-	const uint32_t r4 = getenv("RNB_SCATTER_R4") ? (uint32_t)atoi(getenv("RNB_SCATTER_R4")) : 24u;
-	const uint32_t r16 = getenv("RNB_SCATTER_R16") ? (uint32_t)atoi(getenv("RNB_SCATTER_R16")) : 24u;
+	const uint32_t r4 = c->knobs.scatter_r4, r16 = c->knobs.scatter_r16;
 	for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
 	{
-		const char* kenv = getenv("RNB_SCATTER_K"); // debug: comma list of K per level
+		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
 		for (l = 0; l < L; ++l) {
 			const float run = 590.f / (float)c->grid.resolution[l];
 			Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : run >= 0.55f ? 2 : 1;
 			if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
 		}
 	}
-	if (!getenv("RNB_SCATTER_NOLDS")) // the coarsest levels whose fp32 gradient tables fit in LDS together
+	if (!c->knobs.scatter_nolds) // the coarsest levels whose fp32 gradient tables fit in LDS together
 		for (l = 0; l < L; ++l) if (l == e_lds && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) e_lds = l + 1;
 	if (e16 < e_lds) e16 = e_lds;
 	if (e4 < e_lds) e4 = e_lds;
 	const uint32_t e_c = e4;
 	uint32_t l_plain = e_c, k_min = 16;
 	uint64_t k_log2 = 0;
-	const bool noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr;
+	const bool noquad = c->knobs.scatter_noquad;
 	if (!noquad)
 		for (l = e_c; l < L && Ks[l] > 1 && l - e_c < 16; ++l) {
 			k_log2 |= (uint64_t)ilog2(Ks[l]) << (4 * (l - e_c));
@@ -477,7 +482,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	auto launch_c = [&](hipStream_t st) {
 		if (e_lds) {
 			ScatterLdsArgs la; la.a = sa; la.n_levels = e_lds;
-			const uint32_t wg_cap = getenv("RNB_SCATTER_LDS_WG") ? (uint32_t)atoi(getenv("RNB_SCATTER_LDS_WG")) : 128u;
+			const uint32_t wg_cap = c->knobs.scatter_lds_wg;
 			const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 			la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
 			hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_lds] * 8, st, c->meta(), la);
@@ -486,7 +491,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		if (e4 > e16) hipLaunchKernelGGL(k_grid_scatter<4>, dim3(((B + 3) / 4 + 255) / 256, e4 - e16), dim3(256), 0, st, c->meta(), sa, e16);
 	};
 
-	if (getenv("RNB_SCATTER_SPLIT")) { // profiling aid: serial, one launch per level
+	if (c->knobs.scatter_split) { // profiling aid: serial, one launch per level
 		launch_dw(s);
 		c->prof.mark(s, P_DW);
 		for (l = 0; l < L; ++l) {
@@ -759,6 +764,15 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
 	if (const char* e = getenv("RNB_FWD_K1")) c->fwd_k1 = (uint32_t)atoi(e); // head length of the two-round network evaluation; 0 = one round over all samples
+	{
+		rnb_ctx::Knobs& k = c->knobs;
+		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr;
+		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
+		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
+		if (const char* e = getenv("RNB_SCATTER_R16")) k.scatter_r16 = (uint32_t)atoi(e);
+		if (const char* e = getenv("RNB_SCATTER_LDS_WG")) k.scatter_lds_wg = (uint32_t)atoi(e);
+		if (const char* e = getenv("RNB_SCATTER_K")) k.scatter_k = e;
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
@@ -1052,7 +1066,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->cur_n_rays = n_rays;
 	c->cur_n_rays_total = n_rays_total;
 	c->prof.mark(s, P_NONE);
-	const bool two_round = c->fwd_k1 != 0 && !getenv("RNB_FORWARD_V1");
+	const bool two_round = c->fwd_k1 != 0 && !c->knobs.forward_v1;
 	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p);
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
@@ -1121,7 +1135,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
 	const uint32_t* counters = c->host_rb->counters;
-	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += (c->fwd_k1 && !getenv("RNB_FORWARD_V1")) ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
+	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += (c->fwd_k1 && !c->knobs.forward_v1) ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
 	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];

@@ -147,3 +147,46 @@ def test_overlapped_schedule_matches_serial_order(scene, trained):
     finally:
         ser.close()
         ovl.close()
+
+
+def test_data_parallel_hooks_single_rank(scene, trained):
+    """The entry points a data-parallel caller uses (gradient blocks in completion order, device-side wait, optimizer on the
+    early block, the step vector) driven by hand on one rank: same update as the plain sequence."""
+    _, state = trained
+    plain = _clone(scene, state, overlap=1)
+    hooks = _clone(scene, state, overlap=1)
+    try:
+        plain.train_step_begin()
+        c0, s0 = plain.train_step_local()
+        st0 = plain.train_step_finish(c0, s0)
+        plain.train_step_apply()
+
+        hooks.train_step_begin()
+        c1, s1 = hooks.train_step_local()
+        vec = hooks.get("STEP_VECTOR")
+        assert np.array_equal(vec[:4], c1.astype(np.float64)) and np.array_equal(vec[4:], s1)
+        st1 = hooks.train_step_finish(c1, s1)
+        parts = hooks.gradient_parts()
+        n = hooks.n_params
+        assert len(parts) == 3 and sorted(parts)[0][0] == 0 and sorted(parts)[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(sorted(parts), sorted(parts)[1:]))           # the blocks partition [0, n_params)
+        assert parts[0][1] - parts[0][0] > 0.5 * n                                           # the early block is the bulk of the gradient
+        hooks.gradient_part_wait(0, 0)
+        hooks.train_step_apply_early(0)
+        hooks.train_step_apply()
+        assert np.array_equal(c0, c1) and st0.loss == st1.loss and st0.next_rays_per_batch == st1.next_rays_per_batch
+        pa, pb = plain.get("PARAMS_FP32"), hooks.get("PARAMS_FP32")
+        assert np.allclose(pa, pb, rtol=0, atol=2e-5)
+        assert np.array_equal(plain.get("ADAM_STEPS"), hooks.get("ADAM_STEPS"))
+        assert plain.training_step == hooks.training_step
+        for _ in range(3):  # and the sequence keeps working
+            hooks.train_step_begin()
+            c1, s1 = hooks.train_step_local()
+            hooks.train_step_finish(c1, s1)
+            hooks.gradient_parts()
+            hooks.train_step_apply_early(0)
+            hooks.train_step_apply()
+        assert hooks.training_step == plain.training_step + 3
+    finally:
+        plain.close()
+        hooks.close()
