@@ -1109,12 +1109,18 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 // ray-ordered batch and keeps the four (dy, dz) corner sums of its (dx, feature) in registers while the cell does not
 // change. Same-address lanes of one atomic instruction are serialised by the memory system (one request each), so merging
 // a cell run in registers divides the request count by the run length.
-// One launch covers levels level0 + blockIdx.y; k_log2 holds log2(K) of level0 + i in bits [4i, 4i+4).
-__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint64_t k_log2) {
-	const uint32_t level = level0 + blockIdx.y;
-	const uint32_t K = 1u << ((k_log2 >> (4 * blockIdx.y)) & 15u);
+// One launch covers levels level0 .. level0 + n - 1 with a 1-D grid: level level0 + i owns workgroups [wg_start[i], wg_start[i+1])
+// (exactly as many as its run length needs); k_log2 holds log2(K) of level0 + i in bits [4i, 4i+4).
+struct ScatterRlPlan { uint32_t n; uint32_t wg_start[17]; uint64_t k_log2; };
+
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) {
+	uint32_t li = 0;
+#pragma unroll 1
+	for (uint32_t q = 1; q < plan.n; ++q) if (blockIdx.x >= plan.wg_start[q]) li = q;
+	const uint32_t level = level0 + li;
+	const uint32_t K = 1u << ((plan.k_log2 >> (4 * li)) & 15u);
 	if (level > G.valid_level) return;
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t t = (blockIdx.x - plan.wg_start[li]) * blockDim.x + threadIdx.x;
 	const uint32_t s0 = (t >> 2) * K;
 	if (s0 >= a.B) return;
 	const uint32_t dx = (t >> 1) & 1u, f = t & 1u;

@@ -453,7 +453,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
 		for (l = 0; l < L; ++l) {
 			const float run = 590.f / (float)c->grid.resolution[l];
-			Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : run >= 0.55f ? 2 : 1;
+			Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
 			if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
 		}
 	}
@@ -475,9 +475,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		if (noquad) { if (L > e_c) hipLaunchKernelGGL(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, c->meta(), sa, e_c); }
 		else if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, c->meta(), sa, l_plain);
 	};
-	auto launch_b = [&](hipStream_t st) { // one launch, blockIdx.y = level; rows with a larger K than k_min leave their surplus workgroups at once
-		if (l_plain > e_c)
-			hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + k_min - 1) / k_min) * 4 + 255) / 256, l_plain - e_c), dim3(256), 0, st, c->meta(), sa, e_c, k_log2);
+	auto launch_b = [&](hipStream_t st) { // one launch for all these levels, each with the workgroups its run length needs
+		if (l_plain <= e_c) return;
+		ScatterRlPlan plan;
+		plan.n = l_plain - e_c; plan.k_log2 = k_log2;
+		uint32_t wg = 0;
+		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + Ks[e_c + q] - 1) / Ks[e_c + q]) * 4 + 255) / 256; }
+		plan.wg_start[plan.n] = wg;
+		hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3(wg), dim3(256), 0, st, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st) {
 		if (e_lds) {
@@ -497,7 +502,11 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		for (l = 0; l < L; ++l) {
 			if (l < e16) hipLaunchKernelGGL(k_grid_scatter<16>, dim3(((B + 15) / 16 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
 			else if (l < e4) hipLaunchKernelGGL(k_grid_scatter<4>, dim3(((B + 3) / 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
-			else if (Ks[l] > 1) hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3((((B + Ks[l] - 1) / Ks[l]) * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l, (uint64_t)ilog2(Ks[l]));
+			else if (Ks[l] > 1) {
+				ScatterRlPlan plan;
+				plan.n = 1; plan.k_log2 = ilog2(Ks[l]); plan.wg_start[0] = 0; plan.wg_start[1] = (((B + Ks[l] - 1) / Ks[l]) * 4 + 255) / 256;
+				hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3(plan.wg_start[1]), dim3(256), 0, s, c->meta(), sa, l, plan);
+			}
 			else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
 		}
 	} else if (!c->overlap()) {
