@@ -740,6 +740,194 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K10 + K11 when the colour MLP receives and returns exact zeros (TrainArgs::skip_rgb, i.e. --no-albedo: stage 1 of the
+// pipeline and the headline benchmark). What remains of nerf_network.h:97-452 is the SDF MLP with its first- and
+// second-order backward: 4 GEMMs of the 12, all register-chained as in k_forward_chained (mlp.cuh), a 10 KB weight image,
+// one 5 KB exchange tile per wavefront -> 2+ workgroups per CU instead of 1.
+//   z1 = relu(W0 in)                      dz1 = W1[0,:] (.) relu'(z1)        d sdf/d in = W0^T dz1      (-> g2)
+//   dso = e0 * dL/dsdf                    dz = (W1^T dso) (.) relu'(z1) = dL/dsdf * dz1  (one product per element: the
+//                                         GEMM's other 15 K-terms are zeros)   dL/d in = W0^T dz           (-> g1)
+//   ddin = [dn | dy_dx . dn]              front = (W0 ddin) (.) relu'(z1)
+// The operands of the weight-gradient GEMMs leave in "fragment order": inside a 64-sample tile, sample q sits at position
+// (q & 15) * 4 + (q >> 4). K of those GEMMs is the sample index, i.e. a summation index, and every operand uses the same
+// order, so k_dw is unchanged; a D fragment's four n-tiles then are 8 contiguous bytes per lane (16 stores per 64x64 matrix).
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_S0 = 0;                    // [64][S32] sdf W0, input columns in tile order (below)
+constexpr int SW_S0T = SW_S0 + 64 * S32;    // [32][S64] sdf W0^T, rows in tile order, columns in chain order
+constexpr int SW_W1 = SW_S0T + 32 * S64;    // [64] sdf W1 row 0 in chain order
+constexpr int SW_END = SW_W1 + 64;
+constexpr int FBS_WAVE_HALFS = 2 * TILE * S32 + TILE; // two 32-wide tiles (network input / second-order input) + one half per sample
+constexpr size_t LDS_FBS = (size_t)(SW_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
+// Column order of the 32-wide input tiles: the 28 hash features first (a level's pair is one aligned 4-byte LDS access),
+// then x y z, then the pad -- the input index is a summation index of W0 . in, the weight images follow the same order.
+__host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (p < 31 ? p - 28 : 31); }
+
+// dst[idx] with a wave-uniform base and a 32-bit element index (scalar base + vector byte offset addressing)
+template <typename T>
+__device__ __forceinline__ void st32(T* __restrict__ base, const uint32_t idx, const T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + idx * (uint32_t)sizeof(T)) = v; }
+
+__device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __restrict__ dst, const uint32_t B, const uint32_t tile, const int lane) {
+	const uint32_t r16 = lane & 15, hq = lane >> 4;
+	const uint32_t lane_off = 4u * hq * B + tile * TILE + r16 * 4u; // per-lane part; the row part below is wave-uniform
+#pragma unroll
+	for (uint32_t ks = 0; ks < 2; ++ks)
+#pragma unroll
+		for (uint32_t j = 0; j < 8; ++j) {
+			const uint32_t row_off = (16u * (2u * ks + (j >> 2)) + (j & 3u)) * B;
+			const h4 v = {b[0][ks][j], b[1][ks][j], b[2][ks][j], b[3][ks][j]};
+			*reinterpret_cast<h4*>(reinterpret_cast<char*>(dst) + (row_off + lane_off) * 2u) = v;
+		}
+}
+
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fill_level_meta(lm, G, threadIdx.x);
+	const uint32_t n_live = min(G.n_levels, G.valid_level + 1u); // levels [0, n_live) are encoded, the others are zeros (grid.h:192-210)
+	for (int i = threadIdx.x; i < 64 * 32; i += WG) { const int o = i >> 5, p = i & 31; wts[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
+	for (int i = threadIdx.x; i < 32 * 64; i += WG) { const int q = i >> 6, p = i & 63; wts[SW_S0T + q * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + fbs_logical(q)]; }
+	for (int i = threadIdx.x; i < 64; i += WG) wts[SW_W1 + i] = net.sdf_w1[chain_logical(i)];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* X = wts + SW_END + wave * FBS_WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in
+	half_t* D = X + TILE * S32;                        // second-order input rows (ddin)
+	half_t* Z = D + TILE * S32;
+	const int r16 = lane & 15, hq = lane >> 4;
+	const uint32_t B = a.B;
+	const uint32_t n_tiles = B / TILE;
+	const TrainScratch& T = a.t;
+	const uint32_t pos = (uint32_t)r16 * 4u + (uint32_t)hq; // fragment-order position of sample `lane` inside its tile
+	float var_sum = 0.f;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		const uint32_t sp = tile * TILE + pos;
+		float c[3];
+#pragma unroll
+		for (int q = 0; q < 3; ++q) c[q] = a.coords[(size_t)s * 7 + q];
+		half_t dout[16];
+		{
+			const h8* src = reinterpret_cast<const h8*>(a.dout + (size_t)s * 16);
+			const h8 d0 = src[0], d1 = src[1];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { dout[j] = d0[j]; dout[8 + j] = d1[j]; }
+		}
+		// dn = dL/d(grad sdf) depends on the loss gradient only here (the colour MLP returns zeros), so the second-order input
+		// ddin = [half(dn) | dy_dx . dn | 0] (grid.h:858-883, nerf_network.h:423-433) is formed level by level with the encode:
+		// nothing per level stays in registers, the level loop is not unrolled, and occupancy rather than unrolling hides
+		// the gather latency.
+		float dn[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			float v = 0.f;                             // dL_drgb_network_input rows 35..37 are zero here
+			v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
+			v += h2f(dout[8 + d]);                     // add_positions_view (nerf_network.h:343-373)
+			dn[d] = v;
+			st32(T.dn, (uint32_t)d * B + s, v);
+		}
+		uint32_t* Xrow = reinterpret_cast<uint32_t*>(X + lane * S32);
+		uint32_t* Drow = reinterpret_cast<uint32_t*>(D + lane * S32);
+#pragma unroll 1
+		for (uint32_t level = 0; level < 14; ++level) {
+			half_t f0 = (half_t)0.f, f1 = (half_t)0.f;
+			float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
+			if (level < n_live) encode_level_lm<true>(lm, net.grid, level, c[0], c[1], c[2], f0, f1, d0, d1);
+			float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { r0 += d0[d] * dn[d]; r1 += d1[d] * dn[d]; }
+			const half_t e0 = f2h(r0), e1 = f2h(r1);
+			Xrow[level] = pack_h2(f0, f1);
+			Drow[level] = pack_h2(e0, e1);
+			const uint32_t row = (3u + 2u * level) * B + sp; // operand rows are in the network's own input order
+			st32(T.sdfin, row, f0); st32(T.sdfin, row + B, f1);
+			st32(T.ddin, row, e0); st32(T.ddin, row + B, e1);
+		}
+		{ // x y z (fill_positions_view_with_fixed_offset: half arithmetic, common_operation.cuh:187-199) | pad ; dn | pad
+			const half_t px = f2h(c[0]) - (half_t)0.5f, py = f2h(c[1]) - (half_t)0.5f, pz = f2h(c[2]) - (half_t)0.5f;
+			Xrow[14] = pack_h2(px, py); Xrow[15] = pack_h2(pz, (half_t)0.f);
+			const half_t n0 = f2h(dn[0]), n1 = f2h(dn[1]), n2 = f2h(dn[2]);
+			Drow[14] = pack_h2(n0, n1); Drow[15] = pack_h2(n2, (half_t)0.f);
+			st32(T.sdfin, 0u * B + sp, px); st32(T.sdfin, 1u * B + sp, py); st32(T.sdfin, 2u * B + sp, pz); st32(T.sdfin, 31u * B + sp, (half_t)0.f);
+			st32(T.ddin, 0u * B + sp, n0); st32(T.ddin, 1u * B + sp, n1); st32(T.ddin, 2u * B + sp, n2); st32(T.ddin, 31u * B + sp, (half_t)0.f);
+		}
+		Z[lane] = dout[3];
+		// dso (only dL/dsdf survives, add_density_gradient), variance gradient
+		st32(T.dso, sp, (half_t)0.f + dout[3]);
+#pragma unroll
+		for (uint32_t j = 1; j < 16; ++j) st32(T.dso, j * B + sp, (half_t)0.f);
+		var_sum += h2f(dout[7]);
+		wave_lds_sync();
+		// z1 = relu(W0 in), kept as next-layer fragments; its relu' mask in fragment order
+		h8 bz[4][2];
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + SW_S0, S32, X, S32, acc, lane);
+			chain_pack<true>(acc, bz);
+		}
+		export_frags(bz, T.z1, B, tile, lane);
+		uint64_t mask = 0;
+		half_t d3[4];
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) d3[nt] = Z[16 * nt + r16];
+		// dz1 = W1[0,:] (.) relu'(z1) (the stored half activation is tested, common_device.h:182 ff.); dz = dL/dsdf * dz1
+		h8 bdz[4][2];
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			const h8 w1 = *reinterpret_cast<const h8*>(wts + SW_W1 + 32 * ks + 8 * hq);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const bool on = bz[nt][ks][j] > (half_t)0.f;
+					if (on) mask |= 1ull << ((nt * 2 + ks) * 8 + j);
+					bz[nt][ks][j] = on ? w1[j] : (half_t)0.f;                                   // bz now holds dz1
+					bdz[nt][ks][j] = on ? f2h(h2f(w1[j]) * h2f(d3[nt])) : (half_t)0.f;
+				}
+		}
+		export_frags(bz, T.dz1, B, tile, lane);
+		export_frags(bdz, T.dz, B, tile, lane);
+		wave_lds_sync(); // X (network input) consumed by the first GEMM
+		{ // d sdf / d in = W0^T dz1 -> rows of X
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer_regs<2, 2>(wts + SW_S0T, S64, bz, acc, lane);
+			store_acc<2, false>(acc, X, S32, 0, lane);
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (uint32_t l = 0; l < 14; ++l) st32(T.g2, l * B + s, Xrow[l]); // g2[level] = d sdf / d feat of that level (dL_denc_output of the double backward)
+		wave_lds_sync(); // rows of X read
+		{ // dL/d in = W0^T dz -> rows of X; its feature columns are the first-order dL/dfeat of the grid
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer_regs<2, 2>(wts + SW_S0T, S64, bdz, acc, lane);
+			store_acc<2, false>(acc, X, S32, 0, lane);
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (uint32_t l = 0; l < 14; ++l) st32(T.g1, l * B + s, Xrow[l]);
+		{ // front = (W0 ddin) (.) relu'(z1)   (fully_fused_mlp.cu:1097-1107)
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + SW_S0, S32, D, S32, acc, lane);
+			chain_pack<false>(acc, bdz);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) if (!((mask >> ((nt * 2 + ks) * 8 + j)) & 1ull)) bdz[nt][ks][j] = (half_t)0.f;
+		}
+		export_frags(bdz, T.front, B, tile, lane);
+		wave_lds_sync();
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) var_sum += __shfl_down(var_sum, off, 64);
+	if (lane == 0) T.var_partial[blockIdx.x * WAVES_PER_WG + wave] = var_sum;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight-gradient GEMM: dW[o][i] = sum_s Y[o][s] X[i][s], operands feature-major in global memory, so both MFMA
 // fragments are 16-byte contiguous loads (no LDS). Each wavefront owns K-steps of 32 samples; per-wave partial
 // results go to `partial` and are summed in a fixed order by k_dw_finish (deterministic).

@@ -124,7 +124,7 @@ struct rnb_ctx {
 	uint32_t fwd_k1 = 48;
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
-		bool forward_v1 = false, march_narrow = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
+		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
 		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
 	} knobs;
@@ -404,7 +404,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_fwd_bwd, dim3(c->fwd_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
+	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
+	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
+	if (sdf_only) hipLaunchKernelGGL(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, c->meta(), c->net(false), a);
+	else hipLaunchKernelGGL(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
 	const TrainScratch& T = c->ts;
@@ -434,7 +437,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		DwFinishArgs f;
 		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 		f.n_partials = (uint32_t)slab;
-		f.var_partial = c->var_partial.p; f.n_var_partials = c->fwd_grid * WAVES_PER_WG;
+		f.var_partial = c->var_partial.p; f.n_var_partials = fb_grid * WAVES_PER_WG;
 		f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
 		hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, f);
@@ -733,7 +736,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		T.g1 = c->g1.p; T.g2 = c->g2.p; T.dn = c->dn.p;
 	}
 	c->fwd_grid = std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-	ALLOC(c->var_partial, (size_t)c->fwd_grid * WAVES_PER_WG);
+	ALLOC(c->var_partial, (size_t)c->n_cus * 2 * WAVES_PER_WG);
 	c->ts.var_partial = c->var_partial.p;
 	{ // split-K geometry of the weight-gradient GEMMs: chunk = B / nwg, a multiple of 128 samples
 		const uint32_t units = B / 128;
@@ -763,6 +766,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
@@ -775,7 +779,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (const char* e = getenv("RNB_FWD_K1")) c->fwd_k1 = (uint32_t)atoi(e); // head length of the two-round network evaluation; 0 = one round over all samples
 	{
 		rnb_ctx::Knobs& k = c->knobs;
-		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr;
+		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_R16")) k.scatter_r16 = (uint32_t)atoi(e);
