@@ -190,3 +190,35 @@ def test_data_parallel_hooks_single_rank(scene, trained):
     finally:
         plain.close()
         hooks.close()
+
+
+def test_sdf_only_training_kernel_matches_generic(scene, trained):
+    """--no-albedo runs a specialised forward/backward kernel (k_fwd_bwd_sdf); RNB_FWD_BWD_GENERIC=1 forces the generic one.
+    Same state, same step: identical forward half, gradients equal up to fp32 summation order (MLP weight gradients are
+    narrowed to half by the optimizer stage, so they are compared at half resolution)."""
+    _, state = trained
+    gen = _clone(scene, state, env={"RNB_FWD_BWD_GENERIC": "1"}, overlap=0)
+    spe = _clone(scene, state, overlap=0)
+    try:
+        for c in (gen, spe):
+            c.train_step_begin()
+        g0, g1 = gen.get("GRADS_FP32"), spe.get("GRADS_FP32")
+        lay = gen.param_layout()
+        assert np.array_equal(gen.get("DLOSS_DOUT").view(np.uint16), spe.get("DLOSS_DOUT").view(np.uint16))
+        mlp0, mlp1 = g0[:lay["rgb"]], g1[:lay["rgb"]]
+        scale = np.abs(mlp0).max()
+        assert scale > 0 and np.max(np.abs(mlp0 - mlp1)) <= 2e-3 * scale
+        assert np.all(g0[lay["rgb"]:lay["grid"]] == 0) and np.all(g1[lay["rgb"]:lay["grid"]] == 0)  # colour MLP: exact zeros
+        grid0, grid1 = g0[lay["grid"]:lay["variance"]], g1[lay["grid"]:lay["variance"]]
+        gs = np.abs(grid0).max()
+        assert np.count_nonzero(grid0) > 0.1 * grid0.size and np.array_equal(grid0 != 0, grid1 != 0)
+        assert np.max(np.abs(grid0 - grid1)) <= 1e-4 * gs  # same addends, fp32 atomic order differs
+        assert abs(g0[lay["variance"]] - g1[lay["variance"]]) <= 1e-5 * abs(g0[lay["variance"]]) + 1e-12
+        for c in (gen, spe):
+            cnt, sums = c.train_step_local()
+            c.train_step_finish(cnt, sums)
+            c.train_step_apply()
+        assert np.allclose(gen.get("PARAMS_FP32"), spe.get("PARAMS_FP32"), rtol=0, atol=2e-5)
+    finally:
+        gen.close()
+        spe.close()
