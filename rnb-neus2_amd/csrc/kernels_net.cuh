@@ -160,6 +160,7 @@ struct FwdArgs {
 	half_t* out;               // [n][16]
 	float sdf_bias;
 	const uint32_t* idx;       // optional: evaluate the samples idx[0 .. n) (slots into coords / out) instead of 0 .. n
+	const half_t* wimg;        // optional: the LDS weight image (load_weights_chained layout) prepared once per step by k_prepare_weight_images
 };
 
 __global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW net, const FwdArgs a) {
@@ -296,6 +297,13 @@ __global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW 
 // K7, register-chained flavour (mlp.cuh): per wavefront one 32-wide exchange tile X (sdf_in rows -> d sdf / d in rows -> r
 // rows), 16 bytes per sample of colour-MLP side inputs (Y) and the raw sdf (Z); 6.3 KB instead of 27.6 KB, so two
 // workgroups fit a CU and the encode of one hides behind the MFMA / LDS phases of the other.
+// Every workgroup starts by building its LDS weight image; element-wise with permuted indices that is ~50 dependent 2-byte
+// loads per thread, a visible part of a small launch (second evaluation round). k_prepare_weight_images writes the images
+// once per step into global memory in LDS layout, and the kernels then copy 16 bytes per thread and iteration.
+__device__ __forceinline__ void copy_weight_image(half_t* __restrict__ dst, const half_t* __restrict__ src, const int n_halfs, const int tid, const int nthreads) {
+	for (int i = tid * 8; i < n_halfs; i += nthreads * 8) *reinterpret_cast<h8*>(dst + i) = *reinterpret_cast<const h8*>(src + i);
+}
+
 constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
 constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
 
@@ -305,7 +313,8 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
-	load_weights_chained(wts, net, threadIdx.x, WG);
+	if (a.wimg) copy_weight_image(wts, a.wimg, W_FWD_END, threadIdx.x, WG);
+	else load_weights_chained(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	half_t* X = wts + W_FWD_END + wave * FWD2_WAVE_HALFS;
@@ -459,6 +468,7 @@ struct TrainArgs {
 	float sdf_bias;
 	uint32_t skip_rgb; // --no-albedo: dL/d(rgb logits) is identically 0 (opti_rgb = 0, testbed_nerf.cu:1954-1962), so the
 	                   // colour MLP receives and propagates exact zeros: its forward/backward are skipped, not approximated
+	const half_t* wimg; // optional: k_fwd_bwd_sdf's LDS weight image prepared by k_prepare_weight_images
 	TrainScratch t;
 };
 
@@ -756,11 +766,26 @@ constexpr int SW_S0 = 0;                    // [64][S32] sdf W0, input columns i
 constexpr int SW_S0T = SW_S0 + 64 * S32;    // [32][S64] sdf W0^T, rows in tile order, columns in chain order
 constexpr int SW_W1 = SW_S0T + 32 * S64;    // [64] sdf W1 row 0 in chain order
 constexpr int SW_END = SW_W1 + 64;
+constexpr int SW_END_PADDED = (SW_END + 7) / 8 * 8;
 constexpr int FBS_WAVE_HALFS = 2 * TILE * S32 + TILE; // two 32-wide tiles (network input / second-order input) + one half per sample
 constexpr size_t LDS_FBS = (size_t)(SW_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
 // Column order of the 32-wide input tiles: the 28 hash features first (a level's pair is one aligned 4-byte LDS access),
 // then x y z, then the pad -- the input index is a summation index of W0 . in, the weight images follow the same order.
 __host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (p < 31 ? p - 28 : 31); }
+
+__device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
+	for (int i = tid; i < 64 * 32; i += nthreads) { const int o = i >> 5, p = i & 31; w[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
+	for (int i = tid; i < 32 * 64; i += nthreads) { const int q = i >> 6, p = i & 63; w[SW_S0T + q * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + fbs_logical(q)]; }
+	for (int i = tid; i < 64; i += nthreads) w[SW_W1 + i] = net.sdf_w1[chain_logical(i)];
+	for (int i = SW_END + tid; i < SW_END_PADDED; i += nthreads) w[i] = (half_t)0.f;
+	// (row padding of the images is never read)
+}
+
+// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf. Both from the training weights.
+__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs) {
+	if (blockIdx.x == 0) load_weights_chained(img_fwd, net, threadIdx.x, WG);
+	else load_weights_fbs(img_fbs, net, threadIdx.x, WG);
+}
 
 // dst[idx] with a wave-uniform base and a 32-bit element index (scalar base + vector byte offset addressing)
 template <typename T>
@@ -785,9 +810,8 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_live = min(G.n_levels, G.valid_level + 1u); // levels [0, n_live) are encoded, the others are zeros (grid.h:192-210)
-	for (int i = threadIdx.x; i < 64 * 32; i += WG) { const int o = i >> 5, p = i & 31; wts[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
-	for (int i = threadIdx.x; i < 32 * 64; i += WG) { const int q = i >> 6, p = i & 63; wts[SW_S0T + q * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + fbs_logical(q)]; }
-	for (int i = threadIdx.x; i < 64; i += WG) wts[SW_W1 + i] = net.sdf_w1[chain_logical(i)];
+	if (a.wimg) copy_weight_image(wts, a.wimg, SW_END, threadIdx.x, WG);
+	else load_weights_fbs(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	half_t* X = wts + SW_END + wave * FBS_WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in

@@ -119,6 +119,8 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
+	DevBuf<half_t> wimg_fwd, wimg_fbs; // LDS weight images of the training weights, rebuilt after every optimizer step
+	bool wimg_valid = false;
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
 	uint32_t fwd_k1 = 48;
@@ -303,6 +305,7 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	if (n_max == 0) return RNB_OK;
 	FwdArgs a;
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx;
+	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	if (c->knobs.forward_v1 && !idx) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
 		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
@@ -403,6 +406,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	c->sc.valid = false; c->sc.exchanged = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
+	a.wimg = c->wimg_valid ? c->wimg_fbs.p : nullptr;
 	c->prof.mark(s, P_NONE);
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
@@ -610,6 +614,8 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	}
 	c->opt.begun = false;
 	c->opt.early_done = false;
+	hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
 	HIP_TRY(hipGetLastError());
@@ -666,7 +672,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
+	c->wimg_fwd.free(); c->wimg_fbs.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -722,6 +728,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
+	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED);
 	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
@@ -858,6 +865,7 @@ int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
 	}
 	HIP_TRY(hipMemcpy(c->params_fp32.p + c->off_var, var, sizeof(var), hipMemcpyHostToDevice));
 	c->trainer_rng = rnd;
+	c->wimg_valid = false; // the training weights change outside the optimizer
 	int rc = derive_half_params(c, 0);
 	if (rc != RNB_OK) return rc;
 	HIP_TRY(hipMemset(c->params_ema.p, 0, c->params_ema.bytes()));
@@ -871,6 +879,7 @@ int rnb_set_params(rnb_ctx* c, const float* params) {
 	if (!c || !params) return fail(RNB_ERR_INVALID, "null argument");
 	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
 	HIP_TRY(hipMemcpy(c->params_fp32.p, params, c->params_fp32.bytes(), hipMemcpyHostToDevice));
+	c->wimg_valid = false; // the training weights change outside the optimizer
 	int rc = derive_half_params(c, 0);
 	if (rc != RNB_OK) return rc;
 	HIP_TRY(hipMemcpy(c->params_ema.p, c->params_fp16.p, c->params_fp16.bytes(), hipMemcpyDeviceToDevice));
@@ -885,7 +894,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 #define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
 	switch (id) {
 		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
-		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16);
+		case RNB_BUF_PARAMS_FP16: c->wimg_valid = false; BUF(c->params_fp16); // the caller may write through the pointer: drop the cached weight images
 		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
 		case RNB_BUF_GRADS_FP32: BUF(c->grads);
 		case RNB_BUF_ADAM_M: BUF(c->adam_m);
