@@ -266,6 +266,23 @@ int rnb_gradient_part_wait(rnb_ctx* ctx, uint32_t part, void* stream);
  * rnb_train_step_apply then covers the remaining blocks and joins. Optional. */
 int rnb_train_step_apply_early(rnb_ctx* ctx, void* stream);
 
+/* Data parallel, sharded optimizer: instead of all-reducing the gradients and stepping every parameter on every rank, the
+ * caller reduce-scatters each block, rank r steps chunk r (Adam moments, fp32 masters and EMA of the other chunks are not
+ * touched on this rank), and the fp16 training weights (RNB_BUF_PARAMS_FP16) are all-gathered. Per block, in order:
+ *     rnb_gradient_part_wait(ctx, k, stream)                         block k's gradients are final
+ *     reduce-scatter  GRADS_FP32[lo, hi)   -> [own_lo, own_hi)       (in place, sum)
+ *     rnb_train_step_apply_shard(ctx, k, stream)                     Adam + EMA on the own chunk, the rest of the block's accumulators cleared
+ *     all-gather      PARAMS_FP16[own_lo, own_hi) -> [lo, hi)        (in place)
+ * then rnb_train_step_apply_done on a stream that has joined the blocks' streams (it replaces rnb_train_step_apply).
+ * Blocks are world_size equal chunks of a multiple of 4 parameters; the last block ends at *capacity >= n_params, the
+ * allocated (zero-padded) length of every parameter-shaped buffer of rnb_buffer. The fp32 masters / EMA / Adam state of a
+ * rank are complete only on its own chunks: all-gather them over the same layout before reading them as a whole
+ * (snapshots, inference with EMA weights). No reference counterpart (the reference is single-GPU). */
+typedef struct rnb_shard_part { uint64_t lo, hi, own_lo, own_hi; } rnb_shard_part;
+int rnb_shard_layout(rnb_ctx* ctx, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity);
+int rnb_train_step_apply_shard(rnb_ctx* ctx, uint32_t part, void* stream);
+int rnb_train_step_apply_done(rnb_ctx* ctx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,5 +45,8 @@
 #define rnb_gradient_parts orc_gradient_parts
 #define rnb_gradient_part_wait orc_gradient_part_wait
 #define rnb_train_step_apply_early orc_train_step_apply_early
+#define rnb_shard_layout orc_shard_layout
+#define rnb_train_step_apply_shard orc_train_step_apply_shard
+#define rnb_train_step_apply_done orc_train_step_apply_done
 #define rnb_ctx orc_ctx_s
 #endif

@@ -138,6 +138,8 @@ struct orc_ctx_s {
 	uint32_t measured_batch_size_before_compaction = 0;
 	uint32_t n_rays_total = 0;
 	uint32_t optimizer_step_count = 0;
+	bool opt_begun = false;
+	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays (equal data-parallel shards)
 	float lr_factor = 1.f;
 	// begin/end hand-off
 	uint32_t cur_n_rays = 0, local_measured_before = 0;
@@ -1239,21 +1241,28 @@ void forward_backward(orc_ctx_s* c) {
 	for (int q = 1; q < RNB_N_VARIANCE_PARAMS; ++q) c->grads[c->off_var + q] = 0.f;
 }
 
-void optimizer_step(orc_ctx_s* c) {
+// ExponentialDecayOptimizer::step (exponential_decay.h:61-72): once per optimizer step.
+void optimizer_begin(orc_ctx_s* c) {
+	if (c->opt_begun) return;
 	const rnb_config& cfg = c->cfg;
-	// ExponentialDecayOptimizer::step (exponential_decay.h:61-72)
 	const uint32_t step0 = c->optimizer_step_count;
 	if (step0 == 0) c->lr_factor = 1.0f;
 	if (step0 >= cfg.lr_decay_start && (step0 - cfg.lr_decay_start) % cfg.lr_decay_interval == 0 && step0 <= 10000000u) c->lr_factor *= cfg.lr_decay_base;
+	++c->optimizer_step_count;
+	c->opt_begun = true;
+}
+
+// Parameters [lo, hi) of one optimizer step (the update is independent per parameter).
+void optimizer_range(orc_ctx_s* c, const uint64_t lo, const uint64_t hi) {
+	const rnb_config& cfg = c->cfg;
 	const float base_lr = cfg.learning_rate * c->lr_factor;
 	// AdamOptimizer::step (adam.h:309-368) + adam_step (adam.h:52-202)
-	const uint32_t current_step = ++c->optimizer_step_count;
-	const uint64_t n = c->n_params;
+	const uint32_t current_step = c->optimizer_step_count;
 	const uint64_t n_matrix = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS; // layer_sizes(), nerf_network.h:769-774
 	float* w32 = c->params_fp32.data();
 	half_t* w16 = c->params_fp16.data();
 #pragma omp parallel for schedule(static)
-	for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
+	for (int64_t ii = (int64_t)lo; ii < (int64_t)hi; ++ii) {
 		const uint64_t i = (uint64_t)ii;
 		float gradient = h2f(f2h(c->grads[i])) / LOSS_SCALE;
 		const bool is_matrix = i < n_matrix;
@@ -1280,10 +1289,34 @@ void optimizer_step(orc_ctx_s* c) {
 	const float ema_debias_new = 1.0f / (1 - (float)std::pow(ema_decay, current_step));
 	half_t* ema = c->params_ema.data();
 #pragma omp parallel for schedule(static)
-	for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
+	for (int64_t ii = (int64_t)lo; ii < (int64_t)hi; ++ii) {
 		float filtered = (h2f(ema[ii]) * ema_decay * ema_debias_old + h2f(w16[ii]) * (1 - ema_decay)) * ema_debias_new;
 		ema[ii] = f2h(filtered);
 	}
+}
+
+void optimizer_step(orc_ctx_s* c) {
+	optimizer_begin(c);
+	optimizer_range(c, 0, c->n_params);
+	c->opt_begun = false;
+}
+
+// Blocks of the sharded data-parallel optimizer (rnb_shard_layout): the split sits in front of the four finest levels, as
+// in the HIP library's overlapped schedule, so that the two-block protocol is exercised.
+void shard_layout(const orc_ctx_s* c, rnb_shard_part parts[2], uint32_t* n_parts) {
+	const uint64_t W = std::max(1u, c->cfg.world_size), r = c->cfg.rank, q = 4 * W;
+	const uint32_t L = c->cfg.n_levels;
+	const uint64_t split = L > 4 ? c->off_grid + (uint64_t)c->offsets[L - 4] * 2 : 0;
+	const uint64_t m0 = split / q * q;
+	uint32_t n = 0;
+	if (m0) { parts[n].lo = 0; parts[n].hi = m0; ++n; }
+	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint64_t chunk = (parts[k].hi - parts[k].lo) / W;
+		parts[k].own_lo = parts[k].lo + r * chunk;
+		parts[k].own_hi = parts[k].own_lo + chunk;
+	}
+	*n_parts = n;
 }
 
 uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid.h:1430-1437
@@ -1344,13 +1377,17 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 	c->max_cascade = 0;
 	while ((1u << c->max_cascade) < cfg->aabb_scale) ++c->max_cascade;
 	c->cone_angle = cfg->aabb_scale <= 1 ? 0.0f : (1.0f / 256.0f);
-	c->params_fp32.assign(c->n_params, 0.f);
-	c->params_fp16.assign(c->n_params, 0);
-	c->params_ema.assign(c->n_params, 0);
-	c->grads.assign(c->n_params, 0.f);
-	c->adam_m.assign(c->n_params, 0.f);
-	c->adam_v.assign(c->n_params, 0.f);
-	c->adam_steps.assign(c->n_params, 0);
+	{
+		const uint64_t q = 4ull * std::max(1u, cfg->world_size);
+		c->param_capacity = (c->n_params + q - 1) / q * q;
+	}
+	c->params_fp32.assign(c->param_capacity, 0.f);
+	c->params_fp16.assign(c->param_capacity, 0);
+	c->params_ema.assign(c->param_capacity, 0);
+	c->grads.assign(c->param_capacity, 0.f);
+	c->adam_m.assign(c->param_capacity, 0.f);
+	c->adam_v.assign(c->param_capacity, 0.f);
+	c->adam_steps.assign(c->param_capacity, 0);
 	const uint32_t n_grid = GRID_CELLS * (c->max_cascade + 1);
 	c->density_grid.assign(n_grid, 0.f);
 	c->density_grid_tmp.assign(n_grid, 0.f);
@@ -1484,14 +1521,15 @@ int rnb_set_params(orc_ctx_s* c, const float* params) {
 int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
 #define BUF(vec) do { *ptr = (void*)(vec).data(); *n_bytes = (vec).size() * sizeof((vec)[0]); return RNB_OK; } while (0)
+#define BUF_P(vec) do { *ptr = (void*)(vec).data(); *n_bytes = c->n_params * sizeof((vec)[0]); return RNB_OK; } while (0)
 	switch (id) {
-		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
-		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16);
-		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
-		case RNB_BUF_GRADS_FP32: BUF(c->grads);
-		case RNB_BUF_ADAM_M: BUF(c->adam_m);
-		case RNB_BUF_ADAM_V: BUF(c->adam_v);
-		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
+		case RNB_BUF_PARAMS_FP32: BUF_P(c->params_fp32);
+		case RNB_BUF_PARAMS_FP16: BUF_P(c->params_fp16);
+		case RNB_BUF_PARAMS_EMA: BUF_P(c->params_ema);
+		case RNB_BUF_GRADS_FP32: BUF_P(c->grads);
+		case RNB_BUF_ADAM_M: BUF_P(c->adam_m);
+		case RNB_BUF_ADAM_V: BUF_P(c->adam_v);
+		case RNB_BUF_ADAM_STEPS: BUF_P(c->adam_steps);
 		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
 		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield);
 		case RNB_BUF_DENSITY_MEAN: *ptr = &c->density_mean; *n_bytes = 4; return RNB_OK;
@@ -1749,6 +1787,32 @@ int rnb_set_controller(orc_ctx_s* c, uint32_t training_step, uint32_t rays_per_b
 int rnb_gradient_parts(orc_ctx_s* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
 	ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
+	return RNB_OK;
+}
+int rnb_shard_layout(orc_ctx_s* c, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity) {
+	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
+	shard_layout(c, parts, n_parts);
+	*capacity = c->param_capacity;
+	return RNB_OK;
+}
+int rnb_train_step_apply_shard(orc_ctx_s* c, uint32_t part, void*) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	rnb_shard_part parts[2];
+	uint32_t n = 0;
+	shard_layout(c, parts, &n);
+	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");
+	optimizer_begin(c);
+	const rnb_shard_part& p = parts[part];
+	std::fill(c->grads.begin() + p.lo, c->grads.begin() + p.own_lo, 0.f);
+	std::fill(c->grads.begin() + p.own_hi, c->grads.begin() + p.hi, 0.f);
+	optimizer_range(c, std::min<uint64_t>(p.own_lo, c->n_params), std::min<uint64_t>(p.own_hi, c->n_params));
+	return RNB_OK;
+}
+int rnb_train_step_apply_done(orc_ctx_s* c, void*) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (!c->opt_begun) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_done without rnb_train_step_apply_shard");
+	c->opt_begun = false;
+	++c->training_step;
 	return RNB_OK;
 }
 int rnb_train_step_apply_early(orc_ctx_s* c, void*) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); } // one block: nothing to do early

@@ -155,6 +155,9 @@ PROTOTYPES = {
     "gradient_parts": (_i, [_ctx, C.POINTER(_u64 * 2 * 3), C.POINTER(_u32)]),
     "gradient_part_wait": (_i, [_ctx, _u32, _stream]),
     "train_step_apply_early": (_i, [_ctx, _stream]),
+    "shard_layout": (_i, [_ctx, C.POINTER(_u64 * 4 * 2), C.POINTER(_u32), C.POINTER(_u64)]),
+    "train_step_apply_shard": (_i, [_ctx, _u32, _stream]),
+    "train_step_apply_done": (_i, [_ctx, _stream]),
 }
 
 

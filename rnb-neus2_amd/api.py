@@ -238,6 +238,21 @@ class Context:
     def gradient_part_wait(self, part, stream_handle):
         self._check(self.f.gradient_part_wait(self._h, int(part), C.c_void_p(stream_handle)))
 
+    def shard_layout(self):
+        """([(lo, hi, own_lo, own_hi), ...], capacity): blocks of the sharded data-parallel optimizer in completion order
+        (rnb_shard_layout); every parameter-shaped buffer is allocated up to `capacity` elements."""
+        arr = (C.c_uint64 * 4 * 2)()
+        n = C.c_uint32()
+        cap = C.c_uint64()
+        self._check(self.f.shard_layout(self._h, C.byref(arr), C.byref(n), C.byref(cap)))
+        return [tuple(int(arr[k][j]) for j in range(4)) for k in range(n.value)], int(cap.value)
+
+    def train_step_apply_shard(self, part, stream_handle=None):
+        self._check(self.f.train_step_apply_shard(self._h, int(part), C.c_void_p(stream_handle)))
+
+    def train_step_apply_done(self, stream_handle=None):
+        self._check(self.f.train_step_apply_done(self._h, C.c_void_p(stream_handle)))
+
     def profile_enable(self, on=True):
         self._check(self.f.profile_enable(self._h, int(bool(on))))
 

@@ -37,6 +37,13 @@ struct DevBuf {
 		if (count == 0) { p = nullptr; return hipSuccess; }
 		return hipMalloc((void**)&p, count * sizeof(T));
 	}
+	// `count` elements in use, `capacity` >= count allocated and zeroed (the tail is padding for equal data-parallel shards)
+	hipError_t alloc_padded(size_t count, size_t capacity) {
+		n = count;
+		hipError_t e = hipMalloc((void**)&p, capacity * sizeof(T));
+		if (e != hipSuccess) return e;
+		return hipMemset(p, 0, capacity * sizeof(T));
+	}
 	void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 	size_t bytes() const { return n * sizeof(T); }
 };
@@ -127,6 +134,7 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
+		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
 		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
 	} knobs;
@@ -156,7 +164,12 @@ struct rnb_ctx {
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
-	struct { bool valid = false, exchanged = false; uint64_t split[2] = {0, 0}; } sc;
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false; uint64_t split[2] = {0, 0}; } sc;
+	// level groups of the gradient scatter (forward_backward), fixed at creation
+	struct ScatterGroups { uint32_t e_lds = 0, e16 = 0, e4 = 0, e_c = 0, l_plain = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
+	uint64_t dp_split = 0; // first parameter of the plain-quad levels: boundary of the two data-parallel gradient blocks
+	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
+	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
@@ -403,7 +416,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const uint32_t B = c->cfg.target_batch_size;
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
-	c->sc.valid = false; c->sc.exchanged = false;
+	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	a.wimg = c->wimg_valid ? c->wimg_fbs.p : nullptr;
@@ -453,31 +466,12 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	//   C  coarse levels            levels [0, e_c)       LDS-privatised tables (+ the generic run-length kernel beyond the LDS limit)
 	ScatterArgs sa;
 	sa.coords = c->coords_compacted.p; sa.g1 = T.g1; sa.g2 = T.g2; sa.dn = T.dn; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
-	uint32_t l, e16 = 0, e4 = 0, e_lds = 0, Ks[RNB_MAX_LEVELS];
-	const uint32_t r4 = c->knobs.scatter_r4, r16 = c->knobs.scatter_r16;
-	for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) e4 = l + 1; }
-	{
-		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
-		for (l = 0; l < L; ++l) {
-			const float run = 590.f / (float)c->grid.resolution[l];
-			Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
-			if (kenv && *kenv) { Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
-		}
-	}
-	if (!c->knobs.scatter_nolds) // the coarsest levels whose fp32 gradient tables fit in LDS together
-		for (l = 0; l < L; ++l) if (l == e_lds && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) e_lds = l + 1;
-	if (e16 < e_lds) e16 = e_lds;
-	if (e4 < e_lds) e4 = e_lds;
-	const uint32_t e_c = e4;
-	uint32_t l_plain = e_c, k_min = 16;
-	uint64_t k_log2 = 0;
+	const rnb_ctx::ScatterGroups& sg = c->sg;
+	const uint32_t e16 = sg.e16, e4 = sg.e4, e_lds = sg.e_lds, e_c = sg.e_c, l_plain = sg.l_plain;
+	const uint32_t* Ks = sg.Ks;
+	const uint64_t k_log2 = sg.k_log2;
 	const bool noquad = c->knobs.scatter_noquad;
-	if (!noquad)
-		for (l = e_c; l < L && Ks[l] > 1 && l - e_c < 16; ++l) {
-			k_log2 |= (uint64_t)ilog2(Ks[l]) << (4 * (l - e_c));
-			k_min = std::min(k_min, Ks[l]);
-			l_plain = l + 1;
-		}
+	uint32_t l;
 	auto launch_a = [&](hipStream_t st) {
 		if (noquad) { if (L > e_c) hipLaunchKernelGGL(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, c->meta(), sa, e_c); }
 		else if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, c->meta(), sa, l_plain);
@@ -529,12 +523,23 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
 		launch_dw(sd);
 		HIP_TRY(hipEventRecord(c->ev_dw, sd));
-		launch_b(s);
-		HIP_TRY(hipEventRecord(c->ev_sc[0], s));
-		launch_a(s);
-		HIP_TRY(hipEventRecord(c->ev_sc[1], s));
-		launch_c(s); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
-		HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+		c->sc.dp = c->dp_order();
+		if (c->sc.dp) {
+			// Data parallel: C, B, then A, so that the parameters in front of A's levels (MLPs, C, B: one contiguous block) are
+			// final at ev_sc[0] + ev_dw and their exchange runs beside the scatter of A; A's levels + variance are the second block.
+			launch_c(s);
+			launch_b(s);
+			HIP_TRY(hipEventRecord(c->ev_sc[0], s));
+			launch_a(s);
+			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+		} else {
+			launch_b(s);
+			HIP_TRY(hipEventRecord(c->ev_sc[0], s));
+			launch_a(s);
+			HIP_TRY(hipEventRecord(c->ev_sc[1], s));
+			launch_c(s); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
+			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+		}
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
 		c->sc.split[0] = c->off_grid + (uint64_t)c->grid.offsets[noquad ? e_c : l_plain] * 2; // A = [split0, off_var)
 		c->sc.split[1] = c->off_grid + (uint64_t)c->grid.offsets[e_c] * 2;                      // B = [split1, split0), C = [off_grid, split1)
@@ -542,6 +547,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	c->prof.units[P_DW] += B;
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
+	HIP_TRY(hipEventRecord(c->ev_sc[2], s)); // every gradient is final (rnb_gradient_part_wait)
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -579,24 +585,83 @@ static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi) {
 int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
 	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
 	optimizer_begin(c);
-	adam_launch(c, st, c->sc.split[1], c->sc.split[0]);
+	if (c->sc.dp) adam_launch(c, st, 0, c->sc.split[0]);
+	else adam_launch(c, st, c->sc.split[1], c->sc.split[0]);
 	HIP_TRY(hipEventRecord(c->ev_adam, st));
 	c->opt.early_done = true;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
 
+// Which kernel scatters which level (see forward_backward).
+static void plan_scatter_groups(rnb_ctx* c) {
+	rnb_ctx::ScatterGroups& g = c->sg;
+	const uint32_t L = c->cfg.n_levels;
+	uint32_t l;
+	const uint32_t r4 = c->knobs.scatter_r4, r16 = c->knobs.scatter_r16;
+	for (l = 0; l < L; ++l) { if (c->grid.resolution[l] <= r16) g.e16 = l + 1; if (c->grid.resolution[l] <= std::max(r4, r16)) g.e4 = l + 1; }
+	{
+		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
+		for (l = 0; l < L; ++l) {
+			const float run = 590.f / (float)c->grid.resolution[l];
+			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
+			if (kenv && *kenv) { g.Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
+		}
+	}
+	if (!c->knobs.scatter_nolds) // the coarsest levels whose fp32 gradient tables fit in LDS together
+		for (l = 0; l < L; ++l) if (l == g.e_lds && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) g.e_lds = l + 1;
+	if (g.e16 < g.e_lds) g.e16 = g.e_lds;
+	if (g.e4 < g.e_lds) g.e4 = g.e_lds;
+	g.e_c = g.e4;
+	g.l_plain = g.e_c;
+	if (!c->knobs.scatter_noquad)
+		for (l = g.e_c; l < L && g.Ks[l] > 1 && l - g.e_c < 16; ++l) {
+			g.k_log2 |= (uint64_t)ilog2(g.Ks[l]) << (4 * (l - g.e_c));
+			g.l_plain = l + 1;
+		}
+	c->dp_split = c->off_grid + (uint64_t)c->grid.offsets[c->knobs.scatter_noquad ? g.e_c : g.l_plain] * 2;
+}
+
+// End of a step's parameter update: the LDS weight images of the next step's kernels, bookkeeping.
+static int optimizer_finish(rnb_ctx* c, hipStream_t s) {
+	c->opt.begun = false;
+	c->opt.early_done = false;
+	c->sc.valid = false;
+	hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+	c->wimg_valid = true;
+	c->prof.mark(s, P_ADAM);
+	c->prof.units[P_ADAM] += (double)c->n_params;
+	HIP_TRY(hipGetLastError());
+	c->grads_clean = true;
+	return RNB_OK;
+}
+
+// Blocks of the sharded data-parallel optimizer, in the order their gradients become final: each block is world_size equal
+// chunks (multiples of 4 parameters), chunk r belongs to rank r; the last block ends at param_capacity.
+static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_parts) {
+	const uint64_t W = std::max(1u, c->cfg.world_size), r = c->cfg.rank, q = 4 * W;
+	uint64_t m0 = 0;
+	uint32_t n = 0;
+	m0 = c->dp_split / q * q; // static: the ownership of a parameter must not move between steps
+	if (m0) { parts[n].lo = 0; parts[n].hi = m0; ++n; }
+	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
+	for (uint32_t k = 0; k < n; ++k) {
+		const uint64_t chunk = (parts[k].hi - parts[k].lo) / W;
+		parts[k].own_lo = parts[k].lo + r * chunk;
+		parts[k].own_hi = parts[k].own_lo + chunk;
+	}
+	*n_parts = n;
+}
+
 int optimizer_step(rnb_ctx* c, hipStream_t s) {
-	const rnb_config& cfg = c->cfg;
 	optimizer_begin(c);
 	c->prof.mark(s, P_NONE);
 	if (c->opt.early_done) {
 		// the caller has already stepped the early block (after exchanging it): the rest, then join
-		adam_launch(c, s, 0, c->sc.split[1]);
+		if (!c->sc.dp) adam_launch(c, s, 0, c->sc.split[1]);
 		adam_launch(c, s, c->sc.split[0], c->n_params);
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
-		c->sc.valid = false;
-	} else if (c->overlap() && cfg.world_size == 1 && c->sc.valid && !c->sc.exchanged) {
+	} else if (c->overlap() && !c->sc.dp && c->sc.valid && !c->sc.exchanged) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
 		// on the side stream, beside the scatter of the next group; only the coarse levels' (small) block is left for the end.
 		hipStream_t sa = c->s_adam;
@@ -608,18 +673,25 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
 		adam_launch(c, s, c->off_var, c->n_params);
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
-		c->sc.valid = false;
 	} else {
 		adam_launch(c, s, 0, c->n_params);
 	}
-	c->opt.begun = false;
-	c->opt.early_done = false;
-	hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
-	c->wimg_valid = true;
-	c->prof.mark(s, P_ADAM);
-	c->prof.units[P_ADAM] += (double)c->n_params;
+	return optimizer_finish(c, s);
+}
+
+// Sharded optimizer (data parallel): block `part` of shard_layout has been reduce-scattered by the caller; step this rank's
+// chunk and clear the rest of the block's accumulators (their sums live on the other ranks).
+int optimizer_step_shard(rnb_ctx* c, uint32_t part, hipStream_t st) {
+	rnb_shard_part parts[2];
+	uint32_t n = 0;
+	shard_layout(c, parts, &n);
+	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");
+	const rnb_shard_part& p = parts[part];
+	optimizer_begin(c);
+	if (p.own_lo > p.lo) HIP_TRY(hipMemsetAsync(c->grads.p + p.lo, 0, (p.own_lo - p.lo) * sizeof(float), st));
+	if (p.hi > p.own_hi) HIP_TRY(hipMemsetAsync(c->grads.p + p.own_hi, 0, (p.hi - p.own_hi) * sizeof(float), st));
+	adam_launch(c, st, std::min<uint64_t>(p.own_lo, c->n_params), std::min<uint64_t>(p.own_hi, c->n_params));
 	HIP_TRY(hipGetLastError());
-	c->grads_clean = true;
 	return RNB_OK;
 }
 
@@ -718,8 +790,16 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	do {                                                                                                               \
 		if ((buf).alloc(count) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
 	} while (0)
-	ALLOC(c->params_fp32, c->n_params); ALLOC(c->grads, c->n_params); ALLOC(c->adam_m, c->n_params); ALLOC(c->adam_v, c->n_params);
-	ALLOC(c->params_fp16, c->n_params); ALLOC(c->params_ema, c->n_params); ALLOC(c->adam_steps, c->n_params);
+	{ // parameter-shaped arrays, padded to a whole number of 4-parameter groups per data-parallel rank
+		const uint64_t q = 4ull * std::max(1u, cfg->world_size);
+		c->param_capacity = (c->n_params + q - 1) / q * q;
+	}
+#define ALLOC_P(buf)                                                                                                   \
+	do {                                                                                                               \
+		if ((buf).alloc_padded(c->n_params, c->param_capacity) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
+	} while (0)
+	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
+#undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
@@ -788,11 +868,13 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		rnb_ctx::Knobs& k = c->knobs;
 		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
+		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_R16")) k.scatter_r16 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_LDS_WG")) k.scatter_lds_wg = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_K")) k.scatter_k = e;
 	}
+	plan_scatter_groups(c);
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
@@ -1257,7 +1339,11 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
-	if (c->sc.valid && c->sc.split[1] < c->sc.split[0]) { // scatter order B, A, C: B's levels are final first (ev_sc[0])
+	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A: everything in front of A's levels is final first (ev_sc[0])
+		ranges[0][0] = 0;              ranges[0][1] = c->sc.split[0];
+		ranges[1][0] = c->sc.split[0]; ranges[1][1] = c->n_params;
+		*n_parts = 2;
+	} else if (c->sc.valid && c->sc.split[1] < c->sc.split[0]) { // scatter order B, A, C: B's levels are final first (ev_sc[0])
 		ranges[0][0] = c->sc.split[1]; ranges[0][1] = c->sc.split[0];
 		ranges[1][0] = 0;              ranges[1][1] = c->sc.split[1];
 		ranges[2][0] = c->sc.split[0]; ranges[2][1] = c->n_params;
@@ -1273,10 +1359,35 @@ int rnb_train_step_apply_early(rnb_ctx* c, void* stream) {
 	return optimizer_step_early(c, as_stream(stream));
 }
 
+int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity) {
+	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
+	c->sc.exchanged = true;
+	c->sc.sharded = true;
+	shard_layout(c, parts, n_parts);
+	*capacity = c->param_capacity;
+	return RNB_OK;
+}
+
+int rnb_train_step_apply_shard(rnb_ctx* c, uint32_t part, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	return optimizer_step_shard(c, part, as_stream(stream));
+}
+
+int rnb_train_step_apply_done(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	if (!c->opt.begun) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_done without rnb_train_step_apply_shard");
+	int rc = optimizer_finish(c, as_stream(stream));
+	if (rc != RNB_OK) return rc;
+	++c->training_step;
+	return RNB_OK;
+}
+
 int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	if (part == 0 && c->sc.valid) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_sc[0], 0));
-	// the other blocks are final when the stream given to rnb_train_step_begin is (it has joined the side streams)
+	// block 0 of the overlapped schedule has its own event; everything is final at the end of the backward pass
+	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
+	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : c->ev_sc[2], 0));
+	if (early && c->sc.dp) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // block 0 holds the MLPs' gradients (side stream)
 	return RNB_OK;
 }
 

@@ -4,8 +4,13 @@ The reference is single-GPU (no collective call sites). Sharding (DESIGN.md §mu
 parameter block, occupancy grid and dataset; rank r generates the global rays [r*R, (r+1)*R) of a step of W*R rays
 (same PCG32 stream positions and image assignment as a single process running W*R rays), compacts its own
 ``target_batch_size`` samples, and the ranks exchange
-  * ONE all-reduce (sum) of the fp32 gradient accumulators (10.56 M floats = 42 MB) before the optimizer, and
+  * the fp32 gradient accumulators (10.56 M floats = 42 MB) before the optimizer — by default as a SHARDED optimizer:
+    reduce-scatter of each gradient block, Adam + EMA on this rank's 1/W of the block, all-gather of the fp16 training
+    weights (7/8 * (42 + 21) MB on the wire per rank at W = 8 instead of 7/8 * 84 MB for an all-reduce, and 1/W of the
+    optimizer's HBM traffic); ``sharded=False`` / ``RNB_DP_SHARDED=0`` selects the plain all-reduce + replicated optimizer;
   * one 7-value all-reduce of the step counters / loss sums so all ranks draw the same rays_per_batch next step.
+With the sharded optimizer a rank's fp32 masters, EMA weights and Adam state are current only on its own chunks:
+``sync_parameters()`` all-gathers them (before snapshots / inference with EMA weights).
 The occupancy update is replicated: identical parameters + identical RNG => identical grids, no communication.
 """
 import os
@@ -27,6 +32,44 @@ def grads_tensor(ctx):
     return torch.as_tensor(_DeviceArray(ptr, nbytes // 4, "<f4"), device="cuda")
 
 
+# parameter-shaped buffers and the element type their exchange uses (uint32 counters travel as int32)
+_PARAM_BUFFERS = {"GRADS_FP32": "<f4", "PARAMS_FP16": "<f2", "PARAMS_FP32": "<f4", "PARAMS_EMA": "<f2", "ADAM_M": "<f4", "ADAM_V": "<f4", "ADAM_STEPS": "<i4"}
+
+
+class TorchShardCollectives:
+    """reduce-scatter / all-gather of a block of a parameter-shaped device buffer, in place, over torch.distributed (RCCL)."""
+
+    def __init__(self, ctx, capacity):
+        self.ctx = ctx
+        self.capacity = capacity
+        self._views = {}
+
+    def view(self, name):
+        import torch
+        v = self._views.get(name)
+        if v is None:
+            ptr, _ = self.ctx.buffer(name)  # allocated up to `capacity` elements (rnb_shard_layout)
+            v = self._views[name] = torch.as_tensor(_DeviceArray(ptr, self.capacity, _PARAM_BUFFERS[name]), device="cuda")
+        return v
+
+    def reduce_scatter(self, name, part):
+        import torch.distributed as dist
+        lo, hi, own_lo, own_hi = part
+        v = self.view(name)
+        dist.reduce_scatter_tensor(v[own_lo:own_hi], v[lo:hi], op=dist.ReduceOp.SUM)
+
+    def all_gather(self, name, part):
+        import torch.distributed as dist
+        lo, hi, own_lo, own_hi = part
+        v = self.view(name)
+        dist.all_gather_into_tensor(v[lo:hi], v[own_lo:own_hi])
+
+
+def _raw_stream(stream):
+    """HIP stream handle of a torch stream (None: the library's default stream handling)."""
+    return None if stream is None else getattr(stream, "cuda_stream", stream)
+
+
 class DataParallelTrainer:
     """Drives ``ctx`` (created with world_size/rank in its config) through begin -> all-reduce -> apply -> finish.
 
@@ -34,9 +77,16 @@ class DataParallelTrainer:
     sums a float64 numpy vector. The defaults use torch.distributed; the CPU tests inject gloo/numpy versions.
     """
 
-    def __init__(self, ctx, all_reduce_grads=None, all_reduce_small=None, stream=None):
+    def __init__(self, ctx, all_reduce_grads=None, all_reduce_small=None, stream=None, sharded=None, shard_collectives=None):
+        """``shard_collectives``: object with reduce_scatter(name, part) / all_gather(name, part) working in place on the
+        context's buffers (default: TorchShardCollectives); the CPU tests inject a gloo version over host buffers."""
         self.ctx = ctx
         self.stream = stream
+        if sharded is None:
+            sharded = all_reduce_grads is None and os.environ.get("RNB_DP_SHARDED", "1") != "0"
+        self.sharded = bool(sharded)
+        self._shard = shard_collectives
+        self._layout = None
         self._grads = None
         self._side = None
         self._vec = None
@@ -66,6 +116,57 @@ class DataParallelTrainer:
                 dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
+
+    def _shard_setup(self, ctx):
+        parts, capacity = ctx.shard_layout()
+        if self._layout is not None and self._layout != (parts, capacity):
+            raise RuntimeError("the shard layout changed between steps: a parameter's optimizer state would change ranks")
+        self._layout = (parts, capacity)
+        if self._shard is None:
+            self._shard = TorchShardCollectives(ctx, capacity)
+        return parts
+
+    def _sharded_apply(self, ctx):
+        """Per gradient block, in completion order: reduce-scatter -> Adam + EMA on the own chunk -> all-gather of the fp16
+        training weights. The first block (everything in front of the finest levels) goes through this on a side stream while
+        the finest levels are still being scattered."""
+        parts = self._shard_setup(ctx)
+        on_device = isinstance(self._shard, TorchShardCollectives)
+        early = None
+        if on_device and len(parts) > 1:
+            import torch
+            if self._early is None:
+                self._early = torch.cuda.Stream()
+            early = self._early
+            with torch.cuda.stream(early):
+                ctx.gradient_part_wait(0, early.cuda_stream)
+                self._shard.reduce_scatter("GRADS_FP32", parts[0])
+                ctx.train_step_apply_shard(0, early.cuda_stream)
+                self._shard.all_gather("PARAMS_FP16", parts[0])
+            rest = range(1, len(parts))
+        else:
+            rest = range(len(parts))
+        handle = _raw_stream(self.stream)
+        for k in rest:
+            if on_device:
+                ctx.gradient_part_wait(k, handle)
+            self._shard.reduce_scatter("GRADS_FP32", parts[k])
+            ctx.train_step_apply_shard(k, handle)
+            self._shard.all_gather("PARAMS_FP16", parts[k])
+        if early is not None:
+            import torch
+            (self.stream or torch.cuda.current_stream()).wait_stream(early)
+        ctx.train_step_apply_done(handle)
+
+    def sync_parameters(self, names=("PARAMS_FP32", "PARAMS_EMA", "ADAM_M", "ADAM_V", "ADAM_STEPS")):
+        """All-gather the per-rank chunks of the fp32 masters, EMA weights and Adam state (sharded optimizer only), so that
+        every rank holds them whole: before snapshots, mesh extraction / rendering with the EMA weights, or reading them."""
+        if not (self.sharded and self._collectives) or self._layout is None:
+            return
+        parts, _ = self._layout
+        for name in names:
+            for part in parts:
+                self._shard.all_gather(name, part)
 
     def _torch_reduce_step_vector(self, ctx):
         """All-reduce of the step's 7 counters / loss sums, in place on the library's device block (RNB_BUF_STEP_VECTOR): no
@@ -105,7 +206,10 @@ class DataParallelTrainer:
         try:
             stats = ctx.train_step_finish(counters, sums, allow_no_samples=allow_no_samples)
         finally:  # the optimizer runs even when the step produced no samples, as in the reference
-            if self._collectives:
-                self._reduce_grads(ctx)
-            ctx.train_step_apply(self.stream)
+            if self._collectives and self.sharded:
+                self._sharded_apply(ctx)
+            else:
+                if self._collectives:
+                    self._reduce_grads(ctx)
+                ctx.train_step_apply(self.stream)
         return stats

@@ -58,6 +58,128 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _GlooShardCollectives:
+    """reduce_scatter / all_gather of dp.DataParallelTrainer's sharded optimizer over gloo, in place on the checker's host
+    buffers (gloo has no reduce-scatter: all-reduce a copy and keep the own chunk, which is what a reduce-scatter leaves)."""
+
+    def __init__(self, ctx, capacity):
+        self.ctx, self.capacity = ctx, capacity
+
+    def view(self, name):
+        import ctypes as C
+        from rnb_neus2_amd import dp
+        dt = np.dtype(dp._PARAM_BUFFERS[name])
+        ptr, _ = self.ctx.buffer(name)
+        return np.frombuffer((C.c_char * (self.capacity * dt.itemsize)).from_address(ptr), dtype=dt)
+
+    def reduce_scatter(self, name, part):
+        import torch
+        import torch.distributed as dist
+        lo, hi, own_lo, own_hi = part
+        v = self.view(name)
+        t = torch.from_numpy(v[lo:hi].copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        v[own_lo:own_hi] = t.numpy()[own_lo - lo:own_hi - lo]
+
+    def all_gather(self, name, part):
+        import torch
+        import torch.distributed as dist
+        lo, hi, own_lo, own_hi = part
+        v = self.view(name)
+        mine = torch.from_numpy(v[own_lo:own_hi].copy().view(np.uint8))  # bytes: gloo has no 16-bit integer type
+        chunks = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(chunks, mine)
+        v[lo:hi] = torch.cat(chunks).numpy().view(v.dtype)
+
+
+def _worker_sharded(rank, world, port, q):
+    try:
+        _worker_sharded_body(rank, world, port, q)
+    except Exception:  # report instead of leaving the parent waiting for its queue
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+
+
+def _worker_sharded_body(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_lib
+    from rnb_neus2_amd import dp
+    views, nm, al = _scene()
+    ctxs = []
+    for _ in range(2):
+        c = oracle_lib.context(world_size=world, rank=rank, **KW)
+        c.init_params()
+        c.set_dataset(views, nm, al)
+        ctxs.append(c)
+    rep, sh = ctxs
+
+    def reduce_grads(ctx):
+        t = torch.from_numpy(ctx.get("GRADS_FP32"))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ctx.put("GRADS_FP32", t.numpy())
+
+    parts, capacity = sh.shard_layout()
+    tr_rep = dp.DataParallelTrainer(rep, all_reduce_grads=reduce_grads)
+    tr_sh = dp.DataParallelTrainer(sh, sharded=True, shard_collectives=_GlooShardCollectives(sh, capacity))
+    assert tr_sh.sharded and not tr_rep.sharded
+    out = {"rank": rank, "parts": parts, "capacity": capacity, "n_params": sh.n_params, "same_stats": True}
+    for i in range(3):
+        a, b = tr_rep.step().as_dict(), tr_sh.step().as_dict()
+        for k in a:
+            if k not in ("prep_ms", "step_ms") and a[k] != b[k]:
+                out["same_stats"] = False
+    # the training weights are whole on every rank after each step; masters / EMA / Adam state only on the own chunks
+    out["w16_equal"] = bool(np.array_equal(rep.get("PARAMS_FP16"), sh.get("PARAMS_FP16")))
+    own = np.zeros(sh.n_params, dtype=bool)
+    for lo, hi, own_lo, own_hi in parts:
+        own[own_lo:min(own_hi, sh.n_params)] = True
+    out["own_fraction"] = float(own.mean())
+    out["own_equal"] = {n: bool(np.array_equal(rep.get(n)[own], sh.get(n)[own])) for n in ("PARAMS_FP32", "PARAMS_EMA", "ADAM_M", "ADAM_V", "ADAM_STEPS")}
+    out["foreign_stale"] = bool(not np.array_equal(rep.get("ADAM_STEPS")[~own], sh.get("ADAM_STEPS")[~own]))
+    tr_sh.sync_parameters()
+    out["synced_equal"] = {n: bool(np.array_equal(rep.get(n), sh.get(n))) for n in ("PARAMS_FP32", "PARAMS_EMA", "ADAM_M", "ADAM_V", "ADAM_STEPS")}
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_sharded_optimizer_equals_replicated():
+    """Reduce-scatter -> Adam on the own chunks -> all-gather of the fp16 weights gives, on every rank, the training weights of
+    the all-reduce + replicated optimizer bit for bit; after sync_parameters() also the masters, EMA weights and Adam state."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=800) for _ in procs], key=lambda r: r["rank"])
+    for r in res:
+        assert "error" not in r, r["error"]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["same_stats"] and r["w16_equal"]
+        assert all(r["own_equal"].values()), r["own_equal"]
+        assert all(r["synced_equal"].values()), r["synced_equal"]
+        assert r["foreign_stale"]  # the other rank's chunks really were skipped here
+        assert 0.45 < r["own_fraction"] < 0.55
+        assert r["capacity"] >= r["n_params"] and r["capacity"] % 8 == 0
+    # the two ranks' chunks tile every block without overlap
+    for pa, pb in zip(res[0]["parts"], res[1]["parts"]):
+        assert pa[0] == pb[0] and pa[1] == pb[1]
+        assert pa[2] == pa[0] and pa[3] == pb[2] and pb[3] == pb[1] and (pa[3] - pa[2]) == (pb[3] - pb[2]) and (pa[3] - pa[2]) % 4 == 0
+    assert res[0]["parts"][0][0] == 0 and res[0]["parts"][-1][1] == res[0]["capacity"]
+    assert len(res[0]["parts"]) == 2 and res[0]["parts"][0][1] == res[0]["parts"][1][0]
+
+
 @pytest.mark.timeout(600)
 def test_two_rank_data_parallel_step():
     import torch.multiprocessing as mp

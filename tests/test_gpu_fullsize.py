@@ -138,7 +138,8 @@ def test_overlapped_schedule_matches_serial_order(scene, trained):
             assert getattr(a, f) == getattr(b, f), f
         assert a.loss == b.loss and a.ek_loss == b.ek_loss and a.mask_loss == b.mask_loss
         pa, pb = ser.get("PARAMS_FP32"), ovl.get("PARAMS_FP32")
-        assert np.allclose(pa, pb, rtol=0, atol=2e-5) and np.mean(pa != pb) < 0.2  # same update up to atomic summation order
+        d = np.abs(pa - pb)  # same update up to atomic summation order (a sum that rounds to +-tiny moves a parameter by lr either way)
+        assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5 and np.mean(pa != pb) < 0.2
         for _ in range(20):
             a, b = ser.train_step(), ovl.train_step()
         assert a.training_step == b.training_step
@@ -176,7 +177,8 @@ def test_data_parallel_hooks_single_rank(scene, trained):
         hooks.train_step_apply()
         assert np.array_equal(c0, c1) and st0.loss == st1.loss and st0.next_rays_per_batch == st1.next_rays_per_batch
         pa, pb = plain.get("PARAMS_FP32"), hooks.get("PARAMS_FP32")
-        assert np.allclose(pa, pb, rtol=0, atol=2e-5)
+        d = np.abs(pa - pb)  # same update up to the order of the fp32 atomics (a sum that rounds to +-tiny moves a parameter by lr either way)
+        assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5, (float(d.max()), int((d > 2e-5).sum()))
         assert np.array_equal(plain.get("ADAM_STEPS"), hooks.get("ADAM_STEPS"))
         assert plain.training_step == hooks.training_step
         for _ in range(3):  # and the sequence keeps working
@@ -190,6 +192,117 @@ def test_data_parallel_hooks_single_rank(scene, trained):
     finally:
         plain.close()
         hooks.close()
+
+
+def test_sharded_optimizer_two_emulated_ranks(scene, trained):
+    """Ranks 0 and 1 of a world of 2 as two contexts in one process, the collectives done by hand on the host: reduce-scatter
+    -> rnb_train_step_apply_shard -> all-gather of the fp16 weights gives exactly the weights of all-reduce + replicated
+    optimizer, each rank touches only its own chunks, and the accumulators are left clear."""
+    _, state = trained
+    mk = lambda r: _clone(scene, state, overlap=1, world_size=2, rank=r)  # noqa: E731
+    rep, sh = [mk(0), mk(1)], [mk(0), mk(1)]
+    try:
+        for group in (rep, sh):
+            for c in group:
+                c.train_step_begin()
+            loc = [c.train_step_local() for c in group]
+            assert loc[0][0][2] > 0 and loc[1][0][2] > 0 and not np.array_equal(loc[0][1], loc[1][1])  # both ranks marched, different rays
+            for c in group:
+                c.train_step_finish(loc[0][0] + loc[1][0], loc[0][1] + loc[1][1])
+        n = rep[0].n_params
+        assert rep[0].gradient_parts() == rep[1].gradient_parts() and len(rep[0].gradient_parts()) == 2  # data-parallel scatter order: two blocks
+        g = rep[0].get("GRADS_FP32") + rep[1].get("GRADS_FP32")  # the all-reduce
+        for c in rep:
+            c.put("GRADS_FP32", g)
+            c.train_step_apply()
+        w_rep = rep[0].get("PARAMS_FP16")
+        assert np.array_equal(w_rep, rep[1].get("PARAMS_FP16"))
+        before = {name: sh[0].get(name).copy() for name in ("PARAMS_FP32", "ADAM_STEPS")}
+        layouts = [c.shard_layout() for c in sh]
+        (p0, cap0), (p1, cap1) = layouts
+        assert cap0 == cap1 >= n and cap0 % 8 == 0 and len(p0) == len(p1) == 2
+        assert p0[0][0] == 0 and p0[0][1] == p0[1][0] and p0[1][1] == cap0
+        for a, b in zip(p0, p1):
+            assert a[:2] == b[:2] and a[2] == a[0] and a[3] == b[2] and b[3] == b[1] and (a[3] - a[2]) == (b[3] - b[2]) and (a[3] - a[2]) % 4 == 0
+        own = []
+        for c, (parts, _) in zip(sh, layouts):
+            c.put("GRADS_FP32", g)  # a reduce-scatter leaves the sum in the own chunk; whatever is elsewhere gets cleared
+            m = np.zeros(n, dtype=bool)
+            for k, (lo, hi, own_lo, own_hi) in enumerate(parts):
+                c.gradient_part_wait(k, 0)
+                c.train_step_apply_shard(k, 0)
+                m[own_lo:min(own_hi, n)] = True
+            own.append(m)
+        assert not (own[0] & own[1]).any() and (own[0] | own[1]).all()
+        w = [c.get("PARAMS_FP16") for c in sh]
+        full = np.where(own[0], w[0], w[1])  # the all-gather
+        assert np.array_equal(full, w_rep)
+        for r, c in enumerate(sh):
+            assert np.array_equal(c.get("PARAMS_FP32")[own[r]], rep[0].get("PARAMS_FP32")[own[r]])
+            assert np.array_equal(c.get("PARAMS_EMA")[own[r]], rep[0].get("PARAMS_EMA")[own[r]])
+            assert np.array_equal(c.get("ADAM_STEPS")[own[r]], rep[0].get("ADAM_STEPS")[own[r]])
+            assert not c.get("GRADS_FP32").any()
+        assert np.array_equal(sh[0].get("PARAMS_FP32")[own[1]], before["PARAMS_FP32"][own[1]])  # foreign chunks untouched
+        assert np.array_equal(sh[0].get("ADAM_STEPS")[own[1]], before["ADAM_STEPS"][own[1]])
+        for c in sh:
+            c.put("PARAMS_FP16", full)
+            c.train_step_apply_done(0)
+        assert sh[0].training_step == rep[0].training_step == state["step"] + 1
+        with pytest.raises(Exception):
+            sh[0].train_step_apply_done(0)  # no sharded update in progress
+        for group in (rep, sh):  # the next step starts from the same weights: same rays, same losses
+            for c in group:
+                c.train_step_begin()
+        la, lb = rep[0].train_step_local(), sh[0].train_step_local()
+        assert np.array_equal(la[0], lb[0]) and np.array_equal(la[1], lb[1])
+    finally:
+        for c in rep + sh:
+            c.close()
+
+
+def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch):
+    """dp.DataParallelTrainer through real RCCL calls (a world of 1, RNB_DP_FORCE_COLLECTIVES): the sharded optimizer and the
+    all-reduce path both reproduce the plain training step."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rnb_neus2_amd import dp
+    _, state = trained
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    monkeypatch.setenv("RNB_DP_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    plain = _clone(scene, state, overlap=1)
+    ctxs = [_clone(scene, state, overlap=1), _clone(scene, state, overlap=1)]  # created with the variable set: data-parallel scatter order
+    try:
+        trainers = [dp.DataParallelTrainer(ctxs[0], sharded=True), dp.DataParallelTrainer(ctxs[1], sharded=False)]
+        assert trainers[0].sharded and not trainers[1].sharded and all(t._collectives for t in trainers)
+        ref = plain.train_step()
+        got = [t.step() for t in trainers]
+        torch.cuda.synchronize()
+        for t in trainers:
+            t.sync_parameters()
+        torch.cuda.synchronize()
+        pa = plain.get("PARAMS_FP32")
+        for st, c in zip(got, ctxs):  # first step from a common state: identical statistics, same update up to the order of the atomics
+            assert st.training_step == ref.training_step and st.loss == ref.loss and st.next_rays_per_batch == ref.next_rays_per_batch
+            d = np.abs(pa - c.get("PARAMS_FP32"))
+            assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5, (float(d.max()), float(np.mean(d > 2e-5)))  # a gradient that rounds to +-tiny: one Adam step of lr either way
+            assert np.array_equal(plain.get("ADAM_STEPS"), c.get("ADAM_STEPS"))
+            assert not c.get("GRADS_FP32").any()
+        for _ in range(20):
+            ref = plain.train_step()
+            got = [t.step() for t in trainers]
+        for st in got:
+            assert st.training_step == ref.training_step
+            assert abs(st.loss - ref.loss) <= 0.25 * abs(ref.loss) and abs(st.rays_per_batch - ref.rays_per_batch) <= 0.02 * ref.rays_per_batch
+    finally:
+        dist.destroy_process_group()
+        plain.close()
+        for c in ctxs:
+            c.close()
 
 
 def test_sdf_only_training_kernel_matches_generic(scene, trained):
