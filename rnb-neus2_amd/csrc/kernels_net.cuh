@@ -304,6 +304,68 @@ __device__ __forceinline__ void copy_weight_image(half_t* __restrict__ dst, cons
 	for (int i = tid * 8; i < n_halfs; i += nthreads * 8) *reinterpret_cast<h8*>(dst + i) = *reinterpret_cast<const h8*>(src + i);
 }
 
+// K2 (+K3), register-chained flavour: the two SDF layers of k_forward_chained (same weight image, of which only W_S0 | W_S1
+// are copied), level constants in LDS, no derivative bookkeeping: 9 KB of LDS and few registers, so four workgroups share a CU
+// and the 112 gathers of one sample hide behind those of the others. Results are those of k_forward_chained's sdf channel.
+constexpr int PQ2_WAVE_HALFS = TILE * S32 + TILE;
+constexpr size_t LDS_POINT2 = (size_t)(W_S0T + WAVES_PER_WG * PQ2_WAVE_HALFS) * sizeof(half_t);
+
+__global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fill_level_meta(lm, G, threadIdx.x);
+	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
+	if (wimg) copy_weight_image(wts, wimg, W_S0T, threadIdx.x, WG);
+	else {
+		for (int i = threadIdx.x; i < 64 * 32; i += WG) { int o = i >> 5, k = i & 31; wts[W_S0 + o * S32 + k] = net.sdf_w0[i]; }
+		for (int i = threadIdx.x; i < 16 * 64; i += WG) { int o = i >> 6, q = i & 63; wts[W_S1 + o * S64 + q] = net.sdf_w1[o * 64 + chain_logical(q)]; }
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	half_t* X = wts + W_S0T + wave * PQ2_WAVE_HALFS;
+	half_t* Z = X + TILE * S32;
+	const half_t variance = net.variance[0];
+	const half_t bias = f2h(a.sdf_bias);
+	const uint32_t n_tiles = (a.n + TILE - 1) / TILE;
+	const int r16 = lane & 15, hq = lane >> 4;
+	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+		const uint32_t s = tile * TILE + lane;
+		const bool valid = s < a.n;
+		float x = 0.5f, y = 0.5f, z = 0.5f;
+		if (valid) { x = a.xyz[(size_t)s * 3 + 0]; y = a.xyz[(size_t)s * 3 + 1]; z = a.xyz[(size_t)s * 3 + 2]; }
+		uint32_t cell = 0;
+		if (valid && a.splat_idx) cell = a.splat_idx[s];
+		half_t feat[28];
+		float dummy[1][3];
+		encode_all_lm<false>(lm, n_levels, valid_level, net.grid, x, y, z, feat, dummy);
+		write_sdf_in_row(X, lane, x, y, z, feat);
+		wave_lds_sync();
+		h8 bz[4][2];
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer<4, 1>(wts + W_S0, S32, X, S32, acc, lane);
+			chain_pack<true>(acc, bz);
+		}
+		f4 acc_so[1][4];
+		zero_acc<1>(acc_so);
+		mfma_layer_regs<1, 2>(wts + W_S1, S64, bz, acc_so, lane);
+		if (hq == 0) { // D layout: row 0 (the sdf) of sample 16 nt + r16
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) Z[16 * nt + r16] = f2h(acc_so[0][nt][0]);
+		}
+		wave_lds_sync();
+		half_t v = Z[lane] + bias; // sdf_add_bias (common_operation.cuh:299-309)
+		if (a.want_density) v = sdf_to_density(v, variance);
+		if (valid) {
+			if (a.out) a.out[s] = v;
+			if (a.splat_idx) atomicMax(reinterpret_cast<uint32_t*>(a.grid_tmp) + cell, __float_as_uint(h2f(v))); // testbed_nerf.cu:634
+		}
+		wave_lds_sync(); // X, Z are rewritten by the next tile
+	}
+}
+
 constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
 constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
 

@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ 
 	if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t n, float* __restrict__ mean_out) {
-	if (threadIdx.x == 0 && blockIdx.x == 0) {
-		double s = 0.0;
-		for (uint32_t i = 0; i < n; ++i) s += partial[i];
-		*mean_out = (float)s;
-	}
+	// one wavefront: strided partial sums, then a shuffle tree (a fixed order; fp64, so the float result does not depend on it)
+	double s = 0.0;
+	for (uint32_t i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	if (threadIdx.x == 0) *mean_out = (float)s;
 }
 // grid_to_bitfield (testbed_nerf.cu:693-717)
 __global__ void k_grid_to_bitfield(const uint32_t n_elements, const uint32_t n_nonzero_elements, const float* __restrict__ grid, uint8_t* __restrict__ bitfield, const float* __restrict__ mean_density_ptr) {

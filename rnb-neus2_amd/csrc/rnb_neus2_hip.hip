@@ -272,7 +272,11 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-	hipLaunchKernelGGL(k_point_query, dim3(grid), dim3(WG), LDS_POINT, s, c->meta(), c->net(inference), a);
+	if (c->knobs.forward_v1) hipLaunchKernelGGL(k_point_query, dim3(grid), dim3(WG), LDS_POINT, s, c->meta(), c->net(inference), a);
+	else {
+		const uint32_t grid2 = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
+		hipLaunchKernelGGL(k_point_query_chained, dim3(grid2), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	}
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }

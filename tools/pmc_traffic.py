@@ -7,7 +7,7 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
 F = json.load(open(d + "/FETCH_SIZE.json"))["kernels"]
 W = json.load(open(d + "/WRITE_SIZE.json"))["kernels"]
 fb = [k for k in F if k.startswith("k_fwd_bwd")]
-steps = sum(F[k]["launches"] for k in fb)
+steps = sum(F[k]["launches"] for k in fb)  # one k_fwd_bwd* launch per step
 groups = {"k_forward": ["k_forward_chained"], "k_fwd_bwd": fb, "k_grid_scatter": ["k_grid_scatter_quad_rl", "k_grid_scatter_quad", "k_grid_scatter_lds"],
           "k_adam_ema": ["k_adam_ema"], "k_dw*7+k_dw_finish": [k for k in F if "k_dw" in k], "k_loss_pass1": ["k_loss_pass1"],
           "k_loss_pass2+k_rollover": ["k_loss_pass2"], "k_march_count": ["k_march_count_wide"], "k_march_write": ["k_march_write"]}
