@@ -133,9 +133,21 @@ def main():
                         traffic = json.load(f)["per_step"][kname]["total_bytes"] / max(dom["launches"] / max(args.profile_steps, 1), 1.0)
                 except Exception:
                     pass
+                limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py)
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_pmc_units.json")) as f:
+                        units = json.load(f)
+                    if kname == "k_grid_scatter":
+                        parts = [units["kernels"][k] for k in ("k_grid_scatter_quad", "k_grid_scatter_quad_rl", "k_grid_scatter_lds")]
+                        req = sum(p.get("l2_atomic_requests", 0) for p in parts)
+                        limiter = {"unit": "L2 atomic requests", "per_launch": req, "achieved_per_s": round(req / (avg_ms * 1e-3)),
+                                   "probe_rate_per_s": units["_atomic_probe_requests_per_s"],
+                                   "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3)}
+                except Exception:
+                    pass
                 roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                            "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit}
+                            "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit, "limiter": limiter}
         kernels = {p["kernel"]: {"ms_per_step": round(p["total_ms"] / max(args.profile_steps, 1), 4), "launches": p["launches"]} for p in prof if p["launches"]}
         result = {
             "metric": "training rays/s + ms/step, normals-only SDF 64x800^2",
