@@ -1063,7 +1063,7 @@ __global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counte
 }
 
 // loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
-__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts) {
+__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out) {
 	__shared__ double sh[3][1024];
 	const uint32_t n = min(counters[2], n_max);
 	double s0 = 0, s1 = 0, s2 = 0;
@@ -1080,6 +1080,11 @@ __global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, co
 	// the same numbers as one double[7] {counters, sums}: what data-parallel ranks all-reduce (RNB_BUF_STEP_VECTOR)
 	if (threadIdx.x < 4) out[8 + threadIdx.x] = (double)counters[threadIdx.x];
 	if (threadIdx.x == 0) { out[12] = sh[0][0]; out[13] = sh[1][0]; out[14] = sh[2][0]; }
+	if (host_out) { // the same 48 bytes into host memory (visible to the host once the kernel's completion event has fired)
+		if (threadIdx.x == 0) { host_out[0] = sh[0][0]; host_out[1] = sh[1][0]; host_out[2] = sh[2][0]; }
+		if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(host_out + 3)[threadIdx.x] = counters[threadIdx.x];
+		if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(host_out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
+	}
 }
 
 } // namespace rnb

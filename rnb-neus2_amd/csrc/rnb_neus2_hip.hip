@@ -4,6 +4,8 @@
 #include "kernels_net.cuh"
 #include "kernels_ray.cuh"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -49,6 +51,11 @@ struct DevBuf {
 };
 
 uint32_t next_multiple_u32(uint32_t v, uint32_t m) { return ((v + m - 1) / m) * m; }
+
+// Kernel launch whose completion IS the event `ev` (null: plain launch). hipEventRecord puts a marker packet of its own
+// into the queue, which costs the stream ~6 us between two kernels (measured); binding the event to the kernel's own
+// completion signal costs nothing, and the step's critical stream records 4-5 events.
+#define LAUNCH_EV(kernel, grid, block, lds, stream, ev, ...) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev, 0, __VA_ARGS__)
 
 uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid.h:1430-1437
 	if (training_step <= 0) return cfg.n_levels;
@@ -164,15 +171,17 @@ struct rnb_ctx {
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false; uint64_t split[2] = {0, 0}; } sc;
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false; uint64_t split[2] = {0, 0}; } sc;
 	// level groups of the gradient scatter (forward_backward), fixed at creation
 	struct ScatterGroups { uint32_t e_lds = 0, e16 = 0, e4 = 0, e_c = 0, l_plain = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
+	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
 	uint64_t dp_split = 0; // first parameter of the plain-quad levels: boundary of the two data-parallel gradient blocks
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
-	struct { bool valid = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
-	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned; same layout as the device block k_reduce_losses fills
+	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
+	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills
+	void* host_rb_dev = nullptr;
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
 
 	NetW net(bool inference) const {
@@ -365,7 +374,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	return a;
 }
 
-int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
+int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr) {
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
@@ -374,7 +383,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
-	hipLaunchKernelGGL(k_march_write, dim3((n_rays + 3) / 4), dim3(256), 0, s, a);
+	LAUNCH_EV(k_march_write, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -392,7 +401,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.views = c->views.p; a.counters = c->counters.p; a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p;
 	a.coords = c->coords.p; a.mlp_out = c->mlp_out.p; a.ray_loss = c->ray_loss.p; a.ncomp = c->ncomp.p; a.cbase = c->cbase.p;
 	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss; a.mask_loss = c->mask_loss;
-	HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill
+	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
+	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
 	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
@@ -420,22 +430,24 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const uint32_t B = c->cfg.target_batch_size;
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
-	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false;
+	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	a.wimg = c->wimg_valid ? c->wimg_fbs.p : nullptr;
 	c->prof.mark(s, P_NONE);
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
-	if (sdf_only) hipLaunchKernelGGL(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, c->meta(), c->net(false), a);
-	else hipLaunchKernelGGL(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, c->meta(), c->net(false), a);
+	const bool side_streams = c->overlap() && !c->knobs.scatter_split;
+	hipEvent_t ev_fb = side_streams ? c->ev_fb : nullptr; // the weight-gradient GEMMs start on the side stream when this kernel is done
+	if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
 	const TrainScratch& T = c->ts;
 	const uint32_t L = c->cfg.n_levels;
 
 	// ---- weight-gradient GEMMs (MFMA / streaming)
-	auto launch_dw = [&](hipStream_t sd) {
+	auto launch_dw = [&](hipStream_t sd, hipEvent_t done) {
 		const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
 		const size_t slab = (size_t)nwg; // one partial per workgroup
 		float* p = c->dw_partial.p;
@@ -461,7 +473,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 		f.var_partial = c->var_partial.p; f.n_var_partials = fb_grid * WAVES_PER_WG;
 		f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
-		hipLaunchKernelGGL(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, f);
+		LAUNCH_EV(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, done, f);
 	};
 
 	// ---- hash-grid gradient scatter, in three groups of levels (the addends commute up to fp32 rounding, as with any atomic order):
@@ -476,18 +488,20 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const uint64_t k_log2 = sg.k_log2;
 	const bool noquad = c->knobs.scatter_noquad;
 	uint32_t l;
-	auto launch_a = [&](hipStream_t st) {
-		if (noquad) { if (L > e_c) hipLaunchKernelGGL(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, c->meta(), sa, e_c); }
-		else if (L > l_plain) hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, c->meta(), sa, l_plain);
+	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
+	auto launch_a = [&](hipStream_t st, hipEvent_t done) {
+		if (noquad) { if (L > e_c) { LAUNCH_EV(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, done, c->meta(), sa, e_c); return; } }
+		else if (L > l_plain) { LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, done, c->meta(), sa, l_plain); return; }
+		if (done) (void)hipEventRecord(done, st);
 	};
-	auto launch_b = [&](hipStream_t st) { // one launch for all these levels, each with the workgroups its run length needs
-		if (l_plain <= e_c) return;
+	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
+		if (l_plain <= e_c) { if (done) (void)hipEventRecord(done, st); return; }
 		ScatterRlPlan plan;
 		plan.n = l_plain - e_c; plan.k_log2 = k_log2;
 		uint32_t wg = 0;
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + Ks[e_c + q] - 1) / Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
-		hipLaunchKernelGGL(k_grid_scatter_quad_rl, dim3(wg), dim3(256), 0, st, c->meta(), sa, e_c, plan);
+		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(wg), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st) {
 		if (e_lds) {
@@ -502,7 +516,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	};
 
 	if (c->knobs.scatter_split) { // profiling aid: serial, one launch per level
-		launch_dw(s);
+		launch_dw(s, nullptr);
 		c->prof.mark(s, P_DW);
 		for (l = 0; l < L; ++l) {
 			if (l < e16) hipLaunchKernelGGL(k_grid_scatter<16>, dim3(((B + 15) / 16 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
@@ -515,32 +529,27 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 			else hipLaunchKernelGGL(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, 1), dim3(256), 0, s, c->meta(), sa, l);
 		}
 	} else if (!c->overlap()) {
-		launch_dw(s);
+		launch_dw(s, nullptr);
 		c->prof.mark(s, P_DW);
-		launch_c(s); launch_b(s); launch_a(s);
+		launch_c(s); launch_b(s, nullptr); launch_a(s, nullptr);
 	} else {
 		// The caller's stream carries the scatter (B, A, then C), the side stream the GEMMs. After B and A an event lets the
 		// optimizer step that group's levels while the rest is still being scattered (optimizer_step); what is left after C is
 		// the MLPs' and the two coarsest levels' parameters.
 		hipStream_t sd = c->s_dw;
-		HIP_TRY(hipEventRecord(c->ev_fb, s));
 		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
-		launch_dw(sd);
-		HIP_TRY(hipEventRecord(c->ev_dw, sd));
+		launch_dw(sd, c->ev_dw);
 		c->sc.dp = c->dp_order();
 		if (c->sc.dp) {
 			// Data parallel: C, B, then A, so that the parameters in front of A's levels (MLPs, C, B: one contiguous block) are
 			// final at ev_sc[0] + ev_dw and their exchange runs beside the scatter of A; A's levels + variance are the second block.
 			launch_c(s);
-			launch_b(s);
-			HIP_TRY(hipEventRecord(c->ev_sc[0], s));
-			launch_a(s);
+			launch_b(s, c->ev_sc[0]);
+			launch_a(s, nullptr);
 			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
 		} else {
-			launch_b(s);
-			HIP_TRY(hipEventRecord(c->ev_sc[0], s));
-			launch_a(s);
-			HIP_TRY(hipEventRecord(c->ev_sc[1], s));
+			launch_b(s, c->ev_sc[0]);
+			launch_a(s, c->ev_sc[1]);
 			launch_c(s); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
 			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
 		}
@@ -551,7 +560,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	c->prof.units[P_DW] += B;
 	c->prof.mark(s, P_SCATTER);
 	c->prof.units[P_SCATTER] += B;
-	HIP_TRY(hipEventRecord(c->ev_sc[2], s)); // every gradient is final (rnb_gradient_part_wait)
+	c->backward_stream = s; // rnb_gradient_part_wait records "every gradient is final" there if a caller asks
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -577,21 +586,20 @@ static void optimizer_begin(rnb_ctx* c) {
 	c->opt.early_done = false;
 }
 
-static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi) {
-	if (hi <= lo) return;
+static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi, hipEvent_t done = nullptr) {
+	if (hi <= lo) { if (done) (void)hipEventRecord(done, st); return; }
 	AdamArgs a = c->opt.args;
 	a.begin = lo; a.end = hi;
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
-	hipLaunchKernelGGL(k_adam_ema, dim3(blocks), dim3(256), 0, st, a);
+	LAUNCH_EV(k_adam_ema, dim3(blocks), dim3(256), 0, st, done, a);
 }
 
 // Optimizer on the early gradient block only (rnb_gradient_parts block 0), on the caller's stream.
 int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
 	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
 	optimizer_begin(c);
-	if (c->sc.dp) adam_launch(c, st, 0, c->sc.split[0]);
-	else adam_launch(c, st, c->sc.split[1], c->sc.split[0]);
-	HIP_TRY(hipEventRecord(c->ev_adam, st));
+	if (c->sc.dp) adam_launch(c, st, 0, c->sc.split[0], c->ev_adam);
+	else adam_launch(c, st, c->sc.split[1], c->sc.split[0], c->ev_adam);
 	c->opt.early_done = true;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -672,8 +680,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
 		adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
-		adam_launch(c, sa, c->sc.split[0], c->off_var);      // group A's levels
-		HIP_TRY(hipEventRecord(c->ev_adam, sa));
+		adam_launch(c, sa, c->sc.split[0], c->off_var, c->ev_adam); // group A's levels
 		adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
 		adam_launch(c, s, c->off_var, c->n_params);
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
@@ -882,8 +889,13 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
-	for (hipEvent_t* e : {&c->ev_loss, &c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2]}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocDefault));
+	// ev_loss publishes the step's counters to the HOST (system-scope release). The others only order kernels on this device:
+	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them (RNB_EVENT_SYSTEM_FENCE=1 restores it).
+	HIP_TRY(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
+	const unsigned dev_flags = hipEventDisableTiming | (getenv("RNB_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
+	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
+	HIP_TRY(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	*out = c;
 	return RNB_OK;
 }
@@ -1125,6 +1137,7 @@ static void discard_premarch(rnb_ctx* c) {
 	(void)hipStreamSynchronize(c->s_march);
 	c->n_rays_total = c->pre.n_rays_total;
 	c->pre.valid = false;
+	c->pre.loss_cleared = false;
 }
 
 static uint32_t next_max_inference(rnb_ctx* c) { // testbed_nerf.cu:3891-3896
@@ -1191,7 +1204,9 @@ static int step_back(rnb_ctx* c, hipStream_t s) {
 
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	c->prof.mark(s, P_NONE);
-	hipLaunchKernelGGL(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p);
+	// the 48-byte readback goes straight into the pinned host block (no copy kernel, no marker packet); ev_loss is the kernel's completion
+	LAUNCH_EV(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
+	          reinterpret_cast<double*>(c->host_rb_dev));
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1204,9 +1219,10 @@ static int launch_premarch(rnb_ctx* c) {
 	const uint32_t n_rays = c->rays_per_batch, max_inference = next_max_inference(c), n_rays_total = c->n_rays_total;
 	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
 	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), c->s_march));
-	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference);
+	HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), c->s_march)); // the next loss pass's per-ray rows (k_reduce_losses has read this step's): off the critical stream
+	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
-	HIP_TRY(hipEventRecord(c->ev_march, c->s_march));
+	c->pre.loss_cleared = true;
 	c->n_rays_total += n_rays * c->cfg.world_size;
 	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference;
 	return RNB_OK;
@@ -1223,8 +1239,6 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	// step's march) does not have to wait for the backward pass
 	rc = launch_reduce_losses(c, s);
 	if (rc != RNB_OK) return rc;
-	HIP_TRY(hipMemcpyAsync(c->host_rb, c->loss_sums.p, sizeof(*c->host_rb), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipEventRecord(c->ev_loss, s));
 	return step_back(c, s);
 }
 
@@ -1390,6 +1404,10 @@ int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	// block 0 of the overlapped schedule has its own event; everything is final at the end of the backward pass
 	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
+	if (!early && !c->sc.all_final_recorded) { // only data-parallel callers pay for this marker
+		HIP_TRY(hipEventRecord(c->ev_sc[2], c->backward_stream));
+		c->sc.all_final_recorded = true;
+	}
 	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : c->ev_sc[2], 0));
 	if (early && c->sc.dp) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // block 0 holds the MLPs' gradients (side stream)
 	return RNB_OK;

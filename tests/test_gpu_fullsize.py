@@ -143,7 +143,7 @@ def test_overlapped_schedule_matches_serial_order(scene, trained):
         for _ in range(20):
             a, b = ser.train_step(), ovl.train_step()
         assert a.training_step == b.training_step
-        assert abs(a.rays_per_batch - b.rays_per_batch) <= 0.02 * a.rays_per_batch
+        assert abs(a.rays_per_batch - b.rays_per_batch) <= max(256, 0.02 * a.rays_per_batch)  # the controller rounds to multiples of 128
         assert abs(a.loss - b.loss) <= 0.25 * max(a.loss, b.loss)
     finally:
         ser.close()
@@ -297,7 +297,7 @@ def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch
             got = [t.step() for t in trainers]
         for st in got:
             assert st.training_step == ref.training_step
-            assert abs(st.loss - ref.loss) <= 0.25 * abs(ref.loss) and abs(st.rays_per_batch - ref.rays_per_batch) <= 0.02 * ref.rays_per_batch
+            assert abs(st.loss - ref.loss) <= 0.25 * abs(ref.loss) and abs(st.rays_per_batch - ref.rays_per_batch) <= max(256, 0.02 * ref.rays_per_batch)  # the controller rounds to multiples of 128
     finally:
         dist.destroy_process_group()
         plain.close()
