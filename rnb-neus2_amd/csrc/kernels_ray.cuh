@@ -1048,6 +1048,14 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)
+// Start of a step's ray generation: the four step counters and the first n entries of the three per-ray loss rows (all that
+// k_reduce_losses reads) in one small launch instead of two fills.
+__global__ void k_clear_step(uint32_t* __restrict__ counters, float* __restrict__ loss, const uint32_t row_stride, const uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < 4) counters[i] = 0u;
+	if (i < n) { loss[i] = 0.f; loss[(size_t)row_stride + i] = 0.f; loss[(size_t)row_stride * 2 + i] = 0.f; }
+}
+
 __global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords) {
 	const uint32_t n_in = counters[1];
 	if (n_in == 0 || n_in >= B) return;

@@ -141,6 +141,7 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
+		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
 		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
@@ -170,8 +171,8 @@ struct rnb_ctx {
 	// generation + march — which depends on the occupancy bitfield and the RNG, not on the weights — runs beside this step's
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
-	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_sc[3] = {nullptr, nullptr, nullptr};
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false; uint64_t split[2] = {0, 0}; } sc;
+	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; } sc;
 	// level groups of the gradient scatter (forward_backward), fixed at creation
 	struct ScatterGroups { uint32_t e_lds = 0, e16 = 0, e4 = 0, e_c = 0, l_plain = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
@@ -426,11 +427,11 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	return RNB_OK;
 }
 
-int forward_backward(rnb_ctx* c, hipStream_t s) {
+int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const uint32_t B = c->cfg.target_batch_size;
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
-	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false;
+	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	a.wimg = c->wimg_valid ? c->wimg_fbs.p : nullptr;
@@ -489,10 +490,13 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 	const bool noquad = c->knobs.scatter_noquad;
 	uint32_t l;
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
-	auto launch_a = [&](hipStream_t st, hipEvent_t done) {
-		if (noquad) { if (L > e_c) { LAUNCH_EV(k_grid_scatter<1>, dim3((B + 255) / 256, L - e_c), dim3(256), 0, st, done, c->meta(), sa, e_c); return; } }
-		else if (L > l_plain) { LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_plain), dim3(256), 0, st, done, c->meta(), sa, l_plain); return; }
-		if (done) (void)hipEventRecord(done, st);
+	const uint32_t a_first = noquad ? e_c : l_plain;
+	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0 = 0xffffffffu, uint32_t l1 = 0xffffffffu) { // levels [l0, l1) of the group (default: all)
+		if (l0 == 0xffffffffu) { l0 = a_first; l1 = L; }
+		if (l1 > l0) {
+			if (noquad) LAUNCH_EV(k_grid_scatter<1>, dim3((B + 255) / 256, l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0);
+			else LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0);
+		} else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
 		if (l_plain <= e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -547,11 +551,17 @@ int forward_backward(rnb_ctx* c, hipStream_t s) {
 			launch_b(s, c->ev_sc[0]);
 			launch_a(s, nullptr);
 			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+			c->sc.dw_joined = true;
 		} else {
+			// group A in two halves: the optimizer chunk that trails the second half is then short enough to finish beside C
+			const uint32_t a_mid = a_first + (L - a_first + 1) / 2;
 			launch_b(s, c->ev_sc[0]);
-			launch_a(s, c->ev_sc[1]);
+			launch_a(s, c->ev_sc[1], a_first, a_mid);
+			launch_a(s, c->ev_sc[3], a_mid, L);
+			c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
 			launch_c(s); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
-			HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // join
+			if (join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
+			c->sc.dw_joined = join_dw; // the training step leaves the join to the optimizer, which continues on the side stream (optimizer_step)
 		}
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
 		c->sc.split[0] = c->off_grid + (uint64_t)c->grid.offsets[noquad ? e_c : l_plain] * 2; // A = [split0, off_var)
@@ -635,11 +645,11 @@ static void plan_scatter_groups(rnb_ctx* c) {
 }
 
 // End of a step's parameter update: the LDS weight images of the next step's kernels, bookkeeping.
-static int optimizer_finish(rnb_ctx* c, hipStream_t s) {
+static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false) {
 	c->opt.begun = false;
 	c->opt.early_done = false;
 	c->sc.valid = false;
-	hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
 	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
@@ -668,6 +678,11 @@ static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_
 int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	optimizer_begin(c);
 	c->prof.mark(s, P_NONE);
+	if (!c->sc.dw_joined && (c->opt.early_done || c->sc.exchanged || !c->overlap() || c->sc.dp || !c->sc.valid)) {
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // the paths below step the MLPs on `s`
+		c->sc.dw_joined = true;
+	}
+	bool images_done = false;
 	if (c->opt.early_done) {
 		// the caller has already stepped the early block (after exchanging it): the rest, then join
 		if (!c->sc.dp) adam_launch(c, s, 0, c->sc.split[1]);
@@ -680,14 +695,29 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
 		adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
-		adam_launch(c, sa, c->sc.split[0], c->off_var, c->ev_adam); // group A's levels
-		adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
-		adam_launch(c, s, c->off_var, c->n_params);
+		adam_launch(c, sa, c->sc.split[0], c->sc.split_mid);        // group A's levels, first half beside the second half's scatter
+		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[3], 0));
+		adam_launch(c, sa, c->sc.split_mid, c->off_var, c->ev_adam);
+		if (c->sc.dw_joined) {
+			adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
+			adam_launch(c, s, c->off_var, c->n_params);
+		} else {
+			// behind the dW GEMMs on their stream: the MLPs' and the variance's parameters, then the LDS weight images of the next
+			// step's kernels, all long before the scatter ends; the caller's stream is left with group C's 32 k parameters
+			hipStream_t sd = c->s_dw;
+			adam_launch(c, sd, 0, c->off_grid);
+			adam_launch(c, sd, c->off_var, c->n_params);
+			LAUNCH_EV(k_prepare_weight_images, dim3(2), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+			images_done = true;
+			adam_launch(c, s, c->off_grid, c->sc.split[1]);
+			HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
+			c->sc.dw_joined = true;
+		}
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
 	} else {
 		adam_launch(c, s, 0, c->n_params);
 	}
-	return optimizer_finish(c, s);
+	return optimizer_finish(c, s, images_done);
 }
 
 // Sharded optimizer (data parallel): block `part` of shard_layout has been reduce-scattered by the caller; step this rank's
@@ -699,6 +729,7 @@ int optimizer_step_shard(rnb_ctx* c, uint32_t part, hipStream_t st) {
 	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");
 	const rnb_shard_part& p = parts[part];
 	optimizer_begin(c);
+	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(st, c->ev_dw, 0)); // any block may hold MLP parameters
 	if (p.own_lo > p.lo) HIP_TRY(hipMemsetAsync(c->grads.p + p.lo, 0, (p.own_lo - p.lo) * sizeof(float), st));
 	if (p.hi > p.own_hi) HIP_TRY(hipMemsetAsync(c->grads.p + p.own_hi, 0, (p.hi - p.own_hi) * sizeof(float), st));
 	adam_launch(c, st, std::min<uint64_t>(p.own_lo, c->n_params), std::min<uint64_t>(p.own_hi, c->n_params));
@@ -761,7 +792,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2]}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	delete c;
 	return RNB_OK;
@@ -880,6 +911,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
+		k.tail_on_main = getenv("RNB_TAIL_ON_MAIN") != nullptr;
 		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_R16")) k.scatter_r16 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_LDS_WG")) k.scatter_lds_wg = (uint32_t)atoi(e);
@@ -893,7 +925,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them (RNB_EVENT_SYSTEM_FENCE=1 restores it).
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (getenv("RNB_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	*out = c;
@@ -1196,7 +1228,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
-	int rc = forward_backward(c, s);
+	int rc = forward_backward(c, s, c->knobs.tail_on_main);
 	if (rc != RNB_OK) return rc;
 	c->rng.advance(); // testbed_nerf.cu:4118
 	return RNB_OK;
@@ -1218,8 +1250,8 @@ static int launch_premarch(rnb_ctx* c) {
 	if (!c->overlap() || c->pre.valid || prep_due(c->cur_step + 1)) return RNB_OK; // cur_step + 1: _finish may run before _apply
 	const uint32_t n_rays = c->rays_per_batch, max_inference = next_max_inference(c), n_rays_total = c->n_rays_total;
 	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
-	HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), c->s_march));
-	HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), c->s_march)); // the next loss pass's per-ray rows (k_reduce_losses has read this step's): off the critical stream
+	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's): off the critical stream
+	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;
@@ -1404,6 +1436,7 @@ int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	// block 0 of the overlapped schedule has its own event; everything is final at the end of the backward pass
 	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
+	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // the weight-gradient GEMMs' side stream has not been joined
 	if (!early && !c->sc.all_final_recorded) { // only data-parallel callers pay for this marker
 		HIP_TRY(hipEventRecord(c->ev_sc[2], c->backward_stream));
 		c->sc.all_final_recorded = true;
