@@ -39,6 +39,8 @@ _PARAM_BUFFERS = {"GRADS_FP32": "<f4", "PARAMS_FP16": "<f2", "PARAMS_FP32": "<f4
 class TorchShardCollectives:
     """reduce-scatter / all-gather of a block of a parameter-shaped device buffer, in place, over torch.distributed (RCCL)."""
 
+    on_device = True  # stream-ordered device work: the trainer may put block 0 on a side stream behind rnb_gradient_part_wait
+
     def __init__(self, ctx, capacity):
         self.ctx = ctx
         self.capacity = capacity
@@ -131,7 +133,7 @@ class DataParallelTrainer:
         training weights. The first block (everything in front of the finest levels) goes through this on a side stream while
         the finest levels are still being scattered."""
         parts = self._shard_setup(ctx)
-        on_device = isinstance(self._shard, TorchShardCollectives)
+        on_device = bool(getattr(self._shard, "on_device", False))
         early = None
         if on_device and len(parts) > 1:
             import torch
