@@ -300,6 +300,43 @@ def test_error_behaviour():
         c.close()
 
 
+def test_step_without_samples_reports_the_reference_error():
+    """An occupancy grid without a single occupied cell: every ray marches zero samples and the step fails the way the
+    reference does ("Nerf training generated 0 samples.", src/testbed_nerf.cu:3540); the library stays usable, keeps its
+    ray count, and trains again once the grid is back."""
+    import rnb_neus2_amd as rnb
+    gpu, cpu = _pair()
+    try:
+        grid = cpu.get("DENSITY_GRID").copy()
+        for c in (gpu, cpu):
+            c.set_training_step(1000)  # 1000 % 16 != 0: no occupancy update at the start of this step
+            c.put("DENSITY_GRID", np.full_like(grid, -1.0))
+            c.update_density_bitfield()
+        assert not gpu.get("DENSITY_BITFIELD").any()
+        msgs = []
+        for c in (gpu, cpu):
+            rays = c.rays_per_batch
+            with pytest.raises(rnb.RnbError) as e:
+                c.train_step()
+            msgs.append(str(e.value))
+            assert c.rays_per_batch == rays
+        assert "generated 0 samples" in msgs[0] and msgs[0] == msgs[1]
+        assert gpu.training_step == cpu.training_step
+        for c in (gpu, cpu):  # callers that tolerate it get the statistics of an empty step
+            st = c.train_step(allow_no_samples=True)
+            assert st.measured_batch_size == 0 and st.loss == 0.0
+        for c in (gpu, cpu):
+            c.set_training_step(1000)
+            c.put("DENSITY_GRID", np.ones_like(grid))
+            c.update_density_bitfield()
+        a, b = gpu.train_step(), cpu.train_step()
+        assert a.measured_batch_size_before_compaction == b.measured_batch_size_before_compaction > 0 and a.n_rays_kept == b.n_rays_kept
+        assert abs(a.loss - b.loss) <= 2e-3 * abs(b.loss)
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_only_sdf_training_freezes_colour_mlp():
     """--fractional-training's optimizer switch (adam.h only_sdf_training; src/testbed.cu:1886-1895): with it on, the
     colour MLP's master weights do not move, everything else trains; oracle and HIP agree on which entries moved."""
