@@ -192,7 +192,8 @@ def _stage_samples(gpu, cpu, n_rays=512, step=0):
     return written
 
 
-@pytest.mark.parametrize("flags", [dict(), dict(apply_no_albedo=0), dict(apply_no_albedo=0, apply_light_opti=1, apply_L2=0), dict(apply_bce=1, apply_relu=1, mask_loss_weight=0.3)])
+@pytest.mark.parametrize("flags", [dict(), dict(apply_no_albedo=0), dict(apply_no_albedo=0, apply_light_opti=1, apply_L2=0), dict(apply_bce=1, apply_relu=1, mask_loss_weight=0.3),
+                                   dict(apply_supernormal=1), dict(apply_no_albedo=0, apply_supernormal=1, apply_rgbplus=0), dict(apply_no_albedo=0, apply_rgbplus=0, apply_L2=0, snap_to_pixel_centers=0)])
 def test_compute_loss(flags):
     gpu, cpu = _pair(**flags)
     try:
@@ -298,6 +299,44 @@ def test_error_behaviour():
             c.generate_training_samples(0)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("aabb_scale", [2, 8])
+def test_multi_cascade_scene(aabb_scale):
+    """aabb_scale > 1 (transform.json `aabb_scale`): several occupancy cascades, cone-angle stepping (dt grows with t, mip chosen
+    from dt), larger box. Index / RNG / march work stays bit exact against the oracle; a training step tracks it."""
+    gpu, cpu = _pair(aabb_scale=aabb_scale)
+    try:
+        for c in (gpu, cpu):
+            c.set_training_step(0)
+            c.update_density_grid()
+        assert np.array_equal(gpu.get("GRID_SAMPLE_IDX"), cpu.get("GRID_SAMPLE_IDX"))
+        assert np.array_equal(gpu.get("GRID_SAMPLE_POS").view(np.uint32), cpu.get("GRID_SAMPLE_POS").view(np.uint32))
+        assert gpu.get("DENSITY_GRID").size == cpu.get("DENSITY_GRID").size == 128 ** 3 * (int(np.log2(aabb_scale)) + 1)
+        _half_close(gpu.get("DENSITY_GRID"), cpu.get("DENSITY_GRID"), rel=4e-3, abs_=1e-3, name="density grid")
+        gpu.put("DENSITY_GRID", cpu.get("DENSITY_GRID"))
+        gpu.update_density_bitfield()
+        assert gpu.get("DENSITY_MEAN")[0] == cpu.get("DENSITY_MEAN")[0]
+        assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
+        for n_rays, n_rays_total in ((512, 0), (1500, 4096)):
+            for c in (gpu, cpu):
+                c.generate_training_samples(n_rays, n_rays_total)
+            cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+            assert np.array_equal(cg[[0, 2, 3]], cc[[0, 2, 3]]), (cg, cc)
+            kept, written = int(cc[2]), int(cc[3])
+            assert kept > 0 and written > 0
+            assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+            co_g, co_c = gpu.get("COORDS", written * 7).reshape(-1, 7), cpu.get("COORDS", written * 7).reshape(-1, 7)
+            assert np.array_equal(co_g.view(np.uint32), co_c.view(np.uint32))
+            assert np.unique(co_c[:, 3]).size > 1  # dt varies along the rays: the cone stepping is live
+        sg = sc = None
+        for _ in range(3):
+            sg, sc = gpu.train_step(), cpu.train_step()
+        assert sg.rays_per_batch == sc.rays_per_batch and sg.measured_batch_size_before_compaction == sc.measured_batch_size_before_compaction
+        assert abs(sg.loss - sc.loss) <= 2e-3 * abs(sc.loss) + 1e-6
+    finally:
+        gpu.close()
+        cpu.close()
 
 
 def test_step_without_samples_reports_the_reference_error():
