@@ -549,7 +549,8 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
-	load_weights<true>(wts, net, threadIdx.x, WG);
+	if (a.wimg) copy_weight_image(wts, a.wimg, W_TRAIN_END, threadIdx.x, WG);
+	else load_weights<true>(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	half_t* tA = wts + W_TRAIN_END + wave * 3 * ACT_TILE_HALFS;
@@ -843,10 +844,11 @@ __device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net,
 	// (row padding of the images is never read)
 }
 
-// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf. Both from the training weights.
-__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs) {
+// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf; 2: image of k_fwd_bwd. All from the training weights.
+__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train) {
 	if (blockIdx.x == 0) load_weights_chained(img_fwd, net, threadIdx.x, WG);
-	else load_weights_fbs(img_fbs, net, threadIdx.x, WG);
+	else if (blockIdx.x == 1) load_weights_fbs(img_fbs, net, threadIdx.x, WG);
+	else load_weights<true>(img_train, net, threadIdx.x, WG);
 }
 
 // dst[idx] with a wave-uniform base and a 32-bit element index (scalar base + vector byte offset addressing)

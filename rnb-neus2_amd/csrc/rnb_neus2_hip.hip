@@ -133,7 +133,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
-	DevBuf<half_t> wimg_fwd, wimg_fbs; // LDS weight images of the training weights, rebuilt after every optimizer step
+	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train; // LDS weight images of the training weights, rebuilt after every optimizer step
 	bool wimg_valid = false;
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
@@ -434,7 +434,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
-	a.wimg = c->wimg_valid ? c->wimg_fbs.p : nullptr;
+	a.wimg = !c->wimg_valid ? nullptr : (c->cfg.apply_no_albedo && !c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	c->prof.mark(s, P_NONE);
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
@@ -649,7 +649,7 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 	c->opt.begun = false;
 	c->opt.early_done = false;
 	c->sc.valid = false;
-	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(2), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(3), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p);
 	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
@@ -707,7 +707,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
-			LAUNCH_EV(k_prepare_weight_images, dim3(2), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p);
+			LAUNCH_EV(k_prepare_weight_images, dim3(3), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p);
 			images_done = true;
 			adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
@@ -786,7 +786,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->wimg_fwd.free(); c->wimg_fbs.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
+	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -850,7 +850,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
-	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED);
+	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED); ALLOC(c->wimg_train, W_TRAIN_END);
 	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
