@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Command-line entry of the reconstruction pipeline (same options as the reference's run_pipeline.py:27-92):
+"""Reconstruction pipeline from the command line. The option set is the reference's (run_pipeline.py:27-92), so existing
+invocations keep working:
 
     python run_pipeline.py --input data/scene/ --testbed build/testbed --output out/scene
     python run_pipeline.py --input normals.sfm --testbed build/testbed --albedo-sfm albedos.sfm --mask-sfm masks.sfm --has-albedo
@@ -10,47 +11,66 @@ import numpy as np
 
 from rnb_neus2_amd.pipeline import run_full_pipeline
 
-OPTIONS = [
-    (("--input", "-i"), dict(required=True, help="Input data: directory (cameras.npz), .npz, .sfm, or .json")),
-    (("--testbed", "-t"), dict(required=True, help="Path to the testbed binary")),
-    (("--output", "-o"), dict(default="output", help="Output directory (default: output)")),
-    (("--max-steps",), dict(type=int, default=10000, help="Max training steps (default: 10000)")),
-    (("--mesh-resolution",), dict(type=int, default=1024, help="Marching cubes resolution (default: 1024)")),
-    (("--scaling-mode",), dict(default="auto", choices=["auto", "pcd", "silhouettes", "silhouettes_v2", "cameras", "none"], help="Scene normalization mode (default: auto)")),
-    (("--sphere-scale",), dict(type=float, default=1.0, help="Target sphere radius (default: 1.0)")),
-    (("--margin-px",), dict(type=int, default=20, help="Pixel margin for silhouettes_v2 (default: 20)")),
-    (("--warmup-ratio",), dict(type=float, default=0.1, help="Phase 1 ratio for albedo mode (default: 0.1)")),
-    (("--mask-weight",), dict(type=float, default=1.0, help="Mask loss weight (default: 1.0)")),
-    (("--has-albedo",), dict(action="store_true", help="Enable two-phase training with albedo scaling")),
-    (("--albedo-sfm",), dict(default="", help="Path to albedo SfMData (SfM mode)")),
-    (("--mask-sfm",), dict(default="", help="Path to mask SfMData (SfM mode)")),
-    (("--mask-folder",), dict(default="", help="Folder with mask images")),
-    (("--supernormal",), dict(action="store_true", help="Enable SuperNormal mode")),
-    (("--l1",), dict(action="store_true", help="Use L1 norm for color loss")),
-    (("--no-rgbplus",), dict(action="store_true", help="Disable RGB+ normalization")),
-    (("--n-samples",), dict(type=int, default=2000, help="Samples for albedo scaling (default: 2000)")),
-    (("--seed",), dict(type=int, default=0, help="Random seed (default: 0)")),
-]
+SCALING_MODES = ("auto", "pcd", "silhouettes", "silhouettes_v2", "cameras", "none")
+
+# one line per option:  flags | kind | default | what it does        (kind: str / int / float / flag / mode; default "!" = required)
+_SPEC = """
+--input -i          | str   | !      | where the scene comes from: a folder holding cameras.npz, an .npz, an .sfm or a .json file
+--testbed -t        | str   | !      | the training executable (build/testbed)
+--output -o         | str   | output | folder that receives the prepared scene, snapshots and meshes
+--max-steps         | int   | 10000  | number of training iterations over both stages
+--mesh-resolution   | int   | 1024   | lattice size of the final marching-cubes extraction
+--scaling-mode      | mode  | auto   | how the scene is brought into the unit sphere
+--sphere-scale      | float | 1.0    | radius the normalised scene should fill
+--margin-px         | int   | 20     | silhouettes_v2 only: slack around the masks, in pixels
+--warmup-ratio      | float | 0.1    | --has-albedo only: share of the iterations spent before the albedos are rescaled
+--mask-weight       | float | 1.0    | weight of the silhouette term of the loss
+--has-albedo        | flag  |        | train in two phases and rescale the albedo maps in between
+--albedo-sfm        | str   |        | SfMData file listing the albedo maps (SfM input)
+--mask-sfm          | str   |        | SfMData file listing the masks (SfM input)
+--mask-folder       | str   |        | directory of mask images
+--supernormal       | flag  |        | SuperNormal variant of the shading loss
+--l1                | flag  |        | L1 instead of L2 colour loss
+--no-rgbplus        | flag  |        | switch the RGB+ channel off
+--n-samples         | int   | 2000   | pixels per view used to estimate the albedo gains
+--seed              | int   | 0      | seed of numpy's generator
+"""
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="RNb-NeuS2 on MI355X: neural surface reconstruction pipeline")
-    for names, kw in OPTIONS:
-        parser.add_argument(*names, **kw)
+    parser = argparse.ArgumentParser(description="RNb-NeuS2 pipeline on the MI355X training path")
+    casts = {"int": int, "float": float}
+    for line in _SPEC.strip().splitlines():
+        flags, kind, default, text = (field.strip() for field in line.split("|"))
+        kw = {"help": text}
+        if kind == "flag":
+            kw["action"] = "store_true"
+        else:
+            if kind in casts:
+                kw["type"] = casts[kind]
+            if kind == "mode":
+                kw["choices"] = list(SCALING_MODES)
+            if default == "!":
+                kw["required"] = True
+            else:
+                kw["default"] = casts.get(kind, str)(default) if default else ""
+        parser.add_argument(*flags.split(), **kw)
     return parser
 
 
-def pipeline_kwargs(args):
-    return dict(input_path=args.input, testbed_path=args.testbed, output_dir=args.output, max_steps=args.max_steps, mesh_resolution=args.mesh_resolution,
-                scaling_mode=args.scaling_mode, sphere_scale=args.sphere_scale, margin_px=args.margin_px, warmup_ratio=args.warmup_ratio,
-                mask_weight=args.mask_weight, super_normal=args.supernormal, use_l1=args.l1, use_rgb_plus=not args.no_rgbplus, has_albedo=args.has_albedo,
-                albedo_sfm_path=args.albedo_sfm, mask_sfm_path=args.mask_sfm, mask_folder_path=args.mask_folder, n_samples=args.n_samples)
+def pipeline_kwargs(ns):
+    """argparse namespace -> keywords of rnb_neus2_amd.pipeline.run_full_pipeline."""
+    renamed = {"input": "input_path", "testbed": "testbed_path", "output": "output_dir", "supernormal": "super_normal", "l1": "use_l1",
+               "albedo_sfm": "albedo_sfm_path", "mask_sfm": "mask_sfm_path", "mask_folder": "mask_folder_path"}
+    kw = {renamed.get(k, k): v for k, v in vars(ns).items() if k not in ("seed", "no_rgbplus")}
+    kw["use_rgb_plus"] = not ns.no_rgbplus
+    return kw
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
-    np.random.seed(args.seed)
-    return run_full_pipeline(**pipeline_kwargs(args))
+    ns = build_parser().parse_args(argv)
+    np.random.seed(ns.seed)
+    return run_full_pipeline(**pipeline_kwargs(ns))
 
 
 if __name__ == "__main__":
