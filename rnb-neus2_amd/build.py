@@ -10,7 +10,14 @@ DEPS = [os.path.join(PKG_DIR, "csrc", f) for f in ("rnb_neus2_hip.hip", "common.
     os.path.join(os.path.dirname(PKG_DIR), "include", "rnb_neus2.h")]
 
 # -ffp-contract=off: the index/ray arithmetic must match the CPU checker bit for bit (no FMA contraction).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
+# -packed-fp32-ops (device target feature): no v_pk_{mul,add,fma}_f32. Measured on MI355X / ROCm 7.2 with tools/march_determinism.py: the
+# march of the NEXT step runs on a side stream beside this step's backward pass, and with packed fp32 instructions in it a few
+# rays of wavefront lanes 48-63 came out with a wrong direction (one component of R * d_cam, which the compiler had put on the
+# packed pipe) in 0.8-3 % of the launches -- never on an idle GPU, and never (0 of 1100 launches) in the combination
+# "no packed fp32 + the march starts once k_fwd_bwd is done" (rnb_neus2_hip.hip, launch_premarch). The x86 half of the
+# compilation does not know the feature and says so on stderr; build() drops those lines.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def hipcc():
@@ -33,7 +40,13 @@ def build(force=False, verbose=False):
     cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    noise = "is not a recognized feature for this target"
+    rest = "\n".join(line for line in res.stderr.splitlines() if noise not in line)
+    if rest:
+        print(rest)
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
     return OUT
 
 

@@ -142,6 +142,7 @@ struct rnb_ctx {
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
+		bool march_early = false;
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
 		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
@@ -911,6 +912,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
+		k.march_early = getenv("RNB_MARCH_EARLY") != nullptr;
 		k.tail_on_main = getenv("RNB_TAIL_ON_MAIN") != nullptr;
 		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_R16")) k.scatter_r16 = (uint32_t)atoi(e);
@@ -1249,7 +1251,12 @@ static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 static int launch_premarch(rnb_ctx* c) {
 	if (!c->overlap() || c->pre.valid || prep_due(c->cur_step + 1)) return RNB_OK; // cur_step + 1: _finish may run before _apply
 	const uint32_t n_rays = c->rays_per_batch, max_inference = next_max_inference(c), n_rays_total = c->n_rays_total;
-	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
+	// The march starts when k_fwd_bwd is done, not right after the loss pass (RNB_MARCH_EARLY=1: 2 % faster). Measured with
+	// tools/march_determinism.py: beside k_fwd_bwd the march came out with a wrong direction for a few rays (wavefront lanes 48-63 only) in
+	// 2-3 % of the launches, 26-54 % beside the generic kernel of the albedo mode, i.e. with a sample set that the same launch on
+	// an idle GPU does not produce; beside the scatter, the GEMMs and the optimizer, and compiled without packed fp32
+	// instructions (rnb-neus2_amd/build.py), 0 of 1100 launches. Neither half alone is enough (3 % / 1 % remain).
+	HIP_TRY(hipStreamWaitEvent(c->s_march, (c->knobs.march_early || c->knobs.scatter_split) ? c->ev_loss : c->ev_fb, 0));
 	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's): off the critical stream
 	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);

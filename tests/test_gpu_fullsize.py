@@ -292,12 +292,15 @@ def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch
             assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5, (float(d.max()), float(np.mean(d > 2e-5)))  # a gradient that rounds to +-tiny: one Adam step of lr either way
             assert np.array_equal(plain.get("ADAM_STEPS"), c.get("ADAM_STEPS"))
             assert not c.get("GRADS_FP32").any()
+        history = []
         for _ in range(20):
             ref = plain.train_step()
             got = [t.step() for t in trainers]
+            history.append((ref.loss, got[0].loss, got[1].loss, ref.rays_per_batch, got[0].rays_per_batch, got[1].rays_per_batch))
         for st in got:
             assert st.training_step == ref.training_step
-            assert abs(st.loss - ref.loss) <= 0.25 * abs(ref.loss) and abs(st.rays_per_batch - ref.rays_per_batch) <= max(256, 0.02 * ref.rays_per_batch)  # the controller rounds to multiples of 128
+            assert abs(st.loss - ref.loss) <= 0.05 * abs(ref.loss), history  # measured spread between the variants: 0.3 %
+            assert abs(st.rays_per_batch - ref.rays_per_batch) <= max(256, 0.02 * ref.rays_per_batch), history  # the controller rounds to multiples of 128
     finally:
         dist.destroy_process_group()
         plain.close()
@@ -324,14 +327,17 @@ def test_sdf_only_training_kernel_matches_generic(scene, trained):
         assert np.all(g0[lay["rgb"]:lay["grid"]] == 0) and np.all(g1[lay["rgb"]:lay["grid"]] == 0)  # colour MLP: exact zeros
         grid0, grid1 = g0[lay["grid"]:lay["variance"]], g1[lay["grid"]:lay["variance"]]
         gs = np.abs(grid0).max()
-        assert np.count_nonzero(grid0) > 0.1 * grid0.size and np.array_equal(grid0 != 0, grid1 != 0)
+        mism = np.nonzero((grid0 != 0) != (grid1 != 0))[0]
+        # an entry whose addends cancel ends up exactly zero or a rounding residue, depending on the order of the atomics
+        assert np.count_nonzero(grid0) > 0.1 * grid0.size and (mism.size == 0 or max(np.abs(grid0[mism]).max(), np.abs(grid1[mism]).max()) <= 1e-6 * gs), mism.size
         assert np.max(np.abs(grid0 - grid1)) <= 1e-4 * gs  # same addends, fp32 atomic order differs
         assert abs(g0[lay["variance"]] - g1[lay["variance"]]) <= 1e-5 * abs(g0[lay["variance"]]) + 1e-12
         for c in (gen, spe):
             cnt, sums = c.train_step_local()
             c.train_step_finish(cnt, sums)
             c.train_step_apply()
-        assert np.allclose(gen.get("PARAMS_FP32"), spe.get("PARAMS_FP32"), rtol=0, atol=2e-5)
+        d = np.abs(gen.get("PARAMS_FP32") - spe.get("PARAMS_FP32"))  # a gradient that is zero here and a rounding residue there moves a parameter by lr
+        assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5
     finally:
         gen.close()
         spe.close()
