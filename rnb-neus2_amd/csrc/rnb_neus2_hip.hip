@@ -1256,9 +1256,11 @@ static int launch_premarch(rnb_ctx* c) {
 	// 2-3 % of the launches, 26-54 % beside the generic kernel of the albedo mode, i.e. with a sample set that the same launch on
 	// an idle GPU does not produce; beside the scatter, the GEMMs and the optimizer, and compiled without packed fp32
 	// instructions (rnb-neus2_amd/build.py), 0 of 1100 launches. Neither half alone is enough (3 % / 1 % remain).
-	HIP_TRY(hipStreamWaitEvent(c->s_march, (c->knobs.march_early || c->knobs.scatter_split) ? c->ev_loss : c->ev_fb, 0));
-	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's): off the critical stream
+	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
+	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's):
+	// off the critical stream, and (integer stores only) already beside k_fwd_bwd
 	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
+	if (!(c->knobs.march_early || c->knobs.scatter_split)) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;
