@@ -289,9 +289,12 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 // round of dependent bitfield loads instead of 16), exchange the outcomes with ballots, and every lane replays the
 // reference's sequential visit order over those outcomes with integer bit operations: occupied -> sample, next
 // position; empty -> jump to the first position at or beyond the voxel exit. Visited set and t values are identical.
-constexpr int MG = 16; // lanes per ray
-
+// MG = lanes per ray (16 or 32): more lanes = fewer dependent rounds per ray, more redundant t-chain work per round.
+template <int MG>
 __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
+	static_assert(MG == 8 || MG == 16 || MG == 32, "lanes per ray");
+	constexpr int NB = MG == 8 ? 3 : MG == 16 ? 4 : 5;          // ballots that carry the index of the next visited position
+	constexpr uint64_t GM = (1ull << MG) - 1ull;  // a group's lanes inside a 64-bit ballot
 	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
 	const int lane = threadIdx.x & 63;
 	const int g = lane & (MG - 1);
@@ -370,12 +373,13 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 			}
 		}
 		const unsigned long long occ_w = __ballot(occ), in_w = __ballot(inside);
-		const uint32_t nm1 = nxt - 1u; // 0..15
-		const unsigned long long p0 = __ballot(nm1 & 1u), p1 = __ballot(nm1 & 2u), p2 = __ballot(nm1 & 4u), p3 = __ballot(nm1 & 8u);
-		const uint32_t occ16 = (uint32_t)(occ_w >> gb) & 0xffffu, in16 = (uint32_t)(in_w >> gb) & 0xffffu;
-		const uint32_t q0 = (uint32_t)(p0 >> gb) & 0xffffu, q1 = (uint32_t)(p1 >> gb) & 0xffffu, q2 = (uint32_t)(p2 >> gb) & 0xffffu, q3 = (uint32_t)(p3 >> gb) & 0xffffu;
+		const uint32_t nm1 = nxt - 1u; // 0 .. MG-1
+		uint64_t qn[NB];
+#pragma unroll
+		for (int k = 0; k < NB; ++k) qn[k] = ((uint64_t)__ballot(nm1 & (1u << k)) >> gb) & GM;
+		const uint64_t occ16 = ((uint64_t)occ_w >> gb) & GM, in16 = ((uint64_t)in_w >> gb) & GM;
 		// replay of the sequential visit order over this round's outcomes
-		uint32_t vis = 0;
+		uint64_t vis = 0;
 		const uint32_t j0 = j;
 		int pend_src = -1;
 		if (!term) {
@@ -387,18 +391,20 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 				if (cur < MG) have_pending = false;
 			}
 			while (cur < MG) {
-				if (!((in16 >> cur) & 1u)) { term = true; break; } // left the box (testbed_nerf.cu:1337)
-				if ((occ16 >> cur) & 1u) {
-					const uint32_t run_mask = (occ16 & in16) >> cur;
-					int run = __builtin_ctz(~run_mask);
+				if (!((in16 >> cur) & 1ull)) { term = true; break; } // left the box (testbed_nerf.cu:1337)
+				if ((occ16 >> cur) & 1ull) {
+					const uint64_t run_mask = (occ16 & in16) >> cur;
+					int run = __builtin_ctzll(~run_mask); // bits above the group are zero in run_mask: the complement always has a set bit
 					run = min(run, MG - cur);
 					const int allowed = min(run, (int)(RNB_MAX_STEPS - j));
-					vis |= ((1u << allowed) - 1u) << cur;
+					vis |= ((1ull << allowed) - 1ull) << cur;
 					j += (uint32_t)allowed;
 					cur += allowed;
 					if (j >= RNB_MAX_STEPS) { term = true; break; }
 				} else {
-					const int nx = 1 + (int)(((q0 >> cur) & 1u) | (((q1 >> cur) & 1u) << 1) | (((q2 >> cur) & 1u) << 2) | (((q3 >> cur) & 1u) << 3));
+					int nx = 1;
+#pragma unroll
+					for (int k = 0; k < NB; ++k) nx += (int)((qn[k] >> cur) & 1ull) << k;
 					if (nx >= MG) { have_pending = true; pend_src = cur; }
 					cur = nx;
 				}
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 		// the empty lane that jumped beyond the round hands its voxel-exit target to the whole group
 		const float tgt = __shfl(t_target, gb + (pend_src < 0 ? 0 : pend_src), 64);
 		if (pend_src >= 0) pending_target = tgt;
-		if ((vis >> g) & 1u) tt[j0 + __popc(vis & ((1u << g) - 1u))] = my_t;
+		if ((vis >> g) & 1ull) tt[j0 + __popcll(vis & ((1ull << g) - 1ull))] = my_t;
 		t_cur = T[MG];
 	}
 	if (ray_exists && g == 0) {
