@@ -444,13 +444,20 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
                                                     const uint32_t k1, uint32_t* __restrict__ base1, uint32_t* __restrict__ fwd_counts) {
 	__shared__ uint32_t wsum[4][16];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	constexpr uint32_t E = 4; // consecutive rays per thread: 4096 per tile, so the cross-lane scans are paid once per 4 rays
+	constexpr uint32_t E = 4; // consecutive rays per thread (one 16-byte load): 4096 per tile; 16 per thread measured slower (strided lanes)
 	uint32_t carry[4] = {0, 0, 0, 0}; // steps, kept rays, kept samples, first-round samples
+	// the next tile's counts are requested before this tile's scans: late in training the batch is ~100 k rays = 23 tiles, and one
+	// workgroup cannot hide a global load behind anything else
+	uint32_t st_next[E];
+#pragma unroll
+	for (uint32_t e = 0; e < E; ++e) st_next[e] = tid * E + e < n ? steps[tid * E + e] : 0u;
 	for (uint32_t t0 = 0; t0 < n; t0 += 1024 * E) {
 		const uint32_t i0 = t0 + tid * E;
 		uint32_t st[E];
 #pragma unroll
-		for (uint32_t e = 0; e < E; ++e) st[e] = i0 + e < n ? steps[i0 + e] : 0u;
+		for (uint32_t e = 0; e < E; ++e) st[e] = st_next[e];
+#pragma unroll
+		for (uint32_t e = 0; e < E; ++e) st_next[e] = i0 + 1024 * E + e < n ? steps[i0 + 1024 * E + e] : 0u;
 		// pass A: sample offsets
 		uint32_t mine = 0;
 #pragma unroll
@@ -672,9 +679,12 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 
 // Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
 // t values recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
+// LR lanes per ray: 64 while rays are few and long (early training: ~30 marched samples per ray), 16 once the batch has grown
+// to ~100 k rays with ~8 samples each (a wavefront per ray would leave 7 of 8 lanes idle).
+template <int LR>
 __global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
-	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t i = blockIdx.x * (256 / LR) + threadIdx.x / LR;
+	const uint32_t lane = threadIdx.x & (LR - 1);
 	if (i >= a.n_rays) return;
 	const uint32_t s = a.slot[i];
 	if (s == 0xffffffffu) return;
@@ -706,12 +716,12 @@ __global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
 	}
 	if (a.k1) {
 		const uint32_t b1 = a.base1[i];
-		for (uint32_t j = lane; j < min(steps, a.k1); j += 64) a.idx1[b1 + j] = base + j;
+		for (uint32_t j = lane; j < min(steps, a.k1); j += LR) a.idx1[b1 + j] = base + j;
 	}
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
 	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
 	float* co = a.coords + (size_t)base * 7;
-	for (uint32_t j = lane; j < steps; j += 64) {
+	for (uint32_t j = lane; j < steps; j += LR) {
 		const float t = tt[j];
 		const Vec3 pos = o + t * dir;
 		const float dt = calc_dt(t, a.A.cone_angle);

@@ -143,6 +143,7 @@ struct rnb_ctx {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
 		bool march_early = false;
+		uint32_t march_narrow_from = 32768; // rays per step from which the counting march runs one thread per ray (RNB_MARCH_NARROW_FROM)
 		uint32_t march_mg = 16; // lanes per ray of the counting march (RNB_MARCH_MG=8|16|32; measured alone: 0.19 / 0.22 / 0.32 ms)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;
@@ -381,14 +382,18 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
-	if (c->knobs.march_narrow) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
+	// One thread per ray once there are enough rays to fill the chip that way (late in training the converged occupancy grid
+	// lets the controller raise the batch from 15 k to 100 k rays): 0.23 ms at 94 k rays against 0.77 ms for the 16-lanes-per-ray
+	// kernel, which in turn wins below ~30 k rays (0.20 vs 0.30 ms at 14 k), where a ray per thread leaves the GPU to latency.
+	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
 	else if (c->knobs.march_mg == 16) hipLaunchKernelGGL(k_march_count_wide<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 	else if (c->knobs.march_mg == 8) hipLaunchKernelGGL(k_march_count_wide<8>, dim3((n_rays + 31) / 32), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_march_count_wide<32>, dim3((n_rays + 7) / 8), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_COUNT);
 	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
-	LAUNCH_EV(k_march_write, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
+	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, done, a);
+	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -916,6 +921,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_early = getenv("RNB_MARCH_EARLY") != nullptr;
+		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_MARCH_MG")) k.march_mg = atoi(e) == 16 ? 16u : atoi(e) == 8 ? 8u : 32u;
 		k.tail_on_main = getenv("RNB_TAIL_ON_MAIN") != nullptr;
 		if (const char* e = getenv("RNB_SCATTER_R4")) k.scatter_r4 = (uint32_t)atoi(e);
