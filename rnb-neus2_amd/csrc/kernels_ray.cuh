@@ -506,6 +506,112 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 	if (tid == 0) { counters[0] = carry[0]; counters[2] = carry[1]; counters[3] = carry[2]; fwd_counts[0] = carry[3]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
 }
 
+// The same scans with one workgroup per 4096-ray tile, for batches of tens of thousands of rays (one workgroup walks 23 tiles at
+// 94 k rays: 0.13 ms of a chain that the next kernels wait for): (1) tile sums of the sample counts, (2) offsets + which rays
+// keep their samples + tile sums of the three dependent counts, (3) slots. Integer work: bit-identical to k_scan_rays.
+constexpr uint32_t SCAN_TILE = 4096;
+// exclusive prefix of `mine` over the 1024 threads of the workgroup; `total` = sum over the workgroup
+__device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total) {
+	const uint32_t inc = wave_inclusive_scan(mine, lane);
+	if (lane == 63) wsum[wave] = inc;
+	__syncthreads();
+	uint32_t pre = 0, tot = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; pre += w < wave ? x : 0u; tot += x; }
+	__syncthreads();
+	total = tot;
+	return pre + inc - mine;
+}
+// sum of vals[0 .. count) (count <= 64), by the first wavefront; result in every thread of the workgroup
+__device__ __forceinline__ uint32_t tile_prefix(const uint32_t* __restrict__ vals, const uint32_t stride, const uint32_t count, const uint32_t tid, uint32_t* __restrict__ sh) {
+	if (tid < 64) {
+		uint32_t v = tid < count ? vals[(size_t)tid * stride] : 0u;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+		if (tid == 0) *sh = v;
+	}
+	__syncthreads();
+	const uint32_t r = *sh;
+	__syncthreads();
+	return r;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_rays_sums(const uint32_t n, const uint32_t* __restrict__ steps, uint32_t* __restrict__ tile_sum) {
+	__shared__ uint32_t wsum[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	uint32_t mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) mine += i0 + e < n ? steps[i0 + e] : 0u;
+	uint32_t total;
+	(void)block_exclusive_scan(mine, lane, wave, wsum, total);
+	if (tid == 0) tile_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_rays_base(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
+                                                         const uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ base, uint32_t* __restrict__ tile_v, uint32_t* __restrict__ counters) {
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t tile_base = tile_prefix(tile_sum, 1, blockIdx.x, tid, &sh);
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	uint32_t st[4], mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) { st[e] = i0 + e < n ? steps[i0 + e] : 0u; mine += st[e]; }
+	uint32_t total;
+	uint32_t run = tile_base + block_exclusive_scan(mine, lane, wave, wsum, total);
+	uint32_t v[3] = {0, 0, 0};
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) {
+		if (i0 + e < n) base[i0 + e] = run;
+		const bool ok = st[e] > 0 && run + st[e] <= max_samples; // testbed_nerf.cu:1348-1355
+		run += st[e];
+		v[0] += ok ? 1u : 0u; v[1] += ok ? st[e] : 0u; v[2] += ok ? min(st[e], k1) : 0u;
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		uint32_t t;
+		(void)block_exclusive_scan(v[k], lane, wave, wsum, t);
+		if (tid == 0) tile_v[blockIdx.x * 3 + k] = t;
+	}
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) counters[0] = tile_base + total; // numsteps_counter
+}
+
+__global__ __launch_bounds__(1024) void k_scan_rays_slots(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
+                                                          const uint32_t* __restrict__ base, const uint32_t* __restrict__ tile_v, uint32_t* __restrict__ slot,
+                                                          uint32_t* __restrict__ base1, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_counts) {
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint32_t pre[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) pre[k] = tile_prefix(tile_v + k, 3, blockIdx.x, tid, &sh);
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	uint32_t st[4], v0 = 0, v2 = 0, v1 = 0;
+	bool ok[4];
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) {
+		st[e] = i0 + e < n ? steps[i0 + e] : 0u;
+		const uint32_t b = i0 + e < n ? base[i0 + e] : 0u;
+		ok[e] = st[e] > 0 && b + st[e] <= max_samples;
+		v0 += ok[e] ? 1u : 0u; v1 += ok[e] ? st[e] : 0u; v2 += ok[e] ? min(st[e], k1) : 0u;
+	}
+	uint32_t t0, t1, t2;
+	uint32_t srun = pre[0] + block_exclusive_scan(v0, lane, wave, wsum, t0);
+	uint32_t frun = pre[2] + block_exclusive_scan(v2, lane, wave, wsum, t2);
+	(void)block_exclusive_scan(v1, lane, wave, wsum, t1);
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) {
+		if (i0 + e < n) {
+			slot[i0 + e] = ok[e] ? srun : 0xffffffffu;
+			if (k1) base1[i0 + e] = frun;
+		}
+		srun += ok[e] ? 1u : 0u;
+		frun += ok[e] ? min(st[e], k1) : 0u;
+	}
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) { counters[2] = pre[0] + t0; counters[3] = pre[1] + t1; fwd_counts[0] = pre[2] + t2; fwd_counts[1] = 0; fwd_counts[2] = 0; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8: loss + output gradients (testbed_nerf.cu:1396-2097)
 // ---------------------------------------------------------------------------------------------

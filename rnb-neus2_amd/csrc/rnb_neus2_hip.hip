@@ -130,7 +130,7 @@ struct rnb_ctx {
 	float *ek_loss = nullptr, *mask_loss = nullptr;       // rows 1, 2 of `loss`
 	DevBuf<half_t> mlp_out, dloss_dout;
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
-	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase;
+	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase, scan_tiles; // scan_tiles: [64] tile sums + [64][3] dependent tile sums of the multi-workgroup ray scan
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
 	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train; // LDS weight images of the training weights, rebuilt after every optimizer step
@@ -390,7 +390,13 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	else if (c->knobs.march_mg == 8) hipLaunchKernelGGL(k_march_count_wide<8>, dim3((n_rays + 31) / 32), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_march_count_wide<32>, dim3((n_rays + 7) / 8), dim3(256), 0, s, a);
 	c->prof.mark(s, P_MARCH_COUNT);
-	hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
+	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
+		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
+		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
+		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, c->fwd_k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
+		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, c->fwd_k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
+	} else
+		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, done, a);
 	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
@@ -796,7 +802,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
-	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->ray_loss.free();
+	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
@@ -858,6 +864,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
+	ALLOC(c->scan_tiles, 64 + 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED); ALLOC(c->wimg_train, W_TRAIN_END);
 	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
