@@ -976,6 +976,35 @@ __global__ __launch_bounds__(1024) void k_scan_compact(const uint32_t n_max, con
 	if (tid == 0) counters[1] = carry;
 }
 
+// k_scan_compact with one workgroup per 4096-ray tile (large batches): tile sums, then offsets. ncomp is zero beyond the kept rays.
+__global__ __launch_bounds__(1024) void k_scan_compact_sums(const uint32_t n, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ tile_sum) {
+	__shared__ uint32_t wsum[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	uint32_t mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) mine += i0 + e < n ? ncomp[i0 + e] : 0u;
+	uint32_t total;
+	(void)block_exclusive_scan(mine, lane, wave, wsum, total);
+	if (tid == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_compact_offsets(const uint32_t n, const uint32_t* __restrict__ ncomp, const uint32_t* __restrict__ tile_sum,
+                                                               uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters) {
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t tile_base = tile_prefix(tile_sum, 1, blockIdx.x, tid, &sh);
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	uint32_t v[4], mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) { v[e] = i0 + e < n ? ncomp[i0 + e] : 0u; mine += v[e]; }
+	uint32_t total;
+	uint32_t run = tile_base + block_exclusive_scan(mine, lane, wave, wsum, total);
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) { if (i0 + e < n) cbase[i0 + e] = run; run += v[e]; }
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) counters[1] = tile_base + total; // numsteps_counter_compacted
+}
+
 // Pass 2 (testbed_nerf.cu:1836-2095), one wavefront per ray: lanes own samples; the running sums of the reference's
 // sequential loop are replayed from broadcasts and captured by the lane that owns each sample.
 __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
@@ -1192,12 +1221,35 @@ __global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counte
 	}
 }
 
+// per-tile (4096 rays) fp64 sums of the three loss rows, for batches too large for one workgroup to walk (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void k_reduce_losses_tiles(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1,
+                                                              const float* __restrict__ l2, double* __restrict__ partial) {
+	__shared__ double sh[3][1024];
+	const uint32_t n = min(counters[2], n_max);
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x;
+	double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < 4; ++e) { const uint32_t i = i0 + e * 1024; if (i < n) { s0 += l0[i]; s1 += l1[i]; s2 += l2[i]; } }
+	sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+	__syncthreads();
+	for (int off = 512; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; sh[2][threadIdx.x] += sh[2][threadIdx.x + off]; }
+		__syncthreads();
+	}
+	if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
 // loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
-__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out) {
+__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
+                                                        const double* __restrict__ partial, const uint32_t n_partial) {
 	__shared__ double sh[3][1024];
 	const uint32_t n = min(counters[2], n_max);
 	double s0 = 0, s1 = 0, s2 = 0;
-	for (uint32_t i = threadIdx.x; i < n; i += 1024) { s0 += l0[i]; s1 += l1[i]; s2 += l2[i]; }
+	if (partial) { // large batches: per-tile sums of k_reduce_losses_tiles
+		for (uint32_t i = threadIdx.x; i < n_partial; i += 1024) { s0 += partial[i * 3 + 0]; s1 += partial[i * 3 + 1]; s2 += partial[i * 3 + 2]; }
+	} else {
+		for (uint32_t i = threadIdx.x; i < n; i += 1024) { s0 += l0[i]; s1 += l1[i]; s2 += l2[i]; }
+	}
 	sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
 	__syncthreads();
 	for (int off = 512; off > 0; off >>= 1) {

@@ -130,6 +130,7 @@ struct rnb_ctx {
 	float *ek_loss = nullptr, *mask_loss = nullptr;       // rows 1, 2 of `loss`
 	DevBuf<half_t> mlp_out, dloss_dout;
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
+	DevBuf<double> loss_partial; // per-tile loss sums of large batches
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase, scan_tiles; // scan_tiles: [64] tile sums + [64][3] dependent tile sums of the multi-workgroup ray scan
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
@@ -433,7 +434,12 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	}
 	hipLaunchKernelGGL(k_loss_pass1, dim3(a.phase ? std::min(blocks, 1024u) : blocks), dim3(256), 0, s, a);
 	c->prof.mark(s, P_LOSS_PASS1);
-	hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
+	if (n_rays >= c->knobs.march_narrow_from) {
+		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
+		hipLaunchKernelGGL(k_scan_compact_sums, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256);
+		hipLaunchKernelGGL(k_scan_compact_offsets, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256, c->cbase.p, c->counters.p);
+	} else
+		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
 	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
@@ -802,7 +808,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
-	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->ray_loss.free();
+	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->fm.free(); c->g1.free(); c->g2.free(); c->dn.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
@@ -864,7 +870,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
-	ALLOC(c->scan_tiles, 64 + 64 * 3);
+	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED); ALLOC(c->wimg_train, W_TRAIN_END);
 	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
@@ -1256,8 +1262,11 @@ static int step_back(rnb_ctx* c, hipStream_t s) {
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	c->prof.mark(s, P_NONE);
 	// the 48-byte readback goes straight into the pinned host block (no copy kernel, no marker packet); ev_loss is the kernel's completion
+	const bool tiled = c->cur_n_rays >= c->knobs.march_narrow_from;
+	const uint32_t n_tiles = (c->cur_n_rays + SCAN_TILE - 1) / SCAN_TILE;
+	if (tiled) hipLaunchKernelGGL(k_reduce_losses_tiles, dim3(n_tiles), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_partial.p);
 	LAUNCH_EV(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
-	          reinterpret_cast<double*>(c->host_rb_dev));
+	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
