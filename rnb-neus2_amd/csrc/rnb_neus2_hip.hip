@@ -144,7 +144,7 @@ struct rnb_ctx {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
 		bool march_early = false;
-		uint32_t march_narrow_from = 32768; // rays per step from which the counting march runs one thread per ray (RNB_MARCH_NARROW_FROM)
+		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
 		uint32_t march_mg = 16; // lanes per ray of the counting march (RNB_MARCH_MG=8|16|32; measured alone: 0.19 / 0.22 / 0.32 ms)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		uint32_t scatter_r4 = 24, scatter_r16 = 24, scatter_lds_wg = 128;

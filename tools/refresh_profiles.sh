@@ -7,9 +7,9 @@ python bench.py --albedo --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/
 for mode in serial overlapped; do
   rm -rf /tmp/kt_$mode
   if [ $mode = serial ]; then export RNB_OVERLAP_OFF=1; else unset RNB_OVERLAP_OFF; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-steps 0 > /tmp/kt_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in 1980 --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 > /tmp/kt_$mode.log 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r01/kernel_stats_$mode.csv
-  python tools/steady_stats.py /tmp/kt_$mode 200 > gpurun_out/r01/steady_$mode.json
+  python tools/steady_stats.py /tmp/kt_$mode 100 > gpurun_out/r01/steady_$mode.json
 done
 unset RNB_OVERLAP_OFF
 bash tools/collect_pmc.sh gpurun_out/pmc FETCH_SIZE WRITE_SIZE TCC_ATOMIC_sum SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE > /dev/null 2>&1
