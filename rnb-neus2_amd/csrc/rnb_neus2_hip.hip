@@ -386,10 +386,23 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	// One thread per ray once there are enough rays to fill the chip that way (late in training the converged occupancy grid
 	// lets the controller raise the batch from 15 k to 100 k rays): 0.23 ms at 94 k rays against 0.77 ms for the 16-lanes-per-ray
 	// kernel, which in turn wins below ~30 k rays (0.20 vs 0.30 ms at 14 k), where a ray per thread leaves the GPU to latency.
-	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) hipLaunchKernelGGL(k_march_count, dim3(blocks), dim3(128), 0, s, a);
-	else if (c->knobs.march_mg == 16) hipLaunchKernelGGL(k_march_count_wide<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
-	else if (c->knobs.march_mg == 8) hipLaunchKernelGGL(k_march_count_wide<8>, dim3((n_rays + 31) / 32), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL(k_march_count_wide<32>, dim3((n_rays + 7) / 8), dim3(256), 0, s, a);
+	const bool sc = c->aabb.cone_angle == 0.f && c->aabb.max_cascade == 0; // one cascade, constant step: the specialised instances
+	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
+		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), 0, s, a);
+		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
+	} else {
+		const uint32_t mg = c->knobs.march_mg;
+		const dim3 grid((n_rays + 256 / mg - 1) / (256 / mg));
+#define RNB_MARCH_WIDE(MGV)                                                                               \
+	do {                                                                                                  \
+		if (sc) hipLaunchKernelGGL((k_march_count_wide<MGV, true>), grid, dim3(256), 0, s, a);             \
+		else hipLaunchKernelGGL((k_march_count_wide<MGV, false>), grid, dim3(256), 0, s, a);               \
+	} while (0)
+		if (mg == 16) RNB_MARCH_WIDE(16);
+		else if (mg == 8) RNB_MARCH_WIDE(8);
+		else RNB_MARCH_WIDE(32);
+#undef RNB_MARCH_WIDE
+	}
 	c->prof.mark(s, P_MARCH_COUNT);
 	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
