@@ -143,7 +143,7 @@ struct rnb_ctx {
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
-		bool march_early = false;
+		bool march_early = false, march_late = false; // RNB_MARCH_EARLY / RNB_MARCH_LATE: force the start of the next march after the loss pass / after k_fwd_bwd
 		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
 		uint32_t march_mg = 16; // lanes per ray of the counting march (RNB_MARCH_MG=8|16|32; measured alone: 0.19 / 0.22 / 0.32 ms)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -947,6 +947,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_early = getenv("RNB_MARCH_EARLY") != nullptr;
+		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_MARCH_MG")) k.march_mg = atoi(e) == 16 ? 16u : atoi(e) == 8 ? 8u : 32u;
 		k.tail_on_main = getenv("RNB_TAIL_ON_MAIN") != nullptr;
@@ -1299,7 +1300,9 @@ static int launch_premarch(rnb_ctx* c) {
 	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's):
 	// off the critical stream, and (integer stores only) already beside k_fwd_bwd
 	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
-	if (!(c->knobs.march_early || c->knobs.scatter_split)) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
+	// (the one-thread-per-ray kernel of the large batches has shown no such effect — 0 of 1300 launches beside k_fwd_bwd — and starts early)
+	const bool thread_per_ray = c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from;
+	if (!(c->knobs.march_early || c->knobs.scatter_split || (thread_per_ray && !c->knobs.march_late))) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;
