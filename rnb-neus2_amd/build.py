@@ -13,8 +13,8 @@ DEPS = [os.path.join(PKG_DIR, "csrc", f) for f in ("rnb_neus2_hip.hip", "common.
 # -packed-fp32-ops (device target feature): no v_pk_{mul,add,fma}_f32. Measured on MI355X / ROCm 7.2 with tools/march_determinism.py: the
 # march of the NEXT step runs on a side stream beside this step's backward pass, and with packed fp32 instructions in it a few
 # rays of wavefront lanes 48-63 came out with a wrong direction (one component of R * d_cam, which the compiler had put on the
-# packed pipe) in 0.8-3 % of the launches -- never on an idle GPU, and never (0 of 1100 launches) in the combination
-# "no packed fp32 + the march starts once k_fwd_bwd is done" (rnb_neus2_hip.hip, launch_premarch). The x86 half of the
+# packed pipe) in 0.8-3 % of the launches -- never on an idle GPU, and never (0 of 2000 launches) once, in addition, the march
+# kernel stopped keeping ballot masks in SGPRs that spilled through VGPR lanes (rnb_neus2_hip.hip, launch_premarch). The x86 half of the
 # compilation does not know the feature and says so on stderr; build() drops those lines.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]

@@ -300,7 +300,6 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 template <int MG, bool SC>
 __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 	static_assert(MG == 8 || MG == 16 || MG == 32, "lanes per ray");
-	constexpr int NB = MG == 8 ? 3 : MG == 16 ? 4 : 5;          // ballots that carry the index of the next visited position
 	constexpr uint64_t GM = (1ull << MG) - 1ull;  // a group's lanes inside a 64-bit ballot
 	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
 	const int lane = threadIdx.x & 63;
@@ -380,10 +379,6 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 			}
 		}
 		const unsigned long long occ_w = __ballot(occ), in_w = __ballot(inside);
-		const uint32_t nm1 = nxt - 1u; // 0 .. MG-1
-		uint64_t qn[NB];
-#pragma unroll
-		for (int k = 0; k < NB; ++k) qn[k] = ((uint64_t)__ballot(nm1 & (1u << k)) >> gb) & GM;
 		const uint64_t occ16 = ((uint64_t)occ_w >> gb) & GM, in16 = ((uint64_t)in_w >> gb) & GM;
 		// replay of the sequential visit order over this round's outcomes
 		uint64_t vis = 0;
@@ -409,9 +404,9 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 					cur += allowed;
 					if (j >= RNB_MAX_STEPS) { term = true; break; }
 				} else {
-					int nx = 1;
-#pragma unroll
-					for (int k = 0; k < NB; ++k) nx += (int)((qn[k] >> cur) & 1ull) << k;
+					// the visited empty lane's own answer, through one cross-lane read (carried in four ballot masks = eight more SGPRs, the
+					// kernel spilled masks into VGPR lanes and was not reproducible beside k_fwd_bwd: rnb_neus2_hip.hip, launch_premarch)
+					const int nx = (int)__shfl(nxt, gb + cur, 64);
 					if (nx >= MG) { have_pending = true; pend_src = cur; }
 					cur = nx;
 				}

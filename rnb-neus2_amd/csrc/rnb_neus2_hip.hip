@@ -143,7 +143,7 @@ struct rnb_ctx {
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false, scatter_nolds = false, scatter_noquad = false, scatter_split = false;
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
-		bool march_early = false, march_late = false; // RNB_MARCH_EARLY / RNB_MARCH_LATE: force the start of the next march after the loss pass / after k_fwd_bwd
+		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
 		uint32_t march_mg = 16; // lanes per ray of the counting march (RNB_MARCH_MG=8|16|32; measured alone: 0.19 / 0.22 / 0.32 ms)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -946,7 +946,6 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.scatter_nolds = getenv("RNB_SCATTER_NOLDS") != nullptr; k.scatter_noquad = getenv("RNB_SCATTER_NOQUAD") != nullptr; k.scatter_split = getenv("RNB_SCATTER_SPLIT") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
-		k.march_early = getenv("RNB_MARCH_EARLY") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_MARCH_MG")) k.march_mg = atoi(e) == 16 ? 16u : atoi(e) == 8 ? 8u : 32u;
@@ -1291,18 +1290,18 @@ static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 static int launch_premarch(rnb_ctx* c) {
 	if (!c->overlap() || c->pre.valid || prep_due(c->cur_step + 1)) return RNB_OK; // cur_step + 1: _finish may run before _apply
 	const uint32_t n_rays = c->rays_per_batch, max_inference = next_max_inference(c), n_rays_total = c->n_rays_total;
-	// The march starts when k_fwd_bwd is done, not right after the loss pass (RNB_MARCH_EARLY=1: 2 % faster). Measured with
-	// tools/march_determinism.py: beside k_fwd_bwd the march came out with a wrong direction for a few rays (wavefront lanes 48-63 only) in
-	// 2-3 % of the launches, 26-54 % beside the generic kernel of the albedo mode, i.e. with a sample set that the same launch on
-	// an idle GPU does not produce; beside the scatter, the GEMMs and the optimizer, and compiled without packed fp32
-	// instructions (rnb-neus2_amd/build.py), 0 of 1100 launches. Neither half alone is enough (3 % / 1 % remain).
+	// The march starts right after the loss pass, i.e. beside k_fwd_bwd (RNB_MARCH_LATE=1: only when k_fwd_bwd is done). History,
+	// measured with tools/march_determinism.py: an earlier 16-lanes-per-ray kernel, which carried the index of the next visited
+	// position in four more ballot masks (SGPR pairs, spilled through VGPR lanes) and used packed fp32 instructions, came out
+	// beside k_fwd_bwd with a wrong direction for a few rays (wavefront lanes 48-63 only) in 2-3 % of the launches, 26-54 % beside
+	// the generic kernel of the albedo mode -- a sample set that the same launch on an idle GPU does not produce. Without packed
+	// fp32 (rnb-neus2_amd/build.py) and with that index read through one cross-lane shuffle instead: 0 of 2000 launches beside
+	// k_fwd_bwd (0 of 1300 for the one-thread-per-ray kernel of the large batches). DESIGN.md section 6.
 	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
 	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's):
 	// off the critical stream, and (integer stores only) already beside k_fwd_bwd
 	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
-	// (the one-thread-per-ray kernel of the large batches has shown no such effect — 0 of 1300 launches beside k_fwd_bwd — and starts early)
-	const bool thread_per_ray = c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from;
-	if (!(c->knobs.march_early || c->knobs.scatter_split || (thread_per_ray && !c->knobs.march_late))) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
+	if (c->knobs.march_late && !c->knobs.scatter_split) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;

@@ -1,6 +1,6 @@
 """GPU box: is the backward pass of the overlapped schedule (dW GEMMs / scatter / optimizer / next march side by side) bit-identical to the serial
 schedule? First step from a common trained state, N clones: MLP gradients, dL/dout and grid gradients compared bit for bit with the serial run.
-   python tools/backward_determinism.py [N]      GL_ALBEDO=1: albedo mode; RNB_MARCH_EARLY=1: with the march beside k_fwd_bwd"""
+   python tools/backward_determinism.py [N]      GL_ALBEDO=1: albedo mode; RNB_MARCH_LATE=1: with the march held back until k_fwd_bwd is done"""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,7 +1,7 @@
 """GPU box: does the overlapped schedule (cfg.overlap = 1: the next step's march runs on a side stream beside the backward pass) produce the
 same ray / sample sets as the serial schedule? Clones a trained state N times, runs 6 steps each, and counts the steps whose marched-sample
 counters differ from the serial reference (see DESIGN.md section 6 for what this found).   python tools/march_determinism.py [N]
-Environment: GL_OVERLAP=0 (serial clones), GL_BASE_STEPS=n (trained state to clone; default 400; 3000+ = the large-batch kernels), RNB_MARCH_EARLY=1, RNB_FWD_BWD_GENERIC=1, ..."""
+Environment: GL_OVERLAP=0 (serial clones), GL_BASE_STEPS=n (trained state to clone; default 400; 3000+ = the large-batch kernels), RNB_MARCH_LATE=1, RNB_FWD_BWD_GENERIC=1, ..."""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
