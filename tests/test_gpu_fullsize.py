@@ -1,6 +1,7 @@
-"""GPU tests at BASELINE.json's full size (config 4: 64 views x 800^2, 2^18 compacted samples per step), where the CPU
-oracle is too slow to be the checker: size-independent properties of the path and exactness of the library's own
-scheduling choices (two-round network evaluation, side-stream overlap), which must not change any result."""
+"""GPU tests at BASELINE.json's full size (config 4: 64 views x 800^2, 2^18 compacted samples per step): one full-size step
+of every stage against the CPU oracle (about a second of oracle time per stage on the GPU box's host cores), size-independent
+properties of the path, and exactness of the library's own scheduling choices (two-round network evaluation, side-stream
+overlap), which must not change any result."""
 import os
 
 import numpy as np
@@ -341,3 +342,178 @@ def test_sdf_only_training_kernel_matches_generic(scene, trained):
     finally:
         gen.close()
         spe.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One config-4 step at full size against the oracle, from the trained state: at the controller's own ray count (~12 k,
+# the 16-lanes-per-ray march and single-workgroup scans) and at 40 000 rays (>= 24 576: thread-per-ray march, tiled scans,
+# k_march_write<16>, tiled loss reduction -- the kernels of the late-training regime).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def oracle_full(scene, trained):
+    from tests import oracle_lib
+    _, state = trained
+    cpu = oracle_lib.context(**KW)
+    cpu.init_params()
+    cpu.set_dataset(*scene)
+    cpu.set_params(state["params"])
+    cpu.put("DENSITY_GRID", state["grid"])
+    cpu.update_density_bitfield()
+    cpu.set_controller(state["step"], state["rays"], state["before"], 0)
+    yield cpu
+    cpu.close()
+
+
+def _half_close(a, b, rel, abs_, frac, name):
+    a, b = a.astype(np.float32), b.astype(np.float32)
+    ok = np.abs(a - b) <= abs_ + rel * np.abs(b)
+    assert ok.mean() >= frac, "%s: only %.5f of elements within tolerance" % (name, ok.mean())
+
+
+@pytest.mark.parametrize("n_rays", [0, 40000])
+def test_full_size_step_against_oracle(scene, trained, oracle_full, n_rays):
+    _, state = trained
+    cpu = oracle_full
+    gpu = _clone(scene, state, overlap=0)
+    try:
+        assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
+        R = n_rays or state["rays"]
+        B = 1 << 18
+        # a4 (testbed_nerf.cu:1216-1387): bit exact
+        for c in (gpu, cpu):
+            c.generate_training_samples(R, 4096)
+        cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+        assert np.array_equal(cg[[0, 2, 3]], cc[[0, 2, 3]]), (cg, cc)
+        kept, written = int(cc[2]), int(cc[3])
+        assert kept > 0.2 * R and written > 100000
+        assert np.array_equal(gpu.get("RAY_INDICES", kept), cpu.get("RAY_INDICES", kept))
+        assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+        assert np.array_equal(gpu.get("RAYS", kept * 6).view(np.uint32), cpu.get("RAYS", kept * 6).view(np.uint32))
+        assert np.array_equal(gpu.get("COORDS", written * 7).view(np.uint32), cpu.get("COORDS", written * 7).view(np.uint32))
+        # a5-a7 (nerf_network.h:97-253) on every marched sample
+        for c in (gpu, cpu):
+            c.forward_infer_staged(written)
+        a, b = gpu.get("MLP_OUT", written * 16).reshape(-1, 16), cpu.get("MLP_OUT", written * 16).reshape(-1, 16)
+        assert np.array_equal(a[:, 7:11].view(np.uint16), b[:, 7:11].view(np.uint16))
+        _half_close(a[:, 3], b[:, 3], 2e-3, 2e-4, 0.999, "sdf channel")
+        _half_close(a[:, 4:7], b[:, 4:7], 4e-3, 2e-3, 0.999, "gradient channels")
+        gpu.put("MLP_OUT", b)
+        # a8, a13-a15 (testbed_nerf.cu:1396-2097)
+        for c in (gpu, cpu):
+            c.compute_loss(R, 4096)
+        cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+        assert np.array_equal(cg, cc), (cg, cc)
+        assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+        assert np.array_equal(gpu.get("COORDS_COMPACTED").view(np.uint32), cpu.get("COORDS_COMPACTED").view(np.uint32))
+        for name in ("LOSS", "EK_LOSS", "MASK_LOSS"):
+            x, y = gpu.get(name, R).astype(np.float64), cpu.get(name, R).astype(np.float64)
+            assert abs(x.sum() - y.sum()) <= 1e-4 * abs(y.sum()) + 1e-12, (name, x.sum(), y.sum())  # north star: 1e-4 relative
+            np.testing.assert_allclose(x, y, rtol=2e-4, atol=1e-9, err_msg=name)
+        d0 = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        d1 = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        _half_close(d0[:, :11], d1[:, :11], 3e-3, 1e-6, 0.998, "dL/doutput")
+        # a9-a11 (nerf_network.h:257-452) on the oracle's compacted batch: k_fwd_bwd_sdf, k_dw*, the scatter kernels
+        gpu.put("DLOSS_DOUT", cpu.get("DLOSS_DOUT"))
+        for c in (gpu, cpu):
+            c.forward_backward()
+        g, r = gpu.get("GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
+        lay = cpu.param_layout()
+        sc = np.abs(r[lay["sdf"]:lay["rgb"]]).max()
+        assert sc > 0 and np.abs(g[lay["sdf"]:lay["rgb"]] - r[lay["sdf"]:lay["rgb"]]).max() < 5e-3 * sc
+        assert not g[lay["rgb"]:lay["grid"]].any() and not r[lay["rgb"]:lay["grid"]].any()
+        gg, rg = g[lay["grid"]:lay["variance"]], r[lay["grid"]:lay["variance"]]
+        assert np.mean((gg != 0) != (rg != 0)) < 1e-4
+        scale = np.abs(rg).max()
+        assert np.abs(gg - rg).max() < 2e-3 * scale
+        nz = rg != 0
+        rel = np.abs(gg[nz] - rg[nz]) / (np.abs(rg[nz]) + 1e-3 * scale)
+        assert np.quantile(rel, 0.999) < 2e-2
+        assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2e-3 * abs(r[lay["variance"]]) + 1e-6
+    finally:
+        gpu.close()
+
+
+def _reset(c, state):
+    """Back to the trained state without re-uploading the dataset (set_params also clears the optimizer state)."""
+    c.set_params(state["params"])
+    c.put("DENSITY_GRID", state["grid"])
+    c.update_density_bitfield()
+    c.set_controller(state["step"], state["rays"], state["before"], 0)
+
+
+def test_overlapped_march_equals_serial_over_many_steps(scene, trained):
+    """The next step's march runs on a side stream beside this step's backward pass (DESIGN.md section 6 documents a
+    toolchain hazard found there; tools/march_determinism.py is the long-running form of this test). 22 repetitions x 15
+    consecutive overlapped steps = 300+ side-stream march launches: each step's marched sample set (counters 0 / 2: they
+    depend on the occupancy bitfield, the RNG and the ray count only -- the window holds no occupancy update after its first
+    step) must equal the serial schedule's."""
+    _, state = trained
+    n_steps = 15
+    assert state["step"] % 16 == 0
+    ser = _clone(scene, state, overlap=0)
+    ref = []
+    try:
+        for _ in range(n_steps):
+            st = ser.train_step()
+            ref.append((st.rays_per_batch, st.measured_batch_size_before_compaction, st.n_rays_kept))
+    finally:
+        ser.close()
+    bad, compared = [], 0
+    ovl = _clone(scene, state, overlap=1)
+    try:
+        for rep in range(22):
+            if rep:
+                _reset(ovl, state)
+            for i in range(n_steps):
+                st = ovl.train_step()
+                if st.rays_per_batch != ref[i][0]:
+                    break  # the controllers diverged (compaction depends on weights that differ by atomic order): nothing to compare further
+                compared += 1
+                if (st.measured_batch_size_before_compaction, st.n_rays_kept) != ref[i][1:3]:
+                    bad.append((rep, i, st.measured_batch_size_before_compaction, st.n_rays_kept, ref[i]))
+    finally:
+        ovl.close()
+    assert compared >= 200, compared
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("albedo", [0, 1])
+def test_overlapped_backward_equals_serial(scene, trained, albedo):
+    """tools/backward_determinism.py as a test: 150 overlapped backward passes per mode (dW GEMMs, scatter, optimizer chunks
+    and the next step's march side by side) from one state; dL/dout and the MLP weight gradients (fixed summation order)
+    must be bit-identical to the serial schedule's, the grid gradients equal up to the order of the fp32 atomics."""
+    _, state = trained
+
+    def grads_of(c):
+        c.train_step_begin()
+        cnt, sums = c.train_step_local()
+        c.train_step_finish(cnt, sums)  # queues the next step's march beside the backward pass (overlap = 1)
+        g, d = c.get("GRADS_FP32").copy(), c.get("DLOSS_DOUT").copy()
+        c.train_step_apply()
+        return g, d
+
+    kw = dict(apply_no_albedo=0) if albedo else {}
+    ser = _clone(scene, state, overlap=0, **kw)
+    try:
+        g_ref, d_ref = grads_of(ser)
+        nm = ser.param_layout()["grid"]
+    finally:
+        ser.close()
+    gs = np.abs(g_ref[nm:]).max()
+    assert gs > 0 and np.count_nonzero(g_ref[:nm]) > 1000
+    ovl = _clone(scene, state, overlap=1, **kw)
+    bad = []
+    try:
+        for rep in range(150):
+            if rep:
+                _reset(ovl, state)
+            g, d = grads_of(ovl)
+            if not np.array_equal(d.view(np.uint16), d_ref.view(np.uint16)):
+                bad.append((rep, "dL/dout"))
+            if not np.array_equal(g[:nm].view(np.uint32), g_ref[:nm].view(np.uint32)):
+                bad.append((rep, "mlp gradients", int(np.count_nonzero(g[:nm] != g_ref[:nm]))))
+            if np.max(np.abs(g[nm:] - g_ref[nm:])) > 1e-4 * gs:
+                bad.append((rep, "grid gradients", float(np.max(np.abs(g[nm:] - g_ref[nm:])) / gs)))
+    finally:
+        ovl.close()
+    assert not bad, bad[:10]

@@ -12,14 +12,36 @@ pytestmark = pytest.mark.gpu
 KW = dict(target_batch_size=1 << 13, max_rays_per_batch=1 << 13, initial_rays_per_batch=512, apply_no_albedo=1)
 
 
-def _pair(**over):
+class _env:
+    """Library knobs (RNB_*) are read once, at rnb_create: set them around the construction of a context only."""
+
+    def __init__(self, env):
+        self.env, self.old = env or {}, {}
+
+    def __enter__(self):
+        import os
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _pair(env=None, scene=(4, 96, 168.0), **over):
     import rnb_neus2_amd as rnb
     from rnb_neus2_amd import synthetic
     from tests import oracle_lib
     kw = dict(KW)
     kw.update(over)
-    views, normals, albedos = synthetic.make_scene(4, 96, 168.0)
-    gpu = rnb.Context(**kw)
+    views, normals, albedos = synthetic.make_scene(*scene)
+    with _env(env):
+        gpu = rnb.Context(**kw)
     cpu = oracle_lib.context(**kw)
     for c in (gpu, cpu):
         c.init_params()
@@ -221,8 +243,22 @@ def test_compute_loss(flags):
         cpu.close()
 
 
-def test_forward_backward_gradients(rpair):
-    gpu, cpu = pair = rpair
+@pytest.fixture(scope="module")
+def rpair_no_albedo():
+    """--no-albedo (stage 1 of the pipeline, the benchmarked mode): the backward pass runs k_fwd_bwd_sdf."""
+    gpu, cpu = _pair(apply_no_albedo=1)
+    _randomize(gpu, cpu, seed=1)
+    yield gpu, cpu
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("no_albedo", [0, 1])
+def test_forward_backward_gradients(rpair, rpair_no_albedo, no_albedo):
+    """K10 + K11 (nerf_network.h:257-452) against the oracle: the generic k_fwd_bwd (albedo enabled) and the kernel of the
+    benchmarked --no-albedo path, k_fwd_bwd_sdf, each directly."""
+    gpu, cpu = pair = (rpair_no_albedo if no_albedo else rpair)
+    assert gpu.cfg.apply_no_albedo == no_albedo
     n_rays = 512
     _stage_samples(gpu, cpu, n_rays, step=700)
     cpu.compute_loss(n_rays, 0)
@@ -234,6 +270,10 @@ def test_forward_backward_gradients(rpair):
     lay = cpu.param_layout()
     # dense MLP weights (half-rounded like the reference's gradient matrices): relative to the matrix scale
     for lo, hi, name in ((lay["sdf"], lay["rgb"], "sdf mlp"), (lay["rgb"], lay["grid"], "rgb mlp")):
+        if no_albedo and name == "rgb mlp":  # the colour MLP receives exact zeros (opti_rgb = 0, testbed_nerf.cu:1954-1962)
+            assert not g[lo:hi].any() and not r[lo:hi].any()
+            continue
+        assert np.abs(r[lo:hi]).max() > 0, name
         scale = np.abs(r[lo:hi]).max() + 1e-30
         err = np.abs(g[lo:hi] - r[lo:hi]).max() / scale
         assert err < 5e-3, (name, err)
@@ -247,6 +287,104 @@ def test_forward_backward_gradients(rpair):
     assert np.quantile(rel, 0.999) < 2e-2
     # variance
     assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2e-3 * abs(r[lay["variance"]]) + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Large-batch forms of the per-ray kernels. From 24 576 rays per step on (RNB_MARCH_NARROW_FROM; late in training the
+# controller runs 50-100 k rays) the library switches to k_march_count<>/thread-per-ray, the tiled scans
+# k_scan_rays_{sums,base,slots} / k_scan_compact_{sums,offsets}, k_march_write<16> and k_reduce_losses_tiles. Here the
+# switch is lowered to 256 rays so that the oracle can check the same kernels in seconds; 6 000 rays = two 4 096-ray
+# scan tiles, the second one ragged.
+# ---------------------------------------------------------------------------------------------------------------------
+BIG = dict(target_batch_size=1 << 14, max_rays_per_batch=1 << 13, initial_rays_per_batch=6016)
+BIG_ENV = {"RNB_MARCH_NARROW_FROM": "256"}
+
+
+@pytest.fixture(scope="module")
+def bigpair():
+    gpu, cpu = _pair(env=BIG_ENV, **BIG)
+    yield gpu, cpu
+    gpu.close()
+    cpu.close()
+
+
+def _assert_samples_equal(gpu, cpu):
+    cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+    assert np.array_equal(cg[[0, 2, 3]], cc[[0, 2, 3]]), (cg, cc)
+    kept, written = int(cc[2]), int(cc[3])
+    assert kept > 0 and written > 0
+    assert np.array_equal(gpu.get("RAY_INDICES", kept), cpu.get("RAY_INDICES", kept))
+    assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+    assert np.array_equal(gpu.get("RAYS", kept * 6).view(np.uint32), cpu.get("RAYS", kept * 6).view(np.uint32))
+    assert np.array_equal(gpu.get("COORDS", written * 7).view(np.uint32), cpu.get("COORDS", written * 7).view(np.uint32))
+    return cc
+
+
+def test_large_batch_march_bit_exact(bigpair):
+    """testbed_nerf.cu:1216-1387 through the one-thread-per-ray march, the tiled ray scans and the 16-lane sample writer."""
+    gpu, cpu = bigpair
+    _sync_occupancy(gpu, cpu)
+    B16 = BIG["target_batch_size"] * 16
+    for n_rays, n_rays_total, max_samples in ((6000, 0, B16), (8192, 12345, B16), (4097, 7, B16), (256, 0, B16), (8192, 99, 50000)):
+        for c in bigpair:
+            c.generate_training_samples(n_rays, n_rays_total, max_samples)
+        cc = _assert_samples_equal(gpu, cpu)
+    assert cc[0] > 50000 and cc[3] <= 50000  # the last case overflowed max_samples: rays were dropped identically
+
+
+@pytest.mark.parametrize("narrow_thread_per_ray_only", [False, True])
+def test_large_batch_loss_and_compaction(narrow_thread_per_ray_only):
+    """K8 (testbed_nerf.cu:1396-2097) with the tiled compaction scan and the tiled loss reduction; second parametrisation:
+    RNB_MARCH_NARROW=1 alone (thread-per-ray march feeding the small-batch scans and writer)."""
+    env = {"RNB_MARCH_NARROW": "1"} if narrow_thread_per_ray_only else BIG_ENV
+    gpu, cpu = _pair(env=env, **BIG)
+    try:
+        n_rays = 6000
+        _stage_samples(gpu, cpu, n_rays)
+        _assert_samples_equal(gpu, cpu)
+        for c in (gpu, cpu):
+            c.compute_loss(n_rays, 0)
+        cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+        assert np.array_equal(cg, cc)
+        kept = int(cc[2])
+        B = BIG["target_batch_size"]
+        assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
+        assert np.array_equal(gpu.get("COORDS_COMPACTED").view(np.uint32), cpu.get("COORDS_COMPACTED").view(np.uint32))
+        for name in ("LOSS", "EK_LOSS", "MASK_LOSS"):
+            a, b = gpu.get(name, n_rays).astype(np.float64), cpu.get(name, n_rays).astype(np.float64)
+            assert abs(a.sum() - b.sum()) <= 1e-4 * abs(b.sum()) + 1e-12, (name, a.sum(), b.sum())
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-9, err_msg=name)
+        a = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        b = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(B, 16)
+        _half_close(a[:, :11], b[:, :11], rel=3e-3, abs_=1e-6, frac=0.998, name="dL/doutput")
+    finally:
+        gpu.close()
+        cpu.close()
+
+
+def test_large_batch_train_steps_track_oracle():
+    """Whole steps through the large-batch kernels (k_reduce_losses_tiles feeds the ray controller): step 1000 is not an
+    occupancy-update step, so from a shared occupancy grid the marched sample set is the oracle's, bit for bit."""
+    gpu, cpu = _pair(env=BIG_ENV, **BIG)
+    try:
+        _sync_occupancy(gpu, cpu)
+        for c in (gpu, cpu):
+            c.set_controller(1001, 6016, 0, 0)
+        for i in range(3):
+            sg, sc = gpu.train_step(), cpu.train_step()
+            assert sg.training_step == sc.training_step and sg.rays_per_batch == sc.rays_per_batch >= 256
+            assert sg.measured_batch_size_before_compaction == sc.measured_batch_size_before_compaction
+            assert sg.n_rays_kept == sc.n_rays_kept
+            if i == 0:  # same weights: identical compaction; later steps differ by fp32 summation order in the weights
+                assert sg.measured_batch_size == sc.measured_batch_size and sg.next_rays_per_batch == sc.next_rays_per_batch
+                for k in ("loss", "ek_loss", "mask_loss"):
+                    a, b = getattr(sg, k), getattr(sc, k)
+                    assert abs(a - b) <= 1e-4 * abs(b) + 1e-9, (k, a, b)
+            if sg.next_rays_per_batch != sc.next_rays_per_batch:
+                break
+    finally:
+        gpu.close()
+        cpu.close()
 
 
 def test_optimizer_step(pair):
