@@ -433,17 +433,9 @@ def test_full_size_step_against_oracle(scene, trained, oracle_full, n_rays):
         gpu.close()
 
 
-def _reset(c, state):
-    """Back to the trained state without re-uploading the dataset (set_params also clears the optimizer state)."""
-    c.set_params(state["params"])
-    c.put("DENSITY_GRID", state["grid"])
-    c.update_density_bitfield()
-    c.set_controller(state["step"], state["rays"], state["before"], 0)
-
-
 def test_overlapped_march_equals_serial_over_many_steps(scene, trained):
     """The next step's march runs on a side stream beside this step's backward pass (DESIGN.md section 6 documents a
-    toolchain hazard found there; tools/march_determinism.py is the long-running form of this test). 22 repetitions x 15
+    toolchain hazard found there; tools/march_determinism.py is the long-running form of this test). 22 clones x 15
     consecutive overlapped steps = 300+ side-stream march launches: each step's marched sample set (counters 0 / 2: they
     depend on the occupancy bitfield, the RNG and the ray count only -- the window holds no occupancy update after its first
     step) must equal the serial schedule's."""
@@ -459,11 +451,9 @@ def test_overlapped_march_equals_serial_over_many_steps(scene, trained):
     finally:
         ser.close()
     bad, compared = [], 0
-    ovl = _clone(scene, state, overlap=1)
-    try:
-        for rep in range(22):
-            if rep:
-                _reset(ovl, state)
+    for rep in range(22):
+        ovl = _clone(scene, state, overlap=1)  # a fresh context: the RNG streams advance with every step
+        try:
             for i in range(n_steps):
                 st = ovl.train_step()
                 if st.rays_per_batch != ref[i][0]:
@@ -471,15 +461,15 @@ def test_overlapped_march_equals_serial_over_many_steps(scene, trained):
                 compared += 1
                 if (st.measured_batch_size_before_compaction, st.n_rays_kept) != ref[i][1:3]:
                     bad.append((rep, i, st.measured_batch_size_before_compaction, st.n_rays_kept, ref[i]))
-    finally:
-        ovl.close()
+        finally:
+            ovl.close()
     assert compared >= 200, compared
     assert not bad, bad
 
 
 @pytest.mark.parametrize("albedo", [0, 1])
 def test_overlapped_backward_equals_serial(scene, trained, albedo):
-    """tools/backward_determinism.py as a test: 150 overlapped backward passes per mode (dW GEMMs, scatter, optimizer chunks
+    """tools/backward_determinism.py as a test: 60 overlapped backward passes per mode (dW GEMMs, scatter, optimizer chunks
     and the next step's march side by side) from one state; dL/dout and the MLP weight gradients (fixed summation order)
     must be bit-identical to the serial schedule's, the grid gradients equal up to the order of the fp32 atomics."""
     _, state = trained
@@ -501,19 +491,17 @@ def test_overlapped_backward_equals_serial(scene, trained, albedo):
         ser.close()
     gs = np.abs(g_ref[nm:]).max()
     assert gs > 0 and np.count_nonzero(g_ref[:nm]) > 1000
-    ovl = _clone(scene, state, overlap=1, **kw)
     bad = []
-    try:
-        for rep in range(150):
-            if rep:
-                _reset(ovl, state)
+    for rep in range(60):
+        ovl = _clone(scene, state, overlap=1, **kw)  # a fresh context: the RNG streams advance with every step
+        try:
             g, d = grads_of(ovl)
-            if not np.array_equal(d.view(np.uint16), d_ref.view(np.uint16)):
-                bad.append((rep, "dL/dout"))
-            if not np.array_equal(g[:nm].view(np.uint32), g_ref[:nm].view(np.uint32)):
-                bad.append((rep, "mlp gradients", int(np.count_nonzero(g[:nm] != g_ref[:nm]))))
-            if np.max(np.abs(g[nm:] - g_ref[nm:])) > 1e-4 * gs:
-                bad.append((rep, "grid gradients", float(np.max(np.abs(g[nm:] - g_ref[nm:])) / gs)))
-    finally:
-        ovl.close()
+        finally:
+            ovl.close()
+        if not np.array_equal(d.view(np.uint16), d_ref.view(np.uint16)):
+            bad.append((rep, "dL/dout"))
+        if not np.array_equal(g[:nm].view(np.uint32), g_ref[:nm].view(np.uint32)):
+            bad.append((rep, "mlp gradients", int(np.count_nonzero(g[:nm] != g_ref[:nm]))))
+        if np.max(np.abs(g[nm:] - g_ref[nm:])) > 1e-4 * gs:
+            bad.append((rep, "grid gradients", float(np.max(np.abs(g[nm:] - g_ref[nm:])) / gs)))
     assert not bad, bad[:10]
