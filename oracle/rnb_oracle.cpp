@@ -21,6 +21,9 @@
  *   D4 the per-ray light index is PCG32 draw #7 of the ray's stream, mod 3
  *      (reference: curand_init(clock64(), ...) — irreproducible, testbed_nerf.cu:1557-1561).
  *   D5 density-grid mean is summed in fp64 (reference: fp32 tree reduce_sum).
+ * D1 and D2 can be switched to an EMULATION of the reference's half accumulation (ORC_EMULATE_FP16_ACCUM=1,
+ * ORC_EMULATE_HALF_ATOMICS=1 in the environment of orc_create) so that their size can be measured
+ * (tools/oracle_deviation_report.py). The HIP path is never compared with those modes.
  *
  * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may load
  * this library.
@@ -146,6 +149,9 @@ struct orc_ctx_s {
 	bool grid_updated = false;
 	float prep_ms = 0.f;
 	std::chrono::steady_clock::time_point step_start;
+	// Emulation of the reference's half accumulation (off by default: deviations D1 / D2 are what the HIP path implements)
+	bool emul_fp16_acc = false;     // D1 off: MLP dot products and weight-gradient GEMMs accumulate in half (WMMA / CUTLASS half accumulators)
+	bool emul_half_atomics = false; // D2 off: hash-grid gradients accumulate in half, one rounding per atomicAdd(__half2), in sample order
 };
 
 namespace {
@@ -264,20 +270,37 @@ void encode_sample(const orc_ctx_s* c, const half_t* grid, const float x[3], hal
 // Weights row-major [out][in] (fully_fused_mlp.cu:786-819). Deviation D1: fp32 accumulate.
 // ======================================================================
 
-static inline void matvec(const half_t* W, int n_out, int n_in, const half_t* in, half_t* out, bool relu) {
-	for (int o = 0; o < n_out; ++o) {
+// Dot product of n half pairs (a[i * sa], b[i * sb]). Default (deviation D1): fp32 accumulation.
+// acc16: EMULATION MODEL of a tensor-core path with half accumulators (wmma 16x16x16 fragments of __half,
+// fully_fused_mlp.cu:68,198; CUTLASS TypeAccumulator = half, cutlass_matmul.h:83): products exact, the 16 products of one
+// k-step summed in fp32, the running accumulator rounded to half after every k-step. The order inside a k-step is not
+// documented by the vendor; this is the usual model, used only to SIZE the deviation.
+static inline float dot_h(const half_t* a, int sa, const half_t* b, int sb, int n, bool acc16) {
+	if (!acc16) {
 		float acc = 0.f;
-		const half_t* w = W + (size_t)o * n_in;
-		for (int i = 0; i < n_in; ++i) acc += h2f(w[i]) * h2f(in[i]);
+		for (int i = 0; i < n; ++i) acc += h2f(a[(size_t)i * sa]) * h2f(b[(size_t)i * sb]);
+		return acc;
+	}
+	half_t acc = 0;
+	for (int i0 = 0; i0 < n; i0 += 16) {
+		float part = 0.f;
+		for (int i = i0; i < std::min(n, i0 + 16); ++i) part += h2f(a[(size_t)i * sa]) * h2f(b[(size_t)i * sb]);
+		acc = f2h(h2f(acc) + part);
+	}
+	return h2f(acc);
+}
+
+static inline void matvec(const half_t* W, int n_out, int n_in, const half_t* in, half_t* out, bool relu, bool acc16 = false) {
+	for (int o = 0; o < n_out; ++o) {
+		float acc = dot_h(W + (size_t)o * n_in, 1, in, 1, n_in, acc16);
 		if (relu && !(acc > 0.f)) acc = 0.f; // warp_activation ReLU, common_device.h:69-115
 		out[o] = f2h(acc);
 	}
 }
 // out[i] = sum_o W[o][i] * in[o]; optional ReLU transfer using the forward activation (common_device.h:182 ff.)
-static inline void matvec_t(const half_t* W, int n_out, int n_in, const half_t* in, half_t* out, const half_t* fwd_act) {
+static inline void matvec_t(const half_t* W, int n_out, int n_in, const half_t* in, half_t* out, const half_t* fwd_act, bool acc16 = false) {
 	for (int i = 0; i < n_in; ++i) {
-		float acc = 0.f;
-		for (int o = 0; o < n_out; ++o) acc += h2f(W[(size_t)o * n_in + i]) * h2f(in[o]);
+		float acc = dot_h(W + i, n_in, in, 1, n_out, acc16);
 		if (fwd_act && !(h2f(fwd_act[i]) > 0.f)) acc = 0.f;
 		out[i] = f2h(acc);
 	}
@@ -291,6 +314,7 @@ struct NetParams {
 	const half_t* rgb_w2; // [16][64]
 	const half_t* grid;
 	half_t variance;
+	bool acc16; // orc_ctx_s::emul_fp16_acc
 };
 
 NetParams net_params(const orc_ctx_s* c, bool inference) {
@@ -303,6 +327,7 @@ NetParams net_params(const orc_ctx_s* c, bool inference) {
 	n.rgb_w2 = n.rgb_w1 + 64 * 64;
 	n.grid = p + c->off_grid;
 	n.variance = p[c->off_var];
+	n.acc16 = c->emul_fp16_acc;
 	return n;
 }
 
@@ -315,8 +340,8 @@ half_t sdf_sample(const orc_ctx_s* c, const NetParams& np, const float x[3]) {
 	for (int k = 0; k < 28; ++k) in[3 + k] = feat[k];
 	in[31] = 0;
 	half_t z1[64], out[16];
-	matvec(np.sdf_w0, 64, 32, in, z1, true);
-	matvec(np.sdf_w1, 16, 64, z1, out, false);
+	matvec(np.sdf_w0, 64, 32, in, z1, true, np.acc16);
+	matvec(np.sdf_w1, 16, 64, z1, out, false, np.acc16);
 	return hadd(out[0], f2h(c->cfg.sdf_bias)); // common_operation.cuh:299-309
 }
 
@@ -340,15 +365,15 @@ void forward_sample(const orc_ctx_s* c, const NetParams& np, const float coord[7
 	for (int j = 0; j < 28; ++j) k.sdf_in[3 + j] = k.feat[j];
 	k.sdf_in[31] = 0;
 	// SDF MLP forward (nerf_network.h:159-160)
-	matvec(np.sdf_w0, 64, 32, k.sdf_in, k.z1, true);
-	matvec(np.sdf_w1, 16, 64, k.z1, k.sdf_out, false);
+	matvec(np.sdf_w0, 64, 32, k.sdf_in, k.z1, true, np.acc16);
+	matvec(np.sdf_w1, 16, 64, k.z1, k.sdf_out, false, np.acc16);
 	// SDF MLP backward of dL/dout = e0, parameter gradients ignored (nerf_network.h:163-176)
 	for (int j = 0; j < 64; ++j) {
 		float v = h2f(np.sdf_w1[0 * 64 + j]) * 1.0f;
 		if (!(h2f(k.z1[j]) > 0.f)) v = 0.f;
 		k.dz1[j] = f2h(v);
 	}
-	matvec_t(np.sdf_w0, 64, 32, k.dz1, k.dsdf_din, nullptr);
+	matvec_t(np.sdf_w0, 64, 32, k.dz1, k.dsdf_din, nullptr, np.acc16);
 	// encoding backward to the input (grid.h:527-554) + the direct xyz path (nerf_network.h:177-189)
 	float g[3] = {0.f, 0.f, 0.f};
 	for (int j = 0; j < 28; ++j) {
@@ -360,9 +385,9 @@ void forward_sample(const orc_ctx_s* c, const NetParams& np, const float coord[7
 	for (int j = 0; j < 48; ++j) k.c_in[j] = 0;
 	for (int j = 0; j < 16; ++j) k.c_in[j] = k.sdf_out[j];
 	for (int d = 0; d < 3; ++d) { k.c_in[32 + d] = f2h(k.x[d]); k.c_in[35 + d] = f2h(k.grad[d]); }
-	matvec(np.rgb_w0, 64, 48, k.c_in, k.h1, true);
-	matvec(np.rgb_w1, 64, 64, k.h1, k.h2, true);
-	matvec(np.rgb_w2, 16, 64, k.h2, k.r, false);
+	matvec(np.rgb_w0, 64, 48, k.c_in, k.h1, true, np.acc16);
+	matvec(np.rgb_w1, 64, 64, k.h1, k.h2, true, np.acc16);
+	matvec(np.rgb_w2, 16, 64, k.h2, k.r, false, np.acc16);
 	// output packing (nerf_network.h:221-250)
 	for (int j = 0; j < 16; ++j) out[j] = k.r[j];
 	out[3] = hadd(k.sdf_out[0], f2h(c->cfg.sdf_bias));
@@ -393,13 +418,63 @@ static inline void atomic_add(float* p, float v) {
 	*p += v;
 }
 
-// NerfNetwork::backward_impl (nerf_network.h:257-452) for one compacted sample.
-void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, const half_t dout[16], uint32_t batch_size, float* grid_grad, MlpGrads& mg) {
+// One sample's operands of the weight-gradient GEMMs and of the grid scatter, kept when the accumulation itself is emulated in
+// a second pass (orc_ctx_s::emul_*).
+struct SampleOps {
+	half_t dr[16], h2[64], dh2[64], h1[64], dh1[64], c_in[48], dso[16], z1[64], dz[64], sdf_in[32], dz1[64], ddin[32], front[64];
+	float x[3], dn[3];
+	half_t dsin[32], dsdf_din[32];
+};
+
+// Hash-grid scatter of one sample at one level: first order (kernel_grid_backward, grid.h:366-495; addend (float)grad * weight
+// narrowed to half, grid.h:415-416) and second order (kernel_grid_backward_input_backward_grid, grid.h:556-683) with
+// dL_dy = g2. add(entry * 2 + feature, addend) performs the accumulation.
+template <class Add>
+static inline void scatter_level(const orc_ctx_s* c, uint32_t level, const float x[3], const float g1[2], const float g2[2], const float dn[3], Add&& add) {
+	const uint32_t hashmap_size = c->offsets[level + 1] - c->offsets[level];
+	const float scale = c->scale[level];
+	const uint32_t res = c->resolution[level];
+	float pos[3]; uint32_t pg[3];
+	for (int d = 0; d < 3; ++d) pos_fract(x[d], &pos[d], &pg[d], scale);
+	for (uint32_t idx = 0; idx < 8; ++idx) {
+		float weight = 1;
+		uint32_t pl[3];
+		for (uint32_t d = 0; d < 3; ++d) {
+			if ((idx & (1u << d)) == 0) { weight *= 1 - pos[d]; pl[d] = pg[d]; }
+			else { weight *= pos[d]; pl[d] = pg[d] + 1; }
+		}
+		const uint32_t e = grid_entry(hashmap_size, res, pl);
+		for (int f = 0; f < 2; ++f) add(e * 2 + f, rh(g1[f] * weight)); // grid.h:415-416
+	}
+	for (uint32_t gd = 0; gd < 3; ++gd) {
+		const float grad_in = scale * dn[gd] * 1.0f; // grid.h:656
+		for (uint32_t idx = 0; idx < 4; ++idx) {
+			float weight = grad_in;
+			uint32_t pl[3];
+			for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+				const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+				if ((idx & (1u << ngd)) == 0) { weight *= 1 - pos[d]; pl[d] = pg[d]; }
+				else { weight *= pos[d]; pl[d] = pg[d] + 1; }
+			}
+			pl[gd] = pg[gd];
+			const uint32_t el = grid_entry(hashmap_size, res, pl);
+			for (int f = 0; f < 2; ++f) add(el * 2 + f, rh(g2[f] * -weight));
+			pl[gd] = pg[gd] + 1;
+			const uint32_t er = grid_entry(hashmap_size, res, pl);
+			for (int f = 0; f < 2; ++f) add(er * 2 + f, rh(g2[f] * weight));
+		}
+	}
+}
+
+// NerfNetwork::backward_impl (nerf_network.h:257-452) for one compacted sample. With `ops` the accumulations (weight-gradient
+// outer products, grid scatter) are left to the caller's second pass and only their operands are recorded.
+void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, const half_t dout[16], uint32_t batch_size, float* grid_grad, MlpGrads& mg, SampleOps* ops = nullptr) {
 	float* dW_sdf0 = mg.g1.data();
 	float* dW_sdf1 = dW_sdf0 + 64 * 32;
 	float* dW_rgb0 = mg.g1.data() + RNB_N_SDF_MLP_PARAMS;
 	float* dW_rgb1 = dW_rgb0 + 64 * 48;
 	float* dW_rgb2 = dW_rgb1 + 64 * 64;
+	const bool a16 = np.acc16;
 
 	// dL_drgb = rows 0..2 of dL_doutput (extract_rgb, common_operation.cuh:1010-1025)
 	half_t dr[16];
@@ -407,22 +482,22 @@ void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, c
 	for (int j = 0; j < 3; ++j) dr[j] = dout[j];
 	// color MLP backward (fully_fused_mlp.cu:914-1031)
 	half_t dh2[64], dh1[64], dcin[48];
-	outer_acc(dW_rgb2, 16, 64, dr, k.h2);
-	matvec_t(np.rgb_w2, 16, 64, dr, dh2, k.h2);
-	outer_acc(dW_rgb1, 64, 64, dh2, k.h1);
-	matvec_t(np.rgb_w1, 64, 64, dh2, dh1, k.h1);
-	outer_acc(dW_rgb0, 64, 48, dh1, k.c_in);
-	matvec_t(np.rgb_w0, 64, 48, dh1, dcin, nullptr);
+	if (!ops) outer_acc(dW_rgb2, 16, 64, dr, k.h2);
+	matvec_t(np.rgb_w2, 16, 64, dr, dh2, k.h2, a16);
+	if (!ops) outer_acc(dW_rgb1, 64, 64, dh2, k.h1);
+	matvec_t(np.rgb_w1, 64, 64, dh2, dh1, k.h1, a16);
+	if (!ops) outer_acc(dW_rgb0, 64, 48, dh1, k.c_in);
+	matvec_t(np.rgb_w0, 64, 48, dh1, dcin, nullptr, a16);
 	// dL/d(sdf mlp output) = dL_drgb_network_input[0:16], [0] += dL_doutput[3] (add_density_gradient, common_operation.cuh:1027-1039)
 	half_t dso[16];
 	for (int j = 0; j < 16; ++j) dso[j] = dcin[j];
 	dso[0] = hadd(dso[0], dout[3]);
 	// SDF MLP backward (nerf_network.h:298)
 	half_t dz[64], dsin[32];
-	outer_acc(dW_sdf1, 16, 64, dso, k.z1);
-	matvec_t(np.sdf_w1, 16, 64, dso, dz, k.z1);
-	outer_acc(dW_sdf0, 64, 32, dz, k.sdf_in);
-	matvec_t(np.sdf_w0, 64, 32, dz, dsin, nullptr);
+	if (!ops) outer_acc(dW_sdf1, 16, 64, dso, k.z1);
+	matvec_t(np.sdf_w1, 16, 64, dso, dz, k.z1, a16);
+	if (!ops) outer_acc(dW_sdf0, 64, 32, dz, k.sdf_in);
+	matvec_t(np.sdf_w0, 64, 32, dz, dsin, nullptr, a16);
 
 	// variance gradient: sum of dL_doutput row 7 (nerf_network.h:327-340)
 	mg.var += (double)h2f(dout[7]);
@@ -447,46 +522,15 @@ void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, c
 	}
 	for (int d = 0; d < 3; ++d) ddin[d] = f2h(dn[d]); // nerf_network.h:430-433
 
-	// hash-grid scatter: first order (kernel_grid_backward, grid.h:366-495) and second order
-	// (kernel_grid_backward_input_backward_grid, grid.h:556-683) with dL_dy = dsdf_din[3:31].
+	// hash-grid scatter: first order with dsin[3:31], second order with dL_dy = dsdf_din[3:31]
 	const uint32_t L = c->cfg.n_levels;
-	for (uint32_t level = 0; level < L; ++level) {
-		if (level > c->valid_level) continue;
-		float* gg = grid_grad + (uint64_t)c->offsets[level] * 2;
-		const uint32_t hashmap_size = c->offsets[level + 1] - c->offsets[level];
-		const float scale = c->scale[level];
-		const uint32_t res = c->resolution[level];
-		float pos[3]; uint32_t pg[3];
-		for (int d = 0; d < 3; ++d) pos_fract(k.x[d], &pos[d], &pg[d], scale);
-		const float g1[2] = {h2f(dsin[3 + level * 2]), h2f(dsin[3 + level * 2 + 1])};
-		for (uint32_t idx = 0; idx < 8; ++idx) {
-			float weight = 1;
-			uint32_t pl[3];
-			for (uint32_t d = 0; d < 3; ++d) {
-				if ((idx & (1u << d)) == 0) { weight *= 1 - pos[d]; pl[d] = pg[d]; }
-				else { weight *= pos[d]; pl[d] = pg[d] + 1; }
-			}
-			const uint32_t e = grid_entry(hashmap_size, res, pl);
-			for (int f = 0; f < 2; ++f) atomic_add(&gg[e * 2 + f], rh(g1[f] * weight)); // grid.h:415-416
-		}
-		const float g2[2] = {h2f(k.dsdf_din[3 + level * 2]), h2f(k.dsdf_din[3 + level * 2 + 1])};
-		for (uint32_t gd = 0; gd < 3; ++gd) {
-			const float grad_in = scale * dn[gd] * 1.0f; // grid.h:656
-			for (uint32_t idx = 0; idx < 4; ++idx) {
-				float weight = grad_in;
-				uint32_t pl[3];
-				for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-					const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-					if ((idx & (1u << ngd)) == 0) { weight *= 1 - pos[d]; pl[d] = pg[d]; }
-					else { weight *= pos[d]; pl[d] = pg[d] + 1; }
-				}
-				pl[gd] = pg[gd];
-				const uint32_t el = grid_entry(hashmap_size, res, pl);
-				for (int f = 0; f < 2; ++f) atomic_add(&gg[el * 2 + f], rh(g2[f] * -weight));
-				pl[gd] = pg[gd] + 1;
-				const uint32_t er = grid_entry(hashmap_size, res, pl);
-				for (int f = 0; f < 2; ++f) atomic_add(&gg[er * 2 + f], rh(g2[f] * weight));
-			}
+	if (!ops) {
+		for (uint32_t level = 0; level < L; ++level) {
+			if (level > c->valid_level) continue;
+			float* gg = grid_grad + (uint64_t)c->offsets[level] * 2;
+			const float g1[2] = {h2f(dsin[3 + level * 2]), h2f(dsin[3 + level * 2 + 1])};
+			const float g2[2] = {h2f(k.dsdf_din[3 + level * 2]), h2f(k.dsdf_din[3 + level * 2 + 1])};
+			scatter_level(c, level, k.x, g1, g2, dn, [&](uint32_t q, float v) { atomic_add(&gg[q], v); });
 		}
 	}
 
@@ -495,15 +539,23 @@ void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, c
 	//   dW0 += back ⊗ ddin;  dW1 += e0 ⊗ front
 	half_t front[64];
 	for (int o = 0; o < 64; ++o) {
-		float acc = 0.f;
-		for (int i = 0; i < 32; ++i) acc += h2f(np.sdf_w0[o * 32 + i]) * h2f(ddin[i]);
+		float acc = dot_h(np.sdf_w0 + (size_t)o * 32, 1, ddin, 1, 32, a16);
 		if (!(h2f(k.z1[o]) > 0.f)) acc = 0.f;
 		front[o] = f2h(acc);
 	}
-	float* d2W0 = mg.g2.data();
-	float* d2W1 = d2W0 + 64 * 32;
-	outer_acc(d2W0, 64, 32, k.dz1, ddin);
-	for (int j = 0; j < 64; ++j) d2W1[j] += 1.0f * h2f(front[j]);
+	if (!ops) {
+		float* d2W0 = mg.g2.data();
+		float* d2W1 = d2W0 + 64 * 32;
+		outer_acc(d2W0, 64, 32, k.dz1, ddin);
+		for (int j = 0; j < 64; ++j) d2W1[j] += 1.0f * h2f(front[j]);
+		return;
+	}
+	SampleOps& o = *ops;
+	std::memcpy(o.dr, dr, sizeof(dr)); std::memcpy(o.h2, k.h2, sizeof(o.h2)); std::memcpy(o.dh2, dh2, sizeof(dh2)); std::memcpy(o.h1, k.h1, sizeof(o.h1));
+	std::memcpy(o.dh1, dh1, sizeof(dh1)); std::memcpy(o.c_in, k.c_in, sizeof(o.c_in)); std::memcpy(o.dso, dso, sizeof(dso)); std::memcpy(o.z1, k.z1, sizeof(o.z1));
+	std::memcpy(o.dz, dz, sizeof(dz)); std::memcpy(o.sdf_in, k.sdf_in, sizeof(o.sdf_in)); std::memcpy(o.dz1, k.dz1, sizeof(o.dz1)); std::memcpy(o.ddin, ddin, sizeof(ddin));
+	std::memcpy(o.front, front, sizeof(front)); std::memcpy(o.dsin, dsin, sizeof(dsin)); std::memcpy(o.dsdf_din, k.dsdf_din, sizeof(o.dsdf_din));
+	for (int d = 0; d < 3; ++d) { o.x[d] = k.x[d]; o.dn[d] = dn[d]; }
 }
 
 // ======================================================================
@@ -1195,6 +1247,76 @@ void forward_infer(orc_ctx_s* c, const float* coords, uint32_t n, half_t* out, b
 	for (int64_t i = 0; i < (int64_t)n; ++i) forward_sample(c, np, coords + (size_t)i * 7, out + (size_t)i * 16, nullptr);
 }
 
+// dW[o][i] = sum_s Y_s[o] X_s[i] over the batch as the reference's split-K CUTLASS GEMM with half accumulators would round it
+// (EMULATION MODEL, see dot_h): 4096-sample slices (split_k_factor = batch / 2^12, fully_fused_mlp.cu:953), inside a slice the
+// accumulator is rounded to half after every 16-sample k-step, the slices' results are summed in half (GemmSplitKParallel's
+// reduction, cutlass_matmul.h:315-322).
+template <class GetY, class GetX>
+static float emulated_dw(uint32_t B, bool acc16, GetY&& y, GetX&& x) {
+	if (!acc16) {
+		float acc = 0.f;
+		for (uint32_t s = 0; s < B; ++s) acc += y(s) * x(s);
+		return acc;
+	}
+	half_t total = 0;
+	for (uint32_t s0 = 0; s0 < B; s0 += 4096) {
+		half_t acc = 0;
+		for (uint32_t k0 = s0; k0 < std::min(B, s0 + 4096); k0 += 16) {
+			float part = 0.f;
+			for (uint32_t s = k0; s < std::min(B, k0 + 16); ++s) part += y(s) * x(s);
+			acc = f2h(h2f(acc) + part);
+		}
+		total = hadd(total, acc);
+	}
+	return h2f(total);
+}
+
+// Second pass of forward_backward when an accumulation is emulated: the GEMMs and the scatter from the recorded operands.
+static void emulated_accumulate(orc_ctx_s* c, const std::vector<SampleOps>& ops) {
+	const uint32_t B = (uint32_t)ops.size();
+	const bool a16 = c->emul_fp16_acc;
+	float* g = c->grads.data();
+	struct Gemm { uint64_t off; int n_out, n_in; int which; };
+	const uint64_t s0 = c->off_sdf, r0 = c->off_rgb;
+	const Gemm gemms[5] = {{s0, 64, 32, 0}, {s0 + 2048, 16, 64, 1}, {r0, 64, 48, 2}, {r0 + 3072, 64, 64, 3}, {r0 + 7168, 16, 64, 4}};
+	for (const Gemm& G : gemms) {
+#pragma omp parallel for schedule(static)
+		for (int q = 0; q < G.n_out * G.n_in; ++q) {
+			const int o = q / G.n_in, i = q % G.n_in;
+			float first = 0.f, second = 0.f;
+			bool has_second = false;
+			switch (G.which) {
+				case 0: first = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dz[o]); }, [&](uint32_t s) { return h2f(ops[s].sdf_in[i]); });
+				        second = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dz1[o]); }, [&](uint32_t s) { return h2f(ops[s].ddin[i]); }); has_second = true; break;
+				case 1: first = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dso[o]); }, [&](uint32_t s) { return h2f(ops[s].z1[i]); });
+				        second = o == 0 ? emulated_dw(B, a16, [&](uint32_t) { return 1.0f; }, [&](uint32_t s) { return h2f(ops[s].front[i]); }) : 0.f; has_second = true; break;
+				case 2: first = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dh1[o]); }, [&](uint32_t s) { return h2f(ops[s].c_in[i]); }); break;
+				case 3: first = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dh2[o]); }, [&](uint32_t s) { return h2f(ops[s].h1[i]); }); break;
+				default: first = emulated_dw(B, a16, [&](uint32_t s) { return h2f(ops[s].dr[o]); }, [&](uint32_t s) { return h2f(ops[s].h2[i]); }); break;
+			}
+			float v = rh(first);                  // beta = 0: the GEMM result is stored as half
+			if (has_second) v = rh(second + v);   // beta = 1 (EGradientMode::Accumulate, fully_fused_mlp.cu:1127)
+			g[G.off + q] = v;
+		}
+	}
+	const uint32_t L = c->cfg.n_levels;
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int level = 0; level < (int)L; ++level) {
+		if ((uint32_t)level > c->valid_level) continue;
+		float* gg = g + c->off_grid + (uint64_t)c->offsets[level] * 2;
+		const size_t n = (size_t)(c->offsets[level + 1] - c->offsets[level]) * 2;
+		std::vector<half_t> gh(c->emul_half_atomics ? n : 0, 0);
+		for (uint32_t s = 0; s < B; ++s) {
+			const SampleOps& o = ops[s];
+			const float g1[2] = {h2f(o.dsin[3 + level * 2]), h2f(o.dsin[3 + level * 2 + 1])};
+			const float g2[2] = {h2f(o.dsdf_din[3 + level * 2]), h2f(o.dsdf_din[3 + level * 2 + 1])};
+			if (c->emul_half_atomics) scatter_level(c, level, o.x, g1, g2, o.dn, [&](uint32_t q, float v) { gh[q] = hadd(gh[q], f2h(v)); }); // atomicAdd(__half2), grid.h:416
+			else scatter_level(c, level, o.x, g1, g2, o.dn, [&](uint32_t q, float v) { gg[q] += v; });
+		}
+		if (c->emul_half_atomics) for (size_t q = 0; q < n; ++q) gg[q] = h2f(gh[q]);
+	}
+}
+
 void forward_backward(orc_ctx_s* c) {
 	const uint32_t B = c->cfg.target_batch_size;
 	NetParams np = net_params(c, false);
@@ -1205,6 +1327,8 @@ void forward_backward(orc_ctx_s* c) {
 	n_threads = omp_get_max_threads();
 #endif
 	std::vector<MlpGrads> partial(n_threads);
+	const bool emulate = c->emul_fp16_acc || c->emul_half_atomics;
+	std::vector<SampleOps> ops(emulate ? B : 0);
 #pragma omp parallel
 	{
 		int tid = 0;
@@ -1217,24 +1341,28 @@ void forward_backward(orc_ctx_s* c) {
 			FwdCtx k;
 			half_t out[16];
 			forward_sample(c, np, &c->coords_compacted[(size_t)i * 7], out, &k);
-			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B, grid_grad, mg);
+			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B, grid_grad, mg, emulate ? &ops[i] : nullptr);
 		}
 	}
-	// reduce: weight gradients are stored half after each GEMM (first order: beta = 0; second order: beta = 1)
-	const uint32_t n_mlp = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
 	double var = 0.0;
-	for (uint32_t q = 0; q < n_mlp; ++q) {
-		float s1 = 0.f;
-		for (int t = 0; t < n_threads; ++t) s1 += partial[t].g1[q];
-		float g = rh(s1);
-		if (q < RNB_N_SDF_MLP_PARAMS) {
-			float s2 = 0.f;
-			for (int t = 0; t < n_threads; ++t) s2 += partial[t].g2[q];
-			g = rh(s2 + g);
-		}
-		c->grads[c->off_sdf + q] = g;
-	}
 	for (int t = 0; t < n_threads; ++t) var += partial[t].var;
+	if (emulate) {
+		emulated_accumulate(c, ops);
+	} else {
+		// reduce: weight gradients are stored half after each GEMM (first order: beta = 0; second order: beta = 1)
+		const uint32_t n_mlp = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
+		for (uint32_t q = 0; q < n_mlp; ++q) {
+			float s1 = 0.f;
+			for (int t = 0; t < n_threads; ++t) s1 += partial[t].g1[q];
+			float g = rh(s1);
+			if (q < RNB_N_SDF_MLP_PARAMS) {
+				float s2 = 0.f;
+				for (int t = 0; t < n_threads; ++t) s2 += partial[t].g2[q];
+				g = rh(s2 + g);
+			}
+			c->grads[c->off_sdf + q] = g;
+		}
+	}
 	// variance (nerf_network.h:338-339: fp32 sum narrowed to half) and hash-grid gradients stay fp32 sums here;
 	// the optimizer narrows every gradient to half once (deviation D2), after the data-parallel all-reduce.
 	c->grads[c->off_var] = (float)var;
@@ -1411,6 +1539,8 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 	c->training_step = 0;
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
+	c->emul_fp16_acc = getenv("ORC_EMULATE_FP16_ACCUM") != nullptr && atoi(getenv("ORC_EMULATE_FP16_ACCUM")) != 0;
+	c->emul_half_atomics = getenv("ORC_EMULATE_HALF_ATOMICS") != nullptr && atoi(getenv("ORC_EMULATE_HALF_ATOMICS")) != 0;
 	*out = c;
 	return RNB_OK;
 }
