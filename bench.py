@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=8, help="steps of the CPU checker timed as the baseline (≈1.4 s each on the GPU box host)")
     ap.add_argument("--profile-steps", type=int, default=100, help="serialized steps after the timed region for the per-kernel HIP-event table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-end", type=int, default=2000, help="after the K timed steps the run continues (timed per step) to this training step, so that "
+                    "a short --steps still reports the whole window SURVEY.md 8(d) defines (steps 1000-2000); 0 = off")
+    ap.add_argument("--late-step", type=int, default=6000, help="then train on to this step and time --late-steps more: the converged regime (few samples "
+                    "per ray, ~95 k rays per step) that the >= 1e8 rays/s target is about; 0 = off")
+    ap.add_argument("--late-steps", type=int, default=200)
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
     return ap.parse_args()
@@ -106,6 +111,38 @@ def main():
         samples_before += last.measured_batch_size_before_compaction * world
     barrier()
     elapsed = time.perf_counter() - t0
+
+    def timed_run(n_steps):
+        """n_steps more training steps: (wall seconds, rays, compacted samples, per-step host milliseconds, last stats)."""
+        barrier()
+        tt0 = time.perf_counter()
+        r = smp = 0
+        per_step = []
+        stl = None
+        tp = tt0
+        for _ in range(n_steps):
+            stl = trainer.step()
+            tn = time.perf_counter()
+            per_step.append(1e3 * (tn - tp))
+            tp = tn
+            r += stl.rays_per_batch * world
+            smp += stl.measured_batch_size * world
+        barrier()
+        return time.perf_counter() - tt0, r, smp, per_step, stl
+
+    # The rest of the window the metric is defined on (SURVEY.md 8d: training steps 1000-2000), so that the record carries it
+    # even when --steps is small: the K steps above plus the steps up to --window-end.
+    window = None
+    first_timed = int(last.training_step) - args.steps
+    n_more = args.window_end - int(last.training_step) if args.window_end else 0
+    if n_more > 0:
+        w_el, w_rays, w_smp, w_ms, last_w = timed_run(n_more)
+        n_w = args.steps + n_more
+        window = {"first_step": first_timed, "steps": n_w, "ms_per_step": round(1e3 * (elapsed + w_el) / n_w, 4), "rays_per_s": round((rays + w_rays) / (elapsed + w_el), 1),
+                  "p50_ms_per_step": round(float(np.median(w_ms)), 4), "p90_ms_per_step": round(float(np.quantile(w_ms, 0.9)), 4),
+                  "rays_per_step_first": int(last.rays_per_batch), "rays_per_step_last": int(last_w.rays_per_batch),
+                  "samples_per_s_compacted": round((samples + w_smp) / (elapsed + w_el), 1)}
+        last = last_w
     # Per-kernel durations: HIP events on the step's stream, taken in a second pass over the same workload right after the
     # timed region. In the timed region the next step's march and the weight-gradient GEMMs run on side streams beside the
     # backward pass (cfg.overlap), where a per-kernel duration is not well defined; with the profiler on the library runs the
@@ -117,6 +154,14 @@ def main():
     barrier()
     prof = ctx.profile()
     ctx.profile_enable(False)
+    late = None
+    if args.late_step and args.late_steps > 0:
+        while ctx.training_step < args.late_step:
+            tail = trainer.step()
+        l_el, l_rays, l_smp, l_ms, tail = timed_run(args.late_steps)
+        late = {"first_step": int(tail.training_step) - args.late_steps, "steps": args.late_steps, "ms_per_step": round(1e3 * l_el / args.late_steps, 4),
+                "rays_per_s": round(l_rays / l_el, 1), "rays_per_step": round(l_rays / args.late_steps / world, 1), "p50_ms_per_step": round(float(np.median(l_ms)), 4),
+                "samples_per_s_compacted": round(l_smp / l_el, 1), "loss": round(float(tail.loss), 6)}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,11 +223,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config 4: synthetic %d-view %dx%d normals+mask sphere, %s --mask-weight 1.0, 2^18 compacted samples/step/GPU"
                                    % (args.views, args.res, args.res, "albedo + reflectance loss (NOT the metric's workload)" if args.albedo else "--no-albedo"),
-                       "burn_in_steps": args.burn_in, "first_timed_step": int(last.training_step) - args.steps,
+                       "burn_in_steps": args.burn_in, "first_timed_step": first_timed,
                        "rays_per_step_per_gpu": round(rays / args.steps / world, 1),
                        "samples_per_s_compacted": round(samples / elapsed, 1),
                        "samples_per_s_before_compaction": round(samples_before / elapsed, 1),
                        "loss": round(float(last.loss), 6), "parallelism": "dp%d" % world, "setup_s": round(setup_s, 1)},
+            "window_1000_2000": window,
+            "late_regime": late,
             "roofline": roofline,
             "rooflines_next": rooflines_next,
             "kernels_ms_per_step": kernels,

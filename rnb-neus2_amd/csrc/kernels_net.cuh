@@ -516,10 +516,9 @@ struct TrainScratch {
 	// feature-major [feature][B] halfs: operands of the weight-gradient GEMMs
 	half_t *h2, *h1, *cin, *z1, *sdfin, *dz1; // activations (cin: 32 compact rows)
 	half_t *dr, *dh2, *dh1, *dso, *dz, *ddin, *front; // gradients (dr: 16 rows, dso: 16 rows, ddin: 32 rows)
-	// per-sample inputs of the grid scatter, level-major
-	uint32_t* g1;  // [14][B] half2: dL/dfeat, first order
-	uint32_t* g2;  // [14][B] half2: d sdf / d feat (dL_denc_output of the double backward)
-	float* dn;     // [3][B]: dL/d(grad sdf)
+	// per-sample inputs of the grid scatter: one 8-byte gather per (level, sample), one 32-byte record per sample
+	uint32_t* g12; // [14][B][2] half2 pairs: {dL/dfeat (first order), d sdf / d feat (dL_denc_output of the double backward)}
+	float* srec;   // [B][8]: x y z | dL/d(grad sdf) (3) | 0 0
 	float* var_partial; // [n_waves_total] partial sums of dL_doutput[7]
 };
 
@@ -637,7 +636,7 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 #pragma unroll
 			for (int d = 0; d < 3; ++d) grad[d] += h2f(din[d]);
 #pragma unroll
-			for (int l = 0; l < 14; ++l) T.g2[(size_t)l * B + s] = pack_h2(din[3 + 2 * l], din[3 + 2 * l + 1]);
+			for (int l = 0; l < 14; ++l) T.g12[((size_t)l * B + s) * 2 + 1] = pack_h2(din[3 + 2 * l], din[3 + 2 * l + 1]);
 		}
 		{
 			h8 v0 = {f2h(c[0]), f2h(c[1]), f2h(c[2]), f2h(grad[0]), f2h(grad[1]), f2h(grad[2]), (half_t)0.f, (half_t)0.f};
@@ -737,8 +736,9 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 				v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
 				v += h2f(dout[8 + d]);                     // add_positions_view
 				dn[d] = v;
-				T.dn[(size_t)d * B + s] = v;
 			}
+			reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 0] = f4{c[0], c[1], c[2], dn[0]};
+			reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 1] = f4{dn[1], dn[2], 0.f, 0.f};
 			var_sum += h2f(dout[7]);
 		}
 		wave_lds_sync();
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 				for (int j = 0; j < 8; ++j) dsin[q * 8 + j] = v[j];
 			}
 #pragma unroll
-			for (int l = 0; l < 14; ++l) T.g1[(size_t)l * B + s] = pack_h2(dsin[3 + 2 * l], dsin[3 + 2 * l + 1]);
+			for (int l = 0; l < 14; ++l) T.g12[((size_t)l * B + s) * 2 + 0] = pack_h2(dsin[3 + 2 * l], dsin[3 + 2 * l + 1]);
 		}
 		// ddin = [half(dn) | dL/d(dL_dy) | 0] -> tC (32 wide)   (grid.h:858-883, nerf_network.h:423-433)
 		{
@@ -911,8 +911,9 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 			v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
 			v += h2f(dout[8 + d]);                     // add_positions_view (nerf_network.h:343-373)
 			dn[d] = v;
-			st32(T.dn, (uint32_t)d * B + s, v);
 		}
+		reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 0] = f4{c[0], c[1], c[2], dn[0]};
+		reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 1] = f4{dn[1], dn[2], 0.f, 0.f};
 		uint32_t* Xrow = reinterpret_cast<uint32_t*>(X + lane * S32);
 		uint32_t* Drow = reinterpret_cast<uint32_t*>(D + lane * S32);
 #pragma unroll 1
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		}
 		wave_lds_sync();
 #pragma unroll
-		for (uint32_t l = 0; l < 14; ++l) st32(T.g2, l * B + s, Xrow[l]); // g2[level] = d sdf / d feat of that level (dL_denc_output of the double backward)
+		for (uint32_t l = 0; l < 14; ++l) st32(T.g12, (l * B + s) * 2u + 1u, Xrow[l]); // d sdf / d feat of that level (dL_denc_output of the double backward)
 		wave_lds_sync(); // rows of X read
 		{ // dL/d in = W0^T dz -> rows of X; its feature columns are the first-order dL/dfeat of the grid
 			f4 acc[2][4];
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		}
 		wave_lds_sync();
 #pragma unroll
-		for (uint32_t l = 0; l < 14; ++l) st32(T.g1, l * B + s, Xrow[l]);
+		for (uint32_t l = 0; l < 14; ++l) st32(T.g12, (l * B + s) * 2u + 0u, Xrow[l]);
 		{ // front = (W0 ddin) (.) relu'(z1)   (fully_fused_mlp.cu:1097-1107)
 			f4 acc[4][4];
 			zero_acc<4>(acc);
@@ -1134,103 +1135,56 @@ __global__ __launch_bounds__(1024) void k_dw_finish(const DwFinishArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hash-grid gradient scatter, level-major (blockIdx.y = level) so one level's table stays in the XCD L2s.
-// First-order (grid.h:366-495) and second-order (grid.h:556-683) addends of a corner are summed in registers and
-// issued as one fp32 atomic per (corner, feature). Each addend is narrowed to half first, as the reference does.
+// Hash-grid gradient scatter: first-order (grid.h:366-495) and second-order (grid.h:556-683) addends of a corner, each
+// narrowed to half first as the reference does (grid.h:415-416), summed in fp32. Three mechanisms by level:
+//   coarse  (tables that fit in LDS together)      k_grid_scatter_lds        private LDS copy per workgroup
+//   middle  (a cell spans several march steps)     k_grid_scatter_quad_rl    run-length merge in registers, L2 atomics
+//   fine    (about one sample per cell)            k_bin_* + k_bin_accumulate  no global atomics at all, see below
+// (k_grid_scatter_quad, one L2 atomic per corner, remains for fine levels whose tables exceed the binning plan.)
 // ---------------------------------------------------------------------------------------------
 struct ScatterArgs {
-	const float* coords; // [B][7]
-	const uint32_t* g1;  // [14][B]
-	const uint32_t* g2;  // [14][B]
-	const float* dn;     // [3][B]
+	const uint32_t* g12; // [14][B][2]  TrainScratch::g12
+	const float* srec;   // [B][8]      TrainScratch::srec
 	uint32_t B;
 	float* grid_grad;    // GRADS_FP32 + off_grid
 };
 
-// K = consecutive samples per thread. Compacted samples are in ray order, so neighbouring samples fall into the same
-// cell of the coarse levels (cell >> march step): their addends are summed in registers and flushed once per cell run.
-// This removes the same-address atomic pile-up on the dense levels (level 0 alone cost 0.85 ms of a 2.1 ms scatter).
-template <int K>
-__global__ __launch_bounds__(256) void k_grid_scatter(const GridMeta G, const ScatterArgs a, const uint32_t level0) {
-	const uint32_t level = blockIdx.y + level0;
-	if (level > G.valid_level) return;
-	const uint32_t s0 = (blockIdx.x * blockDim.x + threadIdx.x) * K;
-	if (s0 >= a.B) return;
-	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
-	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
-	const float scale = G.scale[level];
-	const uint32_t res = G.resolution[level];
-	float acc[8][2];
-	uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+struct ScatterSample { float x, y, z, dn[3]; };
+__device__ __forceinline__ ScatterSample load_srec(const float* __restrict__ srec, const uint32_t s) {
+	const f4 a = reinterpret_cast<const f4*>(srec)[(size_t)s * 2 + 0];
+	const f4 b = reinterpret_cast<const f4*>(srec)[(size_t)s * 2 + 1];
+	return ScatterSample{a[0], a[1], a[2], {a[3], b[0], b[1]}};
+}
+
+// The addend of corner c = (cx, cy, cz) for one feature: first order weight = 1 * wx * wy * wz in the reference's multiplication
+// order (grid.h:478-490); second order (grid.h:655-681): for each gradient dimension the corner is a 'left' (-) or 'right' (+) end.
+__device__ __forceinline__ float corner_addend(const float g1, const float g2, const float scale, const float (&dn)[3], const float (&pos)[3], const uint32_t (&c)[3]) {
+	float w[3];
 #pragma unroll
-	for (int q = 0; q < 8; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
-	auto flush = [&]() {
+	for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
+	float weight = 1;
+	weight *= w[0]; weight *= w[1]; weight *= w[2];
+	float add = rh(g1 * weight);
 #pragma unroll
-		for (uint32_t idx = 0; idx < 8; ++idx) {
-			if (acc[idx][0] == 0.f && acc[idx][1] == 0.f) continue;
-			const uint32_t e = grid_entry(hashmap_size, res, cur[0] + (idx & 1u), cur[1] + ((idx >> 1) & 1u), cur[2] + ((idx >> 2) & 1u));
-			if (acc[idx][0] != 0.f) atomicAdd(gg + (size_t)e * 2 + 0, acc[idx][0]);
-			if (acc[idx][1] != 0.f) atomicAdd(gg + (size_t)e * 2 + 1, acc[idx][1]);
-			acc[idx][0] = 0.f; acc[idx][1] = 0.f;
+	for (uint32_t gd = 0; gd < 3; ++gd) {
+		float w2 = scale * dn[gd] * 1.0f;
+#pragma unroll
+		for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+			const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+			w2 *= w[d];
 		}
-	};
-#pragma unroll 1
-	for (int j = 0; j < K; ++j) {
-		const uint32_t s = s0 + j;
-		if (s >= a.B) break;
-		float pos[3];
-		uint32_t pg[3];
-		pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
-		pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
-		pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
-		if (K > 1 && (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2])) {
-			if (cur[0] != 0xffffffffu) flush();
-		}
-		cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-		const h2 q1 = unpack_h2(a.g1[(size_t)level * a.B + s]);
-		const h2 q2 = unpack_h2(a.g2[(size_t)level * a.B + s]);
-		const float g1[2] = {h2f(q1[0]), h2f(q1[1])};
-		const float g2[2] = {h2f(q2[0]), h2f(q2[1])};
-		const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
-#pragma unroll
-		for (uint32_t idx = 0; idx < 8; ++idx) {
-			float weight = 1;
-#pragma unroll
-			for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
-			acc[idx][0] += rh(g1[0] * weight);
-			acc[idx][1] += rh(g1[1] * weight);
-		}
-#pragma unroll
-		for (uint32_t gd = 0; gd < 3; ++gd) {
-			const float grad_in = scale * dn[gd] * 1.0f;
-#pragma unroll
-			for (uint32_t idx = 0; idx < 4; ++idx) {
-				float weight = grad_in;
-				uint32_t corner = 0;
-#pragma unroll
-				for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-					const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-					if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
-					else { weight *= pos[d]; corner |= (1u << d); }
-				}
-				acc[corner][0] += rh(g2[0] * -weight);
-				acc[corner][1] += rh(g2[1] * -weight);
-				acc[corner | (1u << gd)][0] += rh(g2[0] * weight);
-				acc[corner | (1u << gd)][1] += rh(g2[1] * weight);
-			}
-		}
-		if (K == 1) flush();
+		add += rh(g2 * (c[gd] ? w2 : -w2));
 	}
-	if (K > 1) flush();
+	return add;
 }
 
 // Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
 // global atomics pile up on a handful of addresses. Each workgroup accumulates its slice of the batch into a private copy
-// of the level's gradient table in LDS (ds_add_f32), with the same run-length merge in registers, then flushes the
-// non-zero entries once.
+// of the level's gradient table in LDS (ds_add_f32), with a run-length merge in registers (compacted samples are in ray
+// order, so neighbouring samples fall into the same cell), then flushes the non-zero entries once.
 struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_wg; }; // levels [0, n_levels)
 
-// All LDS-resident levels in one pass: the per-sample loads (coords, dn) are shared between the levels and the per-thread
+// All LDS-resident levels in one pass: the per-sample record is shared between the levels and the per-thread
 // dependent-load chain is K = 4 samples long. LDS layout: level l's table at float offset 2 * G.offsets[l].
 __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1245,22 +1199,18 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 	const uint32_t wg_begin = blockIdx.x * p.samples_per_wg;
 	const uint32_t wg_end = min(wg_begin + p.samples_per_wg, a.B);
 	for (uint32_t s0 = wg_begin + threadIdx.x * K; s0 < wg_end; s0 += blockDim.x * K) {
-		float cx[K], cy[K], cz[K], dn[K][3];
+		ScatterSample sm[K];
 #pragma unroll
-		for (int j = 0; j < K; ++j) { // all of the thread's loads that do not depend on the level are issued up front
-			const uint32_t s = min(s0 + j, wg_end - 1);
-			cx[j] = a.coords[(size_t)s * 7 + 0]; cy[j] = a.coords[(size_t)s * 7 + 1]; cz[j] = a.coords[(size_t)s * 7 + 2];
-			dn[j][0] = a.dn[s]; dn[j][1] = a.dn[(size_t)a.B + s]; dn[j][2] = a.dn[(size_t)2 * a.B + s];
-		}
+		for (int j = 0; j < K; ++j) sm[j] = load_srec(a.srec, min(s0 + j, wg_end - 1)); // the loads that do not depend on the level, up front
 #pragma unroll 1
 		for (uint32_t level = 0; level < NL; ++level) {
 			float* lt = tab + (size_t)G.offsets[level] * 2;
 			const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
 			const float scale = G.scale[level];
 			const uint32_t res = G.resolution[level];
-			uint32_t q1[K], q2[K];
+			uint2 q12[K];
 #pragma unroll
-			for (int j = 0; j < K; ++j) { const uint32_t s = min(s0 + j, wg_end - 1); q1[j] = a.g1[(size_t)level * a.B + s]; q2[j] = a.g2[(size_t)level * a.B + s]; }
+			for (int j = 0; j < K; ++j) q12[j] = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + min(s0 + j, wg_end - 1)];
 			float acc[8][2];
 			uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
@@ -1280,43 +1230,20 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 				if (s0 + j >= wg_end) break;
 				float pos[3];
 				uint32_t pg[3];
-				pos_fract(cx[j], scale, &pos[0], &pg[0]);
-				pos_fract(cy[j], scale, &pos[1], &pg[1]);
-				pos_fract(cz[j], scale, &pos[2], &pg[2]);
+				pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
+				pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
+				pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
 				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
 					if (cur[0] != 0xffffffffu) flush();
 				}
 				cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-				const h2 h1 = unpack_h2(q1[j]);
-				const h2 hh2 = unpack_h2(q2[j]);
-				const float g1[2] = {h2f(h1[0]), h2f(h1[1])};
-				const float g2[2] = {h2f(hh2[0]), h2f(hh2[1])};
+				const h2 h1 = unpack_h2(q12[j].x);
+				const h2 hh2 = unpack_h2(q12[j].y);
 #pragma unroll
 				for (uint32_t idx = 0; idx < 8; ++idx) {
-					float weight = 1;
-#pragma unroll
-					for (uint32_t d = 0; d < 3; ++d) weight *= (idx & (1u << d)) ? pos[d] : 1 - pos[d];
-					acc[idx][0] += rh(g1[0] * weight);
-					acc[idx][1] += rh(g1[1] * weight);
-				}
-#pragma unroll
-				for (uint32_t gd = 0; gd < 3; ++gd) {
-					const float grad_in = scale * dn[j][gd] * 1.0f;
-#pragma unroll
-					for (uint32_t idx = 0; idx < 4; ++idx) {
-						float weight = grad_in;
-						uint32_t corner = 0;
-#pragma unroll
-						for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-							const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-							if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
-							else { weight *= pos[d]; corner |= (1u << d); }
-						}
-						acc[corner][0] += rh(g2[0] * -weight);
-						acc[corner][1] += rh(g2[1] * -weight);
-						acc[corner | (1u << gd)][0] += rh(g2[0] * weight);
-						acc[corner | (1u << gd)][1] += rh(g2[1] * weight);
-					}
+					const uint32_t cc[3] = {idx & 1u, (idx >> 1) & 1u, (idx >> 2) & 1u};
+					acc[idx][0] += corner_addend(h2f(h1[0]), h2f(hh2[0]), scale, sm[j].dn, pos, cc);
+					acc[idx][1] += corner_addend(h2f(h1[1]), h2f(hh2[1]), scale, sm[j].dn, pos, cc);
 				}
 			}
 			flush();
@@ -1330,10 +1257,9 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 	}
 }
 
-// Fine (hashed) levels: every sample touches its own cells, so the cost is the number of atomic lane-operations. Four
-// adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a cell is the next table entry
-// (hash prime 1 / dense stride 1), so the four lanes' atomics fall on 16 contiguous bytes of one cache line and travel as
-// one request; each lane issues the 4 (dy, dz) corners.
+// One L2 atomic per corner. Four adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a
+// cell is the next table entry on dense levels and for even x on hashed ones (hash prime 1), so the four lanes' atomics mostly
+// fall on 16 contiguous bytes of one cache line and travel as one request; each lane issues the 4 (dy, dz) corners.
 __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, const ScatterArgs a, const uint32_t level0) {
 	const uint32_t level = blockIdx.y + level0;
 	if (level > G.valid_level) return;
@@ -1345,35 +1271,19 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
 	const float scale = G.scale[level];
 	const uint32_t res = G.resolution[level];
+	const ScatterSample sm = load_srec(a.srec, s);
 	float pos[3];
 	uint32_t pg[3];
-	pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
-	pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
-	pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
-	const float g1 = h2f(unpack_h2(a.g1[(size_t)level * a.B + s])[f]);
-	const float g2 = h2f(unpack_h2(a.g2[(size_t)level * a.B + s])[f]);
-	const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+	pos_fract(sm.x, scale, &pos[0], &pg[0]);
+	pos_fract(sm.y, scale, &pos[1], &pg[1]);
+	pos_fract(sm.z, scale, &pos[2], &pg[2]);
+	const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
+	const float g1 = h2f(unpack_h2(q12.x)[f]);
+	const float g2 = h2f(unpack_h2(q12.y)[f]);
 #pragma unroll
 	for (uint32_t yz = 0; yz < 4; ++yz) {
 		const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
-		float w[3];
-#pragma unroll
-		for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
-		// first order: weight = 1 * wx * wy * wz in the reference's multiplication order (grid.h:478-490)
-		float weight = 1;
-		weight *= w[0]; weight *= w[1]; weight *= w[2];
-		float add = rh(g1 * weight);
-		// second order (grid.h:655-681): for each gradient dimension the corner is a 'left' (-) or 'right' (+) end
-#pragma unroll
-		for (uint32_t gd = 0; gd < 3; ++gd) {
-			float w2 = scale * dn[gd] * 1.0f;
-#pragma unroll
-			for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-				const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-				w2 *= w[d];
-			}
-			add += rh(g2 * (c[gd] ? w2 : -w2));
-		}
+		const float add = corner_addend(g1, g2, scale, sm.dn, pos, c);
 		if (add != 0.f) {
 			const uint32_t e = grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]);
 			atomicAdd(gg + (size_t)e * 2 + f, add);
@@ -1381,7 +1291,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 	}
 }
 
-// Mid levels (cell a few march steps wide): the quad layout above, but each quad walks K consecutive samples of the
+// Middle levels (cell a few march steps wide): the quad layout above, but each quad walks K consecutive samples of the
 // ray-ordered batch and keeps the four (dy, dz) corner sums of its (dx, feature) in registers while the cell does not
 // change. Same-address lanes of one atomic instruction are serialised by the memory system (one request each), so merging
 // a cell run in registers divides the request count by the run length.
@@ -1419,41 +1329,209 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 	const uint32_t s_end = min(s0 + K, a.B);
 #pragma unroll 1
 	for (uint32_t s = s0; s < s_end; ++s) {
+		const ScatterSample sm = load_srec(a.srec, s);
 		float pos[3];
 		uint32_t pg[3];
-		pos_fract(a.coords[(size_t)s * 7 + 0], scale, &pos[0], &pg[0]);
-		pos_fract(a.coords[(size_t)s * 7 + 1], scale, &pos[1], &pg[1]);
-		pos_fract(a.coords[(size_t)s * 7 + 2], scale, &pos[2], &pg[2]);
+		pos_fract(sm.x, scale, &pos[0], &pg[0]);
+		pos_fract(sm.y, scale, &pos[1], &pg[1]);
+		pos_fract(sm.z, scale, &pos[2], &pg[2]);
 		if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
 			if (cur[0] != 0xffffffffu) flush();
 			cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
 		}
-		const float g1 = h2f(unpack_h2(a.g1[(size_t)level * a.B + s])[f]);
-		const float g2 = h2f(unpack_h2(a.g2[(size_t)level * a.B + s])[f]);
-		const float dn[3] = {a.dn[s], a.dn[(size_t)a.B + s], a.dn[(size_t)2 * a.B + s]};
+		const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
+		const float g1 = h2f(unpack_h2(q12.x)[f]);
+		const float g2 = h2f(unpack_h2(q12.y)[f]);
 #pragma unroll
 		for (uint32_t yz = 0; yz < 4; ++yz) {
 			const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
-			float w[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
-			float weight = 1;
-			weight *= w[0]; weight *= w[1]; weight *= w[2];
-			float add = rh(g1 * weight);
-#pragma unroll
-			for (uint32_t gd = 0; gd < 3; ++gd) {
-				float w2 = scale * dn[gd] * 1.0f;
-#pragma unroll
-				for (uint32_t ngd = 0; ngd < 2; ++ngd) {
-					const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
-					w2 *= w[d];
-				}
-				add += rh(g2 * (c[gd] ? w2 : -w2));
-			}
-			acc[yz] += add;
+			acc[yz] += corner_addend(g1, g2, scale, sm.dn, pos, c);
 		}
 	}
 	flush();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fine levels without global atomics. On these levels (cells about a march step wide, hashed tables) every sample touches its
+// own 8 entries, so merging is impossible and the L2 atomic-request rate (~21 G/s measured, tools/probe_atomics*.hip) sets the
+// time: 0.16 ms of a 0.27 ms scatter in round 1. Instead, a level's table is cut into chunks of 2^14 entries (128 KB of fp32
+// pairs = one workgroup's LDS), and the (sample, dy, dz) x-pairs of the batch are binned by the chunk they fall into:
+//   k_bin_count   per (workgroup, chunk) histogram of the pairs               } depend on the sample positions only: they run
+//   k_bin_scan    exclusive offsets: exact packing, nothing can overflow      } on a side stream beside k_fwd_bwd
+//   k_bin_place   4-byte records (sample << 4 | yz << 2 | mode) into the chunk's segment
+//   k_bin_accumulate  one workgroup per (level, chunk): gathers each record's sample (32 B) and gradient pair (8 B), forms the
+//                 addends, ds_add_f32 into the chunk's LDS image, then writes the image to the gradient table with plain
+//                 coalesced stores (it owns the chunk: the table need not be cleared beforehand).
+// The two entries of an x-pair (x, x+1) differ in low index bits only (hash prime 1: (x ^ h) vs ((x+1) ^ h); dense: +1), so
+// they share a chunk except when a carry crosses bit 14; such a pair is recorded twice with mode = which half to apply.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t BIN_CHUNK_LOG2 = 14;
+constexpr uint32_t BIN_CHUNK = 1u << BIN_CHUNK_LOG2;
+constexpr uint32_t BIN_MAX_ITEMS = 512;      // (level, chunk) pairs of a plan
+constexpr uint32_t BIN_SAMPLES_PER_WG = 1024; // of the count / place passes (256 threads x 4 samples)
+
+struct BinPlan {
+	uint32_t level0, n_levels;            // binned levels [level0, level0 + n_levels)
+	uint32_t item0[RNB_MAX_LEVELS + 1];   // first item of level level0 + i; item0[n_levels] = number of items
+	uint32_t n_wg;                        // workgroups of the count / place passes
+	uint32_t rec_cap;                     // records reserved per level (8 B: every pair split)
+};
+struct BinBuffers {
+	uint32_t* counts;     // [n_wg][n_items] pairs of workgroup w in item i
+	uint32_t* wg_base;    // [n_wg][n_items] offset of workgroup w's records inside the item's segment
+	uint32_t* item_range; // [n_items][2] {first record inside the level's region, number of records}
+	uint32_t* records;    // [n_levels][rec_cap]
+};
+
+// the two table entries of x-pair yz of the cell pg, and the item-local chunk index of each
+__device__ __forceinline__ void bin_pair_entries(const uint32_t size, const uint32_t res, const uint32_t (&pg)[3], const uint32_t yz, uint32_t& e0, uint32_t& e1) {
+	e0 = grid_entry(size, res, pg[0], pg[1] + (yz & 1u), pg[2] + (yz >> 1));
+	e1 = grid_entry(size, res, pg[0] + 1u, pg[1] + (yz & 1u), pg[2] + (yz >> 1));
+}
+
+template <bool PLACE>
+__global__ __launch_bounds__(256) void k_bin_count_place(const GridMeta G, const BinPlan plan, const BinBuffers buf, const float* __restrict__ coords, const uint32_t B) {
+	__shared__ uint32_t hist[BIN_MAX_ITEMS];
+	__shared__ uint32_t base[BIN_MAX_ITEMS];
+	const uint32_t n_items = plan.item0[plan.n_levels];
+	for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) hist[q] = 0;
+	if (PLACE) {
+		for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) base[q] = buf.item_range[q * 2] + buf.wg_base[(size_t)blockIdx.x * n_items + q];
+	}
+	__syncthreads();
+	const uint32_t s_begin = blockIdx.x * BIN_SAMPLES_PER_WG;
+#pragma unroll 1
+	for (uint32_t j = 0; j < BIN_SAMPLES_PER_WG / 256; ++j) {
+		const uint32_t s = s_begin + j * 256 + threadIdx.x;
+		if (s >= B) break;
+		const float x = coords[(size_t)s * 7 + 0], y = coords[(size_t)s * 7 + 1], z = coords[(size_t)s * 7 + 2];
+#pragma unroll 1
+		for (uint32_t li = 0; li < plan.n_levels; ++li) {
+			const uint32_t level = plan.level0 + li;
+			if (level > G.valid_level) break;
+			const uint32_t size = G.offsets[level + 1] - G.offsets[level];
+			const uint32_t res = G.resolution[level];
+			const float scale = G.scale[level];
+			float pos;
+			uint32_t pg[3];
+			pos_fract(x, scale, &pos, &pg[0]);
+			pos_fract(y, scale, &pos, &pg[1]);
+			pos_fract(z, scale, &pos, &pg[2]);
+			uint32_t* rec = PLACE ? buf.records + (size_t)li * plan.rec_cap : nullptr;
+#pragma unroll
+			for (uint32_t yz = 0; yz < 4; ++yz) {
+				uint32_t e0, e1;
+				bin_pair_entries(size, res, pg, yz, e0, e1);
+				const uint32_t i0 = plan.item0[li] + (e0 >> BIN_CHUNK_LOG2), i1 = plan.item0[li] + (e1 >> BIN_CHUNK_LOG2);
+				if (i0 == i1) {
+					const uint32_t r = atomicAdd(&hist[i0], 1u);
+					if (PLACE) rec[base[i0] + r] = (s << 4) | (yz << 2);
+				} else {
+					const uint32_t r0 = atomicAdd(&hist[i0], 1u);
+					const uint32_t r1 = atomicAdd(&hist[i1], 1u);
+					if (PLACE) { rec[base[i0] + r0] = (s << 4) | (yz << 2) | 1u; rec[base[i1] + r1] = (s << 4) | (yz << 2) | 2u; }
+				}
+			}
+		}
+	}
+	if (!PLACE) {
+		__syncthreads();
+		for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) buf.counts[(size_t)blockIdx.x * n_items + q] = hist[q];
+	}
+}
+
+// One workgroup: per item the running sum over the count pass's workgroups, then per level the exclusive sum over its items.
+__global__ __launch_bounds__(BIN_MAX_ITEMS) void k_bin_scan(const BinPlan plan, const BinBuffers buf) {
+	__shared__ uint32_t total[BIN_MAX_ITEMS];
+	const uint32_t n_items = plan.item0[plan.n_levels];
+	const uint32_t i = threadIdx.x;
+	if (i < n_items) {
+		uint32_t run = 0;
+		for (uint32_t w = 0; w < plan.n_wg; ++w) {
+			const uint32_t c = buf.counts[(size_t)w * n_items + i];
+			buf.wg_base[(size_t)w * n_items + i] = run;
+			run += c;
+		}
+		total[i] = run;
+	}
+	__syncthreads();
+	if (i < n_items) {
+		uint32_t li = 0;
+		while (li + 1 < plan.n_levels && i >= plan.item0[li + 1]) ++li;
+		uint32_t start = 0;
+		for (uint32_t q = plan.item0[li]; q < i; ++q) start += total[q];
+		buf.item_range[i * 2 + 0] = start;
+		buf.item_range[i * 2 + 1] = total[i];
+	}
+}
+
+constexpr size_t LDS_BIN = (size_t)BIN_CHUNK * 2 * sizeof(float);
+
+__global__ __launch_bounds__(1024) void k_bin_accumulate(const GridMeta G, const BinPlan plan, const BinBuffers buf, const ScatterArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	float* tab = reinterpret_cast<float*>(smem_raw);
+	const uint32_t n_items = plan.item0[plan.n_levels];
+#pragma unroll 1
+	for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+		uint32_t li = 0;
+#pragma unroll 1
+		for (uint32_t q = 1; q < plan.n_levels; ++q) if (item >= plan.item0[q]) li = q;
+		const uint32_t level = plan.level0 + li;
+		if (level > G.valid_level) continue;
+		const uint32_t chunk = item - plan.item0[li];
+		const uint32_t size = G.offsets[level + 1] - G.offsets[level];
+		const uint32_t res = G.resolution[level];
+		const float scale = G.scale[level];
+		const uint32_t e_base = chunk << BIN_CHUNK_LOG2;
+		const uint32_t n_local = min(BIN_CHUNK, size - e_base) * 2; // floats of this chunk (a multiple of 16: tables are multiples of 8 entries)
+		for (uint32_t q = threadIdx.x * 4; q < n_local; q += 1024 * 4) *reinterpret_cast<f4*>(tab + q) = f4{0.f, 0.f, 0.f, 0.f};
+		__syncthreads();
+		const uint32_t first = buf.item_range[item * 2 + 0], count = buf.item_range[item * 2 + 1];
+		const uint32_t* __restrict__ rec = buf.records + (size_t)li * plan.rec_cap + first;
+		const uint2* __restrict__ g12 = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+		constexpr int U = 4; // records in flight per thread: their two gathers each are independent
+#pragma unroll 1
+		for (uint32_t r0 = threadIdx.x; r0 < count; r0 += 1024 * U) {
+			uint32_t rc[U];
+			ScatterSample sm[U];
+			uint2 q12[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) { const uint32_t r = r0 + u * 1024; rc[u] = r < count ? rec[r] : 0xffffffffu; }
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const uint32_t s = rc[u] == 0xffffffffu ? 0u : (rc[u] >> 4);
+				sm[u] = load_srec(a.srec, s);
+				q12[u] = g12[s];
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (rc[u] == 0xffffffffu) continue;
+				const uint32_t yz = (rc[u] >> 2) & 3u, mode = rc[u] & 3u;
+				float pos[3];
+				uint32_t pg[3];
+				pos_fract(sm[u].x, scale, &pos[0], &pg[0]);
+				pos_fract(sm[u].y, scale, &pos[1], &pg[1]);
+				pos_fract(sm[u].z, scale, &pos[2], &pg[2]);
+				uint32_t e[2];
+				bin_pair_entries(size, res, pg, yz, e[0], e[1]);
+				const h2 h1 = unpack_h2(q12[u].x), hh2 = unpack_h2(q12[u].y);
+#pragma unroll
+				for (uint32_t dx = 0; dx < 2; ++dx) {
+					if (mode == 2u - dx) continue; // mode 1: only dx = 0 belongs to this chunk, mode 2: only dx = 1
+					const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+					const float add0 = corner_addend(h2f(h1[0]), h2f(hh2[0]), scale, sm[u].dn, pos, c);
+					const float add1 = corner_addend(h2f(h1[1]), h2f(hh2[1]), scale, sm[u].dn, pos, c);
+					float* dst = tab + (e[dx] - e_base) * 2u;
+					if (add0 != 0.f) atomicAdd(dst + 0, add0);
+					if (add1 != 0.f) atomicAdd(dst + 1, add1);
+				}
+			}
+		}
+		__syncthreads();
+		float* gg = a.grid_grad + ((size_t)G.offsets[level] + e_base) * 2;
+		for (uint32_t q = threadIdx.x * 4; q < n_local; q += 1024 * 4) *reinterpret_cast<f4*>(gg + q) = *reinterpret_cast<const f4*>(tab + q);
+		__syncthreads();
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
