@@ -1139,8 +1139,14 @@ __global__ __launch_bounds__(1024) void k_dw_finish(const DwFinishArgs a) {
 // narrowed to half first as the reference does (grid.h:415-416), summed in fp32. Three mechanisms by level:
 //   coarse  (tables that fit in LDS together)      k_grid_scatter_lds        private LDS copy per workgroup
 //   middle  (a cell spans several march steps)     k_grid_scatter_quad_rl    run-length merge in registers, L2 atomics
-//   fine    (about one sample per cell)            k_bin_* + k_bin_accumulate  no global atomics at all, see below
-// (k_grid_scatter_quad, one L2 atomic per corner, remains for fine levels whose tables exceed the binning plan.)
+//   fine    (about one sample per cell)            k_grid_scatter_quad       one L2 atomic per corner
+// What bounds the two atomic kernels (tools/probe_atomics4.hip, MI355X): the device retires ~21 G atomic LINES per second -- one
+// 64-byte line of one instruction, whether 1 or 16 of its lanes fall into it -- independent of the number of CUs issuing them
+// (64 workgroups reach the same rate as 4096), of scope and of data type. Middle + fine levels put ~2.9 M lines on that path per
+// step: 0.14 ms. A variant without global atomics for the fine levels (pairs binned by 4096-entry table chunk, accumulated in an
+// fp64 LDS image per chunk, written with plain stores) was built and measured in round 2: its accumulate pass is bound by the CU
+// side (8.4 M records x 3 gather lines + ~160 VALU instructions each: 0.10 ms for 8 levels, not better than the atomics' 0.13 ms)
+// and its binning passes (8.4 M scattered 4-byte record stores) contend with k_fwd_bwd; dropped, see DESIGN.md.
 // ---------------------------------------------------------------------------------------------
 struct ScatterArgs {
 	const uint32_t* g12; // [14][B][2]  TrainScratch::g12
@@ -1349,189 +1355,6 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 		}
 	}
 	flush();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fine levels without global atomics. On these levels (cells about a march step wide, hashed tables) every sample touches its
-// own 8 entries, so merging is impossible and the L2 atomic-request rate (~21 G/s measured, tools/probe_atomics*.hip) sets the
-// time: 0.16 ms of a 0.27 ms scatter in round 1. Instead, a level's table is cut into chunks of 2^14 entries (128 KB of fp32
-// pairs = one workgroup's LDS), and the (sample, dy, dz) x-pairs of the batch are binned by the chunk they fall into:
-//   k_bin_count   per (workgroup, chunk) histogram of the pairs               } depend on the sample positions only: they run
-//   k_bin_scan    exclusive offsets: exact packing, nothing can overflow      } on a side stream beside k_fwd_bwd
-//   k_bin_place   4-byte records (sample << 4 | yz << 2 | mode) into the chunk's segment
-//   k_bin_accumulate  one workgroup per (level, chunk): gathers each record's sample (32 B) and gradient pair (8 B), forms the
-//                 addends, ds_add_f32 into the chunk's LDS image, then writes the image to the gradient table with plain
-//                 coalesced stores (it owns the chunk: the table need not be cleared beforehand).
-// The two entries of an x-pair (x, x+1) differ in low index bits only (hash prime 1: (x ^ h) vs ((x+1) ^ h); dense: +1), so
-// they share a chunk except when a carry crosses bit 14; such a pair is recorded twice with mode = which half to apply.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t BIN_CHUNK_LOG2 = 14;
-constexpr uint32_t BIN_CHUNK = 1u << BIN_CHUNK_LOG2;
-constexpr uint32_t BIN_MAX_ITEMS = 512;      // (level, chunk) pairs of a plan
-constexpr uint32_t BIN_SAMPLES_PER_WG = 1024; // of the count / place passes (256 threads x 4 samples)
-
-struct BinPlan {
-	uint32_t level0, n_levels;            // binned levels [level0, level0 + n_levels)
-	uint32_t item0[RNB_MAX_LEVELS + 1];   // first item of level level0 + i; item0[n_levels] = number of items
-	uint32_t n_wg;                        // workgroups of the count / place passes
-	uint32_t rec_cap;                     // records reserved per level (8 B: every pair split)
-};
-struct BinBuffers {
-	uint32_t* counts;     // [n_wg][n_items] pairs of workgroup w in item i
-	uint32_t* wg_base;    // [n_wg][n_items] offset of workgroup w's records inside the item's segment
-	uint32_t* item_range; // [n_items][2] {first record inside the level's region, number of records}
-	uint32_t* records;    // [n_levels][rec_cap]
-};
-
-// the two table entries of x-pair yz of the cell pg, and the item-local chunk index of each
-__device__ __forceinline__ void bin_pair_entries(const uint32_t size, const uint32_t res, const uint32_t (&pg)[3], const uint32_t yz, uint32_t& e0, uint32_t& e1) {
-	e0 = grid_entry(size, res, pg[0], pg[1] + (yz & 1u), pg[2] + (yz >> 1));
-	e1 = grid_entry(size, res, pg[0] + 1u, pg[1] + (yz & 1u), pg[2] + (yz >> 1));
-}
-
-template <bool PLACE>
-__global__ __launch_bounds__(256) void k_bin_count_place(const GridMeta G, const BinPlan plan, const BinBuffers buf, const float* __restrict__ coords, const uint32_t B) {
-	__shared__ uint32_t hist[BIN_MAX_ITEMS];
-	__shared__ uint32_t base[BIN_MAX_ITEMS];
-	const uint32_t n_items = plan.item0[plan.n_levels];
-	for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) hist[q] = 0;
-	if (PLACE) {
-		for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) base[q] = buf.item_range[q * 2] + buf.wg_base[(size_t)blockIdx.x * n_items + q];
-	}
-	__syncthreads();
-	const uint32_t s_begin = blockIdx.x * BIN_SAMPLES_PER_WG;
-#pragma unroll 1
-	for (uint32_t j = 0; j < BIN_SAMPLES_PER_WG / 256; ++j) {
-		const uint32_t s = s_begin + j * 256 + threadIdx.x;
-		if (s >= B) break;
-		const float x = coords[(size_t)s * 7 + 0], y = coords[(size_t)s * 7 + 1], z = coords[(size_t)s * 7 + 2];
-#pragma unroll 1
-		for (uint32_t li = 0; li < plan.n_levels; ++li) {
-			const uint32_t level = plan.level0 + li;
-			if (level > G.valid_level) break;
-			const uint32_t size = G.offsets[level + 1] - G.offsets[level];
-			const uint32_t res = G.resolution[level];
-			const float scale = G.scale[level];
-			float pos;
-			uint32_t pg[3];
-			pos_fract(x, scale, &pos, &pg[0]);
-			pos_fract(y, scale, &pos, &pg[1]);
-			pos_fract(z, scale, &pos, &pg[2]);
-			uint32_t* rec = PLACE ? buf.records + (size_t)li * plan.rec_cap : nullptr;
-#pragma unroll
-			for (uint32_t yz = 0; yz < 4; ++yz) {
-				uint32_t e0, e1;
-				bin_pair_entries(size, res, pg, yz, e0, e1);
-				const uint32_t i0 = plan.item0[li] + (e0 >> BIN_CHUNK_LOG2), i1 = plan.item0[li] + (e1 >> BIN_CHUNK_LOG2);
-				if (i0 == i1) {
-					const uint32_t r = atomicAdd(&hist[i0], 1u);
-					if (PLACE) rec[base[i0] + r] = (s << 4) | (yz << 2);
-				} else {
-					const uint32_t r0 = atomicAdd(&hist[i0], 1u);
-					const uint32_t r1 = atomicAdd(&hist[i1], 1u);
-					if (PLACE) { rec[base[i0] + r0] = (s << 4) | (yz << 2) | 1u; rec[base[i1] + r1] = (s << 4) | (yz << 2) | 2u; }
-				}
-			}
-		}
-	}
-	if (!PLACE) {
-		__syncthreads();
-		for (uint32_t q = threadIdx.x; q < n_items; q += blockDim.x) buf.counts[(size_t)blockIdx.x * n_items + q] = hist[q];
-	}
-}
-
-// One workgroup: per item the running sum over the count pass's workgroups, then per level the exclusive sum over its items.
-__global__ __launch_bounds__(BIN_MAX_ITEMS) void k_bin_scan(const BinPlan plan, const BinBuffers buf) {
-	__shared__ uint32_t total[BIN_MAX_ITEMS];
-	const uint32_t n_items = plan.item0[plan.n_levels];
-	const uint32_t i = threadIdx.x;
-	if (i < n_items) {
-		uint32_t run = 0;
-		for (uint32_t w = 0; w < plan.n_wg; ++w) {
-			const uint32_t c = buf.counts[(size_t)w * n_items + i];
-			buf.wg_base[(size_t)w * n_items + i] = run;
-			run += c;
-		}
-		total[i] = run;
-	}
-	__syncthreads();
-	if (i < n_items) {
-		uint32_t li = 0;
-		while (li + 1 < plan.n_levels && i >= plan.item0[li + 1]) ++li;
-		uint32_t start = 0;
-		for (uint32_t q = plan.item0[li]; q < i; ++q) start += total[q];
-		buf.item_range[i * 2 + 0] = start;
-		buf.item_range[i * 2 + 1] = total[i];
-	}
-}
-
-constexpr size_t LDS_BIN = (size_t)BIN_CHUNK * 2 * sizeof(float);
-
-__global__ __launch_bounds__(1024) void k_bin_accumulate(const GridMeta G, const BinPlan plan, const BinBuffers buf, const ScatterArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	float* tab = reinterpret_cast<float*>(smem_raw);
-	const uint32_t n_items = plan.item0[plan.n_levels];
-#pragma unroll 1
-	for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-		uint32_t li = 0;
-#pragma unroll 1
-		for (uint32_t q = 1; q < plan.n_levels; ++q) if (item >= plan.item0[q]) li = q;
-		const uint32_t level = plan.level0 + li;
-		if (level > G.valid_level) continue;
-		const uint32_t chunk = item - plan.item0[li];
-		const uint32_t size = G.offsets[level + 1] - G.offsets[level];
-		const uint32_t res = G.resolution[level];
-		const float scale = G.scale[level];
-		const uint32_t e_base = chunk << BIN_CHUNK_LOG2;
-		const uint32_t n_local = min(BIN_CHUNK, size - e_base) * 2; // floats of this chunk (a multiple of 16: tables are multiples of 8 entries)
-		for (uint32_t q = threadIdx.x * 4; q < n_local; q += 1024 * 4) *reinterpret_cast<f4*>(tab + q) = f4{0.f, 0.f, 0.f, 0.f};
-		__syncthreads();
-		const uint32_t first = buf.item_range[item * 2 + 0], count = buf.item_range[item * 2 + 1];
-		const uint32_t* __restrict__ rec = buf.records + (size_t)li * plan.rec_cap + first;
-		const uint2* __restrict__ g12 = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
-		constexpr int U = 4; // records in flight per thread: their two gathers each are independent
-#pragma unroll 1
-		for (uint32_t r0 = threadIdx.x; r0 < count; r0 += 1024 * U) {
-			uint32_t rc[U];
-			ScatterSample sm[U];
-			uint2 q12[U];
-#pragma unroll
-			for (int u = 0; u < U; ++u) { const uint32_t r = r0 + u * 1024; rc[u] = r < count ? rec[r] : 0xffffffffu; }
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				const uint32_t s = rc[u] == 0xffffffffu ? 0u : (rc[u] >> 4);
-				sm[u] = load_srec(a.srec, s);
-				q12[u] = g12[s];
-			}
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				if (rc[u] == 0xffffffffu) continue;
-				const uint32_t yz = (rc[u] >> 2) & 3u, mode = rc[u] & 3u;
-				float pos[3];
-				uint32_t pg[3];
-				pos_fract(sm[u].x, scale, &pos[0], &pg[0]);
-				pos_fract(sm[u].y, scale, &pos[1], &pg[1]);
-				pos_fract(sm[u].z, scale, &pos[2], &pg[2]);
-				uint32_t e[2];
-				bin_pair_entries(size, res, pg, yz, e[0], e[1]);
-				const h2 h1 = unpack_h2(q12[u].x), hh2 = unpack_h2(q12[u].y);
-#pragma unroll
-				for (uint32_t dx = 0; dx < 2; ++dx) {
-					if (mode == 2u - dx) continue; // mode 1: only dx = 0 belongs to this chunk, mode 2: only dx = 1
-					const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
-					const float add0 = corner_addend(h2f(h1[0]), h2f(hh2[0]), scale, sm[u].dn, pos, c);
-					const float add1 = corner_addend(h2f(h1[1]), h2f(hh2[1]), scale, sm[u].dn, pos, c);
-					float* dst = tab + (e[dx] - e_base) * 2u;
-					if (add0 != 0.f) atomicAdd(dst + 0, add0);
-					if (add1 != 0.f) atomicAdd(dst + 1, add1);
-				}
-			}
-		}
-		__syncthreads();
-		float* gg = a.grid_grad + ((size_t)G.offsets[level] + e_base) * 2;
-		for (uint32_t q = threadIdx.x * 4; q < n_local; q += 1024 * 4) *reinterpret_cast<f4*>(gg + q) = *reinterpret_cast<const f4*>(tab + q);
-		__syncthreads();
-	}
 }
 
 // ---------------------------------------------------------------------------------------------

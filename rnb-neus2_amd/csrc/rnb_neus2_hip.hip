@@ -67,9 +67,9 @@ uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid
 
 // Per-kernel-group timing with HIP events on the caller's stream (bench.py's roofline leg).
 enum ProfId { P_NONE = -1, P_GRID_SAMPLES = 0, P_POINT_QUERY, P_EMA_BITFIELD, P_MARCH_COUNT, P_SCAN_RAYS, P_MARCH_WRITE, P_FORWARD, P_LOSS_PASS1,
-              P_SCAN_COMPACT, P_LOSS_PASS2, P_BIN, P_FWD_BWD, P_DW, P_SCATTER, P_ADAM, P_REDUCE, P_COUNT };
+              P_SCAN_COMPACT, P_LOSS_PASS2, P_FWD_BWD, P_DW, P_SCATTER, P_ADAM, P_REDUCE, P_COUNT };
 static const char* const PROF_NAMES[P_COUNT] = {"k_grid_samples", "k_point_query", "k_ema_grid+bitfield", "k_march_count", "k_scan_rays", "k_march_write", "k_forward",
-                                                "k_loss_pass1", "k_scan_compact", "k_loss_pass2+k_rollover", "k_bin_count+scan+place", "k_fwd_bwd", "k_dw*7+k_dw_finish", "k_grid_scatter", "k_adam_ema", "k_reduce_losses"};
+                                                "k_loss_pass1", "k_scan_compact", "k_loss_pass2+k_rollover", "k_fwd_bwd", "k_dw*7+k_dw_finish", "k_grid_scatter", "k_adam_ema", "k_reduce_losses"};
 struct Profiler {
 	bool on = false;
 	std::vector<hipEvent_t> ev;
@@ -142,7 +142,6 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false;
-		bool scatter_quad = false; // RNB_SCATTER_QUAD: L2-atomic quad kernel on the fine levels instead of the binned LDS accumulation (A/B aid)
 		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
@@ -156,10 +155,6 @@ struct rnb_ctx {
 	DevBuf<half_t> fm;       // feature-major operand arrays
 	DevBuf<uint32_t> g12;
 	DevBuf<float> srec, var_partial, dw_partial;
-	// binned scatter of the fine levels (kernels_net.cuh, k_bin_*)
-	DevBuf<uint32_t> bin_counts, bin_wg_base, bin_item_range, bin_records;
-	BinPlan bin_plan;
-	BinBuffers bin_buf;
 	TrainScratch ts;
 	uint32_t dw_nwg = 0, dw_chunk = 0;
 	uint32_t fwd_grid = 0;
@@ -180,12 +175,12 @@ struct rnb_ctx {
 	// generation + march — which depends on the occupancy bitfield and the RNG, not on the weights — runs beside this step's
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
-	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_cmp = nullptr, ev_bin = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
-	// Scatter groups of the queued backward pass in completion order: A = fine levels [split0, off_var) (final at ev_sc[1]), B = middle
-	// levels [split1, split0) (ev_sc[0]), C = coarse levels [off_grid, split1) (end of the pass); the MLPs + variance follow the dW GEMMs (ev_dw).
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true, cmp_recorded = false; uint64_t split[2] = {0, 0}; } sc;
-	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L)
-	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; bool binned = false; } sg;
+	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
+	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
+	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; } sc;
+	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
+	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
 	uint64_t dp_split = 0; // first parameter of the plain-quad levels: boundary of the two data-parallel gradient blocks
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
@@ -462,31 +457,17 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
 	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(256), 0, s, a);
-	// its completion = "the compacted batch is final": the binning passes of the gradient scatter start there, on a side stream
-	LAUNCH_EV(k_rollover, dim3(1024), dim3(256), 0, s, c->overlap() ? c->ev_cmp : nullptr, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
-	c->sc.cmp_recorded = c->overlap();
+	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
 	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
 
-// Binning passes of the fine levels' scatter (they read the compacted positions only).
-static void launch_bins(rnb_ctx* c, hipStream_t st, hipEvent_t done) {
-	const uint32_t B = c->cfg.target_batch_size;
-	const BinPlan& P = c->bin_plan;
-	hipLaunchKernelGGL(k_bin_count_place<false>, dim3(P.n_wg), dim3(256), 0, st, c->meta(), P, c->bin_buf, c->coords_compacted.p, B);
-	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(BIN_MAX_ITEMS), 0, st, P, c->bin_buf);
-	LAUNCH_EV(k_bin_count_place<true>, dim3(P.n_wg), dim3(256), 0, st, done, c->meta(), P, c->bin_buf, c->coords_compacted.p, B);
-}
-
-// `in_step`: called from the training step right behind compute_loss on the same stream (ev_cmp marks the compacted batch); the
-// stage entry point rnb_forward_backward passes false and everything is ordered on the caller's stream.
-int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true, bool in_step = false) {
+int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const uint32_t B = c->cfg.target_batch_size;
 	const rnb_ctx::ScatterGroups& sg = c->sg;
 	const uint32_t L = c->cfg.n_levels;
 	const uint32_t e_c = sg.e_c, l_fine = sg.l_fine;
-	// the binned levels' chunks are overwritten, everything else is accumulated with atomics onto cleared accumulators
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
@@ -496,20 +477,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true, bool in_ste
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
 	const bool side_streams = c->overlap();
-	const bool binned = sg.binned && L > l_fine;
-	const bool bins_aside = binned && side_streams && in_step && c->sc.cmp_recorded; // beside k_fwd_bwd, on the dW stream (idle until k_fwd_bwd is done)
-	c->sc.cmp_recorded = false;
 	c->prof.mark(s, P_NONE);
-	if (binned) {
-		if (bins_aside) {
-			HIP_TRY(hipStreamWaitEvent(c->s_dw, c->ev_cmp, 0));
-			launch_bins(c, c->s_dw, c->ev_bin);
-		} else {
-			launch_bins(c, s, nullptr);
-			c->prof.mark(s, P_BIN);
-			c->prof.units[P_BIN] += B;
-		}
-	}
 	hipEvent_t ev_fb = side_streams ? c->ev_fb : nullptr; // the weight-gradient GEMMs start on the side stream when this kernel is done
 	if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
@@ -547,21 +515,17 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true, bool in_ste
 		LAUNCH_EV(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, done, f);
 	};
 
-	// ---- hash-grid gradient scatter, three groups of levels (kernels_net.cuh); the addends commute up to fp32 rounding:
-	//   A  fine    [l_fine, L)   binned, accumulated in LDS, written with plain stores (RNB_SCATTER_QUAD: one L2 atomic per corner)
-	//   B  middle  [e_c, l_fine) run-length quad kernel: a cell spans several march steps (~590 / resolution)
-	//   C  coarse  [0, e_c)      LDS-privatised tables
-	// A first: it is the bulk of the parameters (8.4 M of 10.5 M), so its optimizer chunk -- or, data parallel, its exchange --
-	// runs beside B and C.
+	// ---- hash-grid gradient scatter, three groups of levels (kernels_net.cuh); the addends commute up to fp32 rounding, as with any atomic order:
+	//   A  fine    [l_fine, L)   plain quad kernel: one cell per sample, bound by the L2 atomic line rate
+	//   B  middle  [e_c, l_fine) run-length quad kernel: a cell spans several march steps (~590 / resolution); same bound + the latency of the walk
+	//   C  coarse  [0, e_c)      LDS-privatised tables (beside the atomic groups on the optimizer's stream it stretches 42 -> 158 us and the
+	//                            step loses 4 %, measured in round 2: it stays last on the caller's stream)
 	ScatterArgs sa;
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
-	auto launch_a = [&](hipStream_t st, hipEvent_t done) {
-		if (L <= l_fine) { if (done) (void)hipEventRecord(done, st); return; }
-		if (binned) {
-			const uint32_t n_items = c->bin_plan.item0[c->bin_plan.n_levels];
-			LAUNCH_EV(k_bin_accumulate, dim3(std::min<uint32_t>(n_items, (uint32_t)c->n_cus)), dim3(1024), LDS_BIN, st, done, c->meta(), c->bin_plan, c->bin_buf, sa);
-		} else LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, L - l_fine), dim3(256), 0, st, done, c->meta(), sa, l_fine);
+	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
+		if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0);
+		else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
 		if (l_fine <= e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -572,30 +536,33 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true, bool in_ste
 		plan.wg_start[plan.n] = wg;
 		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(wg), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 	};
-	auto launch_c = [&](hipStream_t st) {
-		if (!e_c) return;
+	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
+		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
 		ScatterLdsArgs la; la.a = sa; la.n_levels = e_c;
 		const uint32_t wg_cap = c->knobs.scatter_lds_wg;
 		const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 		la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
-		hipLaunchKernelGGL(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, c->meta(), la);
+		LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
 	};
 
 	if (!side_streams) {
 		launch_dw(s, nullptr);
 		c->prof.mark(s, P_DW);
-		launch_a(s, nullptr); launch_b(s, nullptr); launch_c(s);
+		launch_c(s, nullptr); launch_b(s, nullptr); launch_a(s, nullptr, l_fine, L);
 	} else {
-		// The caller's stream carries the scatter, the side stream the GEMMs. After A and B an event lets the optimizer step that
-		// group's levels while the rest is still being scattered (optimizer_step); what is left after C is the coarse levels' block.
+		// The caller's stream carries the scatter (B, A in two halves, then C), the side stream the GEMMs. After B and each half of A an
+		// event lets the optimizer step that group's levels while the rest is still being scattered (optimizer_step); what is left
+		// after C is the MLPs' and the coarse levels' parameters.
 		hipStream_t sd = c->s_dw;
 		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
 		launch_dw(sd, c->ev_dw);
 		c->sc.dp = c->dp_order();
-		if (bins_aside) HIP_TRY(hipStreamWaitEvent(s, c->ev_bin, 0));
-		launch_a(s, c->ev_sc[1]);
+		const uint32_t a_mid = l_fine + (L - l_fine + 1) / 2;
 		launch_b(s, c->ev_sc[0]);
-		launch_c(s);
+		launch_a(s, c->ev_sc[1], l_fine, a_mid);
+		launch_a(s, c->ev_sc[3], a_mid, L);
+		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
+		launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter
 		if (c->sc.dp || join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
 		c->sc.dw_joined = c->sc.dp || join_dw; // the training step leaves the join to the optimizer, which continues on the side stream (optimizer_step)
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
@@ -643,51 +610,32 @@ static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi, hi
 int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
 	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
 	optimizer_begin(c);
-	adam_launch(c, st, c->sc.split[0], c->off_var, c->ev_adam); // group A: the early gradient block
+	if (c->sc.dp) adam_launch(c, st, 0, c->sc.split[0], c->ev_adam);
+	else adam_launch(c, st, c->sc.split[1], c->sc.split[0], c->ev_adam);
 	c->opt.early_done = true;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
 
-// Which kernel scatters which level (see forward_backward), and the binning plan of the fine levels.
+// Which kernel scatters which level (see forward_backward).
 static void plan_scatter_groups(rnb_ctx* c) {
 	rnb_ctx::ScatterGroups& g = c->sg;
-	const uint32_t L = c->cfg.n_levels, B = c->cfg.target_batch_size;
+	const uint32_t L = c->cfg.n_levels;
 	uint32_t l;
 	{
 		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
 		for (l = 0; l < L; ++l) {
 			const float run = 590.f / (float)c->grid.resolution[l]; // compacted samples of a ray that share a cell of this level
-			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell there is nothing to merge
+			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
 			if (kenv && *kenv) { g.Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
 		}
 	}
 	for (l = 0; l < L; ++l) if (l == g.e_c && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) g.e_c = l + 1; // the coarsest levels whose fp32 gradient tables fit in LDS together
-	// fine levels: binned from the first level whose cells are shorter than ~4 march steps (L2-atomic mode: from the first without any run)
-	g.binned = !c->knobs.scatter_quad;
-	g.l_fine = L;
-	for (l = L; l > g.e_c; --l) if (g.Ks[l - 1] <= (g.binned ? 8u : 1u)) g.l_fine = l - 1; else break;
-	if (g.l_fine - g.e_c > 16) g.l_fine = g.e_c + 16; // ScatterRlPlan holds 16 levels
-	if (g.binned) {
-		BinPlan& P = c->bin_plan;
-		std::memset(&P, 0, sizeof(P));
-		P.level0 = g.l_fine; P.n_levels = L - g.l_fine;
-		uint32_t items = 0;
-		for (uint32_t i = 0; i < P.n_levels; ++i) {
-			P.item0[i] = items;
-			const uint32_t size = c->grid.offsets[g.l_fine + i + 1] - c->grid.offsets[g.l_fine + i];
-			items += (size + BIN_CHUNK - 1) / BIN_CHUNK;
-		}
-		P.item0[P.n_levels] = items;
-		P.n_wg = (B + BIN_SAMPLES_PER_WG - 1) / BIN_SAMPLES_PER_WG;
-		P.rec_cap = B * 8; // every x-pair of every sample split over two chunks
-		if (items > BIN_MAX_ITEMS || P.n_levels == 0 || B >= (1u << 28)) { // tables beyond the plan (log2_hashmap_size > 19 + ...): L2-atomic mode
-			g.binned = false;
-			g.l_fine = L;
-			for (l = L; l > g.e_c; --l) if (g.Ks[l - 1] <= 1u) g.l_fine = l - 1; else break;
-		}
+	g.l_fine = g.e_c;
+	for (l = g.e_c; l < L && g.Ks[l] > 1 && l - g.e_c < 16; ++l) {
+		g.k_log2 |= (uint64_t)ilog2(g.Ks[l]) << (4 * (l - g.e_c));
+		g.l_fine = l + 1;
 	}
-	for (l = g.e_c; l < g.l_fine; ++l) g.k_log2 |= (uint64_t)ilog2(g.Ks[l]) << (4 * (l - g.e_c));
 	c->dp_split = c->off_grid + (uint64_t)c->grid.offsets[g.l_fine] * 2;
 }
 
@@ -705,15 +653,15 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 	return RNB_OK;
 }
 
-// Blocks of the sharded data-parallel optimizer, in the order their gradients become final: first the fine levels (+ variance and
-// padding: the tail of the parameter vector), then everything in front of them. Each block is world_size equal chunks (multiples of
-// 4 parameters), chunk r belongs to rank r.
+// Blocks of the sharded data-parallel optimizer, in the order their gradients become final: each block is world_size equal
+// chunks (multiples of 4 parameters), chunk r belongs to rank r; the last block ends at param_capacity.
 static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_parts) {
 	const uint64_t W = std::max(1u, c->cfg.world_size), r = c->cfg.rank, q = 4 * W;
+	uint64_t m0 = 0;
 	uint32_t n = 0;
-	const uint64_t m0 = c->dp_split / q * q; // static: the ownership of a parameter must not move between steps
-	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
+	m0 = c->dp_split / q * q; // static: the ownership of a parameter must not move between steps
 	if (m0) { parts[n].lo = 0; parts[n].hi = m0; ++n; }
+	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint64_t chunk = (parts[k].hi - parts[k].lo) / W;
 		parts[k].own_lo = parts[k].lo + r * chunk;
@@ -725,30 +673,33 @@ static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_
 int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	optimizer_begin(c);
 	c->prof.mark(s, P_NONE);
-	if (!c->sc.dw_joined && (c->opt.early_done || c->sc.exchanged || !c->overlap() || c->sc.dp || !c->sc.valid)) {
+	const bool chunked = !c->opt.early_done && c->overlap() && !c->sc.dp && c->sc.valid && !c->sc.exchanged;
+	if (!c->sc.dw_joined && !chunked) {
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // the paths below step the MLPs on `s`
 		c->sc.dw_joined = true;
 	}
 	bool images_done = false;
 	if (c->opt.early_done) {
-		// the caller has already stepped the early block (group A, after exchanging it): the rest, then join
-		adam_launch(c, s, 0, c->sc.split[0]);
-		adam_launch(c, s, c->off_var, c->n_params);
+		// the caller has already stepped the early block (after exchanging it): the rest, then join
+		if (!c->sc.dp) adam_launch(c, s, 0, c->sc.split[1]);
+		adam_launch(c, s, c->sc.split[0], c->n_params);
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
-	} else if (c->overlap() && !c->sc.dp && c->sc.valid && !c->sc.exchanged) {
+	} else if (chunked) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
-		// on the side stream, beside the scatter of the next group; only the coarse levels' (small) block is left for the end.
+		// on the side stream, beside the scatter of the next group; only the last half of group A is left for the end.
 		hipStream_t sa = c->s_adam;
-		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
-		adam_launch(c, sa, c->sc.split[0], c->off_var);               // group A's levels, beside the scatter of B and C
 		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
-		adam_launch(c, sa, c->sc.split[1], c->sc.split[0], c->ev_adam); // group B's levels, beside C
+		adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
+		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
+		adam_launch(c, sa, c->sc.split[0], c->sc.split_mid);        // group A's levels, first half beside the second half's scatter
+		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[3], 0));
+		adam_launch(c, sa, c->sc.split_mid, c->off_var, c->ev_adam);
 		if (c->sc.dw_joined) {
 			adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
 			adam_launch(c, s, c->off_var, c->n_params);
 		} else {
 			// behind the dW GEMMs on their stream: the MLPs' and the variance's parameters, then the LDS weight images of the next
-			// step's kernels, all long before the scatter ends; the caller's stream is left with group C's 32 k parameters
+			// step's kernels, all long before the scatter ends
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
@@ -834,11 +785,10 @@ int rnb_destroy(rnb_ctx* c) {
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
-	c->bin_counts.free(); c->bin_wg_base.free(); c->bin_item_range.free(); c->bin_records.free();
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_cmp, c->ev_bin, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_all, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	delete c;
 	return RNB_OK;
@@ -943,8 +893,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BIN));
+HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
 	c->density_grid_rng = Pcg32{c->rng.next_uint()};
@@ -957,7 +906,6 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	{
 		rnb_ctx::Knobs& k = c->knobs;
 		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
-		k.scatter_quad = getenv("RNB_SCATTER_QUAD") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
@@ -967,16 +915,6 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		if (const char* e = getenv("RNB_SCATTER_K")) k.scatter_k = e;
 	}
 	plan_scatter_groups(c);
-	if (c->sg.binned) {
-		const BinPlan& P = c->bin_plan;
-		const size_t n_items = P.item0[P.n_levels];
-		if (c->bin_counts.alloc((size_t)P.n_wg * n_items) != hipSuccess || c->bin_wg_base.alloc((size_t)P.n_wg * n_items) != hipSuccess ||
-		    c->bin_item_range.alloc(n_items * 2) != hipSuccess || c->bin_records.alloc((size_t)P.n_levels * P.rec_cap) != hipSuccess) {
-			rnb_destroy(c);
-			return fail(RNB_ERR_NOMEM, "hipMalloc failed for the scatter bins");
-		}
-		c->bin_buf.counts = c->bin_counts.p; c->bin_buf.wg_base = c->bin_wg_base.p; c->bin_buf.item_range = c->bin_item_range.p; c->bin_buf.records = c->bin_records.p;
-	}
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
@@ -984,7 +922,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them (RNB_EVENT_SYSTEM_FENCE=1 restores it).
 	HIP_TRY(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (getenv("RNB_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_cmp, &c->ev_bin, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	*out = c;
@@ -1287,7 +1225,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
-	int rc = forward_backward(c, s, c->knobs.tail_on_main, true);
+	int rc = forward_backward(c, s, c->knobs.tail_on_main);
 	if (rc != RNB_OK) return rc;
 	c->rng.advance(); // testbed_nerf.cu:4118
 	return RNB_OK;
@@ -1460,10 +1398,14 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
-	if (c->sc.valid && c->sc.split[0] < c->off_var) { // the fine levels (group A) are final first (ev_sc[1]), the rest at the end of the backward pass
-		ranges[0][0] = c->sc.split[0]; ranges[0][1] = c->off_var;
-		ranges[1][0] = 0;              ranges[1][1] = c->sc.split[0];
-		ranges[2][0] = c->off_var;     ranges[2][1] = c->n_params;
+	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A: everything in front of A's levels is final first (ev_sc[0])
+		ranges[0][0] = 0;              ranges[0][1] = c->sc.split[0];
+		ranges[1][0] = c->sc.split[0]; ranges[1][1] = c->n_params;
+		*n_parts = 2;
+	} else if (c->sc.valid && c->sc.split[1] < c->sc.split[0]) { // scatter order B, A, C: B's levels are final first (ev_sc[0])
+		ranges[0][0] = c->sc.split[1]; ranges[0][1] = c->sc.split[0];
+		ranges[1][0] = 0;              ranges[1][1] = c->sc.split[1];
+		ranges[2][0] = c->sc.split[0]; ranges[2][1] = c->n_params;
 		*n_parts = 3;
 	} else {
 		ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
@@ -1501,15 +1443,15 @@ int rnb_train_step_apply_done(rnb_ctx* c, void* stream) {
 
 int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	// block 0 of the overlapped schedule (the fine levels) has its own event; everything is final at the end of the backward pass
-	const bool early = part == 0 && c->sc.valid;
+	// block 0 of the overlapped schedule has its own event; everything is final at the end of the backward pass
+	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
 	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // the weight-gradient GEMMs' side stream has not been joined
 	if (!early && !c->sc.all_final_recorded) { // only data-parallel callers pay for this marker
-		HIP_TRY(hipEventRecord(c->ev_sc[2], c->backward_stream));
+		HIP_TRY(hipEventRecord(c->ev_all, c->backward_stream));
 		c->sc.all_final_recorded = true;
 	}
-	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[1] : c->ev_sc[2], 0));
-	if (early && c->sc.sharded) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // the sharded block 0 runs to the end of the vector: it holds the variance gradient (k_dw_finish)
+	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : c->ev_all, 0));
+	if (early && c->sc.dp) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // block 0 holds the MLPs' gradients (side stream)
 	return RNB_OK;
 }
 

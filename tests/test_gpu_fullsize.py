@@ -211,7 +211,7 @@ def test_sharded_optimizer_two_emulated_ranks(scene, trained):
             for c in group:
                 c.train_step_finish(loc[0][0] + loc[1][0], loc[0][1] + loc[1][1])
         n = rep[0].n_params
-        assert rep[0].gradient_parts() == rep[1].gradient_parts() and len(rep[0].gradient_parts()) == 3  # fine levels (early), everything in front, variance
+        assert rep[0].gradient_parts() == rep[1].gradient_parts() and len(rep[0].gradient_parts()) == 2  # data-parallel scatter order: two blocks
         g = rep[0].get("GRADS_FP32") + rep[1].get("GRADS_FP32")  # the all-reduce
         for c in rep:
             c.put("GRADS_FP32", g)
@@ -222,7 +222,7 @@ def test_sharded_optimizer_two_emulated_ranks(scene, trained):
         layouts = [c.shard_layout() for c in sh]
         (p0, cap0), (p1, cap1) = layouts
         assert cap0 == cap1 >= n and cap0 % 8 == 0 and len(p0) == len(p1) == 2
-        assert p0[1][0] == 0 and p0[1][1] == p0[0][0] and p0[0][1] == cap0  # completion order: the fine levels' block (tail of the vector) first
+        assert p0[0][0] == 0 and p0[0][1] == p0[1][0] and p0[1][1] == cap0
         for a, b in zip(p0, p1):
             assert a[:2] == b[:2] and a[2] == a[0] and a[3] == b[2] and b[3] == b[1] and (a[3] - a[2]) == (b[3] - b[2]) and (a[3] - a[2]) % 4 == 0
         own = []
