@@ -187,6 +187,11 @@ int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
  * reset Adam state (trainer.h:263-275). Syncs. */
 int rnb_set_params(rnb_ctx* ctx, const float* params_host);
 int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
+/* A caller that keeps a pointer from rnb_buffer(RNB_BUF_PARAMS_FP16) and writes training weights through it later (e.g. an
+ * all-gather of a sharded optimizer) says so here: the kernels' cached LDS weight images are dropped and rebuilt from the
+ * weights at the next launch. (rnb_buffer itself drops them when that pointer is handed out; rnb_train_step_apply_done rebuilds
+ * them.) No reference counterpart: tcnn reads the weights from global memory on every launch (fully_fused_mlp.cu:624-758). */
+int rnb_params_changed(rnb_ctx* ctx);
 /* Caller-owned device scratch (GPUMemory<T> in the reference, e.g. the lattice of get_density_on_grid,
  * src/testbed_nerf.cu:4218-4269). Host memory in the CPU checker. */
 int rnb_device_malloc(rnb_ctx* ctx, uint64_t n_bytes, void** ptr);

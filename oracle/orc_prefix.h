@@ -15,6 +15,7 @@
 #define rnb_init_params orc_init_params
 #define rnb_set_params orc_set_params
 #define rnb_buffer orc_buffer
+#define rnb_params_changed orc_params_changed
 #define rnb_memcpy orc_memcpy
 #define rnb_device_malloc orc_device_malloc
 #define rnb_device_free orc_device_free

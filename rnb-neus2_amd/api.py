@@ -144,6 +144,10 @@ class Context:
         self._check(self.f.buffer(self._h, BUF[name], C.byref(ptr), C.byref(nb)))
         return ptr.value, nb.value
 
+    def params_changed(self):
+        """Training weights were written through a pointer kept from buffer("PARAMS_FP16"): drop the cached LDS weight images."""
+        self._check(self.f.params_changed(self._h))
+
     def get(self, name, count=None, offset=0):
         """Copy (part of) a context buffer to a numpy array; count/offset in elements."""
         ptr, nb = self.buffer(name)

@@ -809,6 +809,12 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
 	if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) return fail(RNB_ERR_DEVICE, std::string("librnb_neus2_hip targets gfx950 (MI355X); found ") + prop.gcnArchName);
 	rnb_ctx* c = new rnb_ctx();
+	// from here on a failing HIP call releases the context (device buffers, streams, events) before returning
+#define HIP_TRY_C(expr)                                                                                                  \
+	do {                                                                                                                 \
+		hipError_t e_ = (expr);                                                                                          \
+		if (e_ != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+	} while (0)
 	c->cfg = *cfg;
 	c->n_cus = prop.multiProcessorCount;
 	build_grid_tables(c);
@@ -874,26 +880,26 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		ALLOC(c->dw_partial, (size_t)nwg * WAVES_PER_WG * per_wave);
 	}
 #undef ALLOC
-	HIP_TRY(hipMemset(c->params_fp32.p, 0, c->params_fp32.bytes()));
-	HIP_TRY(hipMemset(c->params_fp16.p, 0, c->params_fp16.bytes()));
-	HIP_TRY(hipMemset(c->params_ema.p, 0, c->params_ema.bytes()));
-	HIP_TRY(hipMemset(c->density_grid.p, 0, c->density_grid.bytes()));
-	HIP_TRY(hipMemset(c->density_grid_tmp.p, 0, c->density_grid_tmp.bytes()));
-	HIP_TRY(hipMemset(c->bitfield.p, 0, c->bitfield.bytes()));
-	HIP_TRY(hipMemset(c->counters.p, 0, c->counters.bytes()));
-	HIP_TRY(hipMemset(c->density_mean.p, 0, 4));
-	HIP_TRY(hipMemset(c->coords.p, 0, c->coords.bytes()));
-	HIP_TRY(hipMemset(c->coords_compacted.p, 0, c->coords_compacted.bytes()));
-	HIP_TRY(hipMemset(c->dloss_dout.p, 0, c->dloss_dout.bytes()));
-	HIP_TRY(hipMemset(c->mlp_out.p, 0, c->mlp_out.bytes()));
+	HIP_TRY_C(hipMemset(c->params_fp32.p, 0, c->params_fp32.bytes()));
+	HIP_TRY_C(hipMemset(c->params_fp16.p, 0, c->params_fp16.bytes()));
+	HIP_TRY_C(hipMemset(c->params_ema.p, 0, c->params_ema.bytes()));
+	HIP_TRY_C(hipMemset(c->density_grid.p, 0, c->density_grid.bytes()));
+	HIP_TRY_C(hipMemset(c->density_grid_tmp.p, 0, c->density_grid_tmp.bytes()));
+	HIP_TRY_C(hipMemset(c->bitfield.p, 0, c->bitfield.bytes()));
+	HIP_TRY_C(hipMemset(c->counters.p, 0, c->counters.bytes()));
+	HIP_TRY_C(hipMemset(c->density_mean.p, 0, 4));
+	HIP_TRY_C(hipMemset(c->coords.p, 0, c->coords.bytes()));
+	HIP_TRY_C(hipMemset(c->coords_compacted.p, 0, c->coords_compacted.bytes()));
+	HIP_TRY_C(hipMemset(c->dloss_dout.p, 0, c->dloss_dout.bytes()));
+	HIP_TRY_C(hipMemset(c->mlp_out.p, 0, c->mlp_out.bytes()));
 	int rc = reset_optimizer_state(c);
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
-HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
 	c->density_grid_rng = Pcg32{c->rng.next_uint()};
@@ -915,18 +921,19 @@ HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), h
 		if (const char* e = getenv("RNB_SCATTER_K")) k.scatter_k = e;
 	}
 	plan_scatter_groups(c);
-	HIP_TRY(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
+	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
+	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
+	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
 	// ev_loss publishes the step's counters to the HOST (system-scope release). The others only order kernels on this device:
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them (RNB_EVENT_SYSTEM_FENCE=1 restores it).
-	HIP_TRY(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
+	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (getenv("RNB_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY(hipEventCreateWithFlags(e, dev_flags));
-	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
-	HIP_TRY(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
+	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
+	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	*out = c;
 	return RNB_OK;
+#undef HIP_TRY_C
 }
 
 int rnb_update_config(rnb_ctx* c, const rnb_config* cfg) {
@@ -1048,6 +1055,12 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
+}
+
+int rnb_params_changed(rnb_ctx* c) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->wimg_valid = false;
+	return RNB_OK;
 }
 
 int rnb_device_malloc(rnb_ctx* c, uint64_t n_bytes, void** ptr) {

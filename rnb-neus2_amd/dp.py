@@ -65,6 +65,8 @@ class TorchShardCollectives:
         lo, hi, own_lo, own_hi = part
         v = self.view(name)
         dist.all_gather_into_tensor(v[lo:hi], v[own_lo:own_hi])
+        if name == "PARAMS_FP16":  # written through a cached pointer: the kernels' weight images are stale (rnb_params_changed)
+            self.ctx.params_changed()
 
 
 def _raw_stream(stream):

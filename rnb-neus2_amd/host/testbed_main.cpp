@@ -146,6 +146,32 @@ Args parse_cli(int argc, char** argv) {
 		if (rc_ != RNB_OK) throw std::runtime_error(std::string(#expr) + ": " + rnb_last_error()); \
 	} while (0)
 
+// The parsed network configuration travels inside the snapshot (m_network_config, src/testbed.cu:3282-3313): JSON <-> MessagePack values.
+static mpk::Value json_to_mpk(const jsonmin::Value& j) {
+	switch (j.type) {
+		case jsonmin::Value::Null: return mpk::Value();
+		case jsonmin::Value::Bool: return mpk::Value::boolean(j.b);
+		case jsonmin::Value::Number:
+			if (j.num >= 0 && j.num == std::floor(j.num) && j.num < 1.8e19) return mpk::Value::uint((uint64_t)j.num);
+			return mpk::Value::real(j.num);
+		case jsonmin::Value::String: return mpk::Value::str(j.str);
+		case jsonmin::Value::Arr: { mpk::Value a = mpk::Value::array(); for (const auto& e : *j.arr) a.arr.push_back(json_to_mpk(e)); return a; }
+		default: { mpk::Value o = mpk::Value::object(); for (const auto& kv : *j.obj) o.set(kv.first, json_to_mpk(kv.second)); return o; }
+	}
+}
+static jsonmin::Value mpk_to_json(const mpk::Value& m) {
+	jsonmin::Value j;
+	switch (m.type) {
+		case mpk::Value::Nil: case mpk::Value::Bin: break;
+		case mpk::Value::Bool: j.type = jsonmin::Value::Bool; j.b = m.b; break;
+		case mpk::Value::Int: case mpk::Value::UInt: case mpk::Value::Float: j.type = jsonmin::Value::Number; j.num = m.number(); break;
+		case mpk::Value::Str: j.type = jsonmin::Value::String; j.str = m.s; break;
+		case mpk::Value::Arr: j.type = jsonmin::Value::Arr; j.arr = std::make_shared<jsonmin::Array>(); for (const auto& e : m.arr) j.arr->push_back(mpk_to_json(e)); break;
+		default: j.type = jsonmin::Value::Obj; j.obj = std::make_shared<jsonmin::Object>(); for (const auto& kv : m.map) (*j.obj)[kv.first] = mpk_to_json(kv.second); break;
+	}
+	return j;
+}
+
 struct Testbed {
 	rnb_config cfg;
 	rnb_ctx* ctx = nullptr;
@@ -286,22 +312,45 @@ struct Testbed {
 		snap.set("training_step", mpk::Value::uint(training_step));
 		snap.set("loss", mpk::Value::real(loss_scalar));
 		root.set("snapshot", snap);
-		// the network configuration travels with the snapshot (m_network_config, src/testbed.cu:3282-3313)
-		mpk::Value enc = mpk::Value::object();
-		enc.set("otype", mpk::Value::str("HashGrid"));
+		// the whole network configuration travels with the snapshot (m_network_config, src/testbed.cu:3282-3313): optimizer, loss, both
+		// encodings and networks as parsed, so that a resumed run steps with the hyper-parameters of the run that wrote the file
+		if (network_config.is_object())
+			for (const auto& kv : *network_config.obj) if (kv.first != "snapshot") root.set(kv.first, json_to_mpk(kv.second));
+		auto obj = [&](const char* k) -> mpk::Value& { // the block named k, created if the config had none
+			for (auto& kv : root.map) if (kv.first == k && kv.second.type == mpk::Value::MapT) return kv.second;
+			return root.set(k, mpk::Value::object());
+		};
+		// ... overlaid with the values in effect (derived resolutions, command-line overrides such as --mask-weight)
+		mpk::Value& enc = obj("encoding");
+		if (!enc.find("otype")) enc.set("otype", mpk::Value::str("HashGrid"));
 		enc.set("n_levels", mpk::Value::uint(cfg.n_levels)); enc.set("n_features_per_level", mpk::Value::uint(2));
 		enc.set("log2_hashmap_size", mpk::Value::uint(cfg.log2_hashmap_size)); enc.set("base_resolution", mpk::Value::uint(cfg.base_resolution));
 		enc.set("per_level_scale", mpk::Value::real(cfg.per_level_scale));
 		enc.set("valid_level_scale", mpk::Value::real(cfg.valid_level_scale)); enc.set("base_valid_level_scale", mpk::Value::real(cfg.base_valid_level_scale));
 		enc.set("base_training_step", mpk::Value::uint(cfg.base_training_step));
-		root.set("encoding", enc);
-		mpk::Value hp = mpk::Value::object();
+		mpk::Value& hp = obj("hyperparams");
 		hp.set("batch_size", mpk::Value::uint(cfg.target_batch_size));
 		hp.set("mask_loss_weight", mpk::Value::real(cfg.mask_loss_weight)); hp.set("ek_loss_weight", mpk::Value::real(cfg.ek_loss_weight));
-		root.set("hyperparams", hp);
-		mpk::Value net = mpk::Value::object();
-		net.set("otype", mpk::Value::str("FullyFusedMLP")); net.set("sdf_bias", mpk::Value::real(cfg.sdf_bias));
-		root.set("network", net);
+		mpk::Value& net = obj("network");
+		if (!net.find("otype")) net.set("otype", mpk::Value::str("FullyFusedMLP"));
+		net.set("sdf_bias", mpk::Value::real(cfg.sdf_bias));
+		{ // Ema -> ExponentialDecay -> Adam, the nesting of configs/nerf/base.json
+			mpk::Value& ema = obj("optimizer");
+			if (!ema.find("otype")) ema.set("otype", mpk::Value::str("Ema"));
+			ema.set("decay", mpk::Value::real(cfg.ema_decay));
+			auto nested = [](mpk::Value& parent) -> mpk::Value& {
+				for (auto& kv : parent.map) if (kv.first == "nested" && kv.second.type == mpk::Value::MapT) return kv.second;
+				return parent.set("nested", mpk::Value::object());
+			};
+			mpk::Value& dec = nested(ema);
+			if (!dec.find("otype")) dec.set("otype", mpk::Value::str("ExponentialDecay"));
+			dec.set("decay_start", mpk::Value::uint(cfg.lr_decay_start)); dec.set("decay_interval", mpk::Value::uint(cfg.lr_decay_interval));
+			dec.set("decay_base", mpk::Value::real(cfg.lr_decay_base));
+			mpk::Value& adam = nested(dec);
+			if (!adam.find("otype")) adam.set("otype", mpk::Value::str("Adam"));
+			adam.set("learning_rate", mpk::Value::real(cfg.learning_rate)); adam.set("beta1", mpk::Value::real(cfg.beta1)); adam.set("beta2", mpk::Value::real(cfg.beta2));
+			adam.set("epsilon", mpk::Value::real(cfg.epsilon)); adam.set("l2_reg", mpk::Value::real(cfg.l2_reg));
+		}
 		mpk::save(path, root);
 	}
 
@@ -311,17 +360,13 @@ struct Testbed {
 		if (!root.find("snapshot")) throw std::runtime_error("File '" + path + "' does not contain a snapshot.");
 		const mpk::Value& snap = root.at("snapshot");
 		if ((uint32_t)snap.at("density_grid_size").number() != RNB_GRIDSIZE) throw std::runtime_error("Incompatible grid size.");
-		if (const mpk::Value* enc = root.find("encoding")) { // reset_network from the snapshot's own config
-			cfg.n_levels = (uint32_t)enc->at("n_levels").number(); cfg.log2_hashmap_size = (uint32_t)enc->at("log2_hashmap_size").number();
-			cfg.base_resolution = (uint32_t)enc->at("base_resolution").number(); cfg.per_level_scale = (float)enc->at("per_level_scale").number();
-			if (const mpk::Value* v = enc->find("valid_level_scale")) cfg.valid_level_scale = (float)v->number();
-			if (const mpk::Value* v = enc->find("base_valid_level_scale")) cfg.base_valid_level_scale = (float)v->number();
-			if (const mpk::Value* v = enc->find("base_training_step")) cfg.base_training_step = (uint32_t)v->number();
-		}
-		if (const mpk::Value* hp = root.find("hyperparams")) {
-			if (const mpk::Value* v = hp->find("batch_size")) cfg.target_batch_size = (uint32_t)v->number();
-			if (const mpk::Value* v = hp->find("mask_loss_weight")) cfg.mask_loss_weight = (float)v->number();
-			if (const mpk::Value* v = hp->find("ek_loss_weight")) cfg.ek_loss_weight = (float)v->number();
+		{ // reset_network from the snapshot's own config (src/testbed.cu:3352-3357): every block but the binary payload
+			mpk::Value cfg_root = mpk::Value::object();
+			for (const auto& kv : root.map) if (kv.first != "snapshot") cfg_root.set(kv.first, kv.second);
+			network_config = mpk_to_json(cfg_root);
+			const float mask_w = cfg.mask_loss_weight;
+			apply_network_config(network_config);
+			if (!network_config["hyperparams"].contains("mask_loss_weight")) cfg.mask_loss_weight = mask_w;
 		}
 		if (const mpk::Value* v = snap.at("nerf").find("aabb_scale")) cfg.aabb_scale = (uint32_t)v->number();
 		create_context();

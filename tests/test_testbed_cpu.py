@@ -239,3 +239,57 @@ def test_progress_line_and_fractional_training(install, tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
     assert [l.split()[0] for l in lines] == ["iteration=100", "iteration=200"]
     assert all(np.isfinite(float(l.split("loss=")[1])) for l in lines)
+
+
+def test_snapshot_carries_the_whole_network_config(install, tmp_path):
+    """The reference serialises m_network_config with the snapshot (src/testbed.cu:3280-3313) and resets the network from it on
+    load (:3352-3357): a run that was configured with non-default optimizer hyper-parameters must resume with THEM, not with
+    the library defaults. Stage 1 here uses lr = 3e-3, beta2 = 0.95, EMA decay 0.9, l2_reg 1e-5; the snapshot must hold them,
+    and two more steps from the snapshot must equal the same two steps driven through the binding with those values
+    (and differ from a resume with the defaults)."""
+    import copy
+    cfg = copy.deepcopy(SMALL_CFG)
+    cfg["optimizer"]["decay"] = 0.9
+    cfg["optimizer"]["nested"]["decay_start"] = 3
+    cfg["optimizer"]["nested"]["decay_interval"] = 2
+    cfg["optimizer"]["nested"]["decay_base"] = 0.5
+    cfg["optimizer"]["nested"]["nested"].update(learning_rate=3e-3, beta2=0.95, l2_reg=1e-5)
+    cfg["loss"] = {"otype": "Huber"}  # blocks the hot path does not read travel too
+    with open(install / "configs" / "nerf" / "custom_opt.json", "w") as f:
+        json.dump(cfg, f)
+    scene = tmp_path / "s"
+    views, normals, albedos = synthetic.make_scene(4, 48, 84.0)
+    synthetic.write_scene(str(scene), views, normals, albedos)
+    r = run(install, "--scene", scene, "--maxiter", 4, "--no-gui", "--mask-weight", 1.0, "--config", "custom_opt.json", "--no-albedo", "--save-snapshot")
+    assert r.returncode == 0, r.stderr
+    with open(scene / "output" / "snapshot_4.msgpack", "rb") as f:
+        root = msgpack.unpackb(f.read(), raw=False)
+    adam = root["optimizer"]["nested"]["nested"]
+    assert root["optimizer"]["decay"] == pytest.approx(0.9) and root["optimizer"]["nested"]["decay_base"] == pytest.approx(0.5)
+    assert adam["learning_rate"] == pytest.approx(3e-3) and adam["beta2"] == pytest.approx(0.95) and adam["l2_reg"] == pytest.approx(1e-5)
+    assert root["loss"]["otype"] == "Huber" and root["hyperparams"]["batch_size"] == 4096
+    r = run(install, "--scene", scene, "--maxiter", 6, "--no-gui", "--mask-weight", 1.0, "--no-albedo", "--save-snapshot", "--snapshot", scene / "output" / "snapshot_4.msgpack")
+    assert r.returncode == 0, r.stderr
+    with open(scene / "output" / "snapshot_6.msgpack", "rb") as f:
+        root2 = msgpack.unpackb(f.read(), raw=False)
+    assert root2["optimizer"]["nested"]["nested"]["learning_rate"] == pytest.approx(3e-3)  # and travels on
+    snap1, snap2 = root["snapshot"], root2["snapshot"]
+
+    def two_steps(**opt):
+        ctx = oracle_lib.context(**dict(SMALL_KW, **opt))
+        ctx.init_params()
+        ctx.set_dataset(views, normals, albedos)
+        ctx.set_params(np.frombuffer(snap1["params_binary"], np.float16).astype(np.float32))
+        ctx.put("DENSITY_GRID", np.frombuffer(snap1["density_grid_binary"], np.float16).astype(np.float32))
+        ctx.update_density_bitfield()
+        ctx.set_controller(4, snap1["nerf"]["rgb"]["rays_per_batch"], snap1["nerf"]["rgb"]["measured_batch_size_before_compaction"], 0)
+        for _ in range(2):
+            ctx.train_step()
+        out = ctx.get("PARAMS_EMA").view(np.uint16).copy()
+        ctx.close()
+        return out
+
+    got = np.frombuffer(snap2["params_binary"], np.uint16)
+    want = two_steps(learning_rate=3e-3, beta2=0.95, l2_reg=1e-5, ema_decay=0.9, lr_decay_start=3, lr_decay_interval=2, lr_decay_base=0.5)
+    np.testing.assert_array_equal(got, want)
+    assert np.any(got != two_steps())  # the library defaults give another result: the test would catch the old behaviour
