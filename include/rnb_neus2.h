@@ -219,6 +219,18 @@ int rnb_sdf(rnb_ctx* ctx, void* stream, const float* xyz_dev, uint32_t n, uint16
 /* Network::inference_mixed_precision -> NerfNetwork::forward_impl (nerf_network.h:87-253):
  * coords[n,7] f32 -> out[n,16] half. */
 int rnb_forward_infer(rnb_ctx* ctx, void* stream, const float* coords_dev, uint32_t n, uint16_t* out_dev, int use_inference_params);
+/* get_density_on_grid (src/testbed_nerf.cu:4218-4269) for the SDF: the lattice res[0] x res[1] x res[2] (x fastest) of the cube
+ * [lattice_min, lattice_max)^3 -- point (x,y,z) at lattice_min + (x,y,z) / res * (lattice_max - lattice_min), as
+ * generate_grid_samples_nerf_uniform places it (src/testbed_nerf.cu:541-553) -- evaluated into `out` (float[res^3], device) as
+ * rnb_sdf does (sdf + bias). Syncs. */
+int rnb_sdf_lattice(rnb_ctx* ctx, void* stream, const uint32_t res[3], float lattice_min, float lattice_max, float* out, int inference);
+/* marching_cubes_gpu (src/marching_cubes.cu:794-822; gen_vertices :276-327, gen_faces :377-430/676-717) on a device lattice:
+ * one vertex per lattice edge that crosses `thresh` (linear interpolation), triangles from the 256-case table, numbered in
+ * lattice order (deterministic; the reference numbers them by atomicAdd). *verts (float[n_verts][3]) and *indices
+ * (uint32[n_indices], 3 per triangle, counter-clockwise around the value > thresh side's outward normal) are allocated here
+ * and belong to the caller (rnb_device_free). Scratch: 12 bytes per lattice point (the reference's vertidx_grid). Syncs. */
+int rnb_marching_cubes(rnb_ctx* ctx, void* stream, const float* density, const uint32_t res[3], const float aabb_min[3], const float aabb_max[3], float thresh,
+                       float** verts, uint32_t** indices, uint32_t* n_verts, uint32_t* n_indices);
 /* generate_training_samples_nerf_with_global_movement (testbed_nerf.cu:1216-1387), K6.
  * Fills RAY_INDICES/RAYS/NUMSTEPS/COORDS/COUNTERS. Deterministic slot order. */
 int rnb_generate_training_samples(rnb_ctx* ctx, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples);

@@ -33,6 +33,7 @@
 // Export the rnb_neus2.h signatures under the orc_ prefix.
 #include "orc_prefix.h"
 #include "../include/rnb_neus2.h"
+#include "../rnb-neus2_amd/host/mesh.hpp" // the host marching-cubes loop (shared with the testbed CLI)
 
 #include <algorithm>
 #include <chrono>
@@ -1742,6 +1743,42 @@ int rnb_sdf(orc_ctx_s* c, void*, const float* xyz, uint32_t n, uint16_t* out, in
 	for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = sdf_sample(c, np, xyz + (size_t)i * 3);
 	return RNB_OK;
 }
+// get_density_on_grid for the SDF (src/testbed_nerf.cu:4218-4269, 541-553): host twin of rnb_sdf_lattice.
+int rnb_sdf_lattice(orc_ctx_s* c, void*, const uint32_t res[3], float lattice_min, float lattice_max, float* out, int inference) {
+	if (!c || !res || !out) return fail(RNB_ERR_INVALID, "null argument");
+	if (!res[0] || !res[1] || !res[2]) return fail(RNB_ERR_INVALID, "empty lattice");
+	NetParams np = net_params(c, inference != 0);
+	const int64_t n = (int64_t)res[0] * res[1] * res[2];
+	const float size = lattice_max - lattice_min, diag = c->aabb_max - c->aabb_min;
+#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < n; ++i) {
+		const uint32_t p[3] = {(uint32_t)(i % res[0]), (uint32_t)((i / res[0]) % res[1]), (uint32_t)(i / ((int64_t)res[0] * res[1]))};
+		float x[3];
+		for (int k = 0; k < 3; ++k) {
+			const float inv = 1.f / (float)res[k];
+			const float w = (float)p[k] * inv * size + lattice_min;
+			x[k] = (w - c->aabb_min) / diag; // warp_position
+		}
+		out[i] = h2f(sdf_sample(c, np, x));
+	}
+	return RNB_OK;
+}
+
+// marching_cubes_gpu (src/marching_cubes.cu:794-822): host twin of rnb_marching_cubes over the same loop as the testbed's host mesh code.
+int rnb_marching_cubes(orc_ctx_s* c, void*, const float* density, const uint32_t res[3], const float aabb_min[3], const float aabb_max[3], float thresh,
+                       float** verts, uint32_t** indices, uint32_t* n_verts, uint32_t* n_indices) {
+	if (!c || !density || !res || !aabb_min || !aabb_max || !verts || !indices || !n_verts || !n_indices) return fail(RNB_ERR_INVALID, "null argument");
+	mesh::Mesh m;
+	try { m = mesh::marching_cubes(density, (int)res[0], (int)res[1], (int)res[2], aabb_min, aabb_max, thresh, false); }
+	catch (const std::exception& e) { return fail(RNB_ERR_INVALID, e.what()); }
+	*n_verts = (uint32_t)m.verts.size(); *n_indices = (uint32_t)m.indices.size();
+	*verts = m.verts.empty() ? nullptr : (float*)std::malloc(m.verts.size() * 12);
+	*indices = m.indices.empty() ? nullptr : (uint32_t*)std::malloc(m.indices.size() * 4);
+	if (*verts) std::memcpy(*verts, m.verts.data(), m.verts.size() * 12);
+	if (*indices) std::memcpy(*indices, m.indices.data(), m.indices.size() * 4);
+	return RNB_OK;
+}
+
 int rnb_density(orc_ctx_s* c, void*, const float* xyz, uint32_t n, uint16_t* out, int inference) {
 	if (!c || (!xyz && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
 	NetParams np = net_params(c, inference != 0);

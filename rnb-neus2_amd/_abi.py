@@ -137,6 +137,9 @@ PROTOTYPES = {
     "density": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),
     "sdf": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),
     "forward_infer": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),
+    "sdf_lattice": (_i, [_ctx, _stream, C.POINTER(_u32), C.c_float, C.c_float, C.c_void_p, _i]),
+    "marching_cubes": (_i, [_ctx, _stream, C.c_void_p, C.POINTER(_u32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_u32), C.POINTER(_u32)]),
     "generate_training_samples": (_i, [_ctx, _stream, _u32, _u32, _u32]),
     "compute_loss": (_i, [_ctx, _stream, _u32, _u32]),
     "forward_backward": (_i, [_ctx, _stream]),

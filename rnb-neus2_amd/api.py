@@ -305,6 +305,51 @@ class Context:
         self._check(self.f.forward_infer(self._h, None, C.c_void_p(cptr), n, C.c_void_p(optr), int(bool(inference))))
         return self.get("MLP_OUT", n * 16).reshape(n, 16)
 
+    # -- mesh extraction (src/testbed_nerf.cu:4218-4269, src/marching_cubes.cu:794-822) ----------------------
+    def device_malloc(self, n_bytes):
+        ptr = C.c_void_p()
+        self._check(self.f.device_malloc(self._h, int(n_bytes), C.byref(ptr)))
+        return ptr.value
+
+    def device_free(self, ptr):
+        self._check(self.f.device_free(self._h, C.c_void_p(ptr)))
+
+    def sdf_lattice(self, res, lattice_min=0.0, lattice_max=1.0, inference=True):
+        """SDF on the lattice res^3 (int or 3 ints, x fastest) of [lattice_min, lattice_max)^3 -> library-side pointer to
+        float[res^3] (device memory for the HIP library); release with device_free."""
+        r = (C.c_uint32 * 3)(*([int(res)] * 3 if np.isscalar(res) else [int(x) for x in res]))
+        ptr = self.device_malloc(int(r[0]) * int(r[1]) * int(r[2]) * 4)
+        self._check(self.f.sdf_lattice(self._h, None, r, float(lattice_min), float(lattice_max), C.c_void_p(ptr), int(bool(inference))))
+        return ptr
+
+    def marching_cubes(self, density_ptr, res, aabb_min=(0.0, 0.0, 0.0), aabb_max=(1.0, 1.0, 1.0), thresh=0.0):
+        """Iso-surface of a library-side lattice -> (verts float32[n,3], indices uint32[m]) on the host."""
+        r = (C.c_uint32 * 3)(*([int(res)] * 3 if np.isscalar(res) else [int(x) for x in res]))
+        mn, mx = (C.c_float * 3)(*[float(x) for x in aabb_min]), (C.c_float * 3)(*[float(x) for x in aabb_max])
+        pv, pi, nv, ni = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint32()
+        self._check(self.f.marching_cubes(self._h, None, C.c_void_p(density_ptr), r, mn, mx, float(thresh), C.byref(pv), C.byref(pi), C.byref(nv), C.byref(ni)))
+        verts = np.empty((nv.value, 3), np.float32)
+        idx = np.empty(ni.value, np.uint32)
+        if nv.value:
+            self._check(self.f.memcpy(self._h, verts.ctypes.data_as(C.c_void_p), pv, nv.value * 12, _abi.D2H))
+        if ni.value:
+            self._check(self.f.memcpy(self._h, idx.ctypes.data_as(C.c_void_p), pi, ni.value * 4, _abi.D2H))
+        self.device_free(pv.value)
+        self.device_free(pi.value)
+        return verts, idx
+
+    def upload(self, array):
+        """numpy array -> library-side buffer (device_malloc + copy); release with device_free."""
+        a = np.ascontiguousarray(array)
+        ptr = self.device_malloc(a.nbytes)
+        self._check(self.f.memcpy(self._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, _abi.H2D))
+        return ptr
+
+    def download(self, ptr, count, dtype):
+        out = np.empty(int(count), dtype=dtype)
+        self._check(self.f.memcpy(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, _abi.D2H))
+        return out
+
     def forward_infer_staged(self, n, stream=None):
         """Evaluate the first n samples already in COORDS into MLP_OUT (what train_nerf_step does, testbed_nerf.cu:3967)."""
         cptr, _ = self.buffer("COORDS")

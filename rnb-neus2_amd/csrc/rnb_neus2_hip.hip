@@ -3,6 +3,8 @@
 // src/testbed_nerf.cu:3560-4123). No CPU fallback: every entry point runs HIP kernels or fails.
 #include "kernels_net.cuh"
 #include "kernels_ray.cuh"
+#include "kernels_mesh.cuh"
+#include "../host/mesh.hpp" // the marching-cubes case table generator (header only)
 
 #include <hip/hip_ext.h>
 
@@ -151,6 +153,7 @@ struct rnb_ctx {
 		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
+	DevBuf<McTable> mc_table; // marching-cubes case table, uploaded on first use
 	// training scratch
 	DevBuf<half_t> fm;       // feature-major operand arrays
 	DevBuf<uint32_t> g12;
@@ -784,7 +787,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
-	c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
+	c->mc_table.free(); c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -1145,6 +1148,107 @@ int rnb_density(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t
 int rnb_forward_infer(rnb_ctx* c, void* stream, const float* coords, uint32_t n, uint16_t* out, int inference) {
 	if (!c || (!coords && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
 	return launch_forward(c, as_stream(stream), coords, nullptr, n, reinterpret_cast<half_t*>(out), inference != 0);
+}
+
+// ---- mesh extraction (src/testbed_nerf.cu:4218-4269, src/marching_cubes.cu:276-430, 794-822) ----
+int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float lattice_min, float lattice_max, float* out, int inference) {
+	if (!c || !res || !out) return fail(RNB_ERR_INVALID, "null argument");
+	if (!res[0] || !res[1] || !res[2]) return fail(RNB_ERR_INVALID, "empty lattice");
+	hipStream_t s = as_stream(stream);
+	const uint64_t n = (uint64_t)res[0] * res[1] * res[2];
+	const uint32_t batch = 1u << 22; // lattice points per network launch (the reference: 2^20 per call, same arithmetic per point)
+	float* pos = nullptr;
+	half_t* val = nullptr;
+	if (hipMalloc((void**)&pos, (size_t)batch * 12) != hipSuccess || hipMalloc((void**)&val, (size_t)batch * 2) != hipSuccess) {
+		if (pos) (void)hipFree(pos);
+		return fail(RNB_ERR_NOMEM, "hipMalloc failed for the lattice batch");
+	}
+	const float diag = c->aabb.mx - c->aabb.mn;
+	int rc = RNB_OK;
+	for (uint64_t off = 0; off < n && rc == RNB_OK; off += batch) {
+		const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n - off);
+		hipLaunchKernelGGL(k_lattice_positions, dim3((nb + 255) / 256), dim3(256), 0, s, off, nb, res[0], res[1], res[2], lattice_min, lattice_max - lattice_min, c->aabb.mn, diag, pos);
+		rc = launch_point_query(c, s, pos, nb, val, nullptr, nullptr, 0, inference != 0);
+		hipLaunchKernelGGL(k_half_to_float, dim3((nb + 255) / 256), dim3(256), 0, s, val, out + off, nb);
+	}
+	hipError_t e = hipStreamSynchronize(s);
+	(void)hipFree(pos); (void)hipFree(val);
+	if (rc != RNB_OK) return rc;
+	if (e != hipSuccess) return fail(RNB_ERR_DEVICE, std::string("rnb_sdf_lattice: ") + hipGetErrorString(e));
+	return RNB_OK;
+}
+
+namespace {
+// in-place exclusive prefix sums of n counts (device), total to *total_out; scratch for the block sums is allocated per level
+int scan_exclusive(uint32_t* data, uint64_t n, hipStream_t s, uint32_t* total_out) {
+	std::vector<uint32_t*> levels{data};
+	std::vector<uint64_t> sizes{n};
+	int rc = RNB_OK;
+	while (true) {
+		const uint64_t nb = (sizes.back() + 1023) / 1024;
+		uint32_t* sums = nullptr;
+		if (hipMalloc((void**)&sums, nb * 4) != hipSuccess) { rc = fail(RNB_ERR_NOMEM, "hipMalloc failed in scan_exclusive"); break; }
+		hipLaunchKernelGGL(k_scan_blocks, dim3((uint32_t)nb), dim3(1024), 0, s, levels.back(), sizes.back(), sums);
+		levels.push_back(sums); sizes.push_back(nb);
+		if (nb == 1) break;
+	}
+	if (rc == RNB_OK) {
+		if (hipMemcpyAsync(total_out, levels.back(), 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "scan_exclusive: readback failed");
+		// levels.back() holds one value (the total); every level below gets its block offsets added, top-down
+		for (size_t k = levels.size() - 1; k >= 2; --k) { /* levels[k-1] was scanned by the launch that produced levels[k]; add it to levels[k-2] */
+			hipLaunchKernelGGL(k_scan_add, dim3((uint32_t)sizes[k - 1]), dim3(1024), 0, s, levels[k - 2], sizes[k - 2], levels[k - 1]);
+		}
+	}
+	if (hipStreamSynchronize(s) != hipSuccess && rc == RNB_OK) rc = fail(RNB_ERR_DEVICE, "scan_exclusive failed");
+	for (size_t k = 1; k < levels.size(); ++k) (void)hipFree(levels[k]);
+	return rc;
+}
+} // namespace
+
+int rnb_marching_cubes(rnb_ctx* c, void* stream, const float* density, const uint32_t res[3], const float aabb_min[3], const float aabb_max[3], float thresh,
+                       float** verts_out, uint32_t** indices_out, uint32_t* n_verts, uint32_t* n_indices) {
+	if (!c || !density || !res || !aabb_min || !aabb_max || !verts_out || !indices_out || !n_verts || !n_indices) return fail(RNB_ERR_INVALID, "null argument");
+	*verts_out = nullptr; *indices_out = nullptr; *n_verts = 0; *n_indices = 0;
+	const uint64_t res3 = (uint64_t)res[0] * res[1] * res[2];
+	if (res3 == 0 || res3 >= (1ull << 32)) return fail(RNB_ERR_INVALID, "lattice must hold 1 .. 2^32-1 points");
+	hipStream_t s = as_stream(stream);
+	if (!c->mc_table.p) { // the case table of host/mesh.hpp, once
+		static const mesh::Tables T;
+		std::vector<McTable> h(1);
+		for (int m = 0; m < 256; ++m) {
+			int k = 0;
+			for (; T.tri[m][k] >= 0; ++k) h[0].tri[m][k] = T.tri[m][k];
+			h[0].n[m] = (uint8_t)k;
+			for (; k < 40; ++k) h[0].tri[m][k] = -1;
+		}
+		if (c->mc_table.alloc(1) != hipSuccess) return fail(RNB_ERR_NOMEM, "hipMalloc failed for the case table");
+		HIP_TRY(hipMemcpy(c->mc_table.p, h.data(), sizeof(McTable), hipMemcpyHostToDevice));
+	}
+	McArgs a;
+	a.density = density; a.rx = res[0]; a.ry = res[1]; a.rz = res[2]; a.thresh = thresh;
+	for (int d = 0; d < 3; ++d) { a.sc[d] = (aabb_max[d] - aabb_min[d]) / (float)res[d]; a.mn[d] = aabb_min[d]; }
+	const uint64_t n_wg64 = (res3 + MC_WG - 1) / MC_WG;
+	const uint32_t n_wg = (uint32_t)n_wg64;
+	uint32_t* wg = nullptr;
+	int32_t* vidx = nullptr;
+	float* verts = nullptr;
+	uint32_t* indices = nullptr;
+	auto cleanup = [&](int rc) { if (wg) (void)hipFree(wg); if (vidx) (void)hipFree(vidx); if (rc != RNB_OK) { if (verts) (void)hipFree(verts); if (indices) (void)hipFree(indices); } return rc; };
+	if (hipMalloc((void**)&wg, (size_t)n_wg * 4) != hipSuccess || hipMalloc((void**)&vidx, (size_t)res3 * 3 * 4) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the marching-cubes scratch (12 bytes per lattice point)"));
+	uint32_t nv = 0, ni = 0;
+	hipLaunchKernelGGL(k_mc_verts<false>, dim3(n_wg), dim3(MC_WG), 0, s, a, wg, (const uint32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr);
+	int rc = scan_exclusive(wg, n_wg, s, &nv);
+	if (rc != RNB_OK) return cleanup(rc);
+	if (nv && hipMalloc((void**)&verts, (size_t)nv * 12) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the vertices"));
+	hipLaunchKernelGGL(k_mc_verts<true>, dim3(n_wg), dim3(MC_WG), 0, s, a, (uint32_t*)nullptr, wg, verts, vidx);
+	hipLaunchKernelGGL(k_mc_faces<false>, dim3(n_wg), dim3(MC_WG), 0, s, a, c->mc_table.p, wg, (const uint32_t*)nullptr, vidx, (uint32_t*)nullptr);
+	rc = scan_exclusive(wg, n_wg, s, &ni);
+	if (rc != RNB_OK) return cleanup(rc);
+	if (ni && hipMalloc((void**)&indices, (size_t)ni * 4) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the indices"));
+	hipLaunchKernelGGL(k_mc_faces<true>, dim3(n_wg), dim3(MC_WG), 0, s, a, c->mc_table.p, (uint32_t*)nullptr, wg, vidx, indices);
+	if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return cleanup(fail(RNB_ERR_DEVICE, "rnb_marching_cubes: kernel failure"));
+	*verts_out = verts; *indices_out = indices; *n_verts = nv; *n_indices = ni;
+	return cleanup(RNB_OK);
 }
 
 int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {

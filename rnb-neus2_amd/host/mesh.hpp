@@ -70,7 +70,19 @@ struct Mesh {
 };
 
 // density[x + y*rx + z*rx*ry]; lattice point (x,y,z) sits at aabb_min + (x,y,z) * (aabb_max - aabb_min) / res
-inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const float aabb_min[3], const float aabb_max[3], float thresh) {
+// area-weighted vertex normals (compute_mesh_1ring, marching_cubes.cu:330-365), outward orientation
+inline void compute_normals(Mesh& m) {
+	m.normals.assign(m.verts.size(), {0, 0, 0});
+	for (size_t i = 0; i + 2 < m.indices.size(); i += 3) {
+		const uint32_t ia = m.indices[i], ib = m.indices[i + 1], ic = m.indices[i + 2];
+		const Vec3 a = m.verts[ia], b = m.verts[ib], c = m.verts[ic];
+		const Vec3 u = {b.x - a.x, b.y - a.y, b.z - a.z}, v = {c.x - a.x, c.y - a.y, c.z - a.z};
+		const Vec3 n = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+		for (uint32_t q : {ia, ib, ic}) { m.normals[q].x += n.x; m.normals[q].y += n.y; m.normals[q].z += n.z; }
+	}
+}
+
+inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const float aabb_min[3], const float aabb_max[3], float thresh, bool with_normals = true) {
 	static const Tables T;
 	Mesh m;
 	const size_t res2 = (size_t)rx * ry, res3 = res2 * rz;
@@ -114,15 +126,7 @@ inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const f
 			m.indices.push_back((uint32_t)v);
 		}
 	}
-	// area-weighted vertex normals (compute_mesh_1ring, marching_cubes.cu:330-365), outward orientation
-	m.normals.assign(m.verts.size(), {0, 0, 0});
-	for (size_t i = 0; i + 2 < m.indices.size(); i += 3) {
-		const uint32_t ia = m.indices[i], ib = m.indices[i + 1], ic = m.indices[i + 2];
-		const Vec3 a = m.verts[ia], b = m.verts[ib], c = m.verts[ic];
-		const Vec3 u = {b.x - a.x, b.y - a.y, b.z - a.z}, v = {c.x - a.x, c.y - a.y, c.z - a.z};
-		const Vec3 n = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
-		for (uint32_t q : {ia, ib, ic}) { m.normals[q].x += n.x; m.normals[q].y += n.y; m.normals[q].z += n.z; }
-	}
+	if (with_normals) compute_normals(m);
 	return m;
 }
 

@@ -404,30 +404,25 @@ struct Testbed {
 		const float amin = 0.5f - 0.5f * (float)cfg.aabb_scale, amax = 0.5f + 0.5f * (float)cfg.aabb_scale;
 		const float mn[3] = {amin, amin, amin}, mx[3] = {amax, amax, amax};
 		const size_t n = (size_t)res * res * res;
-		std::vector<float> sdf(n);
-		const uint32_t batch = 1u << 20; // get_density_on_grid: 2^20 lattice points per network call, EMA weights
-		void *dpos = nullptr, *dout = nullptr;
-		RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)batch * 12, &dpos));
-		RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)batch * 2, &dout));
-		std::vector<float> hpos((size_t)batch * 3);
-		std::vector<uint16_t> hout(batch);
-		const float inv = 1.f / (float)res, size = amax - amin, diag = amax - amin;
-		for (size_t off = 0; off < n; off += batch) {
-			const uint32_t nb = (uint32_t)std::min<size_t>(batch, n - off);
-			for (uint32_t q = 0; q < nb; ++q) { // generate_grid_samples_nerf_uniform (src/testbed_nerf.cu:541-553)
-				const size_t i = off + q;
-				const uint32_t x = (uint32_t)(i % res), y = (uint32_t)((i / res) % res), z = (uint32_t)(i / ((size_t)res * res));
-				const float p[3] = {(float)x * inv * size + amin, (float)y * inv * size + amin, (float)z * inv * size + amin};
-				for (int k = 0; k < 3; ++k) hpos[(size_t)q * 3 + k] = (p[k] - amin) / diag; // warp_position
-			}
-			RNB_CHECK(rnb_memcpy(ctx, dpos, hpos.data(), (uint64_t)nb * 12, RNB_H2D));
-			RNB_CHECK(rnb_sdf(ctx, nullptr, (const float*)dpos, nb, (uint16_t*)dout, 1));
-			RNB_CHECK(rnb_memcpy(ctx, hout.data(), dout, (uint64_t)nb * 2, RNB_D2H));
-			for (uint32_t q = 0; q < nb; ++q) sdf[off + q] = f16_to_f32(hout[q]);
-		}
-		mesh::Mesh m = mesh::marching_cubes(sdf.data(), (int)res, (int)res, (int)res, mn, mx, 0.0f);
+		const float diag = amax - amin;
+		// get_density_on_grid + marching_cubes_gpu on the device (src/testbed_nerf.cu:4218-4269, src/marching_cubes.cu:794-822): the
+		// lattice (4 bytes per point) and the edge -> vertex grid (12 bytes per point) never leave it; EMA weights
+		const uint32_t res3[3] = {res, res, res};
+		void* lattice = nullptr;
+		RNB_CHECK(rnb_device_malloc(ctx, (uint64_t)n * 4, &lattice));
+		RNB_CHECK(rnb_sdf_lattice(ctx, nullptr, res3, amin, amax, (float*)lattice, 1));
+		float* dverts = nullptr;
+		uint32_t* dindices = nullptr;
+		uint32_t nv = 0, ni = 0;
+		RNB_CHECK(rnb_marching_cubes(ctx, nullptr, (const float*)lattice, res3, mn, mx, 0.0f, &dverts, &dindices, &nv, &ni));
+		rnb_device_free(ctx, lattice);
+		mesh::Mesh m;
+		m.verts.resize(nv); m.indices.resize(ni);
+		if (nv) RNB_CHECK(rnb_memcpy(ctx, m.verts.data(), dverts, (uint64_t)nv * 12, RNB_D2H));
+		if (ni) RNB_CHECK(rnb_memcpy(ctx, m.indices.data(), dindices, (uint64_t)ni * 4, RNB_D2H));
+		rnb_device_free(ctx, dverts); rnb_device_free(ctx, dindices);
+		mesh::compute_normals(m);
 		std::printf("#vertices=%zu #triangles=%zu\n", m.verts.size(), m.indices.size() / 3);
-		sdf.clear(); sdf.shrink_to_fit();
 		// vertex colours: full network at the vertices, outward view direction (src/testbed_nerf.cu:793-799, 4193-4216)
 		m.colors.assign(m.verts.size(), {0, 0, 0});
 		if (!m.verts.empty()) {
@@ -457,7 +452,6 @@ struct Testbed {
 			}
 			rnb_device_free(ctx, dc); rnb_device_free(ctx, dq);
 		}
-		rnb_device_free(ctx, dpos); rnb_device_free(ctx, dout);
 		mesh::save_obj(filename, m, ds.scale, ds.offset, ds.n2w_s, ds.n2w_t);
 	}
 };
