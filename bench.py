@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--late-step", type=int, default=6000, help="then train on to this step and time --late-steps more: the converged regime (few samples "
                     "per ray, ~95 k rays per step) that the >= 1e8 rays/s target is about; 0 = off")
     ap.add_argument("--late-steps", type=int, default=200)
+    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY.md 8e): the job's step stays the single-GPU step (2^18 compacted samples, the "
+                    "controller's ray count); every rank takes 1/N of its rays and samples (dp.strong_scaling_sizes). Default: weak scaling, 2^18 samples per rank")
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
     return ap.parse_args()
@@ -80,7 +82,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
-    ctx = rnb.Context(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0, world_size=world, rank=rank, overlap=0 if os.environ.get("RNB_OVERLAP_OFF") else 1)
+    sizes = dp.strong_scaling_sizes(world) if args.strong else {}
+    ctx = rnb.Context(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0, world_size=world, rank=rank, overlap=0 if os.environ.get("RNB_OVERLAP_OFF") else 1, **sizes)
     ctx.init_params()
     t0 = time.time()
     views, normals, albedos = synthetic.make_scene(args.views, args.res)
@@ -217,12 +220,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f16 storage / f32 accumulate",
             "data": "synthetic",
-            "config": {"workload": "config 4: synthetic %d-view %dx%d normals+mask sphere, %s --mask-weight 1.0, 2^18 compacted samples/step/GPU"
-                                   % (args.views, args.res, args.res, "albedo + reflectance loss (NOT the metric's workload)" if args.albedo else "--no-albedo"),
+            "config": {"workload": "config 4: synthetic %d-view %dx%d normals+mask sphere, %s --mask-weight 1.0, %s compacted samples/step/GPU"
+                                   % (args.views, args.res, args.res, "albedo + reflectance loss (NOT the metric's workload)" if args.albedo else "--no-albedo",
+                                      ("2^18 / %d" % world) if args.strong else "2^18"),
                        "burn_in_steps": args.burn_in, "first_timed_step": first_timed,
                        "rays_per_step_per_gpu": round(rays / args.steps / world, 1),
                        "samples_per_s_compacted": round(samples / elapsed, 1),

@@ -1342,7 +1342,8 @@ void forward_backward(orc_ctx_s* c) {
 			FwdCtx k;
 			half_t out[16];
 			forward_sample(c, np, &c->coords_compacted[(size_t)i * 7], out, &k);
-			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B, grid_grad, mg, emulate ? &ops[i] : nullptr);
+			// batch_size of the Eikonal term = the samples of the whole step (nerf_network.h:359-365): all ranks' batches
+			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B * c->cfg.world_size, grid_grad, mg, emulate ? &ops[i] : nullptr);
 		}
 	}
 	double var = 0.0;

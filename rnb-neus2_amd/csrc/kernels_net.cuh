@@ -526,6 +526,7 @@ struct TrainArgs {
 	const float* coords;   // [B][7] compacted
 	const half_t* dout;    // [B][16]
 	uint32_t B;
+	uint32_t B_global; // the batch the Eikonal term is divided by (nerf_network.h:359-365): B x world_size, the samples of the whole step
 	float sdf_bias;
 	uint32_t skip_rgb; // --no-albedo: dL/d(rgb logits) is identically 0 (opti_rgb = 0, testbed_nerf.cu:1954-1962), so the
 	                   // colour MLP receives and propagates exact zeros: its forward/backward are skipped, not approximated
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
 				float v = h2f(a2[3 + d]);                  // dL_drgb_network_input rows 35..37
-				v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
+				v += h2f(dout[4 + d]) / (float)a.B_global;          // add_positions_view_ekloss (common_operation.cuh:283-296)
 				v += h2f(dout[8 + d]);                     // add_positions_view
 				dn[d] = v;
 			}
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
 			float v = 0.f;                             // dL_drgb_network_input rows 35..37 are zero here
-			v += h2f(dout[4 + d]) / (float)B;          // add_positions_view_ekloss (common_operation.cuh:283-296)
+			v += h2f(dout[4 + d]) / (float)a.B_global;          // add_positions_view_ekloss (common_operation.cuh:283-296)
 			v += h2f(dout[8 + d]);                     // add_positions_view (nerf_network.h:343-373)
 			dn[d] = v;
 		}

@@ -475,7 +475,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	c->grads_clean = false;
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
 	TrainArgs a;
-	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
+	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.B_global = B * c->cfg.world_size; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	a.wimg = !c->wimg_valid ? nullptr : (c->cfg.apply_no_albedo && !c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;

@@ -18,6 +18,20 @@ import os
 import numpy as np
 
 
+def strong_scaling_sizes(world_size, target_batch_size=1 << 18, max_rays_per_batch=1 << 18, initial_rays_per_batch=1 << 12):
+    """Context sizes of ONE rank for strong scaling: the step of the whole job is the single-GPU step --
+    `target_batch_size` compacted samples, `rays_per_batch` rays -- and rank r marches rays [r R/W, (r+1) R/W) of it and compacts
+    B/W samples. (The library always treats a step as world_size x the per-rank sizes: ray indices, image assignment, loss scale
+    128 / R_global and the Eikonal divisor B_global are those of one process running the whole step; with the default sizes on
+    every rank the job is weak scaling, W x the samples per step.) What differs from the single-GPU step: each rank pads ITS
+    compacted batch to B/W (fill_rollover_and_rescale, common_device.h:514-535) and the controller rounds the per-rank ray
+    count, not the global one, to a multiple of 128."""
+    W = int(world_size)
+    if target_batch_size % (128 * W):
+        raise ValueError("target_batch_size must be a multiple of 128 x world_size")
+    return dict(target_batch_size=target_batch_size // W, max_rays_per_batch=max(128, max_rays_per_batch // W), initial_rays_per_batch=max(1, initial_rays_per_batch // W))
+
+
 class _DeviceArray:
     """Minimal __cuda_array_interface__ view of a device buffer owned by the HIP library."""
 

@@ -241,3 +241,94 @@ def test_single_rank_trainer_equals_train_step():
     assert np.array_equal(a.get("PARAMS_FP32"), b.get("PARAMS_FP32"))
     a.close()
     b.close()
+
+
+# few enough rays that nobody's compacted batch overflows at step 0: every comparison below is then unconditional
+KW_STRONG = dict(KW, target_batch_size=1 << 14, initial_rays_per_batch=64)
+
+
+def _worker_strong(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import oracle_lib
+        from rnb_neus2_amd import dp
+        views, nm, al = _scene()
+        kw = dict(KW_STRONG)
+        kw.update(dp.strong_scaling_sizes(world, KW_STRONG["target_batch_size"], KW_STRONG["max_rays_per_batch"], KW_STRONG["initial_rays_per_batch"]))
+        c = oracle_lib.context(world_size=world, rank=rank, **kw)
+        c.init_params()
+        c.set_dataset(views, nm, al)
+
+        def reduce_grads(ctx):
+            t = torch.from_numpy(ctx.get("GRADS_FP32"))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ctx.put("GRADS_FP32", t.numpy())
+
+        tr = dp.DataParallelTrainer(c, all_reduce_grads=reduce_grads)
+        st = tr.step()
+        kept = int(c.get("COUNTERS")[2])
+        n_comp = int(c.get("COUNTERS")[1])
+        q.put({"rank": rank, "stats": st.as_dict(), "ray_indices": c.get("RAY_INDICES", kept), "rays": c.get("RAYS", kept * 6), "n_comp": n_comp,
+               "coords": c.get("COORDS_COMPACTED", min(n_comp, kw["target_batch_size"]) * 7), "loss": c.get("LOSS", st.rays_per_batch), "sizes": kw})
+    except Exception:
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_strong_scaling_two_ranks_run_the_single_gpu_step():
+    """dp.strong_scaling_sizes: two ranks with B/2 samples and R/2 rays each run the step ONE process runs with B and R -- the same
+    rays (PCG32 positions, image assignment), the same compacted samples, the same per-ray losses (scaled by the global ray
+    count), the same counters after the exchange; the controller then keeps the job at B samples per step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    r0, r1 = res
+    assert r0["sizes"]["target_batch_size"] == KW_STRONG["target_batch_size"] // 2 and r0["sizes"]["initial_rays_per_batch"] == KW_STRONG["initial_rays_per_batch"] // 2
+    from tests import oracle_lib
+    views, nm, al = _scene()
+    single = oracle_lib.context(**KW_STRONG)
+    single.init_params()
+    single.set_dataset(views, nm, al)
+    st = single.train_step()
+    R = st.rays_per_batch
+    assert r0["stats"]["rays_per_batch"] == r1["stats"]["rays_per_batch"] == R // 2
+    kept = int(single.get("COUNTERS")[2])
+    union_idx = np.concatenate([r0["ray_indices"], r1["ray_indices"] + R // 2])
+    assert np.array_equal(union_idx, single.get("RAY_INDICES", kept))
+    assert np.array_equal(np.concatenate([r0["rays"], r1["rays"]]).view(np.uint32), single.get("RAYS", kept * 6).view(np.uint32))
+    # compacted samples: rank 0's then rank 1's = the single process's, as long as nobody ran out of room
+    n_comp = int(single.get("COUNTERS")[1])
+    assert r0["n_comp"] + r1["n_comp"] == n_comp
+    assert 0 < n_comp <= KW_STRONG["target_batch_size"] and max(r0["n_comp"], r1["n_comp"]) <= KW_STRONG["target_batch_size"] // 2, (n_comp, r0["n_comp"], r1["n_comp"])
+    both = np.concatenate([r0["coords"], r1["coords"]])
+    assert np.array_equal(both.view(np.uint32), single.get("COORDS_COMPACTED", n_comp * 7).view(np.uint32))
+    # per-ray losses carry the global 1 / R scale
+    # (the per-ray loss rows are indexed by kept ray)
+    got, want = np.concatenate([r0["loss"][:len(r0["ray_indices"])], r1["loss"][:len(r1["ray_indices"])]]), single.get("LOSS", kept)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad, got[bad], want[bad])
+    # exchanged statistics: the job's counters are the single process's
+    for k in ("measured_batch_size_before_compaction", "measured_batch_size", "n_rays_kept"):
+        assert r0["stats"][k] == r1["stats"][k]
+        assert abs(2 * r0["stats"][k] - getattr(st, k)) <= 1, k  # stats report per-rank means
+    for k in ("loss", "ek_loss", "mask_loss"):
+        assert abs(r0["stats"][k] - getattr(st, k)) <= 2e-6 * abs(getattr(st, k)) + 1e-12, k
+    assert abs(2 * r0["stats"]["next_rays_per_batch"] - st.next_rays_per_batch) <= 256  # each rank rounds its share up to a multiple of 128
+    single.close()
