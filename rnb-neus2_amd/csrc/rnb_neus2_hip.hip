@@ -561,11 +561,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		launch_dw(sd, c->ev_dw);
 		c->sc.dp = c->dp_order();
 		const uint32_t a_mid = l_fine + (L - l_fine + 1) / 2;
+		// Data parallel: C, B, then A, so that the parameters in front of A's levels (MLPs, C, B: one contiguous block) are final at
+		// ev_sc[0] + ev_dw and their exchange runs beside the scatter of A; A's levels + variance are the second block.
+		if (c->sc.dp) launch_c(s, nullptr);
 		launch_b(s, c->ev_sc[0]);
 		launch_a(s, c->ev_sc[1], l_fine, a_mid);
 		launch_a(s, c->ev_sc[3], a_mid, L);
 		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
-		launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter
+		if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
 		if (c->sc.dp || join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
 		c->sc.dw_joined = c->sc.dp || join_dw; // the training step leaves the join to the optimizer, which continues on the side stream (optimizer_step)
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
