@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PMC_TRAFFIC, PMC_UNITS = "r02_pmc_traffic.json", "r02_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
 # Algorithmic bytes per unit (restated in DESIGN.md §measurement)
 ALGO_BYTES = {
     "k_forward": 508.0,            # 448 B gathers + 28 B coords + 32 B out, per un-compacted sample
@@ -183,28 +184,33 @@ def main():
             avg_ms = p["total_ms"] / p["launches"]
             units_per_launch = p["units"] / p["launches"]
             achieved = bytes_per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None  # HBM bytes per launch from the PMC passes (tools/collect_pmc.sh -> profiles/r01_pmc_traffic.json); a PMC pass cannot run inside this process
+            # HBM bytes per launch: NOT measured in this process (a PMC pass cannot run inside it) but read from the committed summary of
+            # separate rocprofv3 --pmc passes over the same command (tools/collect_pmc.sh); `traffic_source` says so in the record
+            traffic, traffic_source = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)) as f:
                     traffic = json.load(f)["per_step"][kname]["total_bytes"] / max(p["launches"] / max(args.profile_steps, 1), 1.0)
+                traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run" % PMC_TRAFFIC
             except Exception:
                 pass
-            limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py)
+            limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py); also from a committed file
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_units.json")) as f:
+                with open(os.path.join(ROOT, "profiles", PMC_UNITS)) as f:
                     units = json.load(f)
                 if kname == "k_grid_scatter":
                     parts = [units["kernels"][k] for k in ("k_grid_scatter_quad", "k_grid_scatter_quad_rl", "k_grid_scatter_lds")]
                     req = sum(q.get("l2_atomic_requests", 0) for q in parts)
-                    limiter = {"unit": "L2 atomic requests", "per_launch": req, "achieved_per_s": round(req / (avg_ms * 1e-3)),
+                    limiter = {"unit": "L2 atomic lines (one 64-byte line of one instruction)", "per_launch": req, "achieved_per_s": round(req / (avg_ms * 1e-3)),
                                "probe_rate_per_s": units["_atomic_probe_requests_per_s"],
-                               "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3)}
+                               "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3),
+                               "limiter_source": "per_launch: committed file profiles/%s (TCC_ATOMIC_sum pass at steps 2000-2010, builder-run; the duration is this run's, whose "
+                                                 "regime may put more lines on the path); probe rate: tools/probe_atomics4.hip" % PMC_UNITS}
             except Exception:
                 pass
             if limiter is None and kname in LIMITER_NOTES:
                 limiter = {"unit": LIMITER_NOTES[kname]}
             return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 4),
                     "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit, "limiter": limiter}
 
         ranked = sorted(prof, key=lambda p: -p["total_ms"])

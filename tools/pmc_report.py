@@ -5,8 +5,8 @@ import json
 import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-steady = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_v3_steady_serial.json"
-out_path = sys.argv[3] if len(sys.argv) > 3 else "profiles/r01_pmc_units.json"
+steady = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_steady_serial_step2000.json"
+out_path = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02_pmc_units.json"
 ATOMIC_PROBE = 21.0e9  # L2 atomic requests/s, device-wide, the best any pattern of tools/probe_atomics*.hip reached (one 64-B line of one instruction = one request)
 CLOCK_HZ = 2.4e9       # MI355X peak engine clock
 N_SIMD = 256 * 4

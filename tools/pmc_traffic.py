@@ -3,7 +3,7 @@ import json
 import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
+out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
 F = json.load(open(d + "/FETCH_SIZE.json"))["kernels"]
 W = json.load(open(d + "/WRITE_SIZE.json"))["kernels"]
 fb = [k for k in F if k.startswith("k_fwd_bwd")]

@@ -1,21 +1,30 @@
 #!/bin/bash
-# GPU box: everything profiles/ holds for a round (bench lines, serial / overlapped kernel statistics, PMC passes, smoke) -> gpurun_out/r01, gpurun_out/pmc
-mkdir -p gpurun_out/r01 gpurun_out/pmc
+# GPU box: everything profiles/ holds for a round -> gpurun_out/<round>p/ (copy what is to be judged into profiles/ afterwards)
+#   bash tools/refresh_profiles.sh r02
+R=${1:-r02}
+O=gpurun_out/${R}p
+mkdir -p $O $O/pmc
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python bench.py 2>/dev/null | grep "^{" > gpurun_out/r01/bench_default.json
-python bench.py --albedo --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/r01/bench_albedo.json
+python bench.py 2>$O/bench_default.err | grep "^{" > $O/bench_default.json                        # the defaults: steps 1000-2000 timed, + late regime
+python bench.py --steps 20 2>/dev/null | grep "^{" > $O/bench_steps20.json                        # the driver's command line
+python bench.py --albedo --no-cpu-baseline --late-step 0 2>/dev/null | grep "^{" > $O/bench_albedo.json
+for regime in 980 1980; do
 for mode in serial overlapped; do
   rm -rf /tmp/kt_$mode
   if [ $mode = serial ]; then export RNB_OVERLAP_OFF=1; else unset RNB_OVERLAP_OFF; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in 1980 --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 > /tmp/kt_$mode.log 2>&1
-  f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/r01/kernel_stats_$mode.csv
-  python tools/steady_stats.py /tmp/kt_$mode 100 > gpurun_out/r01/steady_$mode.json
-done
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in $regime --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 > /tmp/kt_$mode.log 2>&1
+  f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_${mode}_step$((regime+20)).csv
+  python tools/steady_stats.py /tmp/kt_$mode 100 > $O/steady_${mode}_step$((regime+20)).json
+done; done
 unset RNB_OVERLAP_OFF
-bash tools/collect_pmc.sh gpurun_out/pmc FETCH_SIZE WRITE_SIZE TCC_ATOMIC_sum SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE > /dev/null 2>&1
+bash tools/collect_pmc.sh $O/pmc FETCH_SIZE WRITE_SIZE TCC_ATOMIC_sum SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE > /dev/null 2>&1
+python tools/pmc_traffic.py $O/pmc $O/pmc_traffic.json
+python tools/pmc_report.py $O/pmc $O/steady_serial_step2000.json $O/pmc_units.json > /dev/null
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-head -c 600 gpurun_out/r01/bench_default.json; echo; head -c 300 gpurun_out/r01/bench_albedo.json; echo
-python -c "
+python - <<PY
 import json
-for m in ('serial','overlapped'):
-    d=json.load(open('gpurun_out/r01/steady_%s.json'%m)); print(m, d['wall_us_per_step'])"
+d=json.load(open('$O/bench_default.json')); print('default:', d['value'], d['ms_per_step'], d['window_1000_2000'], d['late_regime'])
+d=json.load(open('$O/bench_steps20.json')); print('steps20:', d['value'], d['ms_per_step'], d['late_regime'])
+for m in ('serial_step1000','overlapped_step1000','serial_step2000','overlapped_step2000'):
+    s=json.load(open('$O/steady_%s.json'%m)); print(m, s['wall_us_per_step'])
+PY
