@@ -64,8 +64,9 @@ def build_testbed(force=False, verbose=False):
         if not any(os.path.getmtime(d) > t for d in TESTBED_DEPS):
             return TESTBED_OUT
     os.makedirs(os.path.dirname(TESTBED_OUT), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
-           "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    # RNB_WITH_RCCL: one process per GPU over RCCL (tools/launch_testbed.sh); the CPU-checker build of the same file (tests/) leaves it out
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-DRNB_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
+           "-L" + PKG_DIR, "-lrnb_neus2_hip", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

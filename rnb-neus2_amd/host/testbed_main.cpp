@@ -13,6 +13,11 @@
 #include "msgpack_min.hpp"
 #include "png16.hpp"
 
+#ifdef RNB_WITH_RCCL // the HIP build: several processes, one per GPU, exchange counters and gradients over RCCL (no reference counterpart)
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
+
 #include <sys/stat.h>
 #include <dirent.h>
 #include <unistd.h>
@@ -172,6 +177,124 @@ static jsonmin::Value mpk_to_json(const mpk::Value& m) {
 	return j;
 }
 
+// ---- one process per GPU (the reference is single-GPU, so this has no counterpart in src/main.cu) ----
+// Environment, set by tools/launch_testbed.sh (or torchrun-style variables): RNB_WORLD_SIZE | WORLD_SIZE, RNB_RANK | RANK,
+// RNB_LOCAL_RANK | LOCAL_RANK (the HIP device), RNB_RCCL_ID_FILE (rank 0 writes the ncclUniqueId there, the others wait for it).
+// The job trains the SINGLE-GPU step: every rank takes 1/W of the rays and of the compacted batch (RNB_WEAK_SCALING=1: every
+// rank keeps the configured sizes, the step grows W-fold). Per step: the 7 counters / loss sums are all-reduced on the
+// library's device block, then the gradient blocks in the order they become final -- the early block on its own stream, with
+// its optimizer chunk, beside the rest of the scatter. Rank 0 alone writes meshes, snapshots and progress lines.
+struct Dist {
+	int world = 1, rank = 0, local_rank = 0;
+	bool on = false, weak = false;
+#ifdef RNB_WITH_RCCL
+	ncclComm_t comm = nullptr;
+	hipStream_t s_early = nullptr, s_vec = nullptr;
+	double* host7 = nullptr;
+#endif
+	static int env_int(const char* a, const char* b, int def) {
+		const char* v = std::getenv(a);
+		if (!v) v = std::getenv(b);
+		return v ? std::atoi(v) : def;
+	}
+	void init() {
+		world = env_int("RNB_WORLD_SIZE", "WORLD_SIZE", 1);
+		rank = env_int("RNB_RANK", "RANK", 0);
+		local_rank = env_int("RNB_LOCAL_RANK", "LOCAL_RANK", rank);
+		weak = std::getenv("RNB_WEAK_SCALING") != nullptr;
+		on = world > 1 || std::getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr; // the variable exercises the collective path on one rank
+		if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad RNB_WORLD_SIZE / RNB_RANK");
+		if (!on) return;
+#ifdef RNB_WITH_RCCL
+		if (hipSetDevice(local_rank) != hipSuccess) throw std::runtime_error("hipSetDevice(" + std::to_string(local_rank) + ") failed");
+		ncclUniqueId id;
+		const char* idf = std::getenv("RNB_RCCL_ID_FILE");
+		if (world > 1 && !idf) throw std::runtime_error("RNB_RCCL_ID_FILE is not set (use tools/launch_testbed.sh)");
+		if (rank == 0) {
+			if (ncclGetUniqueId(&id) != ncclSuccess) throw std::runtime_error("ncclGetUniqueId failed");
+			if (idf) {
+				const std::string tmp = std::string(idf) + ".tmp";
+				std::FILE* f = std::fopen(tmp.c_str(), "wb");
+				if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+				std::fclose(f);
+				if (std::rename(tmp.c_str(), idf) != 0) throw std::runtime_error(std::string("cannot publish ") + idf);
+			}
+		} else {
+			bool got = false;
+			for (int tries = 0; tries < 1200 && !got; ++tries) { // up to two minutes
+				if (std::FILE* f = std::fopen(idf, "rb")) { got = std::fread(&id, sizeof(id), 1, f) == 1; std::fclose(f); }
+				if (!got) usleep(100000);
+			}
+			if (!got) throw std::runtime_error(std::string("no ncclUniqueId in ") + idf);
+		}
+		if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) throw std::runtime_error("ncclCommInitRank failed");
+		if (hipStreamCreateWithFlags(&s_early, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_vec, hipStreamNonBlocking) != hipSuccess ||
+		    hipHostMalloc((void**)&host7, 7 * sizeof(double), 0) != hipSuccess) throw std::runtime_error("stream / pinned buffer creation failed");
+#else
+		throw std::runtime_error("this build of testbed has no RCCL support (RNB_WORLD_SIZE > 1)");
+#endif
+	}
+	// sizes of ONE rank (dp.strong_scaling_sizes of the Python side)
+	void apply_sizes(rnb_config& cfg) const {
+		cfg.world_size = (uint32_t)world; cfg.rank = (uint32_t)rank;
+		if (world == 1 || weak) return;
+		if (cfg.target_batch_size % (128u * world)) throw std::runtime_error("batch_size must be a multiple of 128 x world size");
+		cfg.target_batch_size /= (uint32_t)world;
+		cfg.max_rays_per_batch = std::max(128u, cfg.max_rays_per_batch / (uint32_t)world);
+		cfg.initial_rays_per_batch = std::max(1u, cfg.initial_rays_per_batch / (uint32_t)world);
+	}
+	int train_step(rnb_ctx* ctx, rnb_step_stats* st) {
+		if (!on) return rnb_train_step(ctx, nullptr, st);
+#ifdef RNB_WITH_RCCL
+		int rc = rnb_train_step_begin(ctx, nullptr);
+		if (rc != RNB_OK) return rc;
+		uint64_t cnt[4]; double sums[3];
+		rc = rnb_train_step_local(ctx, nullptr, cnt, sums); // the host waits for the loss pass only
+		if (rc != RNB_OK) return rc;
+		void* vec; uint64_t nb;
+		rc = rnb_buffer(ctx, RNB_BUF_STEP_VECTOR, &vec, &nb);
+		if (rc != RNB_OK) return rc;
+		if (ncclAllReduce(vec, vec, 7, ncclDouble, ncclSum, comm, s_vec) != ncclSuccess) throw std::runtime_error("ncclAllReduce (step vector) failed");
+		if (hipMemcpyAsync(host7, vec, 7 * sizeof(double), hipMemcpyDeviceToHost, s_vec) != hipSuccess || hipStreamSynchronize(s_vec) != hipSuccess) throw std::runtime_error("step vector readback failed");
+		for (int k = 0; k < 4; ++k) cnt[k] = (uint64_t)std::llround(host7[k]);
+		for (int k = 0; k < 3; ++k) sums[k] = host7[4 + k];
+		const int rc_finish = rnb_train_step_finish(ctx, cnt, sums, st); // ray controller; queues the next step's march
+		if (rc_finish != RNB_OK && rc_finish != RNB_ERR_NO_SAMPLES) return rc_finish;
+		// gradients: sum over the ranks, block by block in completion order; the optimizer runs even when the step had no samples
+		uint64_t ranges[3][2]; uint32_t n_parts = 0;
+		rc = rnb_gradient_parts(ctx, ranges, &n_parts);
+		if (rc != RNB_OK) return rc;
+		void* gp; rc = rnb_buffer(ctx, RNB_BUF_GRADS_FP32, &gp, &nb);
+		if (rc != RNB_OK) return rc;
+		float* g = (float*)gp;
+		uint32_t first = 0;
+		if (n_parts > 1) {
+			rc = rnb_gradient_part_wait(ctx, 0, s_early);
+			if (rc != RNB_OK) return rc;
+			if (ncclAllReduce(g + ranges[0][0], g + ranges[0][0], ranges[0][1] - ranges[0][0], ncclFloat, ncclSum, comm, s_early) != ncclSuccess) throw std::runtime_error("ncclAllReduce (early block) failed");
+			rc = rnb_train_step_apply_early(ctx, s_early); // Adam on that block, beside the rest of the exchange
+			if (rc != RNB_OK) return rc;
+			first = 1;
+		}
+		for (uint32_t k = first; k < n_parts; ++k) {
+			rc = rnb_gradient_part_wait(ctx, k, nullptr);
+			if (rc != RNB_OK) return rc;
+			if (ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm, nullptr) != ncclSuccess) throw std::runtime_error("ncclAllReduce failed");
+		}
+		rc = rnb_train_step_apply(ctx, nullptr);
+		if (rc != RNB_OK) return rc;
+		return rc_finish;
+#else
+		return RNB_ERR_INVALID;
+#endif
+	}
+	void shutdown() {
+#ifdef RNB_WITH_RCCL
+		if (comm) { (void)hipDeviceSynchronize(); ncclCommDestroy(comm); comm = nullptr; }
+#endif
+	}
+};
+
 struct Testbed {
 	rnb_config cfg;
 	rnb_ctx* ctx = nullptr;
@@ -186,6 +309,7 @@ struct Testbed {
 	uint32_t res_mesh = 512;
 	std::string mesh_prefix;
 	jsonmin::Value network_config;
+	Dist dist;
 
 	~Testbed() { if (ctx) rnb_destroy(ctx); }
 
@@ -226,6 +350,7 @@ struct Testbed {
 
 	void create_context() {
 		if (ctx) { rnb_destroy(ctx); ctx = nullptr; }
+		dist.apply_sizes(cfg);
 		RNB_CHECK(rnb_create(&cfg, &ctx));
 		// geometric initialisation of the SDF MLP (nerf_network.h:585-623): <exe_dir>/../utils/...
 		const std::string wpath = parent_path(exe_dir()) + "/utils/mlp_weights_hidden_layer_num_1_hidden_size_32.txt";
@@ -329,7 +454,7 @@ struct Testbed {
 		enc.set("valid_level_scale", mpk::Value::real(cfg.valid_level_scale)); enc.set("base_valid_level_scale", mpk::Value::real(cfg.base_valid_level_scale));
 		enc.set("base_training_step", mpk::Value::uint(cfg.base_training_step));
 		mpk::Value& hp = obj("hyperparams");
-		hp.set("batch_size", mpk::Value::uint(cfg.target_batch_size));
+		hp.set("batch_size", mpk::Value::uint((uint64_t)cfg.target_batch_size * ((dist.world > 1 && !dist.weak) ? dist.world : 1))); // the job's batch, not this rank's share
 		hp.set("mask_loss_weight", mpk::Value::real(cfg.mask_loss_weight)); hp.set("ek_loss_weight", mpk::Value::real(cfg.ek_loss_weight));
 		mpk::Value& net = obj("network");
 		if (!net.find("otype")) net.set("otype", mpk::Value::str("FullyFusedMLP"));
@@ -476,6 +601,8 @@ int main(int argc, char** argv) {
 	try {
 		Testbed tb;
 		rnb_default_config(&tb.cfg);
+		tb.dist.init();
+		const bool lead = tb.dist.rank == 0; // meshes, snapshots and progress lines come from rank 0 only
 		try {
 			if (args.has("maxiter")) tb.max_iter = args.get_u32("maxiter");
 			if (args.has("resolution")) tb.res_mesh = args.get_u32("resolution");
@@ -550,7 +677,7 @@ int main(int argc, char** argv) {
 			while (running) {
 				if (tb.train) {
 					rnb_step_stats st;
-					const int rc = rnb_train_step(tb.ctx, nullptr, &st);
+					const int rc = tb.dist.train_step(tb.ctx, &st);
 					if (rc == RNB_ERR_NO_SAMPLES) { std::cout << "Nerf training generated 0 samples. Aborting training." << std::endl; tb.train = false; tb.loss_scalar = 0.f; }
 					else if (rc != RNB_OK) throw std::runtime_error(rnb_last_error());
 					else {
@@ -567,26 +694,27 @@ int main(int argc, char** argv) {
 						RNB_CHECK(rnb_update_config(tb.ctx, &tb.cfg));
 					}
 				}
-				if (tb.save_each > 0 && step % tb.save_each == 0) {
+				if (lead && tb.save_each > 0 && step % tb.save_each == 0) {
 					const std::string name = tb.mesh_prefix + std::to_string(step) + ".obj";
 					std::printf("%s\n", name.c_str());
 					tb.compute_and_save_marching_cubes_mesh(name, tb.res_mesh);
 				}
 				running = step < tb.max_iter; // Testbed::frame's return value
-				if (running && step % 100 == 0) std::cout << "iteration=" << step << " loss=" << tb.loss_scalar << std::endl; // src/main.cu:444-451
+				if (lead && running && step % 100 == 0) std::cout << "iteration=" << step << " loss=" << tb.loss_scalar << std::endl; // src/main.cu:444-451
 				if (!tb.train) running = false; // the reference would spin here forever once training aborted; stop instead
 			}
-			if (train_ms > 0) std::cout << "throughput: " << (double)rays_total / (train_ms * 1e-3) << " rays/s, " << train_ms / std::max(1u, step - resume.training_step) << " ms/step" << std::endl;
+			if (lead && train_ms > 0) std::cout << "throughput: " << (double)rays_total * tb.dist.world / (train_ms * 1e-3) << " rays/s, " << train_ms / std::max(1u, step - resume.training_step) << " ms/step" << std::endl;
 		}
-		if (args.has("save-mesh")) {
+		if (lead && args.has("save-mesh")) {
 			// --free-memory releases the dataset before meshing in the reference (src/main.cu:455-459; 10 s sleep not reproduced)
 			tb.compute_and_save_marching_cubes_mesh(obj_filename, tb.res_mesh);
 		}
 		const std::string snapshot_filename = tb.output_path + "/snapshot_" + std::to_string(tb.max_iter) + ".msgpack";
-		if (args.has("save-snapshot")) {
+		if (lead && args.has("save-snapshot")) {
 			std::cout << "Saving Snapshot !" << std::endl << snapshot_filename << std::endl;
 			tb.save_snapshot(snapshot_filename, step, rays_per_batch, measured, measured_before);
 		}
+		tb.dist.shutdown();
 	} catch (const std::exception& e) {
 		std::cerr << "Uncaught exception: " << e.what() << std::endl;
 		return 1;

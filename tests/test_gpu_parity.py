@@ -714,3 +714,40 @@ def test_config2_shape_normals_only_10000_steps_gpu(tmp_path):
     rad = np.linalg.norm(v, axis=1)
     assert len(v) > 50000 and abs(np.median(rad) - 0.125) < 0.002 and rad.std() < 0.003, (len(v), np.median(rad), rad.std())
     print("10000 steps + 512^3 mesh: %.1f s wall, final loss %.2e" % (elapsed, losses[-1]))
+
+
+def test_testbed_cli_over_rccl_single_rank(tmp_path):
+    """build/testbed's one-process-per-GPU mode (struct Dist in host/testbed_main.cpp, tools/launch_testbed.sh): with a world of 1
+    and RNB_DP_FORCE_COLLECTIVES the step runs through the RCCL calls of the multi-GPU path -- all-reduce of the 7 counters on
+    the library's device block, gradient blocks in completion order with the early block and its optimizer chunk on their own
+    stream -- and must train like the plain command line (same rays, same first-step loss, the same converged sphere)."""
+    import os
+    import subprocess
+    import msgpack
+    from rnb_neus2_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "testbed")
+    views, normals, albedos = synthetic.make_scene(12, 200, 350.0)
+    snaps = {}
+    for mode in ("plain", "rccl"):
+        scene = str(tmp_path / mode)
+        synthetic.write_scene(scene, views, normals, albedos, scale=2.0, offset=(0.5, 0.5, 0.5))
+        env = dict(os.environ)
+        cmd = [exe, "--scene", scene + "/", "--maxiter", "400", "--no-gui", "--mask-weight", "1.0", "--no-albedo", "--save-snapshot", "--save-mesh", "--resolution", "128"]
+        if mode == "rccl":
+            env["RNB_DP_FORCE_COLLECTIVES"] = "1"
+            cmd = [os.path.join(root, "tools", "launch_testbed.sh"), "1"] + cmd
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
+        its = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
+        assert [l.split()[0] for l in its] == ["iteration=%d" % k for k in range(100, 400, 100)]
+        with open(os.path.join(scene, "output", "snapshot_400.msgpack"), "rb") as f:
+            snaps[mode] = (msgpack.unpackb(f.read(), raw=False), [float(l.split("loss=")[1]) for l in its])
+        v = np.array([[float(x) for x in l.split()[1:4]] for l in open(os.path.join(scene, "output", "mesh_400.obj")) if l.startswith("v ")])
+        rad = np.linalg.norm(v, axis=1)
+        assert abs(np.median(rad) - 0.125) < 0.005 and rad.std() < 0.008, (mode, np.median(rad), rad.std())
+    a, b = snaps["plain"], snaps["rccl"]
+    assert a[0]["snapshot"]["training_step"] == b[0]["snapshot"]["training_step"] == 400
+    assert a[0]["hyperparams"]["batch_size"] == b[0]["hyperparams"]["batch_size"]
+    for x, y in zip(a[1], b[1]):  # same training up to the order of the fp32 atomics
+        assert abs(x - y) <= 0.15 * max(x, y), (a[1], b[1])
