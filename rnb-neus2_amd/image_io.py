@@ -1,20 +1,22 @@
-"""Image helpers of the preparation stages (mirror of rnb_neus2/image_io.py:15-125, PNG only: the target image has
-neither OpenCV nor OpenEXR, decoding goes through librnb_host.so). Arrays are RGB(A) everywhere."""
+"""Image helpers of the preparation stages (mirror of rnb_neus2/image_io.py:15-125; the target image has neither OpenCV nor
+OpenEXR: PNG goes through librnb_host.so, EXR through the scanline codec of exr.py). Arrays are RGB(A) everywhere."""
 import os
+
+from struct import error as struct_error
 
 import numpy as np
 
-from . import hostlib
-
-
-def _no_exr(path):
-    raise NotImplementedError("EXR I/O is not available in this build (no OpenEXR codec on the target image): {}".format(path))
+from . import exr, hostlib
 
 
 def read_unchanged(path):
-    """What `cv2.imread(path, IMREAD_UNCHANGED)` yields for a PNG, but in RGB(A) order; None when unreadable."""
+    """What `cv2.imread(path, IMREAD_UNCHANGED)` yields -- uint8 / uint16 for PNG, float32 for EXR -- but in RGB(A) order; None when
+    unreadable. (An EXR in a compression this build does not decode raises: silently skipping the frame would hide it.)"""
     if str(path).lower().endswith(".exr"):
-        _no_exr(path)
+        try:
+            return exr.read_exr(path)
+        except (OSError, ValueError, KeyError, struct_error):
+            return None
     try:
         return hostlib.png_read(path)
     except RuntimeError:
@@ -22,10 +24,13 @@ def read_unchanged(path):
 
 
 def load_image(path):
-    """PNG 8/16-bit -> float32 in [0, 1], (H, W[, C]) RGB(A). (rnb_neus2/image_io.py:15-45)"""
+    """PNG 8/16-bit -> float32 in [0, 1]; EXR float32 as stored (values may leave [0, 1]); (H, W[, C]) RGB(A).
+    (rnb_neus2/image_io.py:15-45)"""
     image = read_unchanged(path)
     if image is None:
         raise FileNotFoundError("Cannot read image: {}".format(path))
+    if image.dtype == np.float32:
+        return image
     return image.astype(np.float32) / np.float32(255.0 if image.dtype == np.uint8 else 65535.0)
 
 
@@ -36,16 +41,17 @@ def save_image(image, path, bit_depth=16):
 
 
 def save_exr(image, path):
-    _no_exr(path)
+    """float32 RGB image as EXR (FLOAT channels). (image_io.py:73-88)"""
+    exr.write_exr(path, np.asarray(image, np.float32))
 
 
 def load_normal(path):
     """Normal map as float32 in [-1, 1] (PNG stores (n+1)/2). (image_io.py:91-110)"""
-    if os.path.splitext(str(path))[1].lower() == ".exr":
-        _no_exr(path)
     image = load_image(path)
     if image.ndim == 3 and image.shape[2] > 3:
         image = image[:, :, :3]
+    if os.path.splitext(str(path))[1].lower() == ".exr":
+        return image  # already in [-1, 1]
     return image * 2.0 - 1.0
 
 
@@ -55,4 +61,5 @@ def save_normal_16bit(normal, path):
 
 
 def save_normal_exr(normal, path):
-    _no_exr(path)
+    """Raw [-1, 1] values. (image_io.py:123-125)"""
+    save_exr(np.asarray(normal, np.float32), path)

@@ -13,14 +13,16 @@ from .scaling import (compute_scaling_from_silhouettes, compute_scaling_from_sil
 
 def _load_mask_image(mask_path, img_shape, bit_depth):
     """Binary mask as 0 / full-scale samples of the requested depth; all-opaque when there is no mask file.
-    Thresholds: >125 for 8-bit masks, >30000 for 16-bit ones. (prepare.py:23-42)"""
+    Thresholds: >125 for 8-bit masks, >30000 for 16-bit ones, >0.5 for float (EXR) ones. (prepare.py:23-42)"""
     full = 65535 if bit_depth == 16 else 255
     dtype = np.uint16 if bit_depth == 16 else np.uint8
     img = read_unchanged(mask_path) if mask_path and os.path.exists(mask_path) else None
     if img is None:
         return np.full(img_shape, full, dtype)
     if img.ndim == 3:
-        img = img[:, :, 0]
+        img = img[:, :, 2] if img.shape[2] >= 3 else img[:, :, 0]  # cv2's channel 0 is blue; arrays here are RGB(A)
+    if img.dtype == np.float32:  # EXR masks
+        return np.where(img > 0.5, full, 0).astype(dtype)
     return np.where(img > (125 if img.dtype == np.uint8 else 30000), full, 0).astype(dtype)
 
 
@@ -84,10 +86,14 @@ def prepare_testbed_data(data, output_folder, logger, scaling_mode="auto", spher
         if normal is None:
             logger.warning("Cannot read: {}".format(view["normal_path"]))
             continue
+        if normal.dtype == np.float32:  # EXR normals in [-1, 1] -> 16-bit (prepare.py:166-170)
+            normal = (np.clip((normal + 1.0) / 2.0, 0, 1) * 65535).astype(np.uint16)
         normal = _rgb(normal)
         depth = 16 if normal.dtype == np.uint16 else 8
         albedo_path = view.get("albedo_path")
         albedo = read_unchanged(albedo_path) if albedo_path and os.path.exists(albedo_path) else None
+        if albedo is not None and albedo.dtype == np.float32:  # EXR albedos (prepare.py:185-188)
+            albedo = (np.clip(albedo, 0, 1) * 65535).astype(np.uint16)
         albedo = np.full_like(normal, 65535 if depth == 16 else 255) if albedo is None else _rgb(albedo)
         normal_mask = _load_mask_image(view.get("mask_path"), normal.shape[:2], depth)
         albedo_depth = 16 if albedo.dtype == np.uint16 else 8

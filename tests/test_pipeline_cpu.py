@@ -296,8 +296,71 @@ def test_image_io_helpers(tmp_path):
     np.testing.assert_allclose(image_io.load_normal(tmp_path / "n.png"), n, atol=2e-5)
     with pytest.raises(FileNotFoundError):
         image_io.load_image(tmp_path / "nope.png")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):
         image_io.load_image(tmp_path / "x.exr")
+
+
+@pytest.mark.parametrize("compression", ["none", "zips", "zip"])
+@pytest.mark.parametrize("pixel_type", ["float", "half"])
+def test_exr_roundtrip(tmp_path, compression, pixel_type):
+    """The scanline EXR codec (rnb-neus2_amd/exr.py; the reference reads EXR through cv2): all supported compressions and pixel
+    types, sizes that are not multiples of the 16-line ZIP block, 1 / 3 / 4 channels, RGB order in and out."""
+    from rnb_neus2_amd import exr
+    rng = np.random.default_rng(3)
+    for shape in ((37, 23, 3), (16, 5, 4), (1, 1, 3), (40, 31)):
+        img = (rng.standard_normal(shape) * 2).astype(np.float32)
+        if pixel_type == "half":
+            img = img.astype(np.float16).astype(np.float32)
+        img[..., 0] = np.linspace(-1, 1, img[..., 0].size, dtype=np.float32).reshape(img[..., 0].shape) if img.ndim == 3 else img[..., 0]
+        if pixel_type == "half":
+            img = img.astype(np.float16).astype(np.float32)
+        path = tmp_path / ("%s_%s_%d.exr" % (compression, pixel_type, len(shape) * 100 + shape[0]))
+        exr.write_exr(path, img, compression=compression, pixel_type=pixel_type)
+        back = exr.read_exr(path)
+        assert back.dtype == np.float32 and back.shape == img.shape
+        assert np.array_equal(back, img)
+    # smooth data really is deflated (the predictor + byte split is in place, not just a stored block)
+    smooth = np.tile(np.linspace(0, 1, 256, dtype=np.float32)[None, :, None], (64, 1, 3))
+    exr.write_exr(tmp_path / "s.exr", smooth, compression=compression, pixel_type=pixel_type)
+    size = (tmp_path / "s.exr").stat().st_size
+    assert (size < 0.7 * smooth.nbytes) == (compression != "none" or pixel_type == "half")
+    with open(tmp_path / "bad.exr", "wb") as f:
+        f.write(b"not an exr file at all")
+    assert image_io.read_unchanged(tmp_path / "bad.exr") is None
+
+
+def test_exr_normals_albedos_masks_through_prepare(tmp_path):
+    """EXR inputs take the reference's conversions (prepare.py:23-42, 161-190): normals in [-1, 1] -> (n + 1) / 2 * 65535, albedos
+    clipped to [0, 1] * 65535, float masks thresholded at 0.5; load_normal returns EXR values as stored (image_io.py:91-110)."""
+    from rnb_neus2_amd import exr
+    h = w = 24
+    n = np.zeros((h, w, 3), np.float32)
+    n[..., 0], n[..., 1], n[..., 2] = -1.0, 0.25, 1.0
+    a = np.zeros((h, w, 3), np.float32)
+    a[..., 0], a[..., 1], a[..., 2] = 1.5, 0.5, -0.2
+    m = np.zeros((h, w), np.float32)
+    m[4:20, 6:18] = 0.9
+    m[0, 0] = 0.4
+    image_io.save_normal_exr(n, tmp_path / "n.exr")
+    image_io.save_exr(a, tmp_path / "a.exr")
+    exr.write_exr(tmp_path / "m.exr", m, compression="zips")
+    np.testing.assert_array_equal(image_io.load_normal(tmp_path / "n.exr"), n)
+    c2w = np.eye(4, dtype=np.float32)
+    data = dict(views=[dict(c2w=c2w, K=np.eye(3, dtype=np.float32), normal_path=str(tmp_path / "n.exr"), albedo_path=str(tmp_path / "a.exr"), mask_path=str(tmp_path / "m.exr"))],
+                image_width=w, image_height=h, landmarks=None)
+
+    class Log:
+        def info(self, m):
+            pass
+        warning = error = info
+
+    prepare.prepare_testbed_data(data, str(tmp_path / "p"), Log(), scaling_mode="none")
+    nm = hostlib.png_read(tmp_path / "p" / "normals" / "00000.png")
+    al = hostlib.png_read(tmp_path / "p" / "albedos" / "00000.png")
+    assert nm.dtype == np.uint16 and al.dtype == np.uint16 and nm.shape == (h, w, 4)
+    assert nm[5, 7].tolist() == [0, int(np.float32(0.625) * 65535), 65535, 65535]
+    assert al[5, 7].tolist() == [65535, 32767, 0, 65535]
+    assert nm[0, 0, 3] == 0 and nm[3, 7, 3] == 0 and al[19, 17, 3] == 65535 and al[20, 17, 3] == 0
 
 
 # ------------------------------------------------------------------------------- loaders + prepare
