@@ -1,6 +1,6 @@
 // kernels_net.cuh — network kernels of the hot path:
-//   k_point_query   NerfNetwork::sdf / ::density (+ splat, K2+K3)       nerf_network.h:454-537, testbed_nerf.cu:616-635
-//   k_forward       NerfNetwork::forward_impl, inference flavour (K7)    nerf_network.h:97-253
+//   k_point_query_chained   NerfNetwork::sdf / ::density (+ splat, K2+K3)    nerf_network.h:454-537, testbed_nerf.cu:616-635
+//   k_forward_chained       NerfNetwork::forward_impl, inference flavour (K7) nerf_network.h:97-253
 //   k_fwd_bwd       forward + backward data path on the compacted batch (K10+K11)  nerf_network.h:97-452
 //   k_dw / k_dw_finish   weight-gradient GEMMs (K = samples)            fully_fused_mlp.cu:960-1014, 1120-1131
 //   k_grid_scatter  hash-grid gradient scatter, first + second order     grid.h:366-495, 556-683
@@ -32,24 +32,6 @@ __device__ __forceinline__ void write_sdf_in_row(half_t* __restrict__ tile, cons
 #pragma unroll
 		for (int j = 0; j < 8; ++j) v[j] = row[q * 8 + j];
 		*reinterpret_cast<h8*>(tile + lane * S32 + q * 8) = v;
-	}
-}
-
-template <bool GRAD>
-__device__ __forceinline__ void encode_all(const GridMeta& G, const uint32_t* __restrict__ grid, const float x, const float y, const float z, half_t (&feat)[28], float (&dydx)[GRAD ? 28 : 1][3]) {
-#pragma unroll
-	for (uint32_t level = 0; level < 14; ++level) {
-		half_t f0 = (half_t)0.f, f1 = (half_t)0.f;
-		float d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
-		if (level < G.n_levels && level <= G.valid_level) {
-			encode_level<GRAD>(G, grid, level, x, y, z, f0, f1, d0, d1);
-		}
-		feat[level * 2 + 0] = f0;
-		feat[level * 2 + 1] = f1;
-		if (GRAD) {
-#pragma unroll
-			for (int d = 0; d < 3; ++d) { dydx[GRAD ? level * 2 + 0 : 0][d] = d0[d]; dydx[GRAD ? level * 2 + 1 : 0][d] = d1[d]; }
-		}
 	}
 }
 
@@ -92,64 +74,6 @@ struct PointArgs {
 	float sdf_bias;
 };
 
-__global__ __launch_bounds__(WG, 1) void k_point_query(const GridMeta G, const NetW net, const PointArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
-	load_weights<false>(wts, net, threadIdx.x, WG);
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	half_t* tA = wts + W_FWD_END + wave * 2 * ACT_TILE_HALFS;
-	half_t* tB = tA + ACT_TILE_HALFS;
-	const half_t variance = net.variance[0];
-	const half_t bias = f2h(a.sdf_bias);
-	const uint32_t n_tiles = (a.n + TILE - 1) / TILE;
-	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
-		const uint32_t s = tile * TILE + lane;
-		const bool valid = s < a.n;
-		float x = 0.5f, y = 0.5f, z = 0.5f;
-		if (valid) { x = a.xyz[(size_t)s * 3 + 0]; y = a.xyz[(size_t)s * 3 + 1]; z = a.xyz[(size_t)s * 3 + 2]; }
-		half_t feat[28];
-		float dummy[1][3];
-		encode_all<false>(G, net.grid, x, y, z, feat, dummy);
-		write_sdf_in_row(tA, lane, x, y, z, feat);
-		wave_lds_sync();
-		{
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + W_S0, S32, tA, S32, acc, lane);
-			store_acc<4, true>(acc, tB, S64, 0, lane);
-		}
-		wave_lds_sync();
-		{
-			f4 acc[1][4];
-			zero_acc<1>(acc);
-			mfma_layer<1, 2>(wts + W_S1, S64, tB, S64, acc, lane);
-			wave_lds_sync(); // all reads of tB done before tA (free) is overwritten below
-			store_acc<1, false>(acc, tA, S32, 0, lane);
-		}
-		wave_lds_sync();
-		half_t v = tA[lane * S32 + 0] + bias; // sdf_add_bias (common_operation.cuh:299-309)
-		if (a.want_density) v = sdf_to_density(v, variance);
-		if (valid) {
-			if (a.out) a.out[s] = v;
-			if (a.splat_idx) atomicMax(reinterpret_cast<uint32_t*>(a.grid_tmp) + a.splat_idx[s], __float_as_uint(h2f(v))); // testbed_nerf.cu:634
-		}
-		wave_lds_sync();
-	}
-}
-
-// ---------------------------------------------------------------------------------------------
-// Shared forward body (nerf_network.h:97-253) for one 64-sample tile. Leaves in LDS:
-//   tC[.][0..31] = compact rgb input, r in tC[.][0..15] after the last layer (if run).
-// ---------------------------------------------------------------------------------------------
-struct FwdRegs {
-	float x, y, z;
-	float dydx[28][3];
-	float grad[3];
-	half_t sdf0;        // raw sdf_out[0]
-	uint64_t m_z1, m_h1, m_h2; // relu' masks in D-fragment order
-};
-
 // ---------------------------------------------------------------------------------------------
 // K7: inference-flavoured forward
 // ---------------------------------------------------------------------------------------------
@@ -162,137 +86,6 @@ struct FwdArgs {
 	const uint32_t* idx;       // optional: evaluate the samples idx[0 .. n) (slots into coords / out) instead of 0 .. n
 	const half_t* wimg;        // optional: the LDS weight image (load_weights_chained layout) prepared once per step by k_prepare_weight_images
 };
-
-__global__ __launch_bounds__(WG, 1) void k_forward(const GridMeta G, const NetW net, const FwdArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
-	load_weights<false>(wts, net, threadIdx.x, WG);
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	half_t* tA = wts + W_FWD_END + wave * 3 * ACT_TILE_HALFS;
-	half_t* tB = tA + ACT_TILE_HALFS;
-	half_t* tC = tB + ACT_TILE_HALFS;
-	const half_t variance = net.variance[0];
-	const half_t bias = f2h(a.sdf_bias);
-	uint32_t n = a.n_max;
-	if (a.n_ptr) n = min(*a.n_ptr, a.n_max);
-	const uint32_t n_tiles = (n + TILE - 1) / TILE;
-	const int r16 = lane & 15, hq = lane >> 4;
-	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
-		const uint32_t s = tile * TILE + lane;
-		const bool valid = s < n;
-		float c[7] = {0.5f, 0.5f, 0.5f, 0.f, 0.f, 0.f, 0.f};
-		if (valid) {
-#pragma unroll
-			for (int q = 0; q < 7; ++q) c[q] = a.coords[(size_t)s * 7 + q];
-		}
-		half_t feat[28];
-		float dydx[28][3];
-		encode_all<true>(G, net.grid, c[0], c[1], c[2], feat, dydx);
-		write_sdf_in_row(tA, lane, c[0], c[1], c[2], feat);
-		wave_lds_sync();
-		// z1 = relu(W0 sdf_in) -> tB ; dz1 = W1[0,:] (.) relu'(z1) -> tA   (nerf_network.h:159-176)
-		{
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + W_S0, S32, tA, S32, acc, lane);
-			const uint64_t m = store_acc<4, true>(acc, tB, S64, 0, lane);
-			wave_lds_sync(); // tA fully consumed by the MFMAs above
-#pragma unroll
-			for (int mt = 0; mt < 4; ++mt) {
-				const h4 w1 = *reinterpret_cast<const h4*>(wts + W_S1 + 0 * S64 + 16 * mt + 4 * hq);
-#pragma unroll
-				for (int nt = 0; nt < 4; ++nt) {
-					h4 v;
-#pragma unroll
-					for (int r = 0; r < 4; ++r) v[r] = ((m >> ((mt * 4 + nt) * 4 + r)) & 1ull) ? w1[r] : (half_t)0.f;
-					*reinterpret_cast<h4*>(tA + (16 * nt + r16) * S64 + 16 * mt + 4 * hq) = v;
-				}
-			}
-		}
-		wave_lds_sync();
-		// sdf_out = W1 z1 -> tC[.][0..15]
-		{
-			f4 acc[1][4];
-			zero_acc<1>(acc);
-			mfma_layer<1, 2>(wts + W_S1, S64, tB, S64, acc, lane);
-			store_acc<1, false>(acc, tC, S32, 0, lane);
-		}
-		// dsdf_din = W0^T dz1 -> tB[.][0..31] (z1 no longer needed)
-		{
-			f4 acc[2][4];
-			zero_acc<2>(acc);
-			mfma_layer<2, 2>(wts + W_S0T, S64, tA, S64, acc, lane);
-			wave_lds_sync(); // sdf_out MFMAs have read tB
-			store_acc<2, false>(acc, tB, S32, 0, lane);
-		}
-		wave_lds_sync();
-		// per lane: grad = sum_k dsdf_din[3+k] * dy_dx[k] + dsdf_din[0..2]  (grid.h:527-554, nerf_network.h:185-189)
-		float grad[3] = {0.f, 0.f, 0.f};
-		{
-			half_t din[32];
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const h8 v = *reinterpret_cast<const h8*>(tB + lane * S32 + q * 8);
-#pragma unroll
-				for (int j = 0; j < 8; ++j) din[q * 8 + j] = v[j];
-			}
-#pragma unroll
-			for (int k = 0; k < 28; ++k) {
-				const float dl = h2f(din[3 + k]);
-#pragma unroll
-				for (int d = 0; d < 3; ++d) grad[d] += dl * dydx[k][d];
-			}
-#pragma unroll
-			for (int d = 0; d < 3; ++d) grad[d] += h2f(din[d]);
-		}
-		const half_t sdf0 = tC[lane * S32 + 0];
-		// rgb input (compact): [sdf_out(16) | x y z | grad | 0 x10]  (nerf_network.h:206-218)
-		{
-			h8 v0 = {f2h(c[0]), f2h(c[1]), f2h(c[2]), f2h(grad[0]), f2h(grad[1]), f2h(grad[2]), (half_t)0.f, (half_t)0.f};
-			h8 v1 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-			*reinterpret_cast<h8*>(tC + lane * S32 + 16) = v0;
-			*reinterpret_cast<h8*>(tC + lane * S32 + 24) = v1;
-		}
-		wave_lds_sync();
-		{
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + W_C0, S32, tC, S32, acc, lane);
-			store_acc<4, true>(acc, tA, S64, 0, lane);
-		}
-		wave_lds_sync();
-		{
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 2>(wts + W_C1, S64, tA, S64, acc, lane);
-			store_acc<4, true>(acc, tB, S64, 0, lane);
-		}
-		wave_lds_sync();
-		{
-			f4 acc[1][4];
-			zero_acc<1>(acc);
-			mfma_layer<1, 2>(wts + W_C2, S64, tB, S64, acc, lane);
-			store_acc<1, false>(acc, tC, S32, 0, lane);
-		}
-		wave_lds_sync();
-		// output packing (nerf_network.h:221-250)
-		{
-			h8 o0 = *reinterpret_cast<const h8*>(tC + lane * S32 + 0);
-			h8 o1 = *reinterpret_cast<const h8*>(tC + lane * S32 + 8);
-			o0[3] = sdf0 + bias;
-			o0[4] = f2h(grad[0]); o0[5] = f2h(grad[1]); o0[6] = f2h(grad[2]);
-			o0[7] = variance;
-			o1[0] = f2h(c[4]); o1[1] = f2h(c[5]); o1[2] = f2h(c[6]);
-			if (valid) {
-				h8* dst = reinterpret_cast<h8*>(a.out + (size_t)s * 16);
-				dst[0] = o0;
-				dst[1] = o1;
-			}
-		}
-		wave_lds_sync();
-	}
-}
 
 // K7, register-chained flavour (mlp.cuh): per wavefront one 32-wide exchange tile X (sdf_in rows -> d sdf / d in rows -> r
 // rows), 16 bytes per sample of colour-MLP side inputs (Y) and the raw sdf (Z); 6.3 KB instead of 27.6 KB, so two

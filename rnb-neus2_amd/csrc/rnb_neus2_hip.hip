@@ -143,14 +143,10 @@ struct rnb_ctx {
 	uint32_t fwd_k1 = 48;
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
-		bool forward_v1 = false, march_narrow = false, fwd_bwd_generic = false;
-		bool tail_on_main = false; // RNB_TAIL_ON_MAIN: MLP optimizer + weight images on the caller's stream after the scatter (A/B aid)
+		bool march_narrow = false, fwd_bwd_generic = false;
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
-		uint32_t march_mg = 16; // lanes per ray of the counting march (RNB_MARCH_MG=8|16|32; measured alone: 0.19 / 0.22 / 0.32 ms)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
-		uint32_t scatter_lds_wg = 128;
-		std::string scatter_k; // comma list of run lengths per level, empty = derived from the resolutions
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
 	DevBuf<McTable> mc_table; // marching-cubes case table, uploaded on first use
@@ -213,8 +209,6 @@ static void discard_premarch(rnb_ctx* c);
 
 namespace {
 
-constexpr size_t LDS_POINT = (size_t)(W_FWD_END + WAVES_PER_WG * 2 * ACT_TILE_HALFS) * sizeof(half_t);
-constexpr size_t LDS_FWD = (size_t)(W_FWD_END + WAVES_PER_WG * 3 * ACT_TILE_HALFS) * sizeof(half_t);
 constexpr size_t LDS_TRAIN = (size_t)(W_TRAIN_END + WAVES_PER_WG * 3 * ACT_TILE_HALFS) * sizeof(half_t);
 static_assert(LDS_TRAIN <= 160 * 1024, "training kernel LDS exceeds 160 KiB");
 
@@ -290,12 +284,8 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	PointArgs a;
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
-	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-	if (c->knobs.forward_v1) hipLaunchKernelGGL(k_point_query, dim3(grid), dim3(WG), LDS_POINT, s, c->meta(), c->net(inference), a);
-	else {
-		const uint32_t grid2 = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
-		hipLaunchKernelGGL(k_point_query_chained, dim3(grid2), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
-	}
+	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
+	hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -343,13 +333,8 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx;
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
-	if (c->knobs.forward_v1 && !idx) { // the LDS-staged variant (one workgroup per CU), kept for A/B measurements
-		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-		hipLaunchKernelGGL(k_forward, dim3(grid), dim3(WG), LDS_FWD, s, c->meta(), c->net(inference), a);
-	} else {
-		const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
-		hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
-	}
+	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
+	hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -396,17 +381,9 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), 0, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
 	} else {
-		const uint32_t mg = c->knobs.march_mg;
-		const dim3 grid((n_rays + 256 / mg - 1) / (256 / mg));
-#define RNB_MARCH_WIDE(MGV)                                                                               \
-	do {                                                                                                  \
-		if (sc) hipLaunchKernelGGL((k_march_count_wide<MGV, true>), grid, dim3(256), 0, s, a);             \
-		else hipLaunchKernelGGL((k_march_count_wide<MGV, false>), grid, dim3(256), 0, s, a);               \
-	} while (0)
-		if (mg == 16) RNB_MARCH_WIDE(16);
-		else if (mg == 8) RNB_MARCH_WIDE(8);
-		else RNB_MARCH_WIDE(32);
-#undef RNB_MARCH_WIDE
+		const dim3 grid((n_rays + 15) / 16); // 16 lanes per ray (8: 0.19 ms alone but a slower step; 32: 0.32 ms, measured in round 1)
+		if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), 0, s, a);
+		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
 	}
 	c->prof.mark(s, P_MARCH_COUNT);
 	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
@@ -542,7 +519,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
 		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
 		ScatterLdsArgs la; la.a = sa; la.n_levels = e_c;
-		const uint32_t wg_cap = c->knobs.scatter_lds_wg;
+		const uint32_t wg_cap = 128; // workgroups of the LDS scatter (measured optimum: half the CUs, each zeroing / flushing its private table once)
 		const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 		la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
 		LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
@@ -629,11 +606,9 @@ static void plan_scatter_groups(rnb_ctx* c) {
 	const uint32_t L = c->cfg.n_levels;
 	uint32_t l;
 	{
-		const char* kenv = c->knobs.scatter_k.empty() ? nullptr : c->knobs.scatter_k.c_str();
 		for (l = 0; l < L; ++l) {
 			const float run = 590.f / (float)c->grid.resolution[l]; // compacted samples of a ray that share a cell of this level
 			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
-			if (kenv && *kenv) { g.Ks[l] = (uint32_t)atoi(kenv); const char* nx = strchr(kenv, ','); kenv = nx ? nx + 1 : kenv; }
 		}
 	}
 	for (l = 0; l < L; ++l) if (l == g.e_c && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) g.e_c = l + 1; // the coarsest levels whose fp32 gradient tables fit in LDS together
@@ -900,8 +875,6 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY_C(hipMemset(c->mlp_out.p, 0, c->mlp_out.bytes()));
 	int rc = reset_optimizer_state(c);
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
-	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_point_query), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_POINT));
-	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
@@ -917,23 +890,19 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	if (const char* e = getenv("RNB_FWD_K1")) c->fwd_k1 = (uint32_t)atoi(e); // head length of the two-round network evaluation; 0 = one round over all samples
 	{
 		rnb_ctx::Knobs& k = c->knobs;
-		k.forward_v1 = getenv("RNB_FORWARD_V1") != nullptr; k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
+		k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
-		if (const char* e = getenv("RNB_MARCH_MG")) k.march_mg = atoi(e) == 16 ? 16u : atoi(e) == 8 ? 8u : 32u;
-		k.tail_on_main = getenv("RNB_TAIL_ON_MAIN") != nullptr;
-		if (const char* e = getenv("RNB_SCATTER_LDS_WG")) k.scatter_lds_wg = (uint32_t)atoi(e);
-		if (const char* e = getenv("RNB_SCATTER_K")) k.scatter_k = e;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
 	// ev_loss publishes the step's counters to the HOST (system-scope release). The others only order kernels on this device:
-	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them (RNB_EVENT_SYSTEM_FENCE=1 restores it).
+	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them.
 	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
-	const unsigned dev_flags = hipEventDisableTiming | (getenv("RNB_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+	const unsigned dev_flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
 	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
@@ -1336,7 +1305,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->cur_n_rays = n_rays;
 	c->cur_n_rays_total = n_rays_total;
 	c->prof.mark(s, P_NONE);
-	const bool two_round = c->fwd_k1 != 0 && !c->knobs.forward_v1;
+	const bool two_round = c->fwd_k1 != 0;
 	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p);
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
@@ -1345,7 +1314,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
-	int rc = forward_backward(c, s, c->knobs.tail_on_main);
+	int rc = forward_backward(c, s, false);
 	if (rc != RNB_OK) return rc;
 	c->rng.advance(); // testbed_nerf.cu:4118
 	return RNB_OK;
@@ -1418,7 +1387,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
 	const uint32_t* counters = c->host_rb->counters;
-	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += (c->fwd_k1 && !c->knobs.forward_v1) ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
+	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += c->fwd_k1 ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
 	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];

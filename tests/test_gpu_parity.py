@@ -147,36 +147,6 @@ def test_forward_infer(rpair, step):
     _half_close(a[:, [0, 1, 2, 11, 12, 13, 14, 15]], b[:, [0, 1, 2, 11, 12, 13, 14, 15]], rel=4e-3, abs_=2e-3, frac=0.995, name="rgb channels")
 
 
-def test_chained_kernels_match_lds_staged_kernels(rpair, monkeypatch):
-    """Two independent HIP formulations of the network evaluation — activations handed from layer to layer in MFMA fragment
-    registers (default) vs staged through LDS tiles (RNB_FORWARD_V1) — agree on the forward pass and on the point queries."""
-    import rnb_neus2_amd as rnb
-    from rnb_neus2_amd import synthetic
-    gpu, _ = rpair
-    monkeypatch.setenv("RNB_FORWARD_V1", "1")
-    v1 = rnb.Context(**dict(KW, apply_no_albedo=0))  # scheduling / kernel knobs are read at creation
-    monkeypatch.delenv("RNB_FORWARD_V1")
-    try:
-        v1.init_params()
-        v1.set_dataset(*synthetic.make_scene(4, 96, 168.0))
-        v1.set_params(gpu.get("PARAMS_FP32"))
-        rng = np.random.default_rng(5)
-        coords = rng.random((5000, 7), dtype=np.float32)
-        for step in (0, 700):
-            for c in (gpu, v1):
-                c.set_training_step(step)
-            a, b = gpu.forward_infer(coords), v1.forward_infer(coords)
-            assert np.array_equal(a[:, 7:11].view(np.uint16), b[:, 7:11].view(np.uint16))  # variance, direction: copies
-            _half_close(a[:, 3:7], b[:, 3:7], rel=2e-3, abs_=1e-3, name="sdf + gradient, step %d" % step)
-            _half_close(a[:, [0, 1, 2, 11, 12, 13, 14, 15]], b[:, [0, 1, 2, 11, 12, 13, 14, 15]], rel=4e-3, abs_=2e-3, frac=0.995, name="rgb channels")
-            xyz = coords[:, :3]
-            _half_close(gpu.sdf(xyz, inference=False), v1.sdf(xyz, inference=False), name="sdf query")
-            _half_close(gpu.density(xyz), v1.density(xyz), rel=4e-3, abs_=1e-3, name="density query")
-            assert np.array_equal(gpu.sdf(xyz, inference=False).view(np.uint16), gpu.forward_infer(coords)[:, 3].view(np.uint16))  # one arithmetic for both
-    finally:
-        v1.close()
-
-
 def _sync_occupancy(gpu, cpu, step=0):
     for c in (gpu, cpu):
         c.set_training_step(step)
