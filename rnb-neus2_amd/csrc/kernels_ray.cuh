@@ -1209,18 +1209,23 @@ __global__ void k_clear_step(uint32_t* __restrict__ counters, float* __restrict_
 	if (i < n) { loss[i] = 0.f; loss[(size_t)row_stride + i] = 0.f; loss[(size_t)row_stride * 2 + i] = 0.f; }
 }
 
-__global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords) {
+// fill_rollover_and_rescale / fill_rollover (common_device.h:514-535): pad the compacted batch to B by wrapping.
+__device__ __forceinline__ void rollover_body(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords,
+                                              const uint64_t first, const uint64_t stride) {
 	const uint32_t n_in = counters[1];
 	if (n_in == 0 || n_in >= B) return;
 	const uint64_t n_out16 = (uint64_t)B * 16, n_in16 = (uint64_t)n_in * 16;
 	const uint64_t n_out7 = (uint64_t)B * 7, n_in7 = (uint64_t)n_in * 7;
-	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_out16; q += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t q = first; q < n_out16; q += stride) {
 		if (q >= n_in16) {
 			const float v = h2f(dloss[q % n_in16]);
 			dloss[q] = f2h(v * n_in / B);
 		}
 		if (q >= n_in7 && q < n_out7) coords[q] = coords[q % n_in7];
 	}
+}
+__global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords) {
+	rollover_body(B, counters, dloss, coords, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // per-tile (4096 rays) fp64 sums of the three loss rows, for batches too large for one workgroup to walk (fixed order: deterministic)
@@ -1242,7 +1247,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_tiles(const uint32_t n_m
 }
 
 // loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
-__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
+__device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
                                                         const double* __restrict__ partial, const uint32_t n_partial) {
 	__shared__ double sh[3][1024];
 	const uint32_t n = min(counters[2], n_max);
@@ -1269,6 +1274,21 @@ __global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, co
 		if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(host_out + 3)[threadIdx.x] = counters[threadIdx.x];
 		if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(host_out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
 	}
+}
+
+
+__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
+                                                        double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out, const double* __restrict__ partial, const uint32_t n_partial) {
+	reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial);
+}
+
+// The training step's form: workgroup 0 reduces the losses (the step's 48-byte readback), the others pad the compacted batch --
+// both need nothing but the second loss pass, and one launch on the critical stream instead of two saves a kernel boundary.
+__global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1,
+                                                                 const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
+                                                                 const double* __restrict__ partial, const uint32_t n_partial, const uint32_t B, half_t* __restrict__ dloss, float* __restrict__ coords) {
+	if (blockIdx.x == 0) reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial);
+	else rollover_body(B, counters, dloss, coords, (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - 1) * blockDim.x);
 }
 
 } // namespace rnb

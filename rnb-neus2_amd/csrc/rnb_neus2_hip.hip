@@ -402,7 +402,8 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	return RNB_OK;
 }
 
-int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t two_round_n_max = 0) {
+// defer_rollover: the training step pads the batch in the same launch as its loss reduction (launch_reduce_losses)
+int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t two_round_n_max = 0, bool defer_rollover = false) {
 	LossArgs a;
 	a.n_rays = n_rays; a.n_rays_global = n_rays * c->cfg.world_size; a.ray_offset = c->cfg.rank * n_rays; a.n_rays_total = n_rays_total;
 	a.n_images = c->n_views; a.B = c->cfg.target_batch_size;
@@ -437,7 +438,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
 	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
+	if (!defer_rollover) hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
 	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1310,7 +1311,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
-	return compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0);
+	return compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
@@ -1326,8 +1327,8 @@ static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	const bool tiled = c->cur_n_rays >= c->knobs.march_narrow_from;
 	const uint32_t n_tiles = (c->cur_n_rays + SCAN_TILE - 1) / SCAN_TILE;
 	if (tiled) hipLaunchKernelGGL(k_reduce_losses_tiles, dim3(n_tiles), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_partial.p);
-	LAUNCH_EV(k_reduce_losses, dim3(1), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
-	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles);
+	LAUNCH_EV(k_reduce_losses_rollover, dim3(1 + 255), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
+	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles, c->cfg.target_batch_size, c->dloss_dout.p, c->coords_compacted.p);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
