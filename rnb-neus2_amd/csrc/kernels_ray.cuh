@@ -1277,11 +1277,6 @@ __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const u
 }
 
 
-__global__ __launch_bounds__(1024) void k_reduce_losses(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2,
-                                                        double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out, const double* __restrict__ partial, const uint32_t n_partial) {
-	reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial);
-}
-
 // The training step's form: workgroup 0 reduces the losses (the step's 48-byte readback), the others pad the compacted batch --
 // both need nothing but the second loss pass, and one launch on the critical stream instead of two saves a kernel boundary.
 __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1,
