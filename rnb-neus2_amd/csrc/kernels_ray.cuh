@@ -505,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 		carry[0] += ttotal; carry[1] += tot[0]; carry[2] += tot[1]; carry[3] += tot[2];
 		__syncthreads(); // wsum is rewritten by the next tile
 	}
-	if (tid == 0) { counters[0] = carry[0]; counters[2] = carry[1]; counters[3] = carry[2]; fwd_counts[0] = carry[3]; fwd_counts[1] = 0; fwd_counts[2] = 0; }
+	if (tid == 0) { counters[0] = carry[0]; counters[2] = carry[1]; counters[3] = carry[2]; fwd_counts[0] = carry[3]; fwd_counts[1] = 0; fwd_counts[2] = 0; fwd_counts[3] = 0; }
 }
 
 // The same scans with one workgroup per 4096-ray tile, for batches of tens of thousands of rays (one workgroup walks 23 tiles at
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(1024) void k_scan_rays_slots(const uint32_t n, cons
 		srun += ok[e] ? 1u : 0u;
 		frun += ok[e] ? min(st[e], k1) : 0u;
 	}
-	if (blockIdx.x == gridDim.x - 1 && tid == 0) { counters[2] = pre[0] + t0; counters[3] = pre[1] + t1; fwd_counts[0] = pre[2] + t2; fwd_counts[1] = 0; fwd_counts[2] = 0; }
+	if (blockIdx.x == gridDim.x - 1 && tid == 0) { counters[2] = pre[0] + t0; counters[3] = pre[1] + t1; fwd_counts[0] = pre[2] + t2; fwd_counts[1] = 0; fwd_counts[2] = 0; fwd_counts[3] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -652,9 +652,9 @@ struct LossArgs {
 	// two-round network evaluation (cap = 0xffffffff: single round)
 	uint32_t cap;          // samples per ray evaluated in round 1
 	uint32_t phase;        // 0: all rays, at most `cap` samples each; 1: only the rays round 1 could not finish, all their samples
-	uint32_t* unfinished;  // [n_rays] list of the rays round 1 left unsettled (count in fwd_counts[2])
+	uint32_t* unfinished;  // [n_rays] list of the rays round 1 left unsettled (count in fwd_counts[3])
 	uint32_t* idx2;        // sample slots still to evaluate (round 2)
-	uint32_t* fwd_counts;  // [1] = entries of idx2, [2] = entries of `unfinished`
+	uint32_t* fwd_counts;  // [0] = samples of round 1; 8-byte pair [2] = entries of idx2, [3] = entries of `unfinished`
 };
 
 __device__ __forceinline__ void albedo_from_output(const LossFlags& F, const half_t* __restrict__ o, float albedo[4]) { // testbed_nerf.cu:1614-1639
@@ -869,7 +869,9 @@ __device__ __forceinline__ bool composite_replay(const int cnt, const float alph
 // Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), one wavefront per ray: the per-sample terms (alpha, shading)
 // are evaluated by 64 lanes at once; the transmittance recurrence and the early stop at T < 1e-4 are then replayed in the
 // reference's sequential order (identical fp32 rounding) from lane broadcasts.
-__device__ __forceinline__ void loss_pass1_ray(const LossArgs& a, const uint32_t i, const int lane) {
+// Returns (phase 0 of the two-round evaluation) how many samples of the ray are still to be evaluated, 0 if the ray is settled;
+// *base_out = the ray's first sample slot.
+__device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint32_t i, const int lane, uint32_t* base_out = nullptr) {
 	const uint32_t numsteps_all = a.numsteps[(size_t)i * 2 + 0];
 	const uint32_t numsteps = a.phase == 0 ? min(numsteps_all, a.cap) : numsteps_all;
 	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
@@ -915,19 +917,15 @@ __device__ __forceinline__ void loss_pass1_ray(const LossArgs& a, const uint32_t
 		                           : composite_replay<false>(cnt, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
 	}
 	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
+	uint32_t tail = 0;
 	if (a.phase == 0 && a.cap != 0xffffffffu) {
 		// The samples past the point where the transmittance falls below 1e-4 are never read again (testbed_nerf.cu:1609), so
 		// the network is first evaluated on the head of every ray only. A ray is settled if it terminated inside its head, or
-		// has no more samples, or would terminate at the very next check; the others queue their tails for round 2 and are
-		// recomputed in phase 1. Same values as a single full pass.
+		// has no more samples, or would terminate at the very next check; the others queue their tails for round 2 (the caller
+		// allots the queue) and are recomputed in phase 1. Same values as a single full pass.
 		const bool settled = done || numsteps_all <= a.cap || T < EPSILON;
-		if (!settled) {
-			const uint32_t tail = numsteps_all - a.cap;
-			uint32_t off = 0;
-			if (lane == 0) { off = atomicAdd(a.fwd_counts + 1, tail); a.unfinished[atomicAdd(a.fwd_counts + 2, 1u)] = i; }
-			off = __builtin_amdgcn_readfirstlane(off);
-			for (uint32_t j = lane; j < tail; j += 64) a.idx2[off + j] = base + a.cap + j;
-		}
+		if (!settled) tail = numsteps_all - a.cap;
+		if (base_out) *base_out = base;
 	}
 	if (lane == 0) {
 		R.n_comp = n;
@@ -939,19 +937,49 @@ __device__ __forceinline__ void loss_pass1_ray(const LossArgs& a, const uint32_t
 		a.ray_loss[i] = R;
 		a.ncomp[i] = n;
 	}
+	return tail;
 }
 
+// Phase 0 (all rays; their heads only in the two-round evaluation), one wavefront per ray, 16 rays per workgroup. The queue of
+// round 2 -- sample slots in idx2, rays in `unfinished` -- is allotted ONCE per workgroup with one 64-bit atomic on the
+// (entries, rays) pair: returning atomics on one address retire one after the other (≈6 ns each), and two per unsettled ray
+// made this kernel 46 us instead of 10 (measured in round 2 by doubling them: +37 us).
+constexpr uint32_t LOSS1_RAYS_PER_WG = 16;
+__global__ __launch_bounds__(1024) void k_loss_pass1_heads(const LossArgs a) {
+	__shared__ uint32_t s_tail[LOSS1_RAYS_PER_WG], s_off[LOSS1_RAYS_PER_WG], s_slot[LOSS1_RAYS_PER_WG], s_base[2];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * LOSS1_RAYS_PER_WG + wave;
+	uint32_t tail = 0, base = 0;
+	if (i < a.n_rays) {
+		if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; }
+		else tail = loss_pass1_ray(a, i, (int)lane, &base);
+	}
+	if (a.cap == 0xffffffffu) return; // single round: nothing is ever queued (uniform over the launch)
+	if (lane == 0) s_tail[wave] = tail;
+	__syncthreads();
+	if (wave == 0) {
+		const uint32_t t = lane < LOSS1_RAYS_PER_WG ? s_tail[lane] : 0u;
+		const uint32_t u = t ? 1u : 0u;
+		const uint32_t it = wave_inclusive_scan(t, lane), iu = wave_inclusive_scan(u, lane);
+		if (lane < LOSS1_RAYS_PER_WG) { s_off[lane] = it - t; s_slot[lane] = iu - u; }
+		if (lane == LOSS1_RAYS_PER_WG - 1 && iu) {
+			const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(a.fwd_counts + 2), ((unsigned long long)iu << 32) | it);
+			s_base[0] = (uint32_t)old; s_base[1] = (uint32_t)(old >> 32);
+		}
+	}
+	__syncthreads();
+	if (tail) {
+		const uint32_t off = s_base[0] + s_off[wave];
+		if (lane == 0) a.unfinished[s_base[1] + s_slot[wave]] = i;
+		for (uint32_t j = lane; j < tail; j += 64) a.idx2[off + j] = base + a.cap + j;
+	}
+}
+
+// Phase 1: the rays round 1 left unsettled, from the list phase 0 built. Also phase 0 of callers that bring their own launch shape.
 __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 	const int lane = threadIdx.x & 63;
-	if (a.phase == 0) { // one wavefront per ray
-		const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-		if (i >= a.n_rays) return;
-		if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; return; }
-		loss_pass1_ray(a, i, lane);
-	} else { // the rays round 1 left unsettled, from the list phase 0 built
-		const uint32_t n_list = a.fwd_counts[2];
-		for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_list; k += gridDim.x * 4) loss_pass1_ray(a, a.unfinished[k], lane);
-	}
+	const uint32_t n_list = a.fwd_counts[3];
+	for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_list; k += gridDim.x * 4) (void)loss_pass1_ray(a, a.unfinished[k], lane);
 }
 
 // exclusive scan of ncomp over the kept rays; counters[1] = total (numsteps_counter_compacted)
@@ -1265,14 +1293,14 @@ __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const u
 	}
 	if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
 	if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(out + 3)[threadIdx.x] = counters[threadIdx.x]; // one 48-byte readback: sums + counters + evaluated samples
-	if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
+	if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x * 2] : 0u; // samples of round 1, round 2
 	// the same numbers as one double[7] {counters, sums}: what data-parallel ranks all-reduce (RNB_BUF_STEP_VECTOR)
 	if (threadIdx.x < 4) out[8 + threadIdx.x] = (double)counters[threadIdx.x];
 	if (threadIdx.x == 0) { out[12] = sh[0][0]; out[13] = sh[1][0]; out[14] = sh[2][0]; }
 	if (host_out) { // the same 48 bytes into host memory (visible to the host once the kernel's completion event has fired)
 		if (threadIdx.x == 0) { host_out[0] = sh[0][0]; host_out[1] = sh[1][0]; host_out[2] = sh[2][0]; }
 		if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(host_out + 3)[threadIdx.x] = counters[threadIdx.x];
-		if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(host_out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x] : 0u;
+		if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(host_out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x * 2] : 0u;
 	}
 }
 

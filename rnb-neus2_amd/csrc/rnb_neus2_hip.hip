@@ -417,18 +417,20 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
 	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
+	const uint32_t blocks_heads = (n_rays + LOSS1_RAYS_PER_WG - 1) / LOSS1_RAYS_PER_WG;
 	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
 	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
 		a.cap = c->fwd_k1;
-		hipLaunchKernelGGL(k_loss_pass1, dim3(blocks), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_loss_pass1_heads, dim3(blocks_heads), dim3(1024), 0, s, a);
 		c->prof.mark(s, P_LOSS_PASS1);
-		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 1, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
+		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 2, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
 		if (rc != RNB_OK) return rc;
 		c->prof.mark(s, P_FORWARD);
 		a.phase = 1;
 	}
-	hipLaunchKernelGGL(k_loss_pass1, dim3(a.phase ? std::min(blocks, 1024u) : blocks), dim3(256), 0, s, a);
+	if (a.phase) hipLaunchKernelGGL(k_loss_pass1, dim3(std::min(blocks, 1024u)), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL(k_loss_pass1_heads, dim3(blocks_heads), dim3(1024), 0, s, a);
 	c->prof.mark(s, P_LOSS_PASS1);
 	if (n_rays >= c->knobs.march_narrow_from) {
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
