@@ -6,6 +6,7 @@
 // legal outcome of the reference's race; ray order makes the step reproducible and the sample stream coalesced).
 #pragma once
 #include "common.cuh"
+#include "chain.cuh"
 
 namespace rnb {
 
@@ -841,29 +842,29 @@ __global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
 
 
 // The sequential part of the compositing loop (testbed_nerf.cu:1608-1697) for up to 64 samples whose per-sample terms sit
-// one per lane. Every lane carries the same running values; the operations and their order are the reference's, so the
-// rounding (and with it the early stop) is identical. Kept tight on purpose — this chain is the latency of the longest ray:
-// uniform exit test through a ballot, (1 - alpha) formed per lane beforehand, the three equal colour channels of the
-// --no-albedo case (albedo = (1,1,1,0)) accumulated once.
+// one per lane: the recurrence runs through chain.cuh (every lane ends with the running values right after its sample, in
+// the reference's operation order, so the rounding -- and with it the early stop -- is identical); the loop's exit test
+// "T < 1e-4 before sample q" then is one ballot over the lanes, and the running values are read from the lane in front
+// of the first such sample. Returns true if the ray terminated inside these samples.
 template <bool NO_ALBEDO>
-__device__ __forceinline__ bool composite_replay(const int cnt, const float alpha, const float shading, const float (&albedo)[4],
+__device__ __forceinline__ bool composite_replay(const int cnt, const int lane, const float alpha, const float shading, const float (&albedo)[4],
                                                  float& T, float (&rgb)[4], float& weight_sum, uint32_t& n) {
-	const float one_minus = 1.f - alpha;
-	for (int q = 0; q < cnt; ++q) {
-		if (__builtin_amdgcn_ballot_w64(T < 1e-4f) != 0ull) return true;
-		const float al = bcast(alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
-		const float weight = al * T;
-		if (NO_ALBEDO) {
-			rgb[0] += weight * 1.f * sh;
-		} else {
+	const ChainState s = replay_chain<NO_ALBEDO>(cnt, alpha, shading, albedo, 0.f, T, weight_sum, rgb, 0.f);
+	// the transmittance the loop tests before it takes sample `lane`: the lane in front's (wave_shr:1), lane 0 keeps the incoming one
+	const float T_before = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x138, 0xf, 0xf, false));
+	const uint64_t stop = __builtin_amdgcn_ballot_w64(lane < cnt && T_before < 1e-4f);
+	const int taken = stop ? (int)__builtin_ctzll(stop) : cnt; // samples composited here
+	n += (uint32_t)taken;
+	if (taken > 0) {
+		T = bcast(s.T, taken - 1);
+		weight_sum = bcast(s.ws, taken - 1);
+		rgb[0] = bcast(s.rgb[0], taken - 1);
+		if (!NO_ALBEDO) {
 #pragma unroll
-			for (int k = 0; k < 4; ++k) rgb[k] += weight * bcast(albedo[k], q) * sh;
+			for (int k = 1; k < 4; ++k) rgb[k] = bcast(s.rgb[k], taken - 1);
 		}
-		weight_sum += weight;
-		T *= om;
-		++n;
 	}
-	return false;
+	return stop != 0ull;
 }
 
 // Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), one wavefront per ray: the per-sample terms (alpha, shading)
@@ -913,8 +914,8 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		}
 		const int cnt = (int)min(64u, numsteps - c0);
-		done = a.F.apply_no_albedo ? composite_replay<true>(cnt, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
-		                           : composite_replay<false>(cnt, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
+		done = a.F.apply_no_albedo ? composite_replay<true>(cnt, lane, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
+		                           : composite_replay<false>(cnt, lane, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
 	}
 	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
 	uint32_t tail = 0;
@@ -1123,38 +1124,16 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 			gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
 		}
 		const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
-		// replay of the sequential recurrences; lane q keeps its own weight and the running values right after sample q
-		float my_weight = 0.f, my_T = 1.f, my_w2 = 0.f, my_rgb2[4] = {0, 0, 0, 0};
+		// the sequential recurrences (chain.cuh): lane q ends with its own weight and the running values right after sample q
 		const int cnt = (int)min(64u, compacted_numsteps - c0);
-		const float one_minus = 1.f - at.alpha;
-		if (F.apply_no_albedo) { // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
-			for (int q = 0; q < cnt; ++q) {
-				const float al = bcast(at.alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
-				const float weight = al * T;
-				rgb_ray2[0] += weight * 1.f * sh;
-				weight_sum2 += weight;
-				T *= om;
-				ek += bcast(ekterm, q);
-				if (q == lane) { my_weight = weight; my_T = T; my_w2 = weight_sum2; my_rgb2[0] = rgb_ray2[0]; }
-			}
-			rgb_ray2[1] = rgb_ray2[0]; rgb_ray2[2] = rgb_ray2[0];
-			my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3];
-		} else {
-			for (int q = 0; q < cnt; ++q) {
-				const float al = bcast(at.alpha, q), sh = bcast(shading, q), om = bcast(one_minus, q);
-				const float weight = al * T;
+		const ChainState cs = F.apply_no_albedo ? replay_chain<true>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
+		                                        : replay_chain<false>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
+		const float my_weight = cs.w, my_T = cs.T, my_w2 = cs.ws;
+		float my_rgb2[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
+		if (F.apply_no_albedo) { my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3]; } // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
+		T = bcast(cs.T, cnt - 1); weight_sum2 = bcast(cs.ws, cnt - 1); ek = bcast(cs.ek, cnt - 1);
 #pragma unroll
-				for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * bcast(albedo[k], q) * sh;
-				weight_sum2 += weight;
-				T *= om;
-				ek += bcast(ekterm, q);
-				if (q == lane) {
-					my_weight = weight; my_T = T; my_w2 = weight_sum2;
-#pragma unroll
-					for (int k = 0; k < 4; ++k) my_rgb2[k] = rgb_ray2[k];
-				}
-			}
-		}
+		for (int k = 0; k < 4; ++k) rgb_ray2[k] = bcast(my_rgb2[k], cnt - 1);
 		if (valid) {
 			const float alpha = at.alpha;
 			const float weight = my_weight;
