@@ -979,13 +979,15 @@ __device__ __forceinline__ float corner_addend(const float g1, const float g2, c
 }
 
 // Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
-// global atomics pile up on a handful of addresses. Each workgroup accumulates its slice of the batch into a private copy
-// of the level's gradient table in LDS (ds_add_f32), with a run-length merge in registers (compacted samples are in ray
-// order, so neighbouring samples fall into the same cell), then flushes the non-zero entries once.
+// global atomics pile up on a handful of lines. Each workgroup accumulates its slice of the batch into a private copy of
+// the levels' gradient tables in LDS, then flushes the non-zero entries once. ds_add_f32 retires at ~3 cycles per LANE per CU
+// (tools/probe_lds_atomics.hip; integer LDS atomics are 15x faster), so the LDS atomics are what this kernel pays for: it
+// uses the quad walk of k_grid_scatter_quad_rl below -- four lanes = (dx, feature) own K = 16 consecutive samples of the
+// ray-ordered batch and keep the four (dy, dz) corner sums in registers while the cell (37 / 27 march steps wide on levels
+// 0 / 1) does not change -- which issues a third of the LDS atomics of the earlier thread-per-4-samples form (43 -> see DESIGN.md).
 struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_wg; }; // levels [0, n_levels)
 
-// All LDS-resident levels in one pass: the per-sample record is shared between the levels and the per-thread
-// dependent-load chain is K = 4 samples long. LDS layout: level l's table at float offset 2 * G.offsets[l].
+// LDS layout: level l's table at float offset 2 * G.offsets[l]. The per-sample loads of a walk are issued four samples ahead.
 __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	float* tab = reinterpret_cast<float*>(smem_raw);
@@ -995,55 +997,58 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 	const uint32_t n_tab = G.offsets[NL] * 2;
 	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) tab[q] = 0.f;
 	__syncthreads();
-	constexpr int K = 4;
+	constexpr uint32_t K = 16, C = 4;
 	const uint32_t wg_begin = blockIdx.x * p.samples_per_wg;
 	const uint32_t wg_end = min(wg_begin + p.samples_per_wg, a.B);
-	for (uint32_t s0 = wg_begin + threadIdx.x * K; s0 < wg_end; s0 += blockDim.x * K) {
-		ScatterSample sm[K];
-#pragma unroll
-		for (int j = 0; j < K; ++j) sm[j] = load_srec(a.srec, min(s0 + j, wg_end - 1)); // the loads that do not depend on the level, up front
+	const uint32_t quad = threadIdx.x >> 2, n_quads = blockDim.x >> 2;
+	const uint32_t dx = (threadIdx.x >> 1) & 1u, f = threadIdx.x & 1u;
 #pragma unroll 1
-		for (uint32_t level = 0; level < NL; ++level) {
-			float* lt = tab + (size_t)G.offsets[level] * 2;
-			const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
-			const float scale = G.scale[level];
-			const uint32_t res = G.resolution[level];
-			uint2 q12[K];
-#pragma unroll
-			for (int j = 0; j < K; ++j) q12[j] = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + min(s0 + j, wg_end - 1)];
-			float acc[8][2];
+	for (uint32_t level = 0; level < NL; ++level) {
+		float* lt = tab + (size_t)G.offsets[level] * 2;
+		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+		const float scale = G.scale[level];
+		const uint32_t res = G.resolution[level];
+		const uint2* g12 = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+#pragma unroll 1
+		for (uint32_t s0 = wg_begin + quad * K; s0 < wg_end; s0 += n_quads * K) {
+			const uint32_t s_end = min(s0 + K, wg_end);
+			float acc[4] = {0.f, 0.f, 0.f, 0.f};
 			uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-#pragma unroll
-			for (int q = 0; q < 8; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; }
 			auto flush = [&]() {
 #pragma unroll
-				for (uint32_t idx = 0; idx < 8; ++idx) {
-					if (acc[idx][0] == 0.f && acc[idx][1] == 0.f) continue;
-					const uint32_t e = grid_entry(hashmap_size, res, cur[0] + (idx & 1u), cur[1] + ((idx >> 1) & 1u), cur[2] + ((idx >> 2) & 1u));
-					if (acc[idx][0] != 0.f) atomicAdd(lt + e * 2 + 0, acc[idx][0]);
-					if (acc[idx][1] != 0.f) atomicAdd(lt + e * 2 + 1, acc[idx][1]);
-					acc[idx][0] = 0.f; acc[idx][1] = 0.f;
+				for (uint32_t yz = 0; yz < 4; ++yz) {
+					if (acc[yz] != 0.f) {
+						const uint32_t e = grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1));
+						atomicAdd(lt + e * 2 + f, acc[yz]);
+						acc[yz] = 0.f;
+					}
 				}
 			};
+#pragma unroll 1
+			for (uint32_t sc = s0; sc < s_end; sc += C) {
+				ScatterSample sm[C];
+				uint2 q12[C];
 #pragma unroll
-			for (int j = 0; j < K; ++j) {
-				if (s0 + j >= wg_end) break;
-				float pos[3];
-				uint32_t pg[3];
-				pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
-				pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
-				pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
-				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-					if (cur[0] != 0xffffffffu) flush();
-				}
-				cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-				const h2 h1 = unpack_h2(q12[j].x);
-				const h2 hh2 = unpack_h2(q12[j].y);
+				for (uint32_t j = 0; j < C; ++j) { const uint32_t s = min(sc + j, s_end - 1); sm[j] = load_srec(a.srec, s); q12[j] = g12[s]; }
 #pragma unroll
-				for (uint32_t idx = 0; idx < 8; ++idx) {
-					const uint32_t cc[3] = {idx & 1u, (idx >> 1) & 1u, (idx >> 2) & 1u};
-					acc[idx][0] += corner_addend(h2f(h1[0]), h2f(hh2[0]), scale, sm[j].dn, pos, cc);
-					acc[idx][1] += corner_addend(h2f(h1[1]), h2f(hh2[1]), scale, sm[j].dn, pos, cc);
+				for (uint32_t j = 0; j < C; ++j) {
+					if (sc + j >= s_end) break;
+					float pos[3];
+					uint32_t pg[3];
+					pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
+					pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
+					pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
+					if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+						if (cur[0] != 0xffffffffu) flush();
+						cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+					}
+					const float g1 = h2f(unpack_h2(q12[j].x)[f]);
+					const float g2 = h2f(unpack_h2(q12[j].y)[f]);
+#pragma unroll
+					for (uint32_t yz = 0; yz < 4; ++yz) {
+						const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+						acc[yz] += corner_addend(g1, g2, scale, sm[j].dn, pos, c);
+					}
 				}
 			}
 			flush();
