@@ -96,6 +96,35 @@ __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t 
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
 	if (threadIdx.x == 0) *mean_out = (float)s;
 }
+// Coarse occupancy of cascade 0 for the march kernels: one bit per BYTE of the bitfield. The cells are in Morton order, so a byte
+// is a 2x2x2 block of cells and its index is the Morton index of the block: 64^3 bits = 32 KB, which a workgroup keeps in LDS.
+// A clear coarse bit answers "not occupied" without the dependent global load -- in a converged scene nearly every position a
+// ray visits (the march's loop is one such load per visited cell, latency-bound beside the backward pass) -- and a set bit falls
+// through to the bitfield itself: the decisions, and with them the sample set, are the reference's bit for bit.
+constexpr uint32_t COARSE_WORDS = GRID_CELLS / 8 / 32;
+__global__ void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= COARSE_WORDS) return;
+	const uint4 a = reinterpret_cast<const uint4*>(bitfield)[w * 2 + 0], b = reinterpret_cast<const uint4*>(bitfield)[w * 2 + 1];
+	const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	uint32_t bits = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < 8; ++q)
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) if ((v[q] >> (8 * k)) & 0xffu) bits |= 1u << (q * 4 + k);
+	coarse[w] = bits;
+}
+__device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t tid, const uint32_t n_threads) {
+	for (uint32_t q = tid * 4; q < COARSE_WORDS; q += n_threads * 4) *reinterpret_cast<uint4*>(lds + q) = *reinterpret_cast<const uint4*>(g + q);
+}
+// density_grid_occupied_at for mip 0 with the coarse bits in front of the bitfield
+__device__ __forceinline__ bool occupied_mip0(const Vec3& pos, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds) {
+	const uint32_t idx = cascaded_grid_idx_at(pos, 0);
+	const uint32_t byte = idx >> 3;
+	if (!((coarse_lds[byte >> 5] >> (byte & 31u)) & 1u)) return false;
+	return bitfield[byte] & (1 << (idx & 7u));
+}
+
 // grid_to_bitfield (testbed_nerf.cu:693-717)
 __global__ void k_grid_to_bitfield(const uint32_t n_elements, const uint32_t n_nonzero_elements, const float* __restrict__ grid, uint8_t* __restrict__ bitfield, const float* __restrict__ mean_density_ptr) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -199,6 +228,7 @@ struct MarchArgs {
 	SceneAabb A;
 	const ViewDev* views;
 	const uint8_t* bitfield;
+	const uint32_t* coarse; // k_coarse_bitfield of cascade 0
 	// per-ray scratch
 	float* setup;       // [n_rays][8]: o(3) dir(3) startt alive
 	float* ray_t;       // [n_rays][RNB_MAX_STEPS]: t of every sample found by the counting pass
@@ -222,7 +252,7 @@ struct MarchArgs {
 // mip 0 (mip_from_pos clamps to max_cascade = 0, mip_from_dt returns it because dt * 2 * GRIDSIZE < 1), so the per-position
 // frexp / scalbn / variable-resolution arithmetic folds into constants. Same values, fewer dependent instructions per voxel.
 template <bool SC, typename F>
-__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
+__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
 	const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
 	uint32_t j = 0;
 	float t = startt;
@@ -230,7 +260,7 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 	while (aabb_contains(A, pos = o + t * dir) && j < max_steps) {
 		const float dt = SC ? MIN_CONE_STEPSIZE : calc_dt(t, A.cone_angle);
 		const uint32_t mip = SC ? 0u : (uint32_t)mip_from_dt(dt, pos);
-		if (density_grid_occupied_at(pos, bitfield, mip)) {
+		if (SC ? occupied_mip0(pos, bitfield, coarse_lds) : density_grid_occupied_at(pos, bitfield, mip)) {
 			emit(j, pos, dt, t);
 			++j;
 			t += dt;
@@ -247,6 +277,8 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 
 template <bool SC>
 __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
+	__shared__ __attribute__((aligned(16))) uint32_t coarse_lds[SC ? COARSE_WORDS : 4];
+	if (SC) { load_coarse(coarse_lds, a.coarse, threadIdx.x, blockDim.x); __syncthreads(); }
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= a.n_rays) return;
 	const uint32_t gi = a.ray_offset + i;
@@ -283,7 +315,7 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
 		alive = 1.f;
 		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
-		steps = march<SC>(a.A, a.bitfield, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
+		steps = march<SC>(a.A, a.bitfield, coarse_lds, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
 	}
 	float* st = a.setup + (size_t)i * 8;
 	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
@@ -301,6 +333,8 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 template <int MG, bool SC>
 __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 	static_assert(MG == 8 || MG == 16 || MG == 32, "lanes per ray");
+	__shared__ __attribute__((aligned(16))) uint32_t coarse_lds[SC ? COARSE_WORDS : 4];
+	if (SC) { load_coarse(coarse_lds, a.coarse, threadIdx.x, blockDim.x); __syncthreads(); }
 	constexpr uint64_t GM = (1ull << MG) - 1ull;  // a group's lanes inside a 64-bit ballot
 	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
 	const int lane = threadIdx.x & 63;
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 		if (inside) {
 			const float dt = SC ? MIN_CONE_STEPSIZE : calc_dt(my_t, cone);
 			const uint32_t mip = SC ? 0u : (uint32_t)mip_from_dt(dt, pos);
-			occ = density_grid_occupied_at(pos, a.bitfield, mip);
+			occ = SC ? occupied_mip0(pos, a.bitfield, coarse_lds) : density_grid_occupied_at(pos, a.bitfield, mip);
 			if (!occ) {
 				const uint32_t res = GRIDSIZE >> mip;
 				t_target = my_t + distance_to_next_voxel(pos, dir, idir, res);

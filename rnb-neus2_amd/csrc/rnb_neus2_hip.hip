@@ -116,6 +116,7 @@ struct rnb_ctx {
 	DevBuf<float> density_grid, density_grid_tmp, density_mean;
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
+	DevBuf<uint32_t> coarse_bits; // k_coarse_bitfield: one bit per byte of cascade 0's bitfield, rebuilt in front of every march (a caller may have written the bitfield)
 	DevBuf<float> grid_sample_pos;
 	DevBuf<uint32_t> grid_sample_idx;
 	uint32_t n_grid_samples = 0;
@@ -359,7 +360,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.rng = c->rng;
 	a.A = c->aabb;
 	a.views = c->views.p;
-	a.bitfield = c->bitfield.p;
+	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p;
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
 	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = c->fwd_k1;
@@ -377,6 +378,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	// lets the controller raise the batch from 15 k to 100 k rays): 0.23 ms at 94 k rays against 0.77 ms for the 16-lanes-per-ray
 	// kernel, which in turn wins below ~30 k rays (0.20 vs 0.30 ms at 14 k), where a ray per thread leaves the GPU to latency.
 	const bool sc = c->aabb.cone_angle == 0.f && c->aabb.max_cascade == 0; // one cascade, constant step: the specialised instances
+	if (sc) hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 256), dim3(256), 0, s, c->bitfield.p, c->coarse_bits.p);
 	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
 		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), 0, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
@@ -762,7 +764,7 @@ int rnb_default_config(rnb_config* cfg) {
 int rnb_destroy(rnb_ctx* c) {
 	if (!c) return RNB_OK;
 	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free();
-	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free();
+	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
@@ -829,7 +831,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
-	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES);
+	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, COARSE_WORDS);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
