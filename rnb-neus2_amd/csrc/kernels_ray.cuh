@@ -96,33 +96,40 @@ __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t 
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
 	if (threadIdx.x == 0) *mean_out = (float)s;
 }
-// Coarse occupancy of cascade 0 for the march kernels: one bit per BYTE of the bitfield. The cells are in Morton order, so a byte
-// is a 2x2x2 block of cells and its index is the Morton index of the block: 64^3 bits = 32 KB, which a workgroup keeps in LDS.
-// A clear coarse bit answers "not occupied" without the dependent global load -- in a converged scene nearly every position a
-// ray visits (the march's loop is one such load per visited cell, latency-bound beside the backward pass) -- and a set bit falls
-// through to the bitfield itself: the decisions, and with them the sample set, are the reference's bit for bit.
-constexpr uint32_t COARSE_WORDS = GRID_CELLS / 8 / 32;
+// Coarse occupancy of cascade 0 for the march kernels: one bit per 4x4x4 block of cells (the cells are in Morton order, so a block is
+// 8 consecutive bytes of the bitfield), 32^3 bits = 4 KB, which every workgroup keeps in LDS (small enough to sit several times on
+// a CU beside the 118 KB of k_grid_scatter_lds; the 32 KB of a 2x2x2 version filtered better but kept that kernel off the CUs:
+// 33 -> 93 us). The blocks are stored in LINEAR order (x fastest), so the test needs three shifts of the cell coordinates and no
+// Morton code. A clear coarse bit answers "not occupied" without the Morton index and the dependent global load -- in a converged
+// scene nearly every position a ray visits -- and a set bit falls through to the bitfield itself: the decisions, and with them the
+// sample set, are the reference's bit for bit.
+constexpr uint32_t COARSE_WORDS = GRID_CELLS / 64 / 32;
 __global__ void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= COARSE_WORDS) return;
-	const uint4 a = reinterpret_cast<const uint4*>(bitfield)[w * 2 + 0], b = reinterpret_cast<const uint4*>(bitfield)[w * 2 + 1];
-	const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 	uint32_t bits = 0;
-#pragma unroll
-	for (uint32_t q = 0; q < 8; ++q)
-#pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) if ((v[q] >> (8 * k)) & 0xffu) bits |= 1u << (q * 4 + k);
+	for (uint32_t k = 0; k < 32; ++k) {
+		const uint32_t b = w * 32 + k; // linear block id: x | y << 5 | z << 10
+		const uint32_t mb = morton3D(b & 31u, (b >> 5) & 31u, b >> 10);
+		const uint2 v = reinterpret_cast<const uint2*>(bitfield)[mb];
+		if (v.x | v.y) bits |= 1u << k;
+	}
 	coarse[w] = bits;
 }
 __device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t tid, const uint32_t n_threads) {
 	for (uint32_t q = tid * 4; q < COARSE_WORDS; q += n_threads * 4) *reinterpret_cast<uint4*>(lds + q) = *reinterpret_cast<const uint4*>(g + q);
 }
-// density_grid_occupied_at for mip 0 with the coarse bits in front of the bitfield
-__device__ __forceinline__ bool occupied_mip0(const Vec3& pos, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds) {
-	const uint32_t idx = cascaded_grid_idx_at(pos, 0);
-	const uint32_t byte = idx >> 3;
-	if (!((coarse_lds[byte >> 5] >> (byte & 31u)) & 1u)) return false;
-	return bitfield[byte] & (1 << (idx & 7u));
+// density_grid_occupied_at for mip 0 (cascaded_grid_idx_at's arithmetic with mip_scale = 1) with the coarse bits in front of the bitfield
+__device__ __forceinline__ bool occupied_mip0(Vec3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds) {
+	pos = pos - v3(0.5f, 0.5f, 0.5f);
+	pos = 1.0f * pos;
+	pos = pos + v3(0.5f, 0.5f, 0.5f);
+	const int ix = (int)(pos.x * GRIDSIZE), iy = (int)(pos.y * GRIDSIZE), iz = (int)(pos.z * GRIDSIZE);
+	const uint32_t x = (uint32_t)min(max(ix, 0), (int)GRIDSIZE - 1), y = (uint32_t)min(max(iy, 0), (int)GRIDSIZE - 1), z = (uint32_t)min(max(iz, 0), (int)GRIDSIZE - 1);
+	const uint32_t block = (x >> 2) | ((y >> 2) << 5) | ((z >> 2) << 10);
+	if (!((coarse_lds[block >> 5] >> (block & 31u)) & 1u)) return false;
+	const uint32_t idx = morton3D(x, y, z);
+	return bitfield[idx >> 3] & (1 << (idx & 7u));
 }
 
 // grid_to_bitfield (testbed_nerf.cu:693-717)

@@ -116,7 +116,8 @@ struct rnb_ctx {
 	DevBuf<float> density_grid, density_grid_tmp, density_mean;
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
-	DevBuf<uint32_t> coarse_bits; // k_coarse_bitfield: one bit per byte of cascade 0's bitfield, rebuilt in front of every march (a caller may have written the bitfield)
+	DevBuf<uint32_t> coarse_bits; // k_coarse_bitfield: one bit per 4x4x4 block of cascade 0's bitfield
+	bool coarse_valid = false;
 	DevBuf<float> grid_sample_pos;
 	DevBuf<uint32_t> grid_sample_idx;
 	uint32_t n_grid_samples = 0;
@@ -276,6 +277,8 @@ int update_bitfield(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3497-3517
 		hipLaunchKernelGGL(k_bitfield_max_pool, dim3((GRID_CELLS / 64 + 127) / 128), dim3(128), 0, s, GRID_CELLS / 64,
 		                   c->bitfield.p + (size_t)n_bytes_per_mip * (level - 1), c->bitfield.p + (size_t)n_bytes_per_mip * level);
 	}
+	hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 64), dim3(64), 0, s, c->bitfield.p, c->coarse_bits.p); // for the march kernels (kernels_ray.cuh)
+	c->coarse_valid = true;
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -378,7 +381,10 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	// lets the controller raise the batch from 15 k to 100 k rays): 0.23 ms at 94 k rays against 0.77 ms for the 16-lanes-per-ray
 	// kernel, which in turn wins below ~30 k rays (0.20 vs 0.30 ms at 14 k), where a ray per thread leaves the GPU to latency.
 	const bool sc = c->aabb.cone_angle == 0.f && c->aabb.max_cascade == 0; // one cascade, constant step: the specialised instances
-	if (sc) hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 256), dim3(256), 0, s, c->bitfield.p, c->coarse_bits.p);
+	if (sc && !c->coarse_valid) { // after an occupancy update, or when a caller may have written the bitfield (rnb_buffer)
+		hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 64), dim3(64), 0, s, c->bitfield.p, c->coarse_bits.p);
+		c->coarse_valid = true;
+	}
 	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
 		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), 0, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
@@ -1015,7 +1021,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_ADAM_V: BUF(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
 		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
-		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield);
+		case RNB_BUF_DENSITY_BITFIELD: c->coarse_valid = false; BUF(c->bitfield); // the caller may write through the pointer: the coarse bits are rebuilt in front of the next march
 		case RNB_BUF_DENSITY_MEAN: BUF(c->density_mean);
 		case RNB_BUF_RAY_INDICES: BUF(c->ray_indices);
 		case RNB_BUF_RAYS: BUF(c->rays);
