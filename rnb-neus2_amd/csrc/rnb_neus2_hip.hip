@@ -142,7 +142,9 @@ struct rnb_ctx {
 	bool wimg_valid = false;
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
-	uint32_t fwd_k1 = 48;
+	uint32_t fwd_k1 = 48;      // head length of the two-round network evaluation (0 = one round); the longest head of the adaptive rule
+	bool fwd_k1_fixed = false; // RNB_FWD_K1: that value for every step
+	uint32_t gen_k1 = 0, cur_k1 = 0; // head length the last generated batch / the running step was laid out with (k1_for)
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool march_narrow = false, fwd_bwd_generic = false;
@@ -187,7 +189,7 @@ struct rnb_ctx {
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
-	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0; } pre; // samples already generated for the next step
+	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills
 	void* host_rb_dev = nullptr;
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
@@ -351,6 +353,17 @@ static LossFlags loss_flags(const rnb_ctx* c) {
 	return F;
 }
 
+// Head length of the two-round network evaluation for a batch of n_rays rays. Measured in round 2 (ms/step by head length at 19 k /
+// 26 k / 50 k / 85 k / 95 k rays per step, i.e. 13.8 / 9.9 / 5.2 / 3.1 / 2.8 compacted samples per ray): the best head is ~4.5 x the
+// compacted samples per ray -- 48: 0.712 / 0.764 / 0.796 / 0.822 / 0.842; 32: 0.732 / 0.759 / 0.765 / 0.803 / 0.827; 24: 0.789 / 0.784 /
+// 0.754 / 0.788 / 0.816; 16: 0.840 / 0.849 / 0.769 / 0.782 / 0.796 -- and the controller holds the compacted batch at B, so that is
+// 4.5 B / n_rays, kept within [16, 48]. The results do not depend on it (tests/test_gpu_fullsize.py).
+static uint32_t k1_for(const rnb_ctx* c, uint32_t n_rays) {
+	if (c->fwd_k1 == 0 || c->fwd_k1_fixed) return c->fwd_k1;
+	const uint32_t k = (uint32_t)(4.5f * (float)c->cfg.target_batch_size / (float)std::max(1u, n_rays));
+	return std::min(c->fwd_k1, std::max(16u, k));
+}
+
 MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
 	MarchArgs a;
 	a.n_rays = n_rays;
@@ -366,7 +379,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p;
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
-	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = c->fwd_k1;
+	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays);
 	a.F = loss_flags(c);
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.ray_const = c->ray_const.p;
@@ -375,6 +388,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 
 int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr) {
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
+	c->gen_k1 = a.k1;
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
 	// One thread per ray once there are enough rays to fill the chip that way (late in training the converged occupancy grid
@@ -397,10 +411,10 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
 		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
-		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, c->fwd_k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
-		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, c->fwd_k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
+		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
+		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
 	} else
-		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, c->fwd_k1, c->ray_base1.p, c->fwd_counts.p);
+		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, done, a);
 	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
@@ -429,7 +443,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
 	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
-		a.cap = c->fwd_k1;
+		a.cap = c->cur_k1;
 		hipLaunchKernelGGL(k_loss_pass1_heads, dim3(blocks_heads), dim3(1024), 0, s, a);
 		c->prof.mark(s, P_LOSS_PASS1);
 		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 2, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
@@ -898,7 +912,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	c->training_step = 0;
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
-	if (const char* e = getenv("RNB_FWD_K1")) c->fwd_k1 = (uint32_t)atoi(e); // head length of the two-round network evaluation; 0 = one round over all samples
+	if (const char* e = getenv("RNB_FWD_K1")) { c->fwd_k1 = (uint32_t)atoi(e); c->fwd_k1_fixed = true; } // a fixed head length of the two-round network evaluation; 0 = one round over all samples
 	{
 		rnb_ctx::Knobs& k = c->knobs;
 		k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
@@ -1305,6 +1319,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	if (c->pre.valid) { // generated beside the previous step's backward pass
 		n_rays_total = c->pre.n_rays_total;
 		c->pre.valid = false;
+		c->cur_k1 = c->pre.k1;
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
 	} else {
 		n_rays_total = c->n_rays_total;
@@ -1312,11 +1327,12 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
 		rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
 		if (rc != RNB_OK) return rc;
+		c->cur_k1 = c->gen_k1;
 	}
 	c->cur_n_rays = n_rays;
 	c->cur_n_rays_total = n_rays_total;
 	c->prof.mark(s, P_NONE);
-	const bool two_round = c->fwd_k1 != 0;
+	const bool two_round = c->cur_k1 != 0;
 	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p);
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
@@ -1365,7 +1381,7 @@ static int launch_premarch(rnb_ctx* c) {
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;
 	c->n_rays_total += n_rays * c->cfg.world_size;
-	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference;
+	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference; c->pre.k1 = c->gen_k1;
 	return RNB_OK;
 }
 
@@ -1398,7 +1414,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
 	const uint32_t* counters = c->host_rb->counters;
-	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += c->fwd_k1 ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
+	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += c->cur_k1 ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
 	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];
