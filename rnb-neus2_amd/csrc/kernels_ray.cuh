@@ -827,13 +827,35 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 	ray_constants_core(in, a.ray_indices[i], R);
 }
 
-// Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: one wavefront per ray expands the
-// t values recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
+// Second pass of the reference's kernel (testbed_nerf.cu:1366-1380) without re-marching: LR lanes per ray expand the t values
+// recorded by the counting pass into NerfCoordinates (pos = o + t*dir is the same expression the march evaluated).
 // LR lanes per ray: 64 while rays are few and long (early training: ~30 marched samples per ray), 16 once the batch has grown
 // to ~100 k rays with ~8 samples each (a wavefront per ray would leave 7 of 8 lanes idle).
+// The per-ray constants of the loss (pixel fetches, two RNG jumps, sRGB, the light triplet: ~2000 instructions) are worked out by
+// ONE thread per ray -- the first MARCH_WRITE_WG / LR threads of the workgroup, one for each of its rays -- and not by every
+// lane of the ray's group (that was most of this kernel: 65 -> see DESIGN.md section 6).
+constexpr uint32_t MARCH_WRITE_WG = 1024;
 template <int LR>
-__global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
-	const uint32_t i = blockIdx.x * (256 / LR) + threadIdx.x / LR;
+__global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs a) {
+	constexpr uint32_t RAYS = MARCH_WRITE_WG / LR;
+	if (a.ray_const && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
+		const uint32_t i = blockIdx.x * RAYS + threadIdx.x;
+		const uint32_t s = i < a.n_rays ? a.slot[i] : 0xffffffffu;
+		if (s != 0xffffffffu) {
+			RayConstIn in;
+			in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
+			in.views = a.views; in.F = a.F; in.light_dirs = a.light_dirs;
+			struct { float rgbtarget[4], light[3], mask_certainty, mask_gt; } rc;
+			ray_constants_core(in, i, rc);
+			float* q = a.ray_const + (size_t)s * RAY_CONST_FLOATS;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) q[k] = rc.rgbtarget[k];
+#pragma unroll
+			for (int k = 0; k < 3; ++k) q[4 + k] = rc.light[k];
+			q[7] = rc.mask_certainty; q[8] = rc.mask_gt;
+		}
+	}
+	const uint32_t i = blockIdx.x * RAYS + threadIdx.x / LR;
 	const uint32_t lane = threadIdx.x & (LR - 1);
 	if (i >= a.n_rays) return;
 	const uint32_t s = a.slot[i];
@@ -848,21 +870,6 @@ __global__ __launch_bounds__(256) void k_march_write(const MarchArgs a) {
 		ro[3] = a.d_unnorm[(size_t)i * 3 + 0]; ro[4] = a.d_unnorm[(size_t)i * 3 + 1]; ro[5] = a.d_unnorm[(size_t)i * 3 + 2];
 		a.numsteps[(size_t)s * 2 + 0] = steps;
 		a.numsteps[(size_t)s * 2 + 1] = base;
-	}
-	if (a.ray_const) {
-		RayConstIn in;
-		in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
-		in.views = a.views; in.F = a.F; in.light_dirs = a.light_dirs;
-		struct { float rgbtarget[4], light[3], mask_certainty, mask_gt; } rc;
-		ray_constants_core(in, i, rc);
-		if (lane == 0) {
-			float* q = a.ray_const + (size_t)s * RAY_CONST_FLOATS;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) q[k] = rc.rgbtarget[k];
-#pragma unroll
-			for (int k = 0; k < 3; ++k) q[4 + k] = rc.light[k];
-			q[7] = rc.mask_certainty; q[8] = rc.mask_gt;
-		}
 	}
 	if (a.k1) {
 		const uint32_t b1 = a.base1[i];

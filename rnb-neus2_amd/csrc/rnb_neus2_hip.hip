@@ -416,8 +416,8 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	} else
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
-	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, done, a);
-	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + 3) / 4), dim3(256), 0, s, done, a);
+	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, done, a);
+	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
