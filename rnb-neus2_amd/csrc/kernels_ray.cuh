@@ -735,6 +735,12 @@ __device__ __forceinline__ AlphaTerms alpha_terms(const half_t* __restrict__ o, 
 }
 
 __device__ __forceinline__ float bcast(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+// v of lane q of my group of LR lanes (LR = 64: q is wave-uniform; LR = 16: q may differ between the four rows of the wavefront)
+template <int LR>
+__device__ __forceinline__ float group_read(const float v, const int q, const int lane64) {
+	if (LR == 64) return bcast(v, q);
+	return __shfl(v, (lane64 & ~(LR - 1)) + q, 64);
+}
 
 __device__ __forceinline__ void load_out16(const half_t* __restrict__ p, half_t o[16]) {
 	const h8* src = reinterpret_cast<const h8*>(p);
@@ -894,40 +900,42 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 // the reference's operation order, so the rounding -- and with it the early stop -- is identical); the loop's exit test
 // "T < 1e-4 before sample q" then is one ballot over the lanes, and the running values are read from the lane in front
 // of the first such sample. Returns true if the ray terminated inside these samples.
-template <bool NO_ALBEDO>
-__device__ __forceinline__ bool composite_replay(const int cnt, const int lane, const float alpha, const float shading, const float (&albedo)[4],
+template <bool NO_ALBEDO, int LR>
+__device__ __forceinline__ bool composite_replay(const int cnt, const int lane, const int lane64, const float alpha, const float shading, const float (&albedo)[4],
                                                  float& T, float (&rgb)[4], float& weight_sum, uint32_t& n) {
-	const ChainState s = replay_chain<NO_ALBEDO>(cnt, alpha, shading, albedo, 0.f, T, weight_sum, rgb, 0.f);
-	// the transmittance the loop tests before it takes sample `lane`: the lane in front's (wave_shr:1), lane 0 keeps the incoming one
-	const float T_before = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x138, 0xf, 0xf, false));
-	const uint64_t stop = __builtin_amdgcn_ballot_w64(lane < cnt && T_before < 1e-4f);
+	const ChainState s = replay_chain<NO_ALBEDO, LR>(cnt, alpha, shading, albedo, 0.f, T, weight_sum, rgb, 0.f);
+	// the transmittance the loop tests before it takes sample `lane`: the lane in front's (wave_shr:1 / row_shr:1), lane 0 keeps the incoming one
+	const float T_before = LR == 64 ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x138, 0xf, 0xf, false))
+	                                : __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x111, 0xf, 0xf, false));
+	uint64_t stop = __builtin_amdgcn_ballot_w64(lane < cnt && T_before < 1e-4f);
+	if (LR != 64) stop = (stop >> (lane64 & ~(LR - 1))) & ((1ull << LR) - 1ull); // my group's lanes
 	const int taken = stop ? (int)__builtin_ctzll(stop) : cnt; // samples composited here
 	n += (uint32_t)taken;
-	if (taken > 0) {
-		T = bcast(s.T, taken - 1);
-		weight_sum = bcast(s.ws, taken - 1);
-		rgb[0] = bcast(s.rgb[0], taken - 1);
-		if (!NO_ALBEDO) {
+	const int last = max(taken - 1, 0);
+	const float T1 = group_read<LR>(s.T, last, lane64), w1 = group_read<LR>(s.ws, last, lane64), r0 = group_read<LR>(s.rgb[0], last, lane64);
+	if (taken > 0) { T = T1; weight_sum = w1; rgb[0] = r0; }
+	if (!NO_ALBEDO) {
 #pragma unroll
-			for (int k = 1; k < 4; ++k) rgb[k] = bcast(s.rgb[k], taken - 1);
-		}
+		for (int k = 1; k < 4; ++k) { const float rk = group_read<LR>(s.rgb[k], last, lane64); if (taken > 0) rgb[k] = rk; }
 	}
 	return stop != 0ull;
 }
 
-// Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), one wavefront per ray: the per-sample terms (alpha, shading)
-// are evaluated by 64 lanes at once; the transmittance recurrence and the early stop at T < 1e-4 are then replayed in the
-// reference's sequential order (identical fp32 rounding) from lane broadcasts.
+// Pass 1 of the reference kernel (testbed_nerf.cu:1608-1697), LR lanes per ray (64: one wavefront per ray; 16: four rays per
+// wavefront once the batch holds many short rays): the per-sample terms (alpha, shading) are evaluated by the ray's lanes at
+// once; the transmittance recurrence and the early stop at T < 1e-4 then run in the reference's sequential order (identical fp32
+// rounding) across the lanes (chain.cuh). `valid` = the ray exists and is kept; every lane of the wavefront stays active.
 // Returns (phase 0 of the two-round evaluation) how many samples of the ray are still to be evaluated, 0 if the ray is settled;
 // *base_out = the ray's first sample slot.
-__device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint32_t i, const int lane, uint32_t* base_out = nullptr) {
-	const uint32_t numsteps_all = a.numsteps[(size_t)i * 2 + 0];
+template <int LR>
+__device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint32_t i, const bool valid, const int lane, const int lane64, uint32_t* base_out = nullptr) {
+	const uint32_t numsteps_all = valid ? a.numsteps[(size_t)i * 2 + 0] : 0u;
 	const uint32_t numsteps = a.phase == 0 ? min(numsteps_all, a.cap) : numsteps_all;
-	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+	const uint32_t base = valid ? a.numsteps[(size_t)i * 2 + 1] : 0u;
 	const float* coords_in = a.coords + (size_t)base * 7;
 	const half_t* net = a.mlp_out + (size_t)base * 16;
 	RayLoss R;
-	ray_constants(a, i, R);
+	ray_constants(a, valid ? i : 0u, R);
 	float dir[3];
 	{ // BENT_DIR (testbed_nerf.cu:1645-1650): the direction the network echoed for the ray's first sample
 		half_t o0[16];
@@ -943,15 +951,17 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 	bool done = false;
 	uint32_t c_begin = 0;
 	if (a.phase == 1) { // continue where phase 0 stopped (it consumed exactly `cap` samples without terminating)
-		const RayLoss P = a.ray_loss[i];
+		const RayLoss P = a.ray_loss[valid ? i : 0u];
 		T = P.T_resume; weight_sum = P.weight_sum_raw; n = P.n_comp; c_begin = a.cap;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rgb_ray[k] = P.rgb_ray[k];
 	}
-	for (uint32_t c0 = c_begin; c0 < numsteps && !done; c0 += 64) {
+	for (uint32_t c0 = c_begin; ; c0 += LR) {
+		const bool act = c0 < numsteps && !done; // this ray still has samples to composite (LR = 64: the same for the whole wavefront)
+		if (!__any(act)) break;
 		const uint32_t j = c0 + lane;
 		float alpha = 0.f, shading = 0.f, albedo[4] = {1.f, 1.f, 1.f, 0.f};
-		if (j < numsteps) {
+		if (act && j < numsteps) {
 			half_t o[16];
 			load_out16(net + (size_t)j * 16, o);
 			albedo_from_output(a.F, o, albedo);
@@ -961,9 +971,10 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		}
-		const int cnt = (int)min(64u, numsteps - c0);
-		done = a.F.apply_no_albedo ? composite_replay<true>(cnt, lane, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
-		                           : composite_replay<false>(cnt, lane, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
+		const int cnt = act ? (int)min((uint32_t)LR, numsteps - c0) : 0;
+		const bool stopped = a.F.apply_no_albedo ? composite_replay<true, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
+		                                         : composite_replay<false, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
+		done = done || stopped;
 	}
 	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
 	uint32_t tail = 0;
@@ -976,7 +987,7 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 		if (!settled) tail = numsteps_all - a.cap;
 		if (base_out) *base_out = base;
 	}
-	if (lane == 0) {
+	if (valid && lane == 0) {
 		R.n_comp = n;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
@@ -989,46 +1000,47 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 	return tail;
 }
 
-// Phase 0 (all rays; their heads only in the two-round evaluation), one wavefront per ray, 16 rays per workgroup. The queue of
+// Phase 0 (all rays; their heads only in the two-round evaluation), LR lanes per ray, 1024 / LR rays per workgroup. The queue of
 // round 2 -- sample slots in idx2, rays in `unfinished` -- is allotted ONCE per workgroup with one 64-bit atomic on the
 // (entries, rays) pair: returning atomics on one address retire one after the other (≈6 ns each), and two per unsettled ray
 // made this kernel 46 us instead of 10 (measured in round 2 by doubling them: +37 us).
-constexpr uint32_t LOSS1_RAYS_PER_WG = 16;
-__global__ __launch_bounds__(1024) void k_loss_pass1_heads(const LossArgs a) {
-	__shared__ uint32_t s_tail[LOSS1_RAYS_PER_WG], s_off[LOSS1_RAYS_PER_WG], s_slot[LOSS1_RAYS_PER_WG], s_base[2];
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t i = blockIdx.x * LOSS1_RAYS_PER_WG + wave;
-	uint32_t tail = 0, base = 0;
-	if (i < a.n_rays) {
-		if (i >= a.counters[2]) { if (lane == 0) a.ncomp[i] = 0; }
-		else tail = loss_pass1_ray(a, i, (int)lane, &base);
-	}
+constexpr uint32_t LOSS1_WG = 1024;
+template <int LR>
+__global__ __launch_bounds__(LOSS1_WG) void k_loss_pass1_heads(const LossArgs a) {
+	constexpr uint32_t RAYS = LOSS1_WG / LR; // 16 or 64
+	__shared__ uint32_t s_tail[RAYS], s_off[RAYS], s_slot[RAYS], s_base[2];
+	const uint32_t lane64 = threadIdx.x & 63u, lane = threadIdx.x & (LR - 1), r = threadIdx.x / LR;
+	const uint32_t i = blockIdx.x * RAYS + r;
+	const bool valid = i < a.n_rays && i < a.counters[2];
+	if (i < a.n_rays && !valid && lane == 0) a.ncomp[i] = 0;
+	uint32_t base = 0;
+	const uint32_t tail = loss_pass1_ray<LR>(a, i, valid, (int)lane, (int)lane64, &base);
 	if (a.cap == 0xffffffffu) return; // single round: nothing is ever queued (uniform over the launch)
-	if (lane == 0) s_tail[wave] = tail;
+	if (lane == 0) s_tail[r] = tail;
 	__syncthreads();
-	if (wave == 0) {
-		const uint32_t t = lane < LOSS1_RAYS_PER_WG ? s_tail[lane] : 0u;
+	if (threadIdx.x < 64) {
+		const uint32_t t = lane64 < RAYS ? s_tail[lane64] : 0u;
 		const uint32_t u = t ? 1u : 0u;
-		const uint32_t it = wave_inclusive_scan(t, lane), iu = wave_inclusive_scan(u, lane);
-		if (lane < LOSS1_RAYS_PER_WG) { s_off[lane] = it - t; s_slot[lane] = iu - u; }
-		if (lane == LOSS1_RAYS_PER_WG - 1 && iu) {
+		const uint32_t it = wave_inclusive_scan(t, lane64), iu = wave_inclusive_scan(u, lane64);
+		if (lane64 < RAYS) { s_off[lane64] = it - t; s_slot[lane64] = iu - u; }
+		if (lane64 == RAYS - 1 && iu) {
 			const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(a.fwd_counts + 2), ((unsigned long long)iu << 32) | it);
 			s_base[0] = (uint32_t)old; s_base[1] = (uint32_t)(old >> 32);
 		}
 	}
 	__syncthreads();
 	if (tail) {
-		const uint32_t off = s_base[0] + s_off[wave];
-		if (lane == 0) a.unfinished[s_base[1] + s_slot[wave]] = i;
-		for (uint32_t j = lane; j < tail; j += 64) a.idx2[off + j] = base + a.cap + j;
+		const uint32_t off = s_base[0] + s_off[r];
+		if (lane == 0) a.unfinished[s_base[1] + s_slot[r]] = i;
+		for (uint32_t j = lane; j < tail; j += LR) a.idx2[off + j] = base + a.cap + j;
 	}
 }
 
-// Phase 1: the rays round 1 left unsettled, from the list phase 0 built. Also phase 0 of callers that bring their own launch shape.
+// Phase 1: the rays round 1 left unsettled (long ones), from the list phase 0 built: one wavefront per ray.
 __global__ __launch_bounds__(256) void k_loss_pass1(const LossArgs a) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t n_list = a.fwd_counts[3];
-	for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_list; k += gridDim.x * 4) (void)loss_pass1_ray(a, a.unfinished[k], lane);
+	for (uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6); k < n_list; k += gridDim.x * 4) (void)loss_pass1_ray<64>(a, a.unfinished[k], true, lane, lane);
 }
 
 // exclusive scan of ncomp over the kept rays; counters[1] = total (numsteps_counter_compacted)
@@ -1086,20 +1098,25 @@ __global__ __launch_bounds__(1024) void k_scan_compact_offsets(const uint32_t n,
 
 // Pass 2 (testbed_nerf.cu:1836-2095), one wavefront per ray: lanes own samples; the running sums of the reference's
 // sequential loop are replayed from broadcasts and captured by the lane that owns each sample.
+// LR lanes per ray (64: one wavefront per ray; 16: four rays per wavefront for batches of many short rays -- the per-ray part
+// of this kernel, ~200 instructions, then runs once for four rays). Every lane of the wavefront stays active (chain.cuh).
+template <int LR>
 __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
-	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (i >= a.n_rays || i >= a.counters[2]) return;
+	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
+	const int lane = threadIdx.x & (LR - 1), lane64 = threadIdx.x & 63;
+	const bool ray_ok = i_raw < a.n_rays && i_raw < a.counters[2];
+	const uint32_t i = ray_ok ? i_raw : 0u;
 	const RayLoss R = a.ray_loss[i];
 	const uint32_t compacted_base = a.cbase[i];
-	const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
+	const uint32_t compacted_numsteps = ray_ok ? min(a.B - min(a.B, compacted_base), R.n_comp) : 0u; // testbed_nerf.cu:1723
 	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
 	__builtin_amdgcn_wave_barrier();
-	if (lane == 0) {
+	if (ray_ok && lane == 0) {
 		a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
 		a.numsteps[(size_t)i * 2 + 1] = compacted_base;
 	}
-	if (compacted_numsteps == 0) return;
+	if (!__any(compacted_numsteps != 0)) return;
+	const bool ray_live = compacted_numsteps != 0; // a ray without compacted samples writes nothing further (the loss rows stay cleared)
 	const float* coords_in = a.coords + (size_t)base * 7;
 	const half_t* net = a.mlp_out + (size_t)base * 16;
 	float* coords_out = a.coords_compacted + (size_t)compacted_base * 7;
@@ -1136,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		if (F.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * F.mask_loss_weight;
 		else gradient_weight_sum = (sig - R.mask_gt) * F.mask_loss_weight;
 	}
-	if (lane == 0) {
+	if (ray_live && lane == 0) {
 		a.loss[i] = loss / gn;
 		const float sig = 1.0f / (1.0f + expf(-weight_sum));
 		if (F.apply_bce) a.mask_loss[i] = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
@@ -1149,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 	float T = 1.f;
 	const float dir[3] = {R.dir[0], R.dir[1], R.dir[2]};
 	float ek = 0.f;
-	for (uint32_t c0 = 0; c0 < compacted_numsteps; c0 += 64) {
+	for (uint32_t c0 = 0; __any(c0 < compacted_numsteps); c0 += LR) {
 		const uint32_t j = c0 + lane;
 		const bool valid = j < compacted_numsteps;
 		half_t o[16];
@@ -1173,15 +1190,19 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		}
 		const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
 		// the sequential recurrences (chain.cuh): lane q ends with its own weight and the running values right after sample q
-		const int cnt = (int)min(64u, compacted_numsteps - c0);
-		const ChainState cs = F.apply_no_albedo ? replay_chain<true>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
-		                                        : replay_chain<false>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
+		const int cnt = c0 < compacted_numsteps ? (int)min((uint32_t)LR, compacted_numsteps - c0) : 0;
+		const ChainState cs = F.apply_no_albedo ? replay_chain<true, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
+		                                        : replay_chain<false, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
 		const float my_weight = cs.w, my_T = cs.T, my_w2 = cs.ws;
 		float my_rgb2[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
 		if (F.apply_no_albedo) { my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3]; } // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
-		T = bcast(cs.T, cnt - 1); weight_sum2 = bcast(cs.ws, cnt - 1); ek = bcast(cs.ek, cnt - 1);
+		{ // the running values after the chunk's last sample (a ray that is through keeps its own)
+			const int last = max(cnt - 1, 0);
+			const float T1 = group_read<LR>(cs.T, last, lane64), w1 = group_read<LR>(cs.ws, last, lane64), e1 = group_read<LR>(cs.ek, last, lane64);
+			if (cnt > 0) { T = T1; weight_sum2 = w1; ek = e1; }
 #pragma unroll
-		for (int k = 0; k < 4; ++k) rgb_ray2[k] = bcast(my_rgb2[k], cnt - 1);
+			for (int k = 0; k < 4; ++k) { const float rk = group_read<LR>(my_rgb2[k], last, lane64); if (cnt > 0) rgb_ray2[k] = rk; }
+		}
 		if (valid) {
 			const float alpha = at.alpha;
 			const float weight = my_weight;
@@ -1252,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 			dst[1] = w1;
 		}
 	}
-	if (lane == 0) a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
+	if (ray_live && lane == 0) a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)

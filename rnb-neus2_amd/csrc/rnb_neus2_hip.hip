@@ -147,7 +147,7 @@ struct rnb_ctx {
 	uint32_t gen_k1 = 0, cur_k1 = 0; // head length the last generated batch / the running step was laid out with (k1_for)
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
-		bool march_narrow = false, fwd_bwd_generic = false;
+		bool march_narrow = false, fwd_bwd_generic = false, loss_wave_per_ray = false;
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 24576; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM; 16 k .. 48 k measured)
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -439,12 +439,18 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
 	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
-	const uint32_t blocks_heads = (n_rays + LOSS1_RAYS_PER_WG - 1) / LOSS1_RAYS_PER_WG;
+	// 16 lanes per ray (four rays per wavefront) from the batch size at which the march switches kernels: many short rays
+	const bool rows = n_rays >= c->knobs.march_narrow_from && !c->knobs.loss_wave_per_ray;
+	const uint32_t blocks_heads = rows ? (n_rays + LOSS1_WG / 16 - 1) / (LOSS1_WG / 16) : (n_rays + LOSS1_WG / 64 - 1) / (LOSS1_WG / 64);
+	auto launch_heads = [&]() {
+		if (rows) hipLaunchKernelGGL(k_loss_pass1_heads<16>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
+		else hipLaunchKernelGGL(k_loss_pass1_heads<64>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
+	};
 	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
 	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
 		a.cap = c->cur_k1;
-		hipLaunchKernelGGL(k_loss_pass1_heads, dim3(blocks_heads), dim3(1024), 0, s, a);
+		launch_heads();
 		c->prof.mark(s, P_LOSS_PASS1);
 		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 2, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
 		if (rc != RNB_OK) return rc;
@@ -452,7 +458,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		a.phase = 1;
 	}
 	if (a.phase) hipLaunchKernelGGL(k_loss_pass1, dim3(std::min(blocks, 1024u)), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL(k_loss_pass1_heads, dim3(blocks_heads), dim3(1024), 0, s, a);
+	else launch_heads();
 	c->prof.mark(s, P_LOSS_PASS1);
 	if (n_rays >= c->knobs.march_narrow_from) {
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
@@ -461,7 +467,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	} else
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
-	hipLaunchKernelGGL(k_loss_pass2, dim3(blocks), dim3(256), 0, s, a);
+	if (rows) hipLaunchKernelGGL(k_loss_pass2<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL(k_loss_pass2<64>, dim3(blocks), dim3(256), 0, s, a);
 	if (!defer_rollover) hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
 	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
@@ -916,6 +923,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	{
 		rnb_ctx::Knobs& k = c->knobs;
 		k.march_narrow = getenv("RNB_MARCH_NARROW") != nullptr; k.fwd_bwd_generic = getenv("RNB_FWD_BWD_GENERIC") != nullptr;
+		k.loss_wave_per_ray = getenv("RNB_LOSS_WAVE_PER_RAY") != nullptr; // the loss passes with one wavefront per ray whatever the batch (A/B, tests)
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);

@@ -41,6 +41,21 @@ void host_chain(const In* in, int cnt, Out* out) {
 	}
 }
 
+// four rays per wavefront (LR = 16): ray = 4 * wave + row, counts 0..16 per row
+template <bool NO_ALBEDO>
+__global__ void k_chain_row(const In* in, const int* cnts, Out* out) {
+	const int wave = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+	const int ray = wave * 4 + (lane >> 4), q = lane & 15;
+	const int cnt = cnts[ray] % 17;
+	In v = in[ray * 64 + q];
+	if (q >= cnt) { v.alpha = 0.f; v.ekterm = 0.f; v.shading = 0.f; }
+	const float rgb_in[4] = {0.125f, 0.25f, 0.375f, 0.0625f};
+	const ChainState s = replay_chain<NO_ALBEDO, 16>(cnt, v.alpha, v.shading, v.albedo, v.ekterm, 0.875f, 0.03125f, rgb_in, 0.5f);
+	Out o; o.T = s.T; o.w = s.w; o.ws = s.ws; o.ek = s.ek;
+	for (int k = 0; k < 4; ++k) o.rgb[k] = s.rgb[k];
+	out[ray * 64 + q] = o;
+}
+
 int main() {
 	const int n_rays = 64 * 64;
 	std::vector<In> in(n_rays * 64);
@@ -68,6 +83,22 @@ int main() {
 			}
 		}
 		printf("mode %s: %d mismatching lanes so far\n", mode == 0 ? "no-albedo" : "albedo", bad);
+	}
+	for (int mode = 0; mode < 2; ++mode) {
+		if (mode == 0) k_chain_row<true><<<n_rays / 16, 256>>>(d_in, d_c, d_out); else k_chain_row<false><<<n_rays / 16, 256>>>(d_in, d_c, d_out);
+		hipDeviceSynchronize();
+		hipMemcpy(got.data(), d_out, got.size() * sizeof(Out), hipMemcpyDeviceToHost);
+		for (int r = 0; r < n_rays; ++r) {
+			const int cnt = cnts[r] % 17;
+			if (mode == 0) host_chain<true>(&in[r * 64], cnt, want.data()); else host_chain<false>(&in[r * 64], cnt, want.data());
+			for (int q = 0; q < cnt; ++q) {
+				const Out &a = got[r * 64 + q], &b = want[q];
+				bool same = !memcmp(&a.T, &b.T, 4) && !memcmp(&a.w, &b.w, 4) && !memcmp(&a.ws, &b.ws, 4) && !memcmp(&a.ek, &b.ek, 4) && !memcmp(&a.rgb[0], &b.rgb[0], 4);
+				if (mode == 1) same = same && !memcmp(a.rgb, b.rgb, 16);
+				if (!same && bad++ < 20) printf("row mode %d ray %d cnt %d lane %d: T %g/%g w %g/%g ws %g/%g rgb0 %g/%g ek %g/%g\n", mode, r, cnt, q, a.T, b.T, a.w, b.w, a.ws, b.ws, a.rgb[0], b.rgb[0], a.ek, b.ek);
+			}
+		}
+		printf("row mode %s (4 rays per wavefront): %d mismatching lanes so far\n", mode == 0 ? "no-albedo" : "albedo", bad);
 	}
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	for (int mode = 0; mode < 2; ++mode) {
