@@ -96,38 +96,64 @@ __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t 
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
 	if (threadIdx.x == 0) *mean_out = (float)s;
 }
-// Coarse occupancy of cascade 0 for the march kernels: one bit per 4x4x4 block of cells (the cells are in Morton order, so a block is
-// 8 consecutive bytes of the bitfield), 32^3 bits = 4 KB, which every workgroup keeps in LDS (small enough to sit several times on
-// a CU beside the 118 KB of k_grid_scatter_lds; the 32 KB of a 2x2x2 version filtered better but kept that kernel off the CUs:
-// 33 -> 93 us). The blocks are stored in LINEAR order (x fastest), so the test needs three shifts of the cell coordinates and no
-// Morton code. A clear coarse bit answers "not occupied" without the Morton index and the dependent global load -- in a converged
-// scene nearly every position a ray visits -- and a set bit falls through to the bitfield itself: the decisions, and with them the
-// sample set, are the reference's bit for bit.
+// Occupancy of cascade 0 in a form a workgroup keeps in LDS (the march's loop is one occupancy test per visited cell; as a
+// dependent global load it made the thread-per-ray kernel latency-bound: 129 such loads per wavefront, 46 % of its cycles waiting
+// alone, and 319 instead of 185 us beside the backward pass):
+//   coarse[1024]  one bit per 4x4x4 block of cells, blocks in LINEAR order (x fastest): three shifts of the cell coordinates, no Morton code
+//   rank[1024]    number of set bits in front of each coarse word
+//   blocks[n]     the 64 cell bits of every non-empty block (the cells are in Morton order, so a block is 8 consecutive bytes of
+//                 the bitfield and a cell's bit is the low 6 bits of its Morton index), in coarse-bit order
+// 8 KB + 8 B per non-empty block (a surface: 2-3 k blocks). A clear coarse bit answers "not occupied"; a set one reads the block's
+// bits from LDS, or -- for blocks beyond the launch's LDS budget -- the bitfield itself. The decisions, and with them the sample
+// set, are the reference's bit for bit.
 constexpr uint32_t COARSE_WORDS = GRID_CELLS / 64 / 32;
-__global__ void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse) {
-	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	if (w >= COARSE_WORDS) return;
+constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup: 8 KB + 32 KB
+__device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
+// One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
+__global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks) {
+	__shared__ uint32_t wsum[16];
+	const uint32_t w = threadIdx.x, lane = w & 63u, wave = w >> 6;
 	uint32_t bits = 0;
 	for (uint32_t k = 0; k < 32; ++k) {
 		const uint32_t b = w * 32 + k; // linear block id: x | y << 5 | z << 10
-		const uint32_t mb = morton3D(b & 31u, (b >> 5) & 31u, b >> 10);
-		const uint2 v = reinterpret_cast<const uint2*>(bitfield)[mb];
+		const uint2 v = reinterpret_cast<const uint2*>(bitfield)[morton3D(b & 31u, (b >> 5) & 31u, b >> 10)];
 		if (v.x | v.y) bits |= 1u << k;
 	}
-	coarse[w] = bits;
+	uint32_t total;
+	const uint32_t before = block_exclusive_scan(__popc(bits), lane, wave, wsum, total);
+	out[w] = bits;
+	out[COARSE_WORDS + w] = before;
+	uint2* blocks = reinterpret_cast<uint2*>(out + 2 * COARSE_WORDS);
+	uint32_t r = before;
+	for (uint32_t k = 0; k < 32; ++k) {
+		if (!((bits >> k) & 1u)) continue;
+		const uint32_t b = w * 32 + k;
+		if (r < COARSE_MAX_BLOCKS) blocks[r] = reinterpret_cast<const uint2*>(bitfield)[morton3D(b & 31u, (b >> 5) & 31u, b >> 10)];
+		++r;
+	}
+	if (w == 0) *n_blocks = total;
 }
-__device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t tid, const uint32_t n_threads) {
-	for (uint32_t q = tid * 4; q < COARSE_WORDS; q += n_threads * 4) *reinterpret_cast<uint4*>(lds + q) = *reinterpret_cast<const uint4*>(g + q);
+// the first 2 * COARSE_WORDS + 2 * n_blocks_lds words of k_coarse_bitfield's output
+__device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t n_blocks_lds, const uint32_t tid, const uint32_t n_threads) {
+	const uint32_t n_words = 2 * COARSE_WORDS + 2 * n_blocks_lds; // a multiple of 2; the source is 16-byte aligned
+	for (uint32_t q = tid * 2; q < n_words; q += n_threads * 2) *reinterpret_cast<uint2*>(lds + q) = *reinterpret_cast<const uint2*>(g + q);
 }
-// density_grid_occupied_at for mip 0 (cascaded_grid_idx_at's arithmetic with mip_scale = 1) with the coarse bits in front of the bitfield
-__device__ __forceinline__ bool occupied_mip0(Vec3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds) {
+// density_grid_occupied_at for mip 0 (cascaded_grid_idx_at's arithmetic with mip_scale = 1) from the LDS form
+__device__ __forceinline__ bool occupied_mip0(Vec3 pos, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ lds, const uint32_t n_blocks_lds) {
 	pos = pos - v3(0.5f, 0.5f, 0.5f);
 	pos = 1.0f * pos;
 	pos = pos + v3(0.5f, 0.5f, 0.5f);
 	const int ix = (int)(pos.x * GRIDSIZE), iy = (int)(pos.y * GRIDSIZE), iz = (int)(pos.z * GRIDSIZE);
 	const uint32_t x = (uint32_t)min(max(ix, 0), (int)GRIDSIZE - 1), y = (uint32_t)min(max(iy, 0), (int)GRIDSIZE - 1), z = (uint32_t)min(max(iz, 0), (int)GRIDSIZE - 1);
 	const uint32_t block = (x >> 2) | ((y >> 2) << 5) | ((z >> 2) << 10);
-	if (!((coarse_lds[block >> 5] >> (block & 31u)) & 1u)) return false;
+	const uint32_t word = lds[block >> 5], bit = block & 31u;
+	if (!((word >> bit) & 1u)) return false;
+	const uint32_t r = lds[COARSE_WORDS + (block >> 5)] + __popc(word & ((1u << bit) - 1u));
+	if (r < n_blocks_lds) {
+		const uint2 cells = reinterpret_cast<const uint2*>(lds + 2 * COARSE_WORDS)[r];
+		const uint32_t c = (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2) | ((x & 2u) << 2) | ((y & 2u) << 3) | ((z & 2u) << 4); // low 6 bits of morton3D(x, y, z)
+		return (((c & 32u) ? cells.y : cells.x) >> (c & 31u)) & 1u;
+	}
 	const uint32_t idx = morton3D(x, y, z);
 	return bitfield[idx >> 3] & (1 << (idx & 7u));
 }
@@ -236,6 +262,7 @@ struct MarchArgs {
 	const ViewDev* views;
 	const uint8_t* bitfield;
 	const uint32_t* coarse; // k_coarse_bitfield of cascade 0
+	uint32_t n_blocks_lds;  // how many of its blocks the launch's LDS holds
 	// per-ray scratch
 	float* setup;       // [n_rays][8]: o(3) dir(3) startt alive
 	float* ray_t;       // [n_rays][RNB_MAX_STEPS]: t of every sample found by the counting pass
@@ -259,7 +286,7 @@ struct MarchArgs {
 // mip 0 (mip_from_pos clamps to max_cascade = 0, mip_from_dt returns it because dt * 2 * GRIDSIZE < 1), so the per-position
 // frexp / scalbn / variable-resolution arithmetic folds into constants. Same values, fewer dependent instructions per voxel.
 template <bool SC, typename F>
-__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
+__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds, const uint32_t n_blocks_lds, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
 	const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
 	uint32_t j = 0;
 	float t = startt;
@@ -267,7 +294,7 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 	while (aabb_contains(A, pos = o + t * dir) && j < max_steps) {
 		const float dt = SC ? MIN_CONE_STEPSIZE : calc_dt(t, A.cone_angle);
 		const uint32_t mip = SC ? 0u : (uint32_t)mip_from_dt(dt, pos);
-		if (SC ? occupied_mip0(pos, bitfield, coarse_lds) : density_grid_occupied_at(pos, bitfield, mip)) {
+		if (SC ? occupied_mip0(pos, bitfield, coarse_lds, n_blocks_lds) : density_grid_occupied_at(pos, bitfield, mip)) {
 			emit(j, pos, dt, t);
 			++j;
 			t += dt;
@@ -284,8 +311,8 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 
 template <bool SC>
 __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
-	__shared__ __attribute__((aligned(16))) uint32_t coarse_lds[SC ? COARSE_WORDS : 4];
-	if (SC) { load_coarse(coarse_lds, a.coarse, threadIdx.x, blockDim.x); __syncthreads(); }
+	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+	if (SC) { load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x); __syncthreads(); }
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= a.n_rays) return;
 	const uint32_t gi = a.ray_offset + i;
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
 		alive = 1.f;
 		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
-		steps = march<SC>(a.A, a.bitfield, coarse_lds, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
+		steps = march<SC>(a.A, a.bitfield, coarse_lds, a.n_blocks_lds, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
 	}
 	float* st = a.setup + (size_t)i * 8;
 	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
@@ -340,8 +367,8 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 template <int MG, bool SC>
 __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 	static_assert(MG == 8 || MG == 16 || MG == 32, "lanes per ray");
-	__shared__ __attribute__((aligned(16))) uint32_t coarse_lds[SC ? COARSE_WORDS : 4];
-	if (SC) { load_coarse(coarse_lds, a.coarse, threadIdx.x, blockDim.x); __syncthreads(); }
+	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+	if (SC) { load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x); __syncthreads(); }
 	constexpr uint64_t GM = (1ull << MG) - 1ull;  // a group's lanes inside a 64-bit ballot
 	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
 	const int lane = threadIdx.x & 63;
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 		if (inside) {
 			const float dt = SC ? MIN_CONE_STEPSIZE : calc_dt(my_t, cone);
 			const uint32_t mip = SC ? 0u : (uint32_t)mip_from_dt(dt, pos);
-			occ = SC ? occupied_mip0(pos, a.bitfield, coarse_lds) : density_grid_occupied_at(pos, a.bitfield, mip);
+			occ = SC ? occupied_mip0(pos, a.bitfield, coarse_lds, a.n_blocks_lds) : density_grid_occupied_at(pos, a.bitfield, mip);
 			if (!occ) {
 				const uint32_t res = GRIDSIZE >> mip;
 				t_target = my_t + distance_to_next_voxel(pos, dir, idir, res);

@@ -116,8 +116,9 @@ struct rnb_ctx {
 	DevBuf<float> density_grid, density_grid_tmp, density_mean;
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
-	DevBuf<uint32_t> coarse_bits; // k_coarse_bitfield: one bit per 4x4x4 block of cascade 0's bitfield
+	DevBuf<uint32_t> coarse_bits, coarse_count; // k_coarse_bitfield: cascade 0's occupancy in the form the march kernels keep in LDS; its number of non-empty blocks
 	bool coarse_valid = false;
+	uint32_t coarse_n_blocks = 0; // host copy of coarse_count
 	DevBuf<float> grid_sample_pos;
 	DevBuf<uint32_t> grid_sample_idx;
 	uint32_t n_grid_samples = 0;
@@ -268,6 +269,16 @@ int reset_optimizer_state(rnb_ctx* c) {
 }
 
 // ---- K5 ----
+// The LDS form of the occupancy for the march kernels (kernels_ray.cuh) + its block count on the host (the launches size their LDS
+// by it). Runs after an occupancy update (every 16th step, which synchronises anyway) or when a caller may have written the bitfield.
+static int rebuild_coarse(rnb_ctx* c, hipStream_t s) {
+	hipLaunchKernelGGL(k_coarse_bitfield, dim3(1), dim3(1024), 0, s, c->bitfield.p, c->coarse_bits.p, c->coarse_count.p);
+	HIP_TRY(hipMemcpyAsync(&c->coarse_n_blocks, c->coarse_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	c->coarse_valid = true;
+	return RNB_OK;
+}
+
 int update_bitfield(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3497-3517
 	const uint32_t n_blocks = 1024;
 	hipLaunchKernelGGL(k_mean_partial, dim3(n_blocks), dim3(256), 0, s, c->density_grid.p, c->mean_partial.p);
@@ -279,10 +290,8 @@ int update_bitfield(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3497-3517
 		hipLaunchKernelGGL(k_bitfield_max_pool, dim3((GRID_CELLS / 64 + 127) / 128), dim3(128), 0, s, GRID_CELLS / 64,
 		                   c->bitfield.p + (size_t)n_bytes_per_mip * (level - 1), c->bitfield.p + (size_t)n_bytes_per_mip * level);
 	}
-	hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 64), dim3(64), 0, s, c->bitfield.p, c->coarse_bits.p); // for the march kernels (kernels_ray.cuh)
-	c->coarse_valid = true;
 	HIP_TRY(hipGetLastError());
-	return RNB_OK;
+	return rebuild_coarse(c, s);
 }
 
 int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference) {
@@ -376,7 +385,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.rng = c->rng;
 	a.A = c->aabb;
 	a.views = c->views.p;
-	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p;
+	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p; a.n_blocks_lds = c->coarse_n_blocks <= COARSE_MAX_BLOCKS ? c->coarse_n_blocks : 0u; // a volume rather than a surface (early training): coarse bits only, the cell bits from the bitfield
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
 	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays);
@@ -387,6 +396,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 }
 
 int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr) {
+	if (!c->coarse_valid) { const int rc0 = rebuild_coarse(c, s); if (rc0 != RNB_OK) return rc0; } // a caller may have written the bitfield (rnb_buffer)
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	c->gen_k1 = a.k1;
 	const uint32_t blocks = (n_rays + 127) / 128;
@@ -395,16 +405,13 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	// lets the controller raise the batch from 15 k to 100 k rays): 0.23 ms at 94 k rays against 0.77 ms for the 16-lanes-per-ray
 	// kernel, which in turn wins below ~30 k rays (0.20 vs 0.30 ms at 14 k), where a ray per thread leaves the GPU to latency.
 	const bool sc = c->aabb.cone_angle == 0.f && c->aabb.max_cascade == 0; // one cascade, constant step: the specialised instances
-	if (sc && !c->coarse_valid) { // after an occupancy update, or when a caller may have written the bitfield (rnb_buffer)
-		hipLaunchKernelGGL(k_coarse_bitfield, dim3(COARSE_WORDS / 64), dim3(64), 0, s, c->bitfield.p, c->coarse_bits.p);
-		c->coarse_valid = true;
-	}
+	const size_t march_lds = sc ? (size_t)(2 * COARSE_WORDS + 2 * a.n_blocks_lds) * sizeof(uint32_t) : 0;
 	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
-		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), 0, s, a);
+		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
 	} else {
 		const dim3 grid((n_rays + 15) / 16); // 16 lanes per ray (8: 0.19 ms alone but a slower step; 32: 0.32 ms, measured in round 1)
-		if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), 0, s, a);
+		if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), march_lds, s, a);
 		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
 	}
 	c->prof.mark(s, P_MARCH_COUNT);
@@ -791,7 +798,7 @@ int rnb_default_config(rnb_config* cfg) {
 int rnb_destroy(rnb_ctx* c) {
 	if (!c) return RNB_OK;
 	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free();
-	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free();
+	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
@@ -858,7 +865,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
-	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, COARSE_WORDS);
+	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
@@ -910,6 +917,11 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+	{
+		const int march_lds_max = (int)((2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS) * sizeof(uint32_t));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
+	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
