@@ -108,6 +108,7 @@ __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t 
 // set, are the reference's bit for bit.
 constexpr uint32_t COARSE_WORDS = GRID_CELLS / 64 / 32;
 constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup: 8 KB + 32 KB
+template <uint32_t NW = 16>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
 // One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
 __global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks) {
@@ -581,14 +582,18 @@ __global__ __launch_bounds__(1024) void k_scan_rays(const uint32_t n, const uint
 // 94 k rays: 0.13 ms of a chain that the next kernels wait for): (1) tile sums of the sample counts, (2) offsets + which rays
 // keep their samples + tile sums of the three dependent counts, (3) slots. Integer work: bit-identical to k_scan_rays.
 constexpr uint32_t SCAN_TILE = 4096;
-// exclusive prefix of `mine` over the 1024 threads of the workgroup; `total` = sum over the workgroup
+// Workgroups of 256 threads, 16 rays per thread: beside the scatter kernels a CU rarely has the 16 free wavefront slots a
+// 1024-thread workgroup needs at once (k_scan_rays_base waited 45 us for them, measured), 4 are found at once.
+constexpr uint32_t SCAN_WG = 256, SCAN_EPT = SCAN_TILE / SCAN_WG, SCAN_NW = SCAN_WG / 64;
+// exclusive prefix of `mine` over the NW wavefronts of the workgroup; `total` = sum over the workgroup
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total) {
 	const uint32_t inc = wave_inclusive_scan(mine, lane);
 	if (lane == 63) wsum[wave] = inc;
 	__syncthreads();
 	uint32_t pre = 0, tot = 0;
 #pragma unroll
-	for (uint32_t w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; pre += w < wave ? x : 0u; tot += x; }
+	for (uint32_t w = 0; w < NW; ++w) { const uint32_t x = wsum[w]; pre += w < wave ? x : 0u; tot += x; }
 	__syncthreads();
 	total = tot;
 	return pre + inc - mine;
@@ -607,33 +612,33 @@ __device__ __forceinline__ uint32_t tile_prefix(const uint32_t* __restrict__ val
 	return r;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_rays_sums(const uint32_t n, const uint32_t* __restrict__ steps, uint32_t* __restrict__ tile_sum) {
+__global__ __launch_bounds__(SCAN_WG) void k_scan_rays_sums(const uint32_t n, const uint32_t* __restrict__ steps, uint32_t* __restrict__ tile_sum) {
 	__shared__ uint32_t wsum[16];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * SCAN_EPT;
 	uint32_t mine = 0;
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) mine += i0 + e < n ? steps[i0 + e] : 0u;
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) mine += i0 + e < n ? steps[i0 + e] : 0u;
 	uint32_t total;
-	(void)block_exclusive_scan(mine, lane, wave, wsum, total);
+	(void)block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
 	if (tid == 0) tile_sum[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_rays_base(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
+__global__ __launch_bounds__(SCAN_WG) void k_scan_rays_base(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
                                                          const uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ base, uint32_t* __restrict__ tile_v, uint32_t* __restrict__ counters) {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t sh;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t tile_base = tile_prefix(tile_sum, 1, blockIdx.x, tid, &sh);
-	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
-	uint32_t st[4], mine = 0;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * SCAN_EPT;
+	uint32_t st[SCAN_EPT], mine = 0;
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) { st[e] = i0 + e < n ? steps[i0 + e] : 0u; mine += st[e]; }
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { st[e] = i0 + e < n ? steps[i0 + e] : 0u; mine += st[e]; }
 	uint32_t total;
-	uint32_t run = tile_base + block_exclusive_scan(mine, lane, wave, wsum, total);
+	uint32_t run = tile_base + block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
 	uint32_t v[3] = {0, 0, 0};
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) {
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
 		if (i0 + e < n) base[i0 + e] = run;
 		const bool ok = st[e] > 0 && run + st[e] <= max_samples; // testbed_nerf.cu:1348-1355
 		run += st[e];
@@ -642,13 +647,13 @@ __global__ __launch_bounds__(1024) void k_scan_rays_base(const uint32_t n, const
 #pragma unroll
 	for (int k = 0; k < 3; ++k) {
 		uint32_t t;
-		(void)block_exclusive_scan(v[k], lane, wave, wsum, t);
+		(void)block_exclusive_scan<SCAN_NW>(v[k], lane, wave, wsum, t);
 		if (tid == 0) tile_v[blockIdx.x * 3 + k] = t;
 	}
 	if (blockIdx.x == gridDim.x - 1 && tid == 0) counters[0] = tile_base + total; // numsteps_counter
 }
 
-__global__ __launch_bounds__(1024) void k_scan_rays_slots(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
+__global__ __launch_bounds__(SCAN_WG) void k_scan_rays_slots(const uint32_t n, const uint32_t max_samples, const uint32_t k1, const uint32_t* __restrict__ steps,
                                                           const uint32_t* __restrict__ base, const uint32_t* __restrict__ tile_v, uint32_t* __restrict__ slot,
                                                           uint32_t* __restrict__ base1, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwd_counts) {
 	__shared__ uint32_t wsum[16];
@@ -657,22 +662,22 @@ __global__ __launch_bounds__(1024) void k_scan_rays_slots(const uint32_t n, cons
 	uint32_t pre[3];
 #pragma unroll
 	for (int k = 0; k < 3; ++k) pre[k] = tile_prefix(tile_v + k, 3, blockIdx.x, tid, &sh);
-	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
-	uint32_t st[4], v0 = 0, v2 = 0, v1 = 0;
-	bool ok[4];
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * SCAN_EPT;
+	uint32_t st[SCAN_EPT], v0 = 0, v2 = 0, v1 = 0;
+	bool ok[SCAN_EPT];
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) {
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
 		st[e] = i0 + e < n ? steps[i0 + e] : 0u;
 		const uint32_t b = i0 + e < n ? base[i0 + e] : 0u;
 		ok[e] = st[e] > 0 && b + st[e] <= max_samples;
 		v0 += ok[e] ? 1u : 0u; v1 += ok[e] ? st[e] : 0u; v2 += ok[e] ? min(st[e], k1) : 0u;
 	}
 	uint32_t t0, t1, t2;
-	uint32_t srun = pre[0] + block_exclusive_scan(v0, lane, wave, wsum, t0);
-	uint32_t frun = pre[2] + block_exclusive_scan(v2, lane, wave, wsum, t2);
-	(void)block_exclusive_scan(v1, lane, wave, wsum, t1);
+	uint32_t srun = pre[0] + block_exclusive_scan<SCAN_NW>(v0, lane, wave, wsum, t0);
+	uint32_t frun = pre[2] + block_exclusive_scan<SCAN_NW>(v2, lane, wave, wsum, t2);
+	(void)block_exclusive_scan<SCAN_NW>(v1, lane, wave, wsum, t1);
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) {
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
 		if (i0 + e < n) {
 			slot[i0 + e] = ok[e] ? srun : 0xffffffffu;
 			if (k1) base1[i0 + e] = frun;
@@ -1095,31 +1100,31 @@ __global__ __launch_bounds__(1024) void k_scan_compact(const uint32_t n_max, con
 }
 
 // k_scan_compact with one workgroup per 4096-ray tile (large batches): tile sums, then offsets. ncomp is zero beyond the kept rays.
-__global__ __launch_bounds__(1024) void k_scan_compact_sums(const uint32_t n, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ tile_sum) {
+__global__ __launch_bounds__(SCAN_WG) void k_scan_compact_sums(const uint32_t n, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ tile_sum) {
 	__shared__ uint32_t wsum[16];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * SCAN_EPT;
 	uint32_t mine = 0;
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) mine += i0 + e < n ? ncomp[i0 + e] : 0u;
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) mine += i0 + e < n ? ncomp[i0 + e] : 0u;
 	uint32_t total;
-	(void)block_exclusive_scan(mine, lane, wave, wsum, total);
+	(void)block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
 	if (tid == 0) tile_sum[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(1024) void k_scan_compact_offsets(const uint32_t n, const uint32_t* __restrict__ ncomp, const uint32_t* __restrict__ tile_sum,
+__global__ __launch_bounds__(SCAN_WG) void k_scan_compact_offsets(const uint32_t n, const uint32_t* __restrict__ ncomp, const uint32_t* __restrict__ tile_sum,
                                                                uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters) {
 	__shared__ uint32_t wsum[16];
 	__shared__ uint32_t sh;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t tile_base = tile_prefix(tile_sum, 1, blockIdx.x, tid, &sh);
-	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * 4;
-	uint32_t v[4], mine = 0;
+	const uint32_t i0 = blockIdx.x * SCAN_TILE + tid * SCAN_EPT;
+	uint32_t v[SCAN_EPT], mine = 0;
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) { v[e] = i0 + e < n ? ncomp[i0 + e] : 0u; mine += v[e]; }
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { v[e] = i0 + e < n ? ncomp[i0 + e] : 0u; mine += v[e]; }
 	uint32_t total;
-	uint32_t run = tile_base + block_exclusive_scan(mine, lane, wave, wsum, total);
+	uint32_t run = tile_base + block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
 #pragma unroll
-	for (uint32_t e = 0; e < 4; ++e) { if (i0 + e < n) cbase[i0 + e] = run; run += v[e]; }
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { if (i0 + e < n) cbase[i0 + e] = run; run += v[e]; }
 	if (blockIdx.x == gridDim.x - 1 && tid == 0) counters[1] = tile_base + total; // numsteps_counter_compacted
 }
 

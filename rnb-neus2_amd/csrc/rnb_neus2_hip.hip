@@ -417,9 +417,9 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	c->prof.mark(s, P_MARCH_COUNT);
 	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
-		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
-		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
-		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(1024), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
+		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
+		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
+		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
 	} else
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
@@ -469,8 +469,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	c->prof.mark(s, P_LOSS_PASS1);
 	if (n_rays >= c->knobs.march_narrow_from) {
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
-		hipLaunchKernelGGL(k_scan_compact_sums, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256);
-		hipLaunchKernelGGL(k_scan_compact_offsets, dim3(n_tiles), dim3(1024), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256, c->cbase.p, c->counters.p);
+		hipLaunchKernelGGL(k_scan_compact_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256);
+		hipLaunchKernelGGL(k_scan_compact_offsets, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256, c->cbase.p, c->counters.p);
 	} else
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
