@@ -511,3 +511,21 @@ def test_overlapped_backward_equals_serial(scene, trained, albedo):
         if np.max(np.abs(g[nm:] - g_ref[nm:])) > 1e-4 * gs:
             bad.append((rep, "grid gradients", float(np.max(np.abs(g[nm:] - g_ref[nm:])) / gs)))
     assert not bad, bad[:10]
+
+
+def test_dpp_chain_matches_the_sequential_loop(tmp_path):
+    """csrc/chain.cuh (the compositing recurrence across the lanes of a wavefront / of a 16-lane row through DPP shifts) against the
+    plain sequential loop of testbed_nerf.cu:1653-1690 on random inputs: every count 1..64 (0..16 per row), both colour modes,
+    bit for bit (tools/probe_dpp_chain.hip, built here with hipcc)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "probe_dpp_chain")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-value", "-I", os.path.join(root, "rnb-neus2_amd", "csrc"),
+                        os.path.join(root, "tools", "probe_dpp_chain.hip"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "mismatching" in l]
+    assert len(lines) == 4 and all(": 0 mismatching" in l for l in lines), r.stdout

@@ -174,6 +174,56 @@ def test_generate_training_samples_bit_exact(pair):
     assert cc[0] > 20000 and cc[3] <= 20000
 
 
+def _shell_bitfield(radius, half_width):
+    """Cascade-0 bitfield (Morton order, 128^3 cells) of a spherical shell around the cube's centre; the other cascades empty."""
+    g = (np.arange(128) + 0.5) / 128 - 0.5
+    z, y, x = np.meshgrid(g, g, g, indexing="ij")
+    occ = np.abs(np.sqrt(x * x + y * y + z * z) - radius) < half_width
+
+    def spread(v):
+        v = v.astype(np.uint32)
+        v = (v * 0x00010001) & 0xFF0000FF
+        v = (v * 0x00000101) & 0x0F00F00F
+        v = (v * 0x00000011) & 0xC30C30C3
+        v = (v * 0x00000005) & 0x49249249
+        return v
+    i = np.arange(128)
+    morton = spread(i)[None, None, :] | (spread(i)[None, :, None] << 1) | (spread(i)[:, None, None] << 2)
+    bits = np.zeros(128 ** 3, dtype=np.uint8)
+    bits[morton.ravel()] = occ.ravel()
+    return np.packbits(bits, bitorder="little")
+
+
+@pytest.mark.parametrize("kernel", ["wide", "thread_per_ray"])
+def test_march_over_caller_written_bitfields(kernel):
+    """The march kernels read the occupancy from an LDS form of the bitfield (k_coarse_bitfield: coarse bits, rank, the cell bits of
+    the non-empty 4x4x4 blocks) that is rebuilt when a caller has written the bitfield through rnb_buffer. A thin shell (few blocks:
+    all in LDS), a thick one (more blocks than the LDS budget: coarse bits + bitfield loads) and the dense start grid, against
+    the oracle's walk over the same bitfield, bit for bit."""
+    env = BIG_ENV if kernel == "thread_per_ray" else None
+    gpu, cpu = _pair(env=env, **BIG)
+    try:
+        _sync_occupancy(gpu, cpu)
+        full = cpu.get("DENSITY_BITFIELD").copy()
+        n0 = 128 ** 3 // 8
+        for radius, half_width in ((0.27, 0.012), (0.3, 0.2), (None, None)):
+            bf = full.copy()
+            if radius is not None:
+                bf[:] = 0
+                bf[:n0] = _shell_bitfield(radius, half_width)
+                blocks = np.count_nonzero(bf[:n0].reshape(-1, 8).any(axis=1))
+                assert (blocks <= 4096) == (half_width < 0.1), blocks  # the two sides of the LDS budget
+            for c in (gpu, cpu):
+                c.put("DENSITY_BITFIELD", bf)
+            for n_rays, n_rays_total in ((3000, 0), (5000, 123)):
+                for c in (gpu, cpu):
+                    c.generate_training_samples(n_rays, n_rays_total, BIG["target_batch_size"] * 16)
+                _assert_samples_equal(gpu, cpu)
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def _stage_samples(gpu, cpu, n_rays=512, step=0):
     _sync_occupancy(gpu, cpu, step)
     for c in (gpu, cpu):
