@@ -186,6 +186,9 @@ int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
 /* Trainer::deserialize-like: overwrite fp32 master weights from host, re-derive fp16/EMA copies,
  * reset Adam state (trainer.h:263-275). Syncs. */
 int rnb_set_params(rnb_ctx* ctx, const float* params_host);
+/* RNB_BUF_DENSITY_BITFIELD: the march kernels read an LDS form derived from the bitfield (occupancy update, or the next ray
+ * generation after this call handed the pointer out); a caller that writes the bitfield through a pointer it kept calls
+ * rnb_buffer(RNB_BUF_DENSITY_BITFIELD) again before it generates samples. */
 int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
 /* A caller that keeps a pointer from rnb_buffer(RNB_BUF_PARAMS_FP16) and writes training weights through it later (e.g. an
  * all-gather of a sharded optimizer) says so here: the kernels' cached LDS weight images are dropped and rebuilt from the
