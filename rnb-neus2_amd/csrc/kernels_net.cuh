@@ -816,7 +816,8 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 // results go to `partial` and are summed in a fixed order by k_dw_finish (deterministic).
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool ONES>
-__global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, const half_t* __restrict__ XT, const uint32_t B, const uint32_t chunk, float* __restrict__ partial) {
+__device__ __forceinline__ void dw_body(const half_t* __restrict__ YT, const half_t* __restrict__ XT, const uint32_t B, const uint32_t chunk, float* __restrict__ partial,
+                                        const uint32_t wg, float* __restrict__ red) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int r16 = lane & 15, hq = lane >> 4;
 	f4 acc[MT][NT];
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, con
 	for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
 		for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f4{0.f, 0.f, 0.f, 0.f};
-	const uint32_t s_begin = blockIdx.x * chunk, s_end = s_begin + chunk;
+	const uint32_t s_begin = wg * chunk, s_end = s_begin + chunk;
 	for (uint32_t s0 = s_begin + wave * 32; s0 < s_end; s0 += WAVES_PER_WG * 32) {
 		h8 bfr[NT];
 #pragma unroll
@@ -843,16 +844,40 @@ __global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, con
 		}
 	}
 	// the four waves' partials are summed in LDS (fixed order) so that k_dw_finish reads one slab per workgroup, not per wave
-	__shared__ float red[WAVES_PER_WG][MT * 16 * NT * 16];
+	constexpr int N = MT * 16 * NT * 16;
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
 		for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-			for (int r = 0; r < 4; ++r) red[wave][(16 * mt + 4 * hq + r) * (NT * 16) + 16 * nt + r16] = acc[mt][nt][r];
+			for (int r = 0; r < 4; ++r) red[wave * N + (16 * mt + 4 * hq + r) * (NT * 16) + 16 * nt + r16] = acc[mt][nt][r];
 	__syncthreads();
-	float* dst = partial + (size_t)blockIdx.x * (MT * 16) * (NT * 16);
-	for (int q = threadIdx.x; q < MT * 16 * NT * 16; q += WG) dst[q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+	float* dst = partial + (size_t)wg * N;
+	for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
+}
+
+template <int MT, int NT, bool ONES>
+__global__ __launch_bounds__(WG, 1) void k_dw(const half_t* __restrict__ YT, const half_t* __restrict__ XT, const uint32_t B, const uint32_t chunk, float* __restrict__ partial) {
+	__shared__ float red[WAVES_PER_WG * MT * 16 * NT * 16];
+	dw_body<MT, NT, ONES>(YT, XT, B, chunk, partial, blockIdx.x, red);
+}
+
+// All weight-gradient GEMMs of a step in ONE launch (the albedo mode; without the colour MLP the four GEMMs stay separate launches:
+// together they take more from the scatter beside them than they gain, 0.709 vs 0.701 ms/step over the window). Workgroup blockIdx.x works on GEMM blockIdx.x / nwg. Launched one after the
+// other (7 kernels with --has-albedo) each of these bandwidth streams ran alone beside the atomic-bound scatter and the chain
+// became the long pole of the albedo mode (346 us for 65 us of work); together they overlap each other's latency. Two workgroups
+// per CU (the largest instance: 200 registers, 64 KB of LDS).
+enum DwKind : uint32_t { DW_1x4 = 0, DW_4x4, DW_4x2, DW_1x4_ONES };
+struct DwAllArgs { const half_t* YT[7]; const half_t* XT[7]; float* partial[7]; uint32_t kind[7]; uint32_t n, nwg, B, chunk; };
+__global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
+	__shared__ float red[WAVES_PER_WG * 64 * 64];
+	const uint32_t g = blockIdx.x / a.nwg, wg = blockIdx.x - g * a.nwg;
+	switch (a.kind[g]) {
+		case DW_1x4: dw_body<1, 4, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
+		case DW_4x4: dw_body<4, 4, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
+		case DW_4x2: dw_body<4, 2, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
+		default: dw_body<1, 4, true>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
+	}
 }
 
 // Offsets (floats) of the seven partial blocks inside one wave's slab are given by the host.
