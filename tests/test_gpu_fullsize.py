@@ -352,7 +352,7 @@ def test_sdf_only_training_kernel_matches_generic(scene, trained):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # One config-4 step at full size against the oracle, from the trained state: at the controller's own ray count (~12 k,
-# the 16-lanes-per-ray march and single-workgroup scans) and at 40 000 rays (>= 24 576: thread-per-ray march, tiled scans,
+# the 16-lanes-per-ray march and single-workgroup scans) and at 40 000 rays (>= 18 432: thread-per-ray march, tiled scans,
 # k_march_write<16>, tiled loss reduction -- the kernels of the late-training regime).
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")

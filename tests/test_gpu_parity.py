@@ -310,7 +310,7 @@ def test_forward_backward_gradients(rpair, rpair_no_albedo, no_albedo):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Large-batch forms of the per-ray kernels. From 24 576 rays per step on (RNB_MARCH_NARROW_FROM; late in training the
+# Large-batch forms of the per-ray kernels. From 18 432 rays per step on (RNB_MARCH_NARROW_FROM; late in training the
 # controller runs 50-100 k rays) the library switches to k_march_count<>/thread-per-ray, the tiled scans
 # k_scan_rays_{sums,base,slots} / k_scan_compact_{sums,offsets}, k_march_write<16> and k_reduce_losses_tiles. Here the
 # switch is lowered to 256 rays so that the oracle can check the same kernels in seconds; 6 000 rays = two 4 096-ray
