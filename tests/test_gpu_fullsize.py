@@ -513,6 +513,28 @@ def test_overlapped_backward_equals_serial(scene, trained, albedo):
     assert not bad, bad[:10]
 
 
+def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, trained):
+    """From 18 432 rays per step on the loss passes give a ray 16 lanes (four rays per wavefront, the recurrence through row_shr:1);
+    forced back to one wavefront per ray (RNB_LOSS_WAVE_PER_RAY) the same 40 000-ray step yields the same bits everywhere:
+    compaction, dL/d(output), per-ray losses. Both through the two-round evaluation of a whole training step."""
+    _, state = trained
+    out = []
+    for env in (None, {"RNB_LOSS_WAVE_PER_RAY": "1"}):
+        c = _clone(scene, state, env=env, overlap=0)
+        try:
+            c.set_controller(state["step"] | 1, 40000, state["before"], 0)
+            st = c.train_step()
+            n = int(st.n_rays_kept)
+            out.append((st, {name: c.get(name, count).copy() for name, count in (("NUMSTEPS", 2 * n), ("COORDS_COMPACTED", None), ("DLOSS_DOUT", None), ("LOSS", n), ("EK_LOSS", n), ("MASK_LOSS", n))}))
+        finally:
+            c.close()
+    (s1, a), (s2, b) = out
+    assert s1.rays_per_batch == 40000 and s1.n_rays_kept == s2.n_rays_kept and s1.measured_batch_size == s2.measured_batch_size
+    assert s1.loss == s2.loss and s1.ek_loss == s2.ek_loss and s1.mask_loss == s2.mask_loss
+    for name in a:
+        assert np.array_equal(a[name].view(np.uint8), b[name].view(np.uint8)), name
+
+
 def test_dpp_chain_matches_the_sequential_loop(tmp_path):
     """csrc/chain.cuh (the compositing recurrence across the lanes of a wavefront / of a 16-lane row through DPP shifts) against the
     plain sequential loop of testbed_nerf.cu:1653-1690 on random inputs: every count 1..64 (0..16 per row), both colour modes,
