@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — training rays/s of the normals-only SDF path on synthetic 64-view 800x800 normal+mask data.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a plain shell: the script starts its own N ranks (python -m torch.distributed.run, one rank per GPU, rendezvous on
+127.0.0.1); launched by torch.distributed.run itself (RANK / WORLD_SIZE in the environment) it is one of those ranks.
 
 One "step" = one pass of the hot path over one batch: Testbed::train (occupancy update when due, ray generation +
 march, network forward on the un-compacted samples, loss + compaction, forward/backward on 2^18 compacted samples,
 Adam+EMA). Inputs are resident in HBM before the timed region. Prints ONE JSON line (rank 0).
+On several GPUs the line carries BOTH scaling modes: `value` / `scaling` for the mode asked for (weak by default: 2^18
+compacted samples per rank and step; --strong: the single-GPU step divided over the ranks) and the other mode's value in
+`strong_scaling` / `weak_scaling`, measured in the same job.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +30,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_TRAFFIC, PMC_UNITS = "r02_pmc_traffic.json", "r02_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
+PMC_TRAFFIC, PMC_UNITS = "r03_pmc_traffic.json", "r03_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
+PMC_FALLBACK = {"r03_pmc_traffic.json": "r02_pmc_traffic.json", "r03_pmc_units.json": "r02_pmc_units.json"}
+# committed rocprofv3 summaries of this same command from which every `frac` of the record can be recomputed (profiles/README.md)
+PROFILE_FILES = {"kernel_trace_serial": "profiles/r03_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r03_steady_overlapped_step1000.json",
+                 "pmc_traffic": "profiles/" + PMC_TRAFFIC, "pmc_units": "profiles/" + PMC_UNITS}
 # Algorithmic bytes per unit (restated in DESIGN.md §measurement)
 ALGO_BYTES = {
     "k_forward": 508.0,            # 448 B gathers + 28 B coords + 32 B out, per un-compacted sample
@@ -40,7 +52,7 @@ LIMITER_NOTES = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed steps; default = the window SURVEY.md section 8(d) defines: training steps 1000-2000")
@@ -49,7 +61,10 @@ def parse():
                     "regime the metric is quoted on (burn-in + warmup = 1000: all 14 levels live, occupancy converged; SURVEY.md §8d)")
     ap.add_argument("--views", type=int, default=64)
     ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--focal", type=float, default=None, help="focal length in pixels (default: the generator's, 1.75 x res as in SURVEY.md 8d)")
+    ap.add_argument("--batch-log2", type=int, default=18, help="log2 of the compacted samples per step; anything but 18 is NOT the metric's workload (launcher tests)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=8, help="steps of the CPU checker timed as the baseline (≈1.4 s each on the GPU box host)")
+    ap.add_argument("--cpu-baseline-late-steps", type=int, default=3, help="the same for the late regime's state (second baseline, next to `late_regime`)")
     ap.add_argument("--profile-steps", type=int, default=100, help="serialized steps after the timed region for the per-kernel HIP-event table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-end", type=int, default=2000, help="after the K timed steps the run continues (timed per step) to this training step, so that "
@@ -58,69 +73,119 @@ def parse():
                     "per ray, ~95 k rays per step) that the >= 1e8 rays/s target is about; 0 = off")
     ap.add_argument("--late-steps", type=int, default=200)
     ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY.md 8e): the job's step stays the single-GPU step (2^18 compacted samples, the "
-                    "controller's ray count); every rank takes 1/N of its rays and samples (dp.strong_scaling_sizes). Default: weak scaling, 2^18 samples per rank")
+                    "controller's ray count); every rank takes 1/N of its rays and samples (dp.strong_scaling_sizes). Default: weak scaling, 2^18 samples per rank. "
+                    "With N > 1 the other mode is measured as a second leg of the same job and reported beside `value`")
+    ap.add_argument("--other-leg-steps", type=int, default=200, help="timed steps of that second leg (0 = skip it)")
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
-    import torch
-    import rnb_neus2_amd as rnb
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` from a plain shell: one rank per GPU under torch.distributed.run on this node. RNB_BENCH_ENTRY names
+    the script the ranks run (default: this file; the CPU test of the launcher points it at an entry that injects a gloo engine)."""
+    entry = os.environ.get("RNB_BENCH_ENTRY") or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), entry] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class HipEngine:
+    """The product: librnb_neus2_hip.so on the rank's GPU, collectives over RCCL (torch.distributed backend "nccl")."""
+    name, backend = "hip", "nccl"
+
+    def setup(self, local_rank):
+        import torch
+        self.torch = torch
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+
+    def init_process_group(self):
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=self.torch.device("cuda", self.local_rank))
+        return dist
+
+    def context(self, **kw):
+        import rnb_neus2_amd as rnb
+        return rnb.Context(overlap=0 if os.environ.get("RNB_OVERLAP_OFF") else 1, **kw)
+
+    def trainer(self, ctx):
+        from rnb_neus2_amd import dp
+        return dp.DataParallelTrainer(ctx)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def reduce_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device="cuda")
+
+
+def main(argv=None, engine=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
     from rnb_neus2_amd import synthetic, dp
 
+    engine = engine or HipEngine()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    engine.setup(local_rank)
     dist = None
     if world > 1 or (os.environ.get("RNB_DP_FORCE_COLLECTIVES") and "MASTER_ADDR" in os.environ):  # the env var exercises the RCCL path on one rank
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
-    sizes = dp.strong_scaling_sizes(world) if args.strong else {}
-    ctx = rnb.Context(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0, world_size=world, rank=rank, overlap=0 if os.environ.get("RNB_OVERLAP_OFF") else 1, **sizes)
-    ctx.init_params()
-    t0 = time.time()
-    views, normals, albedos = synthetic.make_scene(args.views, args.res)
-    ctx.set_dataset(views, normals, albedos)
-    del normals, albedos
-    setup_s = time.time() - t0
-    trainer = dp.DataParallelTrainer(ctx)
+        dist = engine.init_process_group()
+    comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size()} if dist is not None else {"backend": None, "ranks": 1}
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        engine.sync()
 
-    for _ in range(args.burn_in):
-        trainer.step()
-    for _ in range(args.warmup):
-        trainer.step()
-    barrier()
-    t0 = time.perf_counter()
-    rays = 0
-    samples = 0
-    samples_before = 0
-    last = None
-    for _ in range(args.steps):
-        last = trainer.step()
-        rays += last.rays_per_batch * world
-        samples += last.measured_batch_size * world
-        samples_before += last.measured_batch_size_before_compaction * world
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = engine.reduce_tensor([x])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def timed_run(n_steps):
-        """n_steps more training steps: (wall seconds, rays, compacted samples, per-step host milliseconds, last stats)."""
+    B = 1 << args.batch_log2
+    t0 = time.time()
+    scene = synthetic.make_scene(args.views, args.res) if args.focal is None else synthetic.make_scene(args.views, args.res, args.focal)
+    scene_s = time.time() - t0
+    flags = dict(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0)  # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
+
+    def state_of(ctx, st):
+        return dict(params=ctx.get("PARAMS_FP32").copy(), grid=ctx.get("DENSITY_GRID").copy(), step=ctx.training_step, rays=ctx.rays_per_batch,
+                    before=st.measured_batch_size_before_compaction)
+
+    def open_leg(strong):
+        if strong:
+            sizes = dp.strong_scaling_sizes(world, B, min(1 << 18, B), min(1 << 12, B))
+        else:
+            sizes = dict(target_batch_size=B, max_rays_per_batch=min(1 << 18, B), initial_rays_per_batch=min(1 << 12, B)) if B != (1 << 18) else {}
+        ctx = engine.context(world_size=world, rank=rank, **flags, **sizes)
+        ctx.init_params()
+        ctx.set_dataset(*scene)
+        return ctx, engine.trainer(ctx)
+
+    def timed_run(trainer, n_steps):
+        """n_steps training steps between two barriers: (wall seconds (max over ranks), rays, compacted samples, samples before compaction, per-step host ms, last stats)."""
         barrier()
         tt0 = time.perf_counter()
-        r = smp = 0
+        r = smp = smp_before = 0
         per_step = []
         stl = None
         tp = tt0
@@ -131,8 +196,19 @@ def main():
             tp = tn
             r += stl.rays_per_batch * world
             smp += stl.measured_batch_size * world
+            smp_before += stl.measured_batch_size_before_compaction * world
         barrier()
-        return time.perf_counter() - tt0, r, smp, per_step, stl
+        return max_over_ranks(time.perf_counter() - tt0), r, smp, smp_before, per_step, stl
+
+    # ---- the leg `value` is taken from ----
+    t0 = time.time()
+    ctx, trainer = open_leg(args.strong)
+    setup_s = scene_s + time.time() - t0
+    for _ in range(args.burn_in + args.warmup):
+        trainer.step()
+    elapsed, rays, samples, samples_before, _, last = timed_run(trainer, args.steps)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu_state = state_of(ctx, last) if want_cpu and args.cpu_baseline_steps > 0 else None  # the regime `value` was measured in
 
     # The rest of the window the metric is defined on (training steps 1000-2000), so that the record carries it
     # even when --steps is small: the K steps above plus the steps up to --window-end.
@@ -140,7 +216,7 @@ def main():
     first_timed = int(last.training_step) - args.steps
     n_more = args.window_end - int(last.training_step) if args.window_end else 0
     if n_more > 0:
-        w_el, w_rays, w_smp, w_ms, last_w = timed_run(n_more)
+        w_el, w_rays, w_smp, _, w_ms, last_w = timed_run(trainer, n_more)
         n_w = args.steps + n_more
         window = {"first_step": first_timed, "steps": n_w, "ms_per_step": round(1e3 * (elapsed + w_el) / n_w, 4), "rays_per_s": round((rays + w_rays) / (elapsed + w_el), 1),
                   "p50_ms_per_step": round(float(np.median(w_ms)), 4), "p90_ms_per_step": round(float(np.quantile(w_ms, 0.9)), 4),
@@ -151,30 +227,50 @@ def main():
     # timed region. In the timed region the next step's march and the weight-gradient GEMMs run on side streams beside the
     # backward pass (cfg.overlap), where a per-kernel duration is not well defined; with the profiler on the library runs the
     # same kernels strictly one after the other.
-    ctx.profile_enable(True)
+    prof = []
     tail = last
-    for _ in range(args.profile_steps):
-        tail = trainer.step()
-    barrier()
-    prof = ctx.profile()
-    ctx.profile_enable(False)
+    if args.profile_steps > 0:
+        ctx.profile_enable(True)
+        for _ in range(args.profile_steps):
+            tail = trainer.step()
+        barrier()
+        prof = ctx.profile()
+        ctx.profile_enable(False)
     late = None
+    late_state = None
     if args.late_step and args.late_steps > 0:
         while ctx.training_step < args.late_step:
             tail = trainer.step()
-        l_el, l_rays, l_smp, l_ms, tail = timed_run(args.late_steps)
+        l_el, l_rays, l_smp, _, l_ms, tail = timed_run(trainer, args.late_steps)
         late = {"first_step": int(tail.training_step) - args.late_steps, "steps": args.late_steps, "ms_per_step": round(1e3 * l_el / args.late_steps, 4),
                 "rays_per_s": round(l_rays / l_el, 1), "rays_per_step": round(l_rays / args.late_steps / world, 1), "p50_ms_per_step": round(float(np.median(l_ms)), 4),
                 "samples_per_s_compacted": round(l_smp / l_el, 1), "loss": round(float(tail.loss), 6)}
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if want_cpu and args.cpu_baseline_late_steps > 0:
+            late_state = state_of(ctx, tail)
+    final_loss = float(last.loss)
+    ctx.close()
+
+    # ---- several ranks: the other scaling mode, same job ----
+    other = None
+    if world > 1 and args.other_leg_steps > 0:
+        ctx2, trainer2 = open_leg(not args.strong)
+        for _ in range(args.burn_in + args.warmup):
+            trainer2.step()
+        o_el, o_rays, o_smp, _, _, o_last = timed_run(trainer2, args.other_leg_steps)
+        other = {"scaling": "weak" if args.strong else "strong", "value": round(o_rays / o_el, 1), "unit": "rays/s", "steps": args.other_leg_steps,
+                 "ms_per_step": round(1e3 * o_el / args.other_leg_steps, 4), "rays_per_step_per_gpu": round(o_rays / args.other_leg_steps / world, 1),
+                 "samples_per_step_per_gpu": ctx2.cfg.target_batch_size, "samples_per_s_compacted": round(o_smp / o_el, 1), "loss": round(float(o_last.loss), 6)}
+        ctx2.close()
 
     result = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays / elapsed
+
+        def pmc_file(name):
+            p = os.path.join(ROOT, "profiles", name)
+            return (p, name) if os.path.exists(p) else (os.path.join(ROOT, "profiles", PMC_FALLBACK[name]), PMC_FALLBACK[name])
+
         # roofline of the dominant kernel (by accumulated HIP-event time of the per-kernel pass), and of the two next ones
         def roofline_of(p):
             kname = p["kernel"]
@@ -188,30 +284,34 @@ def main():
             # separate rocprofv3 --pmc passes over the same command (tools/collect_pmc.sh); `traffic_source` says so in the record
             traffic, traffic_source = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC)) as f:
+                path, fname = pmc_file(PMC_TRAFFIC)
+                with open(path) as f:
                     traffic = json.load(f)["per_step"][kname]["total_bytes"] / max(p["launches"] / max(args.profile_steps, 1), 1.0)
-                traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run" % PMC_TRAFFIC
+                traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run" % fname
             except Exception:
                 pass
             limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py); also from a committed file
             try:
-                with open(os.path.join(ROOT, "profiles", PMC_UNITS)) as f:
+                path, fname = pmc_file(PMC_UNITS)
+                with open(path) as f:
                     units = json.load(f)
                 if kname == "k_grid_scatter":
-                    parts = [units["kernels"][k] for k in ("k_grid_scatter_quad", "k_grid_scatter_quad_rl", "k_grid_scatter_lds")]
+                    parts = [units["kernels"][k] for k in units["kernels"] if k.startswith("k_grid_scatter")]
                     req = sum(q.get("l2_atomic_requests", 0) for q in parts)
                     limiter = {"unit": "L2 atomic lines (one 64-byte line of one instruction)", "per_launch": req, "achieved_per_s": round(req / (avg_ms * 1e-3)),
                                "probe_rate_per_s": units["_atomic_probe_requests_per_s"],
                                "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3),
                                "limiter_source": "per_launch: committed file profiles/%s (TCC_ATOMIC_sum pass at steps 2000-2010, builder-run; the duration is this run's, whose "
-                                                 "regime may put more lines on the path); probe rate: tools/probe_atomics4.hip" % PMC_UNITS}
+                                                 "regime may put more lines on the path); probe rate: tools/probe_atomics4.hip" % fname}
             except Exception:
                 pass
             if limiter is None and kname in LIMITER_NOTES:
                 limiter = {"unit": LIMITER_NOTES[kname]}
             return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 4),
-                    "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit, "limiter": limiter}
+                    "units_per_launch": round(units_per_launch, 1), "algorithmic_bytes_per_unit": bytes_per_unit, "limiter": limiter,
+                    "recompute_from": "frac = algorithmic_bytes_per_unit x units_per_launch / avg_launch_ms / peak; avg_launch_ms: this run's HIP events (serialised pass), cross-check: "
+                                      "the kernel's per-step duration in %s" % PROFILE_FILES["kernel_trace_serial"]}
 
         ranked = sorted(prof, key=lambda p: -p["total_ms"])
         roofline = roofline_of(ranked[0]) if ranked else None
@@ -232,51 +332,62 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config 4: synthetic %d-view %dx%d normals+mask sphere, %s --mask-weight 1.0, %s compacted samples/step/GPU"
                                    % (args.views, args.res, args.res, "albedo + reflectance loss (NOT the metric's workload)" if args.albedo else "--no-albedo",
-                                      ("2^18 / %d" % world) if args.strong else "2^18"),
+                                      ("2^%d / %d" % (args.batch_log2, world)) if args.strong else "2^%d" % args.batch_log2),
                        "burn_in_steps": args.burn_in, "first_timed_step": first_timed,
                        "rays_per_step_per_gpu": round(rays / args.steps / world, 1),
                        "samples_per_s_compacted": round(samples / elapsed, 1),
                        "samples_per_s_before_compaction": round(samples_before / elapsed, 1),
-                       "loss": round(float(last.loss), 6), "parallelism": "dp%d" % world, "setup_s": round(setup_s, 1)},
+                       "loss": round(final_loss, 6), "parallelism": "dp%d" % world, "setup_s": round(setup_s, 1), "engine": engine.name},
+            "communicator": comm,
             "window_1000_2000": window,
             "late_regime": late,
             "roofline": roofline,
             "rooflines_next": rooflines_next,
             "kernels_ms_per_step": kernels,
+            "profiles": PROFILE_FILES,
         }
+        if comm["backend"] == "nccl":
+            result["rccl_ranks"] = comm["ranks"]
+        if other is not None:
+            result["weak_scaling" if args.strong else "strong_scaling"] = other
 
-    # CPU baseline: the oracle (a port, not the reference — the reference has no CPU path) continues from the GPU's
-    # trained state on the same workload, all host cores, a bounded number of steps.
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline_steps > 0:
+    # CPU baseline: the oracle (a port, not the reference — the reference has no CPU path) continues from the GPU's state at the END OF
+    # THE TIMED K STEPS (the regime `value` was measured in) on the same workload, all host cores, a bounded number of steps; a second,
+    # shorter one from the late regime's state stands next to `late_regime`.
+    def cpu_leg(state, n_steps):
+        from tests import oracle_lib
+        cpu = oracle_lib.context(**flags)
         try:
-            from tests import oracle_lib
-            cpu = oracle_lib.context(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0)
-            views2, normals2, albedos2 = synthetic.make_scene(args.views, args.res)
-            cpu.set_dataset(views2, normals2, albedos2)
-            del normals2, albedos2
-            cpu.set_params(ctx.get("PARAMS_FP32"))
-            cpu.put("DENSITY_GRID", ctx.get("DENSITY_GRID"))
+            cpu.set_dataset(*scene)
+            cpu.set_params(state["params"])
+            cpu.put("DENSITY_GRID", state["grid"])
             cpu.update_density_bitfield()
-            cpu.set_controller(ctx.training_step, ctx.rays_per_batch, tail.measured_batch_size_before_compaction, 0)
-            t0 = time.perf_counter()
+            cpu.set_controller(state["step"], state["rays"], state["before"], 0)
+            t0c = time.perf_counter()
             crays = 0
-            for _ in range(args.cpu_baseline_steps):
-                st = cpu.train_step()
-                crays += st.rays_per_batch
-            cel = time.perf_counter() - t0
-            result["cpu_baseline"] = {"value": round(crays / cel, 1), "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-                                      "sample": "%d training steps of the CPU oracle (OpenMP, all host cores) continued from the GPU's state at step %d, same dataset/flags; %.1f s"
-                                                % (args.cpu_baseline_steps, ctx.training_step, cel),
-                                      "ms_per_step": round(1e3 * cel / args.cpu_baseline_steps, 1)}
+            for _ in range(n_steps):
+                crays += cpu.train_step().rays_per_batch
+            cel = time.perf_counter() - t0c
+        finally:
             cpu.close()
+        return {"value": round(crays / cel, 1), "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "%d training steps of the CPU oracle (OpenMP, all host cores) continued from the GPU's state at step %d (%d rays per step), same dataset/flags; %.1f s"
+                          % (n_steps, state["step"], state["rays"], cel),
+                "ms_per_step": round(1e3 * cel / n_steps, 1), "rays_per_step": round(crays / n_steps, 1)}
+
+    if want_cpu and cpu_state is not None:
+        try:
+            result["cpu_baseline"] = cpu_leg(cpu_state, args.cpu_baseline_steps)
+            if late_state is not None:
+                result["late_regime"]["cpu_baseline"] = cpu_leg(late_state, args.cpu_baseline_late_steps)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
             result["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

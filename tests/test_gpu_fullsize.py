@@ -18,20 +18,51 @@ def scene():
     return synthetic.make_scene(64, 800)
 
 
+WINDOW_STEP = 1008  # a multiple of 16 inside the window the metric is quoted on (steps 1000-2000); valid_level reaches 14 at step 660
+LATE_STEP = 6000    # the converged regime: ~2.8 compacted samples per ray, ~94 k rays per step (bench.py's late_regime leg)
+
+
+def _state_of(ctx, st):
+    return dict(params=ctx.get("PARAMS_FP32").copy(), grid=ctx.get("DENSITY_GRID").copy(), step=ctx.training_step, rays=ctx.rays_per_batch,
+                before=st.measured_batch_size_before_compaction)
+
+
 @pytest.fixture(scope="module")
 def trained(scene):
-    """A context trained into the regime the metric is quoted on, plus the state needed to clone it."""
+    """A context trained into the regime the metric is quoted on (step 1008: every one of the 14 levels is live, so the fine-level
+    kernels k_grid_scatter_quad / k_fwd_bwd_sdf run on levels 10-13), plus the state needed to clone it."""
     import rnb_neus2_amd as rnb
     ctx = rnb.Context(overlap=0, **KW)
     ctx.init_params()
     ctx.set_dataset(*scene)
     st = None
-    for _ in range(400):
+    for _ in range(WINDOW_STEP):
         st = ctx.train_step()
-    state = dict(params=ctx.get("PARAMS_FP32").copy(), grid=ctx.get("DENSITY_GRID").copy(), step=ctx.training_step, rays=ctx.rays_per_batch,
-                 before=st.measured_batch_size_before_compaction)
+    assert ctx.training_step == WINDOW_STEP and ctx.valid_level == 14
+    state = _state_of(ctx, st)
     yield ctx, state
     ctx.close()
+
+
+@pytest.fixture(scope="module")
+def late(scene, trained):
+    """The same run continued to step 6000 (overlapped schedule, as bench.py runs it): the state of the late-training regime."""
+    _, state = trained
+    c = _clone(scene, state, overlap=1)
+    try:
+        st = None
+        while c.training_step < LATE_STEP:
+            st = c.train_step()
+        out = _state_of(c, st)
+    finally:
+        c.close()
+    assert out["step"] == LATE_STEP and out["rays"] > 60000, out["rays"]  # the controller has raised the batch to short rays
+    return out
+
+
+@pytest.fixture(scope="module")
+def states(trained, late):
+    return {"window": trained[1], "late": late}
 
 
 def _clone(scene, state, env=None, **over):
@@ -355,19 +386,41 @@ def test_sdf_only_training_kernel_matches_generic(scene, trained):
 # the 16-lanes-per-ray march and single-workgroup scans) and at 40 000 rays (>= 18 432: thread-per-ray march, tiled scans,
 # k_march_write<16>, tiled loss reduction -- the kernels of the late-training regime).
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def oracle_full(scene, trained):
+def _oracle_clone(scene, state, env=None):
+    """The CPU checker in `state` (ORC_EMULATE_* are read at creation)."""
     from tests import oracle_lib
-    _, state = trained
-    cpu = oracle_lib.context(**KW)
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        cpu = oracle_lib.context(**KW)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     cpu.init_params()
     cpu.set_dataset(*scene)
     cpu.set_params(state["params"])
     cpu.put("DENSITY_GRID", state["grid"])
     cpu.update_density_bitfield()
     cpu.set_controller(state["step"], state["rays"], state["before"], 0)
-    yield cpu
-    cpu.close()
+    return cpu
+
+
+@pytest.fixture(scope="module")
+def oracle_full(scene, states):
+    made = {}
+
+    def get(regime):
+        if regime not in made:
+            made[regime] = _oracle_clone(scene, states[regime])
+        return made[regime]
+    yield get
+    for c in made.values():
+        c.close()
 
 
 def _half_close(a, b, rel, abs_, frac, name):
@@ -376,12 +429,15 @@ def _half_close(a, b, rel, abs_, frac, name):
     assert ok.mean() >= frac, "%s: only %.5f of elements within tolerance" % (name, ok.mean())
 
 
-@pytest.mark.parametrize("n_rays", [0, 40000])
-def test_full_size_step_against_oracle(scene, trained, oracle_full, n_rays):
-    _, state = trained
-    cpu = oracle_full
+@pytest.mark.parametrize("regime,n_rays", [("window", 0), ("window", 40000), ("late", 0)])
+def test_full_size_step_against_oracle(scene, states, oracle_full, regime, n_rays):
+    """window: step 1008, all 14 levels live (levels 10-13 of k_grid_scatter_quad at 2^18 samples), ~12 k rays and 40 000 rays;
+    late: step 6000, ~94 k short rays (thread-per-ray march, tiled scans, 16 lanes per ray in the loss passes, short heads)."""
+    state = states[regime]
+    cpu = oracle_full(regime)
     gpu = _clone(scene, state, overlap=0)
     try:
+        assert gpu.valid_level == cpu.valid_level == 14
         assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
         R = n_rays or state["rays"]
         B = 1 << 18
@@ -391,7 +447,7 @@ def test_full_size_step_against_oracle(scene, trained, oracle_full, n_rays):
         cg, cc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
         assert np.array_equal(cg[[0, 2, 3]], cc[[0, 2, 3]]), (cg, cc)
         kept, written = int(cc[2]), int(cc[3])
-        assert kept > 0.2 * R and written > 100000
+        assert kept > 0.1 * R and written > 100000
         assert np.array_equal(gpu.get("RAY_INDICES", kept), cpu.get("RAY_INDICES", kept))
         assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
         assert np.array_equal(gpu.get("RAYS", kept * 6).view(np.uint32), cpu.get("RAYS", kept * 6).view(np.uint32))
@@ -437,6 +493,53 @@ def test_full_size_step_against_oracle(scene, trained, oracle_full, n_rays):
         assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2e-3 * abs(r[lay["variance"]]) + 1e-6
     finally:
         gpu.close()
+
+
+def test_hip_against_the_reference_as_coded_emulation(scene, states):
+    """Deviations D1 / D2 as a tested number: the HIP path accumulates the MLP dot products and the grid
+    gradients in fp32, the reference in half (fully_fused_mlp.cu:68 WMMA half accumulators, grid.h:410-430 half2 atomics). The oracle
+    emulates the reference as coded (ORC_EMULATE_FP16_ACCUM, ORC_EMULATE_HALF_ATOMICS); one whole config-4 training step of the HIP
+    library at step 1009 (all 14 levels, 2^18 samples) must stay within: marched sample set identical, compaction count 1e-4,
+    loss sums 2e-4 relative (the north star's 1e-4 is met against the default oracle mode, the emulated forward sits 1.3e-4 from
+    it), gradient cosine >= 0.98 per block. The measured distances are written to gpurun_out/ for DESIGN.md's table."""
+    import json
+    state = states["window"]
+    cpu = _oracle_clone(scene, state, env={"ORC_EMULATE_FP16_ACCUM": "1", "ORC_EMULATE_HALF_ATOMICS": "1"})
+    gpu = _clone(scene, state, overlap=0)
+    try:
+        for c in (gpu, cpu):
+            c.set_controller(state["step"] | 1, state["rays"], state["before"], 0)  # not an occupancy-update step
+            c.train_step_begin()
+        (cg, sg), (cc, sc) = gpu.train_step_local(), cpu.train_step_local()
+        assert cg[0] == cc[0] and cg[2] == cc[2] and cg[3] == cc[3], (cg, cc)      # the march does not depend on the network
+        assert abs(int(cg[1]) - int(cc[1])) <= 1e-4 * int(cc[1]) + 1, (cg, cc)     # compaction: T < 1e-4 cuts flip on a few rays
+        rel = [abs(x - y) / abs(y) for x, y in zip(sg, sc)]
+        assert max(rel) <= 2e-4, rel
+        g, r = gpu.get("GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
+        lay = cpu.param_layout()
+        out = {"step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_emulated": [int(x) for x in cc],
+               "loss_sums_rel_dev": [float(x) for x in rel]}
+        for name, (lo, hi) in {"sdf_mlp": (lay["sdf"], lay["rgb"]), "hash_grid": (lay["grid"], lay["variance"])}.items():
+            x, y = g[lo:hi], r[lo:hi]
+            cos = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
+            out[name] = {"cosine": cos, "rms_dev_over_rms": float(np.sqrt(np.mean((x - y) ** 2)) / np.sqrt(np.mean(y ** 2))),
+                         "max_dev_over_scale": float(np.abs(x - y).max() / np.abs(y).max())}
+            assert cos >= 0.98, (name, out[name])
+            assert out[name]["rms_dev_over_rms"] <= 0.06, (name, out[name])
+        vg, vr = g[lay["variance"]], r[lay["variance"]]
+        out["variance_grad_rel_dev"] = float(abs(vg - vr) / (abs(vr) + 1e-12))
+        assert out["variance_grad_rel_dev"] <= 2e-2
+        print("emulated-reference bound:", json.dumps(out))
+        try:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "r03_emulated_reference_bound.json"), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    finally:
+        gpu.close()
+        cpu.close()
 
 
 def test_overlapped_march_equals_serial_over_many_steps(scene, trained):
