@@ -186,15 +186,18 @@ int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
 /* Trainer::deserialize-like: overwrite fp32 master weights from host, re-derive fp16/EMA copies,
  * reset Adam state (trainer.h:263-275). Syncs. */
 int rnb_set_params(rnb_ctx* ctx, const float* params_host);
-/* RNB_BUF_DENSITY_BITFIELD: the march kernels read an LDS form derived from the bitfield (occupancy update, or the next ray
- * generation after this call handed the pointer out); a caller that writes the bitfield through a pointer it kept calls
- * rnb_buffer(RNB_BUF_DENSITY_BITFIELD) again before it generates samples. */
+/* Handing a pointer out has no side effect: reads need nothing further; a caller that WRITES the training weights or the occupancy
+ * bitfield through one says so afterwards (rnb_params_changed, rnb_bitfield_changed), because the kernels work from cached forms of both. */
 int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
 /* A caller that keeps a pointer from rnb_buffer(RNB_BUF_PARAMS_FP16) and writes training weights through it later (e.g. an
  * all-gather of a sharded optimizer) says so here: the kernels' cached LDS weight images are dropped and rebuilt from the
- * weights at the next launch. (rnb_buffer itself drops them when that pointer is handed out; rnb_train_step_apply_done rebuilds
- * them.) No reference counterpart: tcnn reads the weights from global memory on every launch (fully_fused_mlp.cu:624-758). */
+ * weights at the next launch (rnb_train_step_apply_done rebuilds them). No reference counterpart: tcnn reads the weights from global memory on every launch (fully_fused_mlp.cu:624-758). */
 int rnb_params_changed(rnb_ctx* ctx);
+/* The occupancy bitfield was written through a pointer kept from rnb_buffer(RNB_BUF_DENSITY_BITFIELD): the march kernels' LDS form
+ * of it is rebuilt in front of the next march and a batch already generated ahead of time with the old bits is dropped.
+ * Reading the buffer needs no call. (none in the reference: its march reads the bitfield from global memory,
+ * src/testbed_nerf.cu:1320-1345; the LDS form is this build's.) */
+int rnb_bitfield_changed(rnb_ctx* ctx);
 /* Caller-owned device scratch (GPUMemory<T> in the reference, e.g. the lattice of get_density_on_grid,
  * src/testbed_nerf.cu:4218-4269). Host memory in the CPU checker. */
 int rnb_device_malloc(rnb_ctx* ctx, uint64_t n_bytes, void** ptr);

@@ -16,6 +16,7 @@
 #define rnb_set_params orc_set_params
 #define rnb_buffer orc_buffer
 #define rnb_params_changed orc_params_changed
+#define rnb_bitfield_changed orc_bitfield_changed
 #define rnb_sdf_lattice orc_sdf_lattice
 #define rnb_marching_cubes orc_marching_cubes
 #define rnb_memcpy orc_memcpy

@@ -1686,6 +1686,7 @@ int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 }
 
 int rnb_params_changed(orc_ctx_s* c) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); } // nothing is cached here
+int rnb_bitfield_changed(orc_ctx_s* c) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); } // the march reads the bitfield itself
 int rnb_device_malloc(orc_ctx_s* c, uint64_t n_bytes, void** ptr) {
 	if (!c || !ptr) return fail(RNB_ERR_INVALID, "null argument");
 	*ptr = n_bytes ? std::malloc(n_bytes) : nullptr;

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "set_params": (_i, [_ctx, C.POINTER(C.c_float)]),
     "buffer": (_i, [_ctx, _i, C.POINTER(C.c_void_p), C.POINTER(_u64)]),
     "params_changed": (_i, [_ctx]),
+    "bitfield_changed": (_i, [_ctx]),
     "memcpy": (_i, [_ctx, C.c_void_p, C.c_void_p, _u64, _i]),
     "device_malloc": (_i, [_ctx, _u64, C.POINTER(C.c_void_p)]),
     "device_free": (_i, [_ctx, C.c_void_p]),

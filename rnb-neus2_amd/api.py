@@ -148,6 +148,10 @@ class Context:
         """Training weights were written through a pointer kept from buffer("PARAMS_FP16"): drop the cached LDS weight images."""
         self._check(self.f.params_changed(self._h))
 
+    def bitfield_changed(self):
+        """The occupancy bitfield was written through a pointer kept from buffer("DENSITY_BITFIELD") (put() calls this itself)."""
+        self._check(self.f.bitfield_changed(self._h))
+
     def get(self, name, count=None, offset=0):
         """Copy (part of) a context buffer to a numpy array; count/offset in elements."""
         ptr, nb = self.buffer(name)
@@ -172,6 +176,10 @@ class Context:
         if a.size:
             self._check(self.f.memcpy(self._h, C.c_void_p(ptr + offset * dt.itemsize), a.ctypes.data_as(C.c_void_p),
                                       a.size * dt.itemsize, _abi.H2D))
+            if name == "DENSITY_BITFIELD":
+                self.bitfield_changed()
+            elif name == "PARAMS_FP16":
+                self.params_changed()
 
     # -- parameters -----------------------------------------------------
     def init_params(self, sdf_weights=None):

@@ -64,9 +64,17 @@ def build_testbed(force=False, verbose=False):
         if not any(os.path.getmtime(d) > t for d in TESTBED_DEPS):
             return TESTBED_OUT
     os.makedirs(os.path.dirname(TESTBED_OUT), exist_ok=True)
-    # RNB_WITH_RCCL: one process per GPU over RCCL (tools/launch_testbed.sh); the CPU-checker build of the same file (tests/) leaves it out
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-DRNB_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
-           "-L" + PKG_DIR, "-lrnb_neus2_hip", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    # RNB_WITH_RCCL: one process per GPU over RCCL (tools/launch_testbed.sh); the CPU-checker build of the same file (tests/) leaves it out,
+    # and so does a ROCm installation without the RCCL development files (RNB_NO_RCCL=1 forces that): the single-GPU command line needs none of it
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    with_rccl = (not os.environ.get("RNB_NO_RCCL") and os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h"))
+                 and any(os.path.exists(os.path.join(rocm, d, "librccl.so")) for d in ("lib", "lib64")))
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT, "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz",
+           "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd"]
+    if with_rccl:
+        cmd += ["-DRNB_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    elif verbose:
+        print("build_testbed: no RCCL development files under %s -- single-GPU command line only" % rocm)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -273,6 +273,7 @@ int reset_optimizer_state(rnb_ctx* c) {
 // by it). Runs after an occupancy update (every 16th step, which synchronises anyway) or when a caller may have written the bitfield.
 static int rebuild_coarse(rnb_ctx* c, hipStream_t s) {
 	hipLaunchKernelGGL(k_coarse_bitfield, dim3(1), dim3(1024), 0, s, c->bitfield.p, c->coarse_bits.p, c->coarse_count.p);
+	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(&c->coarse_n_blocks, c->coarse_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	c->coarse_valid = true;
@@ -1059,14 +1060,14 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 #define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
 	switch (id) {
 		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
-		case RNB_BUF_PARAMS_FP16: c->wimg_valid = false; BUF(c->params_fp16); // the caller may write through the pointer: drop the cached weight images
+		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16); // a caller that writes through the pointer says so with rnb_params_changed
 		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
 		case RNB_BUF_GRADS_FP32: BUF(c->grads);
 		case RNB_BUF_ADAM_M: BUF(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
 		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
-		case RNB_BUF_DENSITY_BITFIELD: c->coarse_valid = false; BUF(c->bitfield); // the caller may write through the pointer: the coarse bits are rebuilt in front of the next march
+		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield); // a caller that writes through the pointer says so with rnb_bitfield_changed
 		case RNB_BUF_DENSITY_MEAN: BUF(c->density_mean);
 		case RNB_BUF_RAY_INDICES: BUF(c->ray_indices);
 		case RNB_BUF_RAYS: BUF(c->rays);
@@ -1091,6 +1092,13 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 int rnb_params_changed(rnb_ctx* c) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->wimg_valid = false;
+	return RNB_OK;
+}
+
+int rnb_bitfield_changed(rnb_ctx* c) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c); // a batch generated ahead of time marched through the old bits
+	c->coarse_valid = false;
 	return RNB_OK;
 }
 
@@ -1197,7 +1205,9 @@ int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float latti
 		const uint32_t nb = (uint32_t)std::min<uint64_t>(batch, n - off);
 		hipLaunchKernelGGL(k_lattice_positions, dim3((nb + 255) / 256), dim3(256), 0, s, off, nb, res[0], res[1], res[2], lattice_min, lattice_max - lattice_min, c->aabb.mn, diag, pos);
 		rc = launch_point_query(c, s, pos, nb, val, nullptr, nullptr, 0, inference != 0);
+		if (rc != RNB_OK) break;
 		hipLaunchKernelGGL(k_half_to_float, dim3((nb + 255) / 256), dim3(256), 0, s, val, out + off, nb);
+		if (hipGetLastError() != hipSuccess) rc = fail(RNB_ERR_DEVICE, "rnb_sdf_lattice: kernel launch failed");
 	}
 	hipError_t e = hipStreamSynchronize(s);
 	(void)hipFree(pos); (void)hipFree(val);
@@ -1207,29 +1217,34 @@ int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float latti
 }
 
 namespace {
-// in-place exclusive prefix sums of n counts (device), total to *total_out; scratch for the block sums is allocated per level
-int scan_exclusive(uint32_t* data, uint64_t n, hipStream_t s, uint32_t* total_out) {
+// elements of block-sum scratch scan_exclusive needs for n counts: sum over the levels of ceil(n / 1024^k)
+uint64_t scan_scratch_elems(uint64_t n) {
+	uint64_t total = 0;
+	do { n = (n + 1023) / 1024; total += n; } while (n > 1);
+	return total;
+}
+// in-place exclusive prefix sums of n counts (device), total to *total_out; `scratch` holds scan_scratch_elems(n) uint32 (allocated once per
+// rnb_marching_cubes call and shared by its two scans)
+int scan_exclusive(uint32_t* data, uint64_t n, hipStream_t s, uint32_t* total_out, uint32_t* scratch) {
 	std::vector<uint32_t*> levels{data};
 	std::vector<uint64_t> sizes{n};
-	int rc = RNB_OK;
 	while (true) {
 		const uint64_t nb = (sizes.back() + 1023) / 1024;
-		uint32_t* sums = nullptr;
-		if (hipMalloc((void**)&sums, nb * 4) != hipSuccess) { rc = fail(RNB_ERR_NOMEM, "hipMalloc failed in scan_exclusive"); break; }
+		uint32_t* sums = scratch;
+		scratch += nb;
 		hipLaunchKernelGGL(k_scan_blocks, dim3((uint32_t)nb), dim3(1024), 0, s, levels.back(), sizes.back(), sums);
 		levels.push_back(sums); sizes.push_back(nb);
 		if (nb == 1) break;
 	}
-	if (rc == RNB_OK) {
-		if (hipMemcpyAsync(total_out, levels.back(), 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "scan_exclusive: readback failed");
-		// levels.back() holds one value (the total); every level below gets its block offsets added, top-down
-		for (size_t k = levels.size() - 1; k >= 2; --k) { /* levels[k-1] was scanned by the launch that produced levels[k]; add it to levels[k-2] */
-			hipLaunchKernelGGL(k_scan_add, dim3((uint32_t)sizes[k - 1]), dim3(1024), 0, s, levels[k - 2], sizes[k - 2], levels[k - 1]);
-		}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(total_out, levels.back(), 4, hipMemcpyDeviceToHost, s));
+	// levels.back() holds one value (the total); every level below gets its block offsets added, top-down
+	for (size_t k = levels.size() - 1; k >= 2; --k) { /* levels[k-1] was scanned by the launch that produced levels[k]; add it to levels[k-2] */
+		hipLaunchKernelGGL(k_scan_add, dim3((uint32_t)sizes[k - 1]), dim3(1024), 0, s, levels[k - 2], sizes[k - 2], levels[k - 1]);
 	}
-	if (hipStreamSynchronize(s) != hipSuccess && rc == RNB_OK) rc = fail(RNB_ERR_DEVICE, "scan_exclusive failed");
-	for (size_t k = 1; k < levels.size(); ++k) (void)hipFree(levels[k]);
-	return rc;
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s));
+	return RNB_OK;
 }
 } // namespace
 
@@ -1258,19 +1273,20 @@ int rnb_marching_cubes(rnb_ctx* c, void* stream, const float* density, const uin
 	const uint64_t n_wg64 = (res3 + MC_WG - 1) / MC_WG;
 	const uint32_t n_wg = (uint32_t)n_wg64;
 	uint32_t* wg = nullptr;
+	uint32_t* scan_scratch = nullptr;
 	int32_t* vidx = nullptr;
 	float* verts = nullptr;
 	uint32_t* indices = nullptr;
-	auto cleanup = [&](int rc) { if (wg) (void)hipFree(wg); if (vidx) (void)hipFree(vidx); if (rc != RNB_OK) { if (verts) (void)hipFree(verts); if (indices) (void)hipFree(indices); } return rc; };
-	if (hipMalloc((void**)&wg, (size_t)n_wg * 4) != hipSuccess || hipMalloc((void**)&vidx, (size_t)res3 * 3 * 4) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the marching-cubes scratch (12 bytes per lattice point)"));
+	auto cleanup = [&](int rc) { if (wg) (void)hipFree(wg); if (scan_scratch) (void)hipFree(scan_scratch); if (vidx) (void)hipFree(vidx); if (rc != RNB_OK) { if (verts) (void)hipFree(verts); if (indices) (void)hipFree(indices); } return rc; };
+	if (hipMalloc((void**)&wg, (size_t)n_wg * 4) != hipSuccess || hipMalloc((void**)&scan_scratch, scan_scratch_elems(n_wg) * 4) != hipSuccess || hipMalloc((void**)&vidx, (size_t)res3 * 3 * 4) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the marching-cubes scratch (12 bytes per lattice point)"));
 	uint32_t nv = 0, ni = 0;
 	hipLaunchKernelGGL(k_mc_verts<false>, dim3(n_wg), dim3(MC_WG), 0, s, a, wg, (const uint32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr);
-	int rc = scan_exclusive(wg, n_wg, s, &nv);
+	int rc = scan_exclusive(wg, n_wg, s, &nv, scan_scratch);
 	if (rc != RNB_OK) return cleanup(rc);
 	if (nv && hipMalloc((void**)&verts, (size_t)nv * 12) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the vertices"));
 	hipLaunchKernelGGL(k_mc_verts<true>, dim3(n_wg), dim3(MC_WG), 0, s, a, (uint32_t*)nullptr, wg, verts, vidx);
 	hipLaunchKernelGGL(k_mc_faces<false>, dim3(n_wg), dim3(MC_WG), 0, s, a, c->mc_table.p, wg, (const uint32_t*)nullptr, vidx, (uint32_t*)nullptr);
-	rc = scan_exclusive(wg, n_wg, s, &ni);
+	rc = scan_exclusive(wg, n_wg, s, &ni, scan_scratch);
 	if (rc != RNB_OK) return cleanup(rc);
 	if (ni && hipMalloc((void**)&indices, (size_t)ni * 4) != hipSuccess) return cleanup(fail(RNB_ERR_NOMEM, "hipMalloc failed for the indices"));
 	hipLaunchKernelGGL(k_mc_faces<true>, dim3(n_wg), dim3(MC_WG), 0, s, a, c->mc_table.p, (uint32_t*)nullptr, wg, vidx, indices);

@@ -179,18 +179,26 @@ static jsonmin::Value mpk_to_json(const mpk::Value& m) {
 
 // ---- one process per GPU (the reference is single-GPU, so this has no counterpart in src/main.cu) ----
 // Environment, set by tools/launch_testbed.sh (or torchrun-style variables): RNB_WORLD_SIZE | WORLD_SIZE, RNB_RANK | RANK,
-// RNB_LOCAL_RANK | LOCAL_RANK (the HIP device), RNB_RCCL_ID_FILE (rank 0 writes the ncclUniqueId there, the others wait for it).
+// RNB_LOCAL_RANK | LOCAL_RANK (the HIP device), RNB_RCCL_ID_FILE (rank 0 writes three ncclUniqueIds there, the others wait for them).
 // The job trains the SINGLE-GPU step: every rank takes 1/W of the rays and of the compacted batch (RNB_WEAK_SCALING=1: every
 // rank keeps the configured sizes, the step grows W-fold). Per step: the 7 counters / loss sums are all-reduced on the
-// library's device block, then the gradient blocks in the order they become final -- the early block on its own stream, with
-// its optimizer chunk, beside the rest of the scatter. Rank 0 alone writes meshes, snapshots and progress lines.
+// library's device block, then the gradient blocks are exchanged in the order they become final through the SHARDED optimizer
+// (the C++ form of dp.DataParallelTrainer._sharded_apply): reduce-scatter of a block -> Adam + EMA on this rank's 1/W of it ->
+// all-gather of the fp16 training weights; block 0 (everything in front of the finest levels) on its own stream and its own
+// communicator beside the scatter of the finest levels. RNB_DP_SHARDED=0: all-reduce + replicated optimizer instead.
+// RCCL orders the operations of ONE communicator, whatever streams they are given; the three exchanges that are meant to run
+// beside each other (step vector, early block, the rest) therefore use three communicators, each with its own non-blocking stream.
+// Rank 0 alone writes meshes, snapshots and progress lines (after sync_parameters(): with the sharded optimizer a rank's fp32
+// masters, EMA weights and Adam state are current on its own chunks only).
 struct Dist {
 	int world = 1, rank = 0, local_rank = 0;
-	bool on = false, weak = false;
+	bool on = false, weak = false, sharded = true;
 #ifdef RNB_WITH_RCCL
-	ncclComm_t comm = nullptr;
-	hipStream_t s_early = nullptr, s_vec = nullptr;
+	ncclComm_t comm = nullptr, comm_early = nullptr, comm_vec = nullptr;
+	hipStream_t s_main = nullptr, s_early = nullptr, s_vec = nullptr;
+	hipEvent_t ev_early = nullptr;
 	double* host7 = nullptr;
+	bool synced = true; // no sharded update since the last sync_parameters()
 #endif
 	static int env_int(const char* a, const char* b, int def) {
 		const char* v = std::getenv(a);
@@ -202,33 +210,39 @@ struct Dist {
 		rank = env_int("RNB_RANK", "RANK", 0);
 		local_rank = env_int("RNB_LOCAL_RANK", "LOCAL_RANK", rank);
 		weak = std::getenv("RNB_WEAK_SCALING") != nullptr;
+		if (const char* e = std::getenv("RNB_DP_SHARDED")) sharded = std::atoi(e) != 0;
 		on = world > 1 || std::getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr; // the variable exercises the collective path on one rank
 		if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad RNB_WORLD_SIZE / RNB_RANK");
 		if (!on) return;
 #ifdef RNB_WITH_RCCL
 		if (hipSetDevice(local_rank) != hipSuccess) throw std::runtime_error("hipSetDevice(" + std::to_string(local_rank) + ") failed");
-		ncclUniqueId id;
+		ncclUniqueId ids[3];
 		const char* idf = std::getenv("RNB_RCCL_ID_FILE");
 		if (world > 1 && !idf) throw std::runtime_error("RNB_RCCL_ID_FILE is not set (use tools/launch_testbed.sh)");
 		if (rank == 0) {
-			if (ncclGetUniqueId(&id) != ncclSuccess) throw std::runtime_error("ncclGetUniqueId failed");
+			for (auto& id : ids) if (ncclGetUniqueId(&id) != ncclSuccess) throw std::runtime_error("ncclGetUniqueId failed");
 			if (idf) {
 				const std::string tmp = std::string(idf) + ".tmp";
 				std::FILE* f = std::fopen(tmp.c_str(), "wb");
-				if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+				if (!f || std::fwrite(ids, sizeof(ids), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
 				std::fclose(f);
 				if (std::rename(tmp.c_str(), idf) != 0) throw std::runtime_error(std::string("cannot publish ") + idf);
 			}
 		} else {
 			bool got = false;
 			for (int tries = 0; tries < 1200 && !got; ++tries) { // up to two minutes
-				if (std::FILE* f = std::fopen(idf, "rb")) { got = std::fread(&id, sizeof(id), 1, f) == 1; std::fclose(f); }
+				if (std::FILE* f = std::fopen(idf, "rb")) { got = std::fread(ids, sizeof(ids), 1, f) == 1; std::fclose(f); }
 				if (!got) usleep(100000);
 			}
-			if (!got) throw std::runtime_error(std::string("no ncclUniqueId in ") + idf);
+			if (!got) throw std::runtime_error(std::string("no ncclUniqueIds in ") + idf);
 		}
-		if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) throw std::runtime_error("ncclCommInitRank failed");
-		if (hipStreamCreateWithFlags(&s_early, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_vec, hipStreamNonBlocking) != hipSuccess ||
+		ncclComm_t* comms[3] = {&comm, &comm_early, &comm_vec};
+		for (int k = 0; k < 3; ++k) if (ncclCommInitRank(comms[k], world, ids[k], rank) != ncclSuccess) throw std::runtime_error("ncclCommInitRank failed");
+		int n_ranks = 0;
+		if (ncclCommCount(comm, &n_ranks) != ncclSuccess || n_ranks != world) throw std::runtime_error("RCCL communicator does not span the job");
+		if (rank == 0) std::cout << "rccl_ranks: " << n_ranks << (sharded ? " (sharded optimizer)" : " (all-reduce, replicated optimizer)") << std::endl;
+		if (hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_early, hipStreamNonBlocking) != hipSuccess ||
+		    hipStreamCreateWithFlags(&s_vec, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess ||
 		    hipHostMalloc((void**)&host7, 7 * sizeof(double), 0) != hipSuccess) throw std::runtime_error("stream / pinned buffer creation failed");
 #else
 		throw std::runtime_error("this build of testbed has no RCCL support (RNB_WORLD_SIZE > 1)");
@@ -243,54 +257,117 @@ struct Dist {
 		cfg.max_rays_per_batch = std::max(128u, cfg.max_rays_per_batch / (uint32_t)world);
 		cfg.initial_rays_per_batch = std::max(1u, cfg.initial_rays_per_batch / (uint32_t)world);
 	}
+#ifdef RNB_WITH_RCCL
+	static void nccl_ok(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
+	template <typename T>
+	static T* buffer(rnb_ctx* ctx, int id) {
+		void* p; uint64_t nb;
+		if (rnb_buffer(ctx, id, &p, &nb) != RNB_OK) throw std::runtime_error(rnb_last_error());
+		return (T*)p;
+	}
+	// one block of the sharded optimizer on `st` / `cm`: reduce-scatter in place (the own chunk receives the sum), Adam + EMA on the own
+	// chunk, all-gather of the fp16 training weights in place
+	int shard_block(rnb_ctx* ctx, const rnb_shard_part& p, uint32_t k, float* g, uint16_t* w16, ncclComm_t cm, hipStream_t st) {
+		const uint64_t chunk = p.own_hi - p.own_lo;
+		int rc = rnb_gradient_part_wait(ctx, k, st);
+		if (rc != RNB_OK) return rc;
+		nccl_ok(ncclReduceScatter(g + p.lo, g + p.own_lo, chunk, ncclFloat, ncclSum, cm, st), "ncclReduceScatter");
+		rc = rnb_train_step_apply_shard(ctx, k, st);
+		if (rc != RNB_OK) return rc;
+		nccl_ok(ncclAllGather(w16 + p.own_lo, w16 + p.lo, chunk, ncclHalf, cm, st), "ncclAllGather");
+		return RNB_OK;
+	}
+#endif
 	int train_step(rnb_ctx* ctx, rnb_step_stats* st) {
 		if (!on) return rnb_train_step(ctx, nullptr, st);
 #ifdef RNB_WITH_RCCL
-		int rc = rnb_train_step_begin(ctx, nullptr);
+		int rc = rnb_train_step_begin(ctx, s_main);
 		if (rc != RNB_OK) return rc;
 		uint64_t cnt[4]; double sums[3];
-		rc = rnb_train_step_local(ctx, nullptr, cnt, sums); // the host waits for the loss pass only
+		rc = rnb_train_step_local(ctx, s_main, cnt, sums); // the host waits for the loss pass only
 		if (rc != RNB_OK) return rc;
-		void* vec; uint64_t nb;
-		rc = rnb_buffer(ctx, RNB_BUF_STEP_VECTOR, &vec, &nb);
-		if (rc != RNB_OK) return rc;
-		if (ncclAllReduce(vec, vec, 7, ncclDouble, ncclSum, comm, s_vec) != ncclSuccess) throw std::runtime_error("ncclAllReduce (step vector) failed");
+		double* vec = buffer<double>(ctx, RNB_BUF_STEP_VECTOR);
+		nccl_ok(ncclAllReduce(vec, vec, 7, ncclDouble, ncclSum, comm_vec, s_vec), "ncclAllReduce (step vector)");
 		if (hipMemcpyAsync(host7, vec, 7 * sizeof(double), hipMemcpyDeviceToHost, s_vec) != hipSuccess || hipStreamSynchronize(s_vec) != hipSuccess) throw std::runtime_error("step vector readback failed");
 		for (int k = 0; k < 4; ++k) cnt[k] = (uint64_t)std::llround(host7[k]);
 		for (int k = 0; k < 3; ++k) sums[k] = host7[4 + k];
 		const int rc_finish = rnb_train_step_finish(ctx, cnt, sums, st); // ray controller; queues the next step's march
 		if (rc_finish != RNB_OK && rc_finish != RNB_ERR_NO_SAMPLES) return rc_finish;
-		// gradients: sum over the ranks, block by block in completion order; the optimizer runs even when the step had no samples
+		// gradients: block by block in completion order; the optimizer runs even when the step had no samples
+		float* g = buffer<float>(ctx, RNB_BUF_GRADS_FP32);
+		if (sharded) {
+			rnb_shard_part parts[2]; uint32_t n_parts = 0; uint64_t capacity = 0;
+			rc = rnb_shard_layout(ctx, parts, &n_parts, &capacity);
+			if (rc != RNB_OK) return rc;
+			uint16_t* w16 = buffer<uint16_t>(ctx, RNB_BUF_PARAMS_FP16);
+			uint32_t first = 0;
+			if (n_parts > 1) { // beside the scatter of the finest levels
+				rc = shard_block(ctx, parts[0], 0, g, w16, comm_early, s_early);
+				if (rc != RNB_OK) return rc;
+				if (hipEventRecord(ev_early, s_early) != hipSuccess) throw std::runtime_error("hipEventRecord failed");
+				first = 1;
+			}
+			for (uint32_t k = first; k < n_parts; ++k) {
+				rc = shard_block(ctx, parts[k], k, g, w16, comm, s_main);
+				if (rc != RNB_OK) return rc;
+			}
+			if (first && hipStreamWaitEvent(s_main, ev_early, 0) != hipSuccess) throw std::runtime_error("hipStreamWaitEvent failed");
+			rc = rnb_params_changed(ctx); // the training weights were written through a pointer: the kernels' weight images are stale
+			if (rc != RNB_OK) return rc;
+			rc = rnb_train_step_apply_done(ctx, s_main);
+			if (rc != RNB_OK) return rc;
+			synced = false;
+			return rc_finish;
+		}
 		uint64_t ranges[3][2]; uint32_t n_parts = 0;
 		rc = rnb_gradient_parts(ctx, ranges, &n_parts);
 		if (rc != RNB_OK) return rc;
-		void* gp; rc = rnb_buffer(ctx, RNB_BUF_GRADS_FP32, &gp, &nb);
-		if (rc != RNB_OK) return rc;
-		float* g = (float*)gp;
 		uint32_t first = 0;
 		if (n_parts > 1) {
 			rc = rnb_gradient_part_wait(ctx, 0, s_early);
 			if (rc != RNB_OK) return rc;
-			if (ncclAllReduce(g + ranges[0][0], g + ranges[0][0], ranges[0][1] - ranges[0][0], ncclFloat, ncclSum, comm, s_early) != ncclSuccess) throw std::runtime_error("ncclAllReduce (early block) failed");
-			rc = rnb_train_step_apply_early(ctx, s_early); // Adam on that block, beside the rest of the exchange
+			nccl_ok(ncclAllReduce(g + ranges[0][0], g + ranges[0][0], ranges[0][1] - ranges[0][0], ncclFloat, ncclSum, comm_early, s_early), "ncclAllReduce (early block)");
+			rc = rnb_train_step_apply_early(ctx, s_early); // Adam on that block, beside the scatter of the finest levels and their exchange
 			if (rc != RNB_OK) return rc;
 			first = 1;
 		}
 		for (uint32_t k = first; k < n_parts; ++k) {
-			rc = rnb_gradient_part_wait(ctx, k, nullptr);
+			rc = rnb_gradient_part_wait(ctx, k, s_main);
 			if (rc != RNB_OK) return rc;
-			if (ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm, nullptr) != ncclSuccess) throw std::runtime_error("ncclAllReduce failed");
+			nccl_ok(ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm, s_main), "ncclAllReduce");
 		}
-		rc = rnb_train_step_apply(ctx, nullptr);
+		rc = rnb_train_step_apply(ctx, s_main);
 		if (rc != RNB_OK) return rc;
 		return rc_finish;
 #else
 		return RNB_ERR_INVALID;
 #endif
 	}
+	// Sharded optimizer: all-gather the per-rank chunks of the fp32 masters, EMA weights and Adam state so that every rank holds them
+	// whole (dp.DataParallelTrainer.sync_parameters). A collective: every rank calls it, before rank 0 writes a mesh or a snapshot.
+	void sync_parameters(rnb_ctx* ctx) {
+#ifdef RNB_WITH_RCCL
+		if (!on || !sharded || synced) return;
+		rnb_shard_part parts[2]; uint32_t n_parts = 0; uint64_t capacity = 0;
+		if (rnb_shard_layout(ctx, parts, &n_parts, &capacity) != RNB_OK) throw std::runtime_error(rnb_last_error());
+		if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
+		const struct { int id; ncclDataType_t type; size_t size; } bufs[] = {{RNB_BUF_PARAMS_FP32, ncclFloat, 4}, {RNB_BUF_PARAMS_EMA, ncclHalf, 2}, {RNB_BUF_ADAM_M, ncclFloat, 4},
+		                                                                  {RNB_BUF_ADAM_V, ncclFloat, 4}, {RNB_BUF_ADAM_STEPS, ncclInt32, 4}};
+		for (const auto& b : bufs) {
+			char* base = buffer<char>(ctx, b.id);
+			for (uint32_t k = 0; k < n_parts; ++k)
+				nccl_ok(ncclAllGather(base + parts[k].own_lo * b.size, base + parts[k].lo * b.size, parts[k].own_hi - parts[k].own_lo, b.type, comm, s_main), "ncclAllGather (sync_parameters)");
+		}
+		if (hipStreamSynchronize(s_main) != hipSuccess) throw std::runtime_error("sync_parameters failed");
+		synced = true;
+#else
+		(void)ctx;
+#endif
+	}
 	void shutdown() {
 #ifdef RNB_WITH_RCCL
-		if (comm) { (void)hipDeviceSynchronize(); ncclCommDestroy(comm); comm = nullptr; }
+		if (comm) (void)hipDeviceSynchronize();
+		for (ncclComm_t* c : {&comm, &comm_early, &comm_vec}) if (*c) { ncclCommDestroy(*c); *c = nullptr; }
 #endif
 	}
 };
@@ -694,6 +771,7 @@ int main(int argc, char** argv) {
 						RNB_CHECK(rnb_update_config(tb.ctx, &tb.cfg));
 					}
 				}
+				if (tb.save_each > 0 && step % tb.save_each == 0) tb.dist.sync_parameters(tb.ctx); // collective: every rank
 				if (lead && tb.save_each > 0 && step % tb.save_each == 0) {
 					const std::string name = tb.mesh_prefix + std::to_string(step) + ".obj";
 					std::printf("%s\n", name.c_str());
@@ -705,6 +783,7 @@ int main(int argc, char** argv) {
 			}
 			if (lead && train_ms > 0) std::cout << "throughput: " << (double)rays_total * tb.dist.world / (train_ms * 1e-3) << " rays/s, " << train_ms / std::max(1u, step - resume.training_step) << " ms/step" << std::endl;
 		}
+		if (args.has("save-mesh") || args.has("save-snapshot")) tb.dist.sync_parameters(tb.ctx); // collective: every rank
 		if (lead && args.has("save-mesh")) {
 			// --free-memory releases the dataset before meshing in the reference (src/main.cu:455-459; 10 s sleep not reproduced)
 			tb.compute_and_save_marching_cubes_mesh(obj_filename, tb.res_mesh);

@@ -1,6 +1,7 @@
 """Image helpers of the preparation stages (mirror of rnb_neus2/image_io.py:15-125; the target image has neither OpenCV nor
 OpenEXR: PNG goes through librnb_host.so, EXR through the scanline codec of exr.py). Arrays are RGB(A) everywhere."""
 import os
+import zlib
 
 from struct import error as struct_error
 
@@ -15,7 +16,7 @@ def read_unchanged(path):
     if str(path).lower().endswith(".exr"):
         try:
             return exr.read_exr(path)
-        except (OSError, ValueError, KeyError, struct_error):
+        except (OSError, ValueError, KeyError, IndexError, struct_error, zlib.error):  # truncated / corrupt file: cv2 would return None
             return None
     try:
         return hostlib.png_read(path)
