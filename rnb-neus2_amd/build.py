@@ -6,7 +6,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "rnb_neus2_hip.hip")
 OUT = os.path.join(PKG_DIR, "librnb_neus2_hip.so")
-DEPS = [os.path.join(PKG_DIR, "csrc", f) for f in ("rnb_neus2_hip.hip", "common.cuh", "mlp.cuh", "kernels_net.cuh", "kernels_ray.cuh")] + [
+DEPS = [os.path.join(PKG_DIR, "csrc", f) for f in ("rnb_neus2_hip.hip", "common.cuh", "mlp.cuh", "chain.cuh", "kernels_net.cuh", "kernels_ray.cuh", "kernels_mesh.cuh")] + [
+    os.path.join(PKG_DIR, "host", f) for f in ("mesh.hpp", "mc_table.hpp")] + [
     os.path.join(os.path.dirname(PKG_DIR), "include", "rnb_neus2.h")]
 
 # -ffp-contract=off: the index/ray arithmetic must match the CPU checker bit for bit (no FMA contraction).
@@ -53,7 +54,7 @@ def build(force=False, verbose=False):
 ROOT = os.path.dirname(PKG_DIR)
 TESTBED_SRC = os.path.join(PKG_DIR, "host", "testbed_main.cpp")
 TESTBED_OUT = os.path.join(ROOT, "build", "testbed")
-TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "dataset.hpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp")] + [
+TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "dataset.hpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp", "mc_table.hpp")] + [
     os.path.join(ROOT, "include", "rnb_neus2.h")]
 
 

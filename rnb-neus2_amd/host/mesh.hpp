@@ -1,9 +1,9 @@
 // mesh.hpp — iso-surface extraction and OBJ output for `--save-mesh` (src/marching_cubes.cu:276-430, 794-982;
 // src/testbed_nerf.cu:4218-4350). Vertices sit on lattice edges exactly where the reference's gen_vertices puts them
-// (linear interpolation of the SDF lattice, one shared vertex per crossing edge). The cell triangulation table is
-// generated here from first principles (face-by-face contour tracing with the "separate the inside corners" rule) rather
-// than taken from the published Bourke table: same vertex set, watertight, possibly different diagonals in ambiguous
-// cells. Faces are wound counter-clockwise around the outward (sdf > threshold side) normal.
+// (linear interpolation of the SDF lattice, one shared vertex per crossing edge). Cells are triangulated with the table the
+// reference uses (mc_table.hpp: the public Bourke / PyMCubes table, src/marching_cubes.cu:401-659), so on identical lattices the
+// triangle set is the reference's; vertices and triangles are numbered in lattice order (the reference numbers them with atomic
+// counters, i.e. in no particular order). Normals and face order follow save_mesh (src/marching_cubes.cu:354-356, 930-975).
 #pragma once
 #include <array>
 #include <cmath>
@@ -12,6 +12,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "mc_table.hpp"
 
 namespace mesh {
 
@@ -22,44 +24,13 @@ static const int CORNER[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0,
 static const int EDGE[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
 
 struct Tables {
-	// tri[mask] = list of edge ids, 3 per triangle, -1 terminated (at most 12 triangles)
+	// tri[mask] = list of edge ids, 3 per triangle, -1 terminated (at most 5 triangles; the array keeps the length the device copy uses)
 	std::array<std::array<int8_t, 40>, 256> tri;
 	Tables() {
-		// faces with corners in counter-clockwise order seen from OUTSIDE the cube
-		static const int FACE[6][4] = {{0, 3, 2, 1} /* z=0 */, {4, 5, 6, 7} /* z=1 */, {0, 1, 5, 4} /* y=0 */, {2, 3, 7, 6} /* y=1 */, {0, 4, 7, 3} /* x=0 */, {1, 2, 6, 5} /* x=1 */};
-		auto edge_between = [](int a, int b) {
-			for (int e = 0; e < 12; ++e) if ((EDGE[e][0] == a && EDGE[e][1] == b) || (EDGE[e][0] == b && EDGE[e][1] == a)) return e;
-			return -1;
-		};
 		for (int mask = 0; mask < 256; ++mask) {
-			int next[12];
-			for (int e = 0; e < 12; ++e) next[e] = -1;
-			for (int f = 0; f < 6; ++f) {
-				bool in[4];
-				int n_in = 0;
-				for (int k = 0; k < 4; ++k) { in[k] = (mask >> FACE[f][k]) & 1; n_in += in[k]; }
-				if (n_in == 0 || n_in == 4) continue;
-				// every maximal run of inside corners along the CCW cycle contributes one segment: from the edge where the
-				// run is left (inside -> outside) to the edge where it was entered (outside -> inside); inside lies on its left.
-				for (int k = 0; k < 4; ++k) {
-					if (in[k] && !in[(k + 1) & 3]) { // run ends at corner k
-						int s = k;
-						while (in[(s + 3) & 3]) s = (s + 3) & 3; // first corner of the run
-						const int exit_edge = edge_between(FACE[f][k], FACE[f][(k + 1) & 3]);
-						const int entry_edge = edge_between(FACE[f][(s + 3) & 3], FACE[f][s]);
-						next[exit_edge] = entry_edge;
-					}
-				}
-			}
 			int n = 0;
-			bool used[12] = {false};
-			for (int e0 = 0; e0 < 12; ++e0) {
-				if (next[e0] < 0 || used[e0]) continue;
-				int loop[12], len = 0;
-				for (int e = e0; !used[e]; e = next[e]) { used[e] = true; loop[len++] = e; if (next[e] < 0) { len = 0; break; } }
-				for (int k = 1; k + 1 < len; ++k) { tri[mask][n++] = (int8_t)loop[0]; tri[mask][n++] = (int8_t)loop[k]; tri[mask][n++] = (int8_t)loop[k + 1]; }
-			}
-			tri[mask][n] = -1;
+			for (const char* c = MC_TRIANGLES[mask]; *c; ++c) tri[mask][n++] = (int8_t)(*c <= '9' ? *c - '0' : *c - 'a' + 10);
+			for (; n < 40; ++n) tri[mask][n] = -1;
 		}
 	}
 };
@@ -70,13 +41,15 @@ struct Mesh {
 };
 
 // density[x + y*rx + z*rx*ry]; lattice point (x,y,z) sits at aabb_min + (x,y,z) * (aabb_max - aabb_min) / res
-// area-weighted vertex normals (compute_mesh_1ring, marching_cubes.cu:330-365), outward orientation
+// area-weighted vertex normals exactly as accumulate_1ring forms them (marching_cubes.cu:354-356): n = (pb - pa) x (pa - pc), i.e. the
+// NEGATIVE of the counter-clockwise normal of (a, b, c). With the table's winding and "corner bit = sdf > 0" that is the direction of
+// decreasing SDF (into the object); the reference writes these to the OBJ as they are, and so does save_obj.
 inline void compute_normals(Mesh& m) {
 	m.normals.assign(m.verts.size(), {0, 0, 0});
 	for (size_t i = 0; i + 2 < m.indices.size(); i += 3) {
 		const uint32_t ia = m.indices[i], ib = m.indices[i + 1], ic = m.indices[i + 2];
 		const Vec3 a = m.verts[ia], b = m.verts[ib], c = m.verts[ic];
-		const Vec3 u = {b.x - a.x, b.y - a.y, b.z - a.z}, v = {c.x - a.x, c.y - a.y, c.z - a.z};
+		const Vec3 u = {b.x - a.x, b.y - a.y, b.z - a.z}, v = {a.x - c.x, a.y - c.y, a.z - c.z};
 		const Vec3 n = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
 		for (uint32_t q : {ia, ib, ic}) { m.normals[q].x += n.x; m.normals[q].y += n.y; m.normals[q].z += n.z; }
 	}
@@ -130,8 +103,10 @@ inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const f
 	return m;
 }
 
-// OBJ with per-vertex colours and normals (save_mesh, marching_cubes.cu:922-981): v = n2w_s * ((p - offset) / scale) + n2w_t
-inline void save_obj(const std::string& path, const Mesh& m, float nerf_scale, const float nerf_offset[3], float n2w_s, const float n2w_t[3]) {
+// OBJ with per-vertex colours and normals (save_mesh, marching_cubes.cu:922-981): v = n2w_s * ((p - offset) / scale) + n2w_t.
+// invert_normals = the dataset's from_na flag (src/testbed.cu:376-379): faces are written (a, b, c) when set -- counter-clockwise seen
+// from the sdf > 0 side -- and (c, b, a) otherwise (marching_cubes.cu:966-975); the vn records are not touched by it.
+inline void save_obj(const std::string& path, const Mesh& m, float nerf_scale, const float nerf_offset[3], float n2w_s, const float n2w_t[3], bool invert_normals = true) {
 	FILE* f = std::fopen(path.c_str(), "wb");
 	if (!f) throw std::runtime_error("cannot write " + path);
 	for (size_t i = 0; i < m.verts.size(); ++i) {
@@ -147,8 +122,10 @@ inline void save_obj(const std::string& path, const Mesh& m, float nerf_scale, c
 		if (l > 0.f) { n.x /= l; n.y /= l; n.z /= l; }
 		std::fprintf(f, "vn %0.5f %0.5f %0.5f\n", n.x, n.y, n.z);
 	}
-	for (size_t i = 0; i + 2 < m.indices.size(); i += 3)
-		std::fprintf(f, "f %u//%u %u//%u %u//%u\n", m.indices[i] + 1, m.indices[i] + 1, m.indices[i + 1] + 1, m.indices[i + 1] + 1, m.indices[i + 2] + 1, m.indices[i + 2] + 1);
+	for (size_t i = 0; i + 2 < m.indices.size(); i += 3) {
+		const uint32_t a = m.indices[invert_normals ? i : i + 2] + 1, b = m.indices[i + 1] + 1, c = m.indices[invert_normals ? i + 2 : i] + 1;
+		std::fprintf(f, "f %u//%u %u//%u %u//%u\n", a, a, b, b, c, c);
+	}
 	std::fclose(f);
 }
 

@@ -654,7 +654,7 @@ struct Testbed {
 			}
 			rnb_device_free(ctx, dc); rnb_device_free(ctx, dq);
 		}
-		mesh::save_obj(filename, m, ds.scale, ds.offset, ds.n2w_s, ds.n2w_t);
+		mesh::save_obj(filename, m, ds.scale, ds.offset, ds.n2w_s, ds.n2w_t, ds.from_na);
 	}
 };
 

@@ -39,6 +39,25 @@ def test_marching_cubes_equals_host_loop(gpu, shape):
         assert len(got_v) > 100
 
 
+@pytest.mark.parametrize("shape", [(19, 23, 31), (12, 12, 12)])
+def test_marching_cubes_triangle_set_equals_the_numpy_statement(gpu, shape):
+    """Parity with the reference's triangulation, pinned independently: the device extraction against tests/mc_numpy.py -- plain numpy
+    over the same lattice with the golden copy of the reference's triangle table (src/marching_cubes.cu:401-659), no code shared with
+    host/mesh.hpp or kernels_mesh.cuh. Equal triangle SETS (each triangle = three lattice edges, orientation kept), and vertices where
+    gen_vertices (src/marching_cubes.cu:291-327) puts them. Random fields: every one of the 254 non-trivial cases occurs."""
+    from tests import mc_numpy
+    rz, ry, rx = shape
+    rng = np.random.default_rng(rx + 7 * ry)
+    density = rng.standard_normal(shape).astype(np.float32)
+    mn, mx = (0.0, -1.0, 0.5), (2.0, 1.0, 1.5)
+    ptr = gpu.upload(density)
+    v, i = gpu.marching_cubes(ptr, (rx, ry, rz), mn, mx, 0.05)
+    gpu.device_free(ptr)
+    want = mc_numpy.triangles_by_edge(density, 0.05)
+    got = mc_numpy.triangles_of_mesh(v, i, density, 0.05, mn, mx)
+    assert len(want) > 1000 and got == want, (len(got), len(want), len(got ^ want))
+
+
 def test_sdf_lattice_matches_point_queries_and_oracle(gpu):
     from tests import oracle_lib
     res = (24, 20, 16)

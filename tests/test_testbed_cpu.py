@@ -217,7 +217,13 @@ def test_mesh_obj(trained):
     r = np.linalg.norm(v[:, :3] - 0.5, axis=1)
     assert r.std() < 0.05 and 0.1 < r.mean() < 0.6
     outward = np.sum(vn * (v[:, :3] - 0.5), axis=1)
-    assert (outward > 0).mean() > 0.95  # normals follow the SDF gradient (point outward)
+    # the reference's vn records are (pb - pa) x (pa - pc) summed over the 1-ring (src/marching_cubes.cu:354-356) and written as they are
+    # (:933-936): with its table and "corner bit = sdf > 0" they point down the SDF gradient, into the object
+    assert (outward < 0).mean() > 0.95
+    # from_na datasets (invert_normals, src/testbed.cu:376-379; marching_cubes.cu:966-975): faces counter-clockwise seen from outside
+    tri = v[np.array(f) - 1][:, :, :3]
+    geo = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert (np.sum(geo * (tri.mean(axis=1) - 0.5), axis=1) > 0).mean() > 0.95
     edges = {}
     for a, b, c in f:
         for e in ((a, b), (b, c), (c, a)):
