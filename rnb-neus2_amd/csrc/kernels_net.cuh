@@ -615,9 +615,10 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 //   dso = e0 * dL/dsdf                    dz = (W1^T dso) (.) relu'(z1) = dL/dsdf * dz1  (one product per element: the
 //                                         GEMM's other 15 K-terms are zeros)   dL/d in = W0^T dz           (-> g1)
 //   ddin = [dn | dy_dx . dn]              front = (W0 ddin) (.) relu'(z1)
-// The operands of the weight-gradient GEMMs leave in "fragment order": inside a 64-sample tile, sample q sits at position
-// (q & 15) * 4 + (q >> 4). K of those GEMMs is the sample index, i.e. a summation index, and every operand uses the same
-// order, so k_dw is unchanged; a D fragment's four n-tiles then are 8 contiguous bytes per lane (16 stores per 64x64 matrix).
+// Weight gradients (round 3): the kernel exports only what cannot be recomputed cheaply -- per sample the two 32-wide rows `in` and
+// `ddin` (sample-major, 64 B each, 4 coalesced 16-byte stores per lane) and dL/dsdf -- and k_dw_sdf rebuilds z1, dz and front from them
+// on the matrix cores (MFMA is 3 % busy on this path) in the orientation its GEMMs need. Round 2 exported z1, dz1, dz, front, dso and both
+// inputs feature-major, 672 B per sample of 2-byte stores (176 MB per step, read back by four GEMM launches beside the atomic-bound scatter).
 // ---------------------------------------------------------------------------------------------
 constexpr int SW_S0 = 0;                    // [64][S32] sdf W0, input columns in tile order (below)
 constexpr int SW_S0T = SW_S0 + 64 * S32;    // [32][S64] sdf W0^T, rows in tile order, columns in chain order
@@ -662,7 +663,7 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 		}
 }
 
-__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
+__global__ __launch_bounds__(WG, 3) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
@@ -679,11 +680,9 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 	const uint32_t B = a.B;
 	const uint32_t n_tiles = B / TILE;
 	const TrainScratch& T = a.t;
-	const uint32_t pos = (uint32_t)r16 * 4u + (uint32_t)hq; // fragment-order position of sample `lane` inside its tile
 	float var_sum = 0.f;
 	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
 		const uint32_t s = tile * TILE + lane;
-		const uint32_t sp = tile * TILE + pos;
 		float c[3];
 #pragma unroll
 		for (int q = 0; q < 3; ++q) c[q] = a.coords[(size_t)s * 7 + q];
@@ -721,25 +720,24 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 			const half_t e0 = f2h(r0), e1 = f2h(r1);
 			Xrow[level] = pack_h2(f0, f1);
 			Drow[level] = pack_h2(e0, e1);
-			const uint32_t row = (3u + 2u * level) * B + sp; // operand rows are in the network's own input order
-			st32(T.sdfin, row, f0); st32(T.sdfin, row + B, f1);
-			st32(T.ddin, row, e0); st32(T.ddin, row + B, e1);
 		}
 		{ // x y z (fill_positions_view_with_fixed_offset: half arithmetic, common_operation.cuh:187-199) | pad ; dn | pad
 			const half_t px = f2h(c[0]) - (half_t)0.5f, py = f2h(c[1]) - (half_t)0.5f, pz = f2h(c[2]) - (half_t)0.5f;
 			Xrow[14] = pack_h2(px, py); Xrow[15] = pack_h2(pz, (half_t)0.f);
 			const half_t n0 = f2h(dn[0]), n1 = f2h(dn[1]), n2 = f2h(dn[2]);
 			Drow[14] = pack_h2(n0, n1); Drow[15] = pack_h2(n2, (half_t)0.f);
-			st32(T.sdfin, 0u * B + sp, px); st32(T.sdfin, 1u * B + sp, py); st32(T.sdfin, 2u * B + sp, pz); st32(T.sdfin, 31u * B + sp, (half_t)0.f);
-			st32(T.ddin, 0u * B + sp, n0); st32(T.ddin, 1u * B + sp, n1); st32(T.ddin, 2u * B + sp, n2); st32(T.ddin, 31u * B + sp, (half_t)0.f);
 		}
 		Z[lane] = dout[3];
-		// dso (only dL/dsdf survives, add_density_gradient), variance gradient
-		st32(T.dso, sp, (half_t)0.f + dout[3]);
-#pragma unroll
-		for (uint32_t j = 1; j < 16; ++j) st32(T.dso, j * B + sp, (half_t)0.f);
+		// dL/dsdf (only that row of dso survives, add_density_gradient), variance gradient
+		T.dso[s] = (half_t)0.f + dout[3];
 		var_sum += h2f(dout[7]);
 		wave_lds_sync();
+		{ // this sample's rows of the two 32-wide inputs, in tile order (fbs_logical), for k_dw_sdf
+			h8* gi = reinterpret_cast<h8*>(T.sdfin + (size_t)s * 32);
+			h8* gd = reinterpret_cast<h8*>(T.ddin + (size_t)s * 32);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { gi[q] = *reinterpret_cast<const h8*>(X + lane * S32 + 8 * q); gd[q] = *reinterpret_cast<const h8*>(D + lane * S32 + 8 * q); }
+		}
 		// z1 = relu(W0 in), kept as next-layer fragments; its relu' mask in fragment order
 		h8 bz[4][2];
 		{
@@ -748,8 +746,6 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 			mfma_layer<4, 1>(wts + SW_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
-		export_frags(bz, T.z1, B, tile, lane);
-		uint64_t mask = 0;
 		half_t d3[4];
 #pragma unroll
 		for (int nt = 0; nt < 4; ++nt) d3[nt] = Z[16 * nt + r16];
@@ -763,13 +759,10 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 #pragma unroll
 				for (int j = 0; j < 8; ++j) {
 					const bool on = bz[nt][ks][j] > (half_t)0.f;
-					if (on) mask |= 1ull << ((nt * 2 + ks) * 8 + j);
 					bz[nt][ks][j] = on ? w1[j] : (half_t)0.f;                                   // bz now holds dz1
 					bdz[nt][ks][j] = on ? f2h(h2f(w1[j]) * h2f(d3[nt])) : (half_t)0.f;
 				}
 		}
-		export_frags(bz, T.dz1, B, tile, lane);
-		export_frags(bdz, T.dz, B, tile, lane);
 		wave_lds_sync(); // X (network input) consumed by the first GEMM
 		{ // d sdf / d in = W0^T dz1 -> rows of X
 			f4 acc[2][4];
@@ -790,20 +783,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		wave_lds_sync();
 #pragma unroll
 		for (uint32_t l = 0; l < 14; ++l) st32(T.g12, (l * B + s) * 2u + 0u, Xrow[l]);
-		{ // front = (W0 ddin) (.) relu'(z1)   (fully_fused_mlp.cu:1097-1107)
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + SW_S0, S32, D, S32, acc, lane);
-			chain_pack<false>(acc, bdz);
-#pragma unroll
-			for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-				for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-					for (int j = 0; j < 8; ++j) if (!((mask >> ((nt * 2 + ks) * 8 + j)) & 1ull)) bdz[nt][ks][j] = (half_t)0.f;
-		}
-		export_frags(bdz, T.front, B, tile, lane);
-		wave_lds_sync();
+		wave_lds_sync(); // (front = (W0 ddin) (.) relu'(z1), fully_fused_mlp.cu:1097-1107, is rebuilt by k_dw_sdf from the exported rows)
 	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) var_sum += __shfl_down(var_sum, off, 64);
@@ -877,6 +857,124 @@ __global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
 		case DW_4x4: dw_body<4, 4, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
 		case DW_4x2: dw_body<4, 2, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
 		default: dw_body<1, 4, true>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
+	}
+}
+
+// --no-albedo: all four weight-gradient GEMMs of the SDF MLP in one kernel that rebuilds its operands (see k_fwd_bwd_sdf's header).
+// Per 64-sample tile, from the exported sample-major rows `in`, `ddin` [B][32] (columns in tile order, fbs_logical) and dL/dsdf [B]:
+//   z1^T  = in W0^T      MFMA with the SAMPLES as M and the hidden units as N: D puts 4 samples of one hidden unit in a lane, so two
+//   fr^T  = ddin W0^T    m-tiles are the 8 K-values (K = samples) an A operand of the weight-gradient GEMM needs -- no transpose
+//   dz    = relu'(z1) (.) half(w1 * dL/dsdf),   front = relu'(z1) (.) half(fr)        (same roundings as k_fwd_bwd_sdf / k_fwd_bwd)
+//   in^T, ddin^T         the B operands (input feature in the lane, 8 samples in registers): MFMA against the identity (exact)
+//   dW0 += dz in^T (64x32), dW0' += front ddin^T (64x32)   MFMA, K = the tile's samples;   dW1[0,:] += dL/dsdf . z1, dW1'[0,:] += sum front (VALU)
+// Partials per workgroup in k_dw's layout (k_dw_finish sums them in a fixed order). 80 MFMAs and 192 bytes read per tile.
+__global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* __restrict__ in_sm, const half_t* __restrict__ dd_sm, const half_t* __restrict__ dsdf, const uint32_t chunk,
+                                                  float* __restrict__ p_w0, float* __restrict__ p_w0b, float* __restrict__ p_w1, float* __restrict__ p_w1b) {
+	__shared__ __attribute__((aligned(16))) half_t w0[64 * S32];
+	__shared__ half_t w1s[64];
+	__shared__ float red[WAVES_PER_WG * 64 * 32];
+	for (int i = threadIdx.x; i < 64 * 32; i += WG) { const int o = i >> 5, p = i & 31; w0[o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
+	if (threadIdx.x < 64) w1s[threadIdx.x] = net.sdf_w1[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int r16 = lane & 15, hq = lane >> 4;
+	h8 wb[4], idf[2];
+	float w1v[4];
+#pragma unroll
+	for (int nt = 0; nt < 4; ++nt) { wb[nt] = *reinterpret_cast<const h8*>(w0 + (16 * nt + r16) * S32 + 8 * hq); w1v[nt] = h2f(w1s[16 * nt + r16]); }
+#pragma unroll
+	for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) idf[n2][j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
+	f4 acc_w0[4][2], acc_w0b[4][2];
+	float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc1b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+		for (int ni = 0; ni < 2; ++ni) { acc_w0[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; acc_w0b[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; }
+	const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+	const uint32_t tiles = chunk / TILE, tile0 = blockIdx.x * tiles;
+	for (uint32_t tile = tile0 + wave; tile < tile0 + tiles; tile += WAVES_PER_WG) {
+		const size_t s0 = (size_t)tile * TILE;
+		h8 ain[4], add[4];
+		h4 d3[4];
+#pragma unroll
+		for (int mt = 0; mt < 4; ++mt) {
+			ain[mt] = *reinterpret_cast<const h8*>(in_sm + (s0 + 16 * mt + r16) * 32 + 8 * hq);
+			add[mt] = *reinterpret_cast<const h8*>(dd_sm + (s0 + 16 * mt + r16) * 32 + 8 * hq);
+			d3[mt] = *reinterpret_cast<const h4*>(dsdf + s0 + 16 * mt + 4 * hq);
+		}
+		// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
+		h8 b_in[2][2], b_dd[2][2];
+#pragma unroll
+		for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const f4 ti = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[2 * ks + h], idf[n2], zero4, 0, 0, 0);
+					const f4 td = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[2 * ks + h], idf[n2], zero4, 0, 0, 0);
+#pragma unroll
+					for (int r = 0; r < 4; ++r) { b_in[n2][ks][4 * h + r] = f2h(ti[r]); b_dd[n2][ks][4 * h + r] = f2h(td[r]); }
+				}
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
+			h8 a_dz[2], a_fr[2];
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int mt = 2 * ks + h;
+					const f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wb[nt], zero4, 0, 0, 0);
+					const f4 fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wb[nt], zero4, 0, 0, 0);
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const half_t zh = f2h(z[r]);
+						const bool on = zh > (half_t)0.f; // relu' tests the stored half activation (common_device.h:182 ff.)
+						const float d = h2f(d3[mt][r]);
+						const half_t dzv = on ? f2h(w1v[nt] * d) : (half_t)0.f;
+						const half_t frv = on ? f2h(fr[r]) : (half_t)0.f;
+						acc1[nt] += on ? d * h2f(zh) : 0.f;
+						acc1b[nt] += h2f(frv);
+						a_dz[ks][4 * h + r] = dzv;
+						a_fr[ks][4 * h + r] = frv;
+					}
+				}
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+				for (int ni = 0; ni < 2; ++ni) {
+					acc_w0[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz[ks], b_in[ni][ks], acc_w0[nt][ni], 0, 0, 0);
+					acc_w0b[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_fr[ks], b_dd[ni][ks], acc_w0b[nt][ni], 0, 0, 0);
+				}
+		}
+	}
+	// the four waves' partials, summed in a fixed order; D layout: lane = input column 16 ni + r16 (tile order), register r = hidden unit 16 mo + 4 hq + r
+	constexpr int N = 64 * 32;
+	for (int pass = 0; pass < 2; ++pass) {
+		__syncthreads();
+#pragma unroll
+		for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+			for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) red[wave * N + (16 * mo + 4 * hq + r) * 32 + fbs_logical(16 * ni + r16)] = pass ? acc_w0b[mo][ni][r] : acc_w0[mo][ni][r];
+		__syncthreads();
+		float* dst = (pass ? p_w0b : p_w0) + (size_t)blockIdx.x * N;
+		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
+	}
+	// row 0 of the two 16x64 gradients of W1: per lane the sum over its samples; 16 lane groups (wave, hq) per hidden unit
+	for (int pass = 0; pass < 2; ++pass) {
+		__syncthreads();
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) red[(wave * 4 + hq) * 64 + 16 * nt + r16] = pass ? acc1b[nt] : acc1[nt];
+		__syncthreads();
+		float* dst = (pass ? p_w1b : p_w1) + (size_t)blockIdx.x * (16 * 64);
+		for (int q = threadIdx.x; q < 16 * 64; q += WG) {
+			float v = 0.f;
+			if (q < 64) for (int g = 0; g < 16; ++g) v += red[g * 64 + q];
+			dst[q] = v; // rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
+		}
 	}
 }
 
@@ -1193,7 +1291,21 @@ struct AdamArgs {
 	float ema_decay, ema_debias_old, ema_debias_new;
 	uint64_t begin, end;       // parameter range of this launch (multiples of 4)
 	uint64_t skip_lo, skip_hi; // only_sdf_training: parameters [skip_lo, skip_hi) (the colour MLP) get no Adam update (adam.h:121-165)
+	const float* lr_table;     // [lr_table_n] bias-correction factor by per-parameter step count (k_adam_lr_table); entry 0 unused
+	uint32_t lr_table_n;
 };
+
+// The bias correction of adam.h:182-183, sqrt(1 - beta2^t) / (1 - beta1^t), depends on the parameter's own step count t only. Evaluated per
+// parameter it was most of k_adam_ema: two powf per live parameter made the kernel VALU-bound (3.6 k wave instructions per wavefront, 110 us
+// of issue time for a 240 MB stream, profiles/r02_pmc_sq.json). The table holds the same expression, evaluated by the same device functions,
+// for t < lr_table_n; a step count beyond the table is computed in place.
+__device__ __forceinline__ float adam_bias_correction(const float beta1, const float beta2, const uint32_t t) {
+	return sqrtf(1 - powf(beta2, (float)t)) / (1 - powf(beta1, (float)t));
+}
+__global__ void k_adam_lr_table(float* __restrict__ table, const uint32_t n, const float beta1, const float beta2) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n) table[t] = t ? adam_bias_correction(beta1, beta2, t) : 0.f;
+}
 
 // Four parameters per thread (n_params, n_matrix are multiples of 4): 16-byte fp32 / 8-byte fp16 accesses. Entries of
 // the hash grid whose gradient is zero only take the EMA path (adam.h:111-114), i.e. 10 B of traffic per parameter.
@@ -1228,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 				const float second_moment = v[k] = a.beta2 * v[k] + (1 - a.beta2) * gradient_sq;
 				float learning_rate = a.base_lr;
 				const uint32_t cs = ++stp[k];
-				learning_rate *= sqrtf(1 - powf(a.beta2, (float)cs)) / (1 - powf(a.beta1, (float)cs));
+				learning_rate *= cs < a.lr_table_n ? a.lr_table[cs] : adam_bias_correction(a.beta1, a.beta2, cs);
 				const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), 0.f), 3.402823466e+38f);
 				const float decayed_weight = (1 - 0.f * learning_rate) * weight_fp - copysignf(0.f * learning_rate, weight_fp);
 				const float new_weight = decayed_weight - effective_learning_rate * first_moment;

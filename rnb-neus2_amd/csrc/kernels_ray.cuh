@@ -1147,8 +1147,11 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
 		a.numsteps[(size_t)i * 2 + 1] = compacted_base;
 	}
-	if (!__any(compacted_numsteps != 0)) return;
-	const bool ray_live = compacted_numsteps != 0; // a ray without compacted samples writes nothing further (the loss rows stay cleared)
+	const bool ray_live = compacted_numsteps != 0;
+	// a kept ray without compacted samples contributes zeros to the three loss rows (the reference's rows are zero-filled before the
+	// step, Counters::prepare_for_training_steps testbed_nerf.cu:3527-3529; writing the zeros here spares the step a fill launch in front of the next march)
+	if (ray_ok && !ray_live && lane == 0) { a.loss[i] = 0.f; a.ek_loss[i] = 0.f; a.mask_loss[i] = 0.f; }
+	if (!__any(ray_live)) return;
 	const float* coords_in = a.coords + (size_t)base * 7;
 	const half_t* net = a.mlp_out + (size_t)base * 16;
 	float* coords_out = a.coords_compacted + (size_t)compacted_base * 7;
@@ -1309,14 +1312,6 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)
-// Start of a step's ray generation: the four step counters and the first n entries of the three per-ray loss rows (all that
-// k_reduce_losses reads) in one small launch instead of two fills.
-__global__ void k_clear_step(uint32_t* __restrict__ counters, float* __restrict__ loss, const uint32_t row_stride, const uint32_t n) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < 4) counters[i] = 0u;
-	if (i < n) { loss[i] = 0.f; loss[(size_t)row_stride + i] = 0.f; loss[(size_t)row_stride * 2 + i] = 0.f; }
-}
-
 // fill_rollover_and_rescale / fill_rollover (common_device.h:514-535): pad the compacted batch to B by wrapping.
 __device__ __forceinline__ void rollover_body(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords,
                                               const uint64_t first, const uint64_t stride) {

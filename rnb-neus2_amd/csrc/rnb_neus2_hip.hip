@@ -113,6 +113,8 @@ struct rnb_ctx {
 	DevBuf<float> params_fp32, grads, adam_m, adam_v;
 	DevBuf<half_t> params_fp16, params_ema;
 	DevBuf<uint32_t> adam_steps;
+	DevBuf<float> adam_lr_table; // k_adam_lr_table
+	float lr_table_beta1 = -1.f, lr_table_beta2 = -1.f; // the betas the table was filled for
 	DevBuf<float> density_grid, density_grid_tmp, density_mean;
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
@@ -149,6 +151,7 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool march_narrow = false, fwd_bwd_generic = false, loss_wave_per_ray = false;
+		uint32_t fbs_wg_per_cu = 3; // RNB_FBS_WG_PER_CU: workgroups of k_fwd_bwd_sdf per CU (122 VGPRs, 51 KB of LDS: three fit; round 2's 242-register form ran two)
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -495,7 +498,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.B_global = B * c->cfg.world_size; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	a.wimg = !c->wimg_valid ? nullptr : (c->cfg.apply_no_albedo && !c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
-	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2) : c->fwd_grid;
+	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
 	const bool side_streams = c->overlap();
 	c->prof.mark(s, P_NONE);
 	hipEvent_t ev_fb = side_streams ? c->ev_fb : nullptr; // the weight-gradient GEMMs start on the side stream when this kernel is done
@@ -530,13 +533,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		add(DW_1x4, T.dso, T.z1, p_sdf1);
 		add(DW_1x4_ONES, nullptr, T.front, p_sdf1b);
 		for (uint32_t q = d.n; q < 7; ++q) { d.kind[q] = DW_1x4; d.YT[q] = nullptr; d.XT[q] = nullptr; d.partial[q] = nullptr; }
-		if (!a.skip_rgb) hipLaunchKernelGGL(k_dw_all, dim3(nwg * d.n), dim3(WG), 0, sd, d); // seven GEMMs: one launch (0.852 -> 0.831 ms/step)
-		else {
-			hipLaunchKernelGGL((k_dw<1, 4, false>), dim3(nwg), dim3(WG), 0, sd, T.dso, T.z1, B, chunk, p_sdf1);
-			hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz, T.sdfin, B, chunk, p_sdf0);
-			hipLaunchKernelGGL((k_dw<4, 2, false>), dim3(nwg), dim3(WG), 0, sd, T.dz1, T.ddin, B, chunk, p_sdf0b);
-			hipLaunchKernelGGL((k_dw<1, 4, true>), dim3(nwg), dim3(WG), 0, sd, (const half_t*)nullptr, T.front, B, chunk, p_sdf1b);
-		}
+		if (!sdf_only) hipLaunchKernelGGL(k_dw_all, dim3(nwg * d.n), dim3(WG), 0, sd, d); // the generic kernel's feature-major operands: seven (four with --no-albedo) GEMMs in one launch (0.852 -> 0.831 ms/step)
+		else hipLaunchKernelGGL(k_dw_sdf, dim3(nwg), dim3(WG), 0, sd, c->net(false), T.sdfin, T.ddin, T.dso, chunk, p_sdf0, p_sdf0b, p_sdf1, p_sdf1b); // k_fwd_bwd_sdf's sample-major rows
 		DwFinishArgs f;
 		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 		f.n_partials = (uint32_t)slab;
@@ -612,9 +610,19 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 }
 
 // Once per step: learning-rate schedule, step count, EMA debias terms (exponential_decay.h:61-72, ema.h:116-117).
+constexpr uint32_t ADAM_LR_TABLE_N = 1u << 16;
+static void fill_lr_table(rnb_ctx* c, hipStream_t s) { // stream-ordered in front of the optimizer kernels that read it
+	if (c->lr_table_beta1 == c->cfg.beta1 && c->lr_table_beta2 == c->cfg.beta2) return;
+	(void)hipDeviceSynchronize(); // a chunk of the previous step may still be reading the old table (rnb_update_config changed a beta)
+	hipLaunchKernelGGL(k_adam_lr_table, dim3(ADAM_LR_TABLE_N / 256), dim3(256), 0, s, c->adam_lr_table.p, ADAM_LR_TABLE_N, c->cfg.beta1, c->cfg.beta2);
+	(void)hipStreamSynchronize(s); // the optimizer's chunks run on several streams
+	c->lr_table_beta1 = c->cfg.beta1; c->lr_table_beta2 = c->cfg.beta2;
+}
+
 static void optimizer_begin(rnb_ctx* c) {
 	if (c->opt.begun) return;
 	const rnb_config& cfg = c->cfg;
+	fill_lr_table(c, nullptr);
 	const uint32_t step0 = c->optimizer_step_count;
 	if (step0 == 0) c->lr_factor = 1.0f;
 	if (step0 >= cfg.lr_decay_start && (step0 - cfg.lr_decay_start) % cfg.lr_decay_interval == 0 && step0 <= 10000000u) c->lr_factor *= cfg.lr_decay_base;
@@ -628,6 +636,7 @@ static void optimizer_begin(rnb_ctx* c) {
 	a.skip_lo = cfg.only_sdf_training ? (uint64_t)c->off_rgb : 0; a.skip_hi = cfg.only_sdf_training ? (uint64_t)c->off_grid : 0;
 	a.ema_debias_old = 1 - (float)std::pow(cfg.ema_decay, current_step - 1);
 	a.ema_debias_new = 1.0f / (1 - (float)std::pow(cfg.ema_decay, current_step));
+	a.lr_table = c->adam_lr_table.p; a.lr_table_n = (uint32_t)c->adam_lr_table.n;
 	c->opt.begun = true;
 	c->opt.early_done = false;
 }
@@ -809,7 +818,7 @@ int rnb_default_config(rnb_config* cfg) {
 
 int rnb_destroy(rnb_ctx* c) {
 	if (!c) return RNB_OK;
-	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free();
+	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
@@ -874,6 +883,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	do {                                                                                                               \
 		if ((buf).alloc_padded(c->n_params, c->param_capacity) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
 	} while (0)
+	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
 	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
@@ -900,7 +910,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		T.g12 = c->g12.p; T.srec = c->srec.p;
 	}
 	c->fwd_grid = std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus);
-	ALLOC(c->var_partial, (size_t)c->n_cus * 2 * WAVES_PER_WG);
+	ALLOC(c->var_partial, (size_t)c->n_cus * 3 * WAVES_PER_WG);
 	c->ts.var_partial = c->var_partial.p;
 	{ // split-K geometry of the weight-gradient GEMMs: chunk = B / nwg, a multiple of 128 samples
 		const uint32_t units = B / 128;
@@ -951,6 +961,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
+		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = std::max(1, std::min(3, atoi(e)));
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1420,9 +1431,9 @@ static int launch_premarch(rnb_ctx* c) {
 	// fp32 (rnb-neus2_amd/build.py) and with that index read through one cross-lane shuffle instead: 0 of 2000 launches beside
 	// k_fwd_bwd (0 of 1300 for the one-thread-per-ray kernel of the large batches). DESIGN.md section 6.
 	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
-	// counters (Counters::prepare_for_training_steps) + the next loss pass's per-ray rows (k_reduce_losses has read this step's):
-	// off the critical stream, and (integer stores only) already beside k_fwd_bwd
-	hipLaunchKernelGGL(k_clear_step, dim3(std::max(1u, (n_rays + 255) / 256)), dim3(256), 0, c->s_march, c->counters.p, c->loss.p, c->cfg.max_rays_per_batch, n_rays);
+	// No fill in front of the march: every step counter is written with a plain store by the scans (k_scan_rays*, k_scan_compact*), and the
+	// loss rows are written for every kept ray by k_loss_pass2 (zeros for a ray without compacted samples) -- k_reduce_losses reads nothing
+	// else. (Round 2 queued a k_clear_step here: 62 us behind k_fwd_bwd_sdf's workgroups at the head of the march chain.)
 	if (c->knobs.march_late) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
