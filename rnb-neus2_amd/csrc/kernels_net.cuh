@@ -866,7 +866,9 @@ __global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
 //   fr^T  = ddin W0^T    m-tiles are the 8 K-values (K = samples) an A operand of the weight-gradient GEMM needs -- no transpose
 //   dz    = relu'(z1) (.) half(w1 * dL/dsdf),   front = relu'(z1) (.) half(fr)        (same roundings as k_fwd_bwd_sdf / k_fwd_bwd)
 //   in^T, ddin^T         the B operands (input feature in the lane, 8 samples in registers): MFMA against the identity (exact)
-//   dW0 += dz in^T (64x32), dW0' += front ddin^T (64x32)   MFMA, K = the tile's samples;   dW1[0,:] += dL/dsdf . z1, dW1'[0,:] += sum front (VALU)
+//   dz1   = relu'(z1) (.) w1                                                         (d sdf / d z1, the double backward's d L / d front)
+//   dW0 += dz in^T (64x32), dW0' += dz1 ddin^T (64x32)     MFMA, K = the tile's samples;   dW1[0,:] += dL/dsdf . z1, dW1'[0,:] += sum front (VALU)
+//   (first order: fully_fused_mlp.cu:953-1030; second order: fully_fused_mlp.cu:1097-1131)
 // Partials per workgroup in k_dw's layout (k_dw_finish sums them in a fixed order). 80 MFMAs and 192 bytes read per tile.
 __global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* __restrict__ in_sm, const half_t* __restrict__ dd_sm, const half_t* __restrict__ dsdf, const uint32_t chunk,
                                                   float* __restrict__ p_w0, float* __restrict__ p_w0b, float* __restrict__ p_w1, float* __restrict__ p_w1b) {
@@ -919,7 +921,8 @@ __global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* 
 				}
 #pragma unroll
 		for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
-			h8 a_dz[2], a_fr[2];
+			h8 a_dz[2], a_dz1[2];
+			const half_t w1h = w1s[16 * nt + r16];
 #pragma unroll
 			for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* 
 						acc1[nt] += on ? d * h2f(zh) : 0.f;
 						acc1b[nt] += h2f(frv);
 						a_dz[ks][4 * h + r] = dzv;
-						a_fr[ks][4 * h + r] = frv;
+						a_dz1[ks][4 * h + r] = on ? w1h : (half_t)0.f;
 					}
 				}
 #pragma unroll
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* 
 #pragma unroll
 				for (int ni = 0; ni < 2; ++ni) {
 					acc_w0[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz[ks], b_in[ni][ks], acc_w0[nt][ni], 0, 0, 0);
-					acc_w0b[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_fr[ks], b_dd[ni][ks], acc_w0b[nt][ni], 0, 0, 0);
+					acc_w0b[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz1[ks], b_dd[ni][ks], acc_w0b[nt][ni], 0, 0, 0);
 				}
 		}
 	}

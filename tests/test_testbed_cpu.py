@@ -299,3 +299,32 @@ def test_snapshot_carries_the_whole_network_config(install, tmp_path):
     want = two_steps(learning_rate=3e-3, beta2=0.95, l2_reg=1e-5, ema_decay=0.9, lr_decay_start=3, lr_decay_interval=2, lr_decay_base=0.5)
     np.testing.assert_array_equal(got, want)
     assert np.any(got != two_steps())  # the library defaults give another result: the test would catch the old behaviour
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0], at its exact shape
+@pytest.mark.timeout(900)
+def test_config_1_single_256x256_view_200_steps(install, tmp_path):
+    """BASELINE.json configs[0]: "Single 256x256 view, normals+mask only, 200 steps on CPU reference path (plumbing, no GPU)" --
+    SURVEY.md section 8d's generator with 1 view, 256 x 256, fx = 448, through the reference's command line (stage 1 flags of the
+    pipeline) on the CPU checker. The network is tests/conftest.py's SMALL_CFG (4 levels, 2^12 samples per step: the full network
+    costs the checker ~1.4 s per step on 256 cores, this one 200 steps in well under a minute on 8); everything else is the
+    product's host code. A single view cannot pin the geometry, so the test checks the plumbing: 200 steps, the progress lines,
+    a finite and falling loss, the snapshot and a closed mesh."""
+    scene = tmp_path / "one_view"
+    views, normals, albedos = synthetic.make_scene(1, 256, 448.0)
+    assert len(views) == 1 and views[0]["width"] == views[0]["height"] == 256 and views[0]["focal_length"][0] == 448.0
+    synthetic.write_scene(str(scene), views, normals, albedos, scale=0.5, offset=(0.5, 0.5, 0.5))
+    r = run(install, "--scene", str(scene) + "/", "--maxiter", 200, "--no-gui", "--mask-weight", 1.0, "--no-albedo", "--config", "small.json",
+            "--save-snapshot", "--save-mesh", "--resolution", 48)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Number of iterations : 200" in r.stdout
+    losses = [float(l.split("loss=")[1]) for l in r.stdout.splitlines() if l.startswith("iteration=")]
+    assert [l.split()[0] for l in r.stdout.splitlines() if l.startswith("iteration=")] == ["iteration=100"]  # every 100 steps, not at maxiter (src/main.cu:444-451)
+    assert all(np.isfinite(losses)) and losses[0] > 0
+    out = scene / "output"
+    assert (out / "snapshot_200.msgpack").exists() and (out / "mesh_200.obj").exists() and (out / "log.txt").exists()
+    import msgpack
+    snap = msgpack.unpackb((out / "snapshot_200.msgpack").read_bytes(), raw=False)["snapshot"]
+    assert snap["training_step"] == 200 and np.isfinite(snap["loss"])
+    n_v = sum(1 for l in open(out / "mesh_200.obj") if l.startswith("v "))
+    assert n_v > 50
