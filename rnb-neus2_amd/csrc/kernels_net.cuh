@@ -324,6 +324,7 @@ struct TrainArgs {
 	uint32_t skip_rgb; // --no-albedo: dL/d(rgb logits) is identically 0 (opti_rgb = 0, testbed_nerf.cu:1954-1962), so the
 	                   // colour MLP receives and propagates exact zeros: its forward/backward are skipped, not approximated
 	const half_t* wimg; // optional: k_fwd_bwd_sdf's LDS weight image prepared by k_prepare_weight_images
+	float *dw_w0, *dw_w0b, *dw_w1, *dw_w1b; // k_fwd_bwd_sdf: one partial per workgroup of the four SDF-MLP weight gradients (k_dw's layout)
 	TrainScratch t;
 };
 
@@ -615,15 +616,25 @@ __global__ __launch_bounds__(WG, 1) void k_fwd_bwd(const GridMeta G, const NetW 
 //   dso = e0 * dL/dsdf                    dz = (W1^T dso) (.) relu'(z1) = dL/dsdf * dz1  (one product per element: the
 //                                         GEMM's other 15 K-terms are zeros)   dL/d in = W0^T dz           (-> g1)
 //   ddin = [dn | dy_dx . dn]              front = (W0 ddin) (.) relu'(z1)
-// Weight gradients (round 3): the kernel exports only what cannot be recomputed cheaply -- per sample the two 32-wide rows `in` and
-// `ddin` (sample-major, 64 B each, 4 coalesced 16-byte stores per lane) and dL/dsdf -- and k_dw_sdf rebuilds z1, dz and front from them
-// on the matrix cores (MFMA is 3 % busy on this path) in the orientation its GEMMs need. Round 2 exported z1, dz1, dz, front, dso and both
-// inputs feature-major, 672 B per sample of 2-byte stores (176 MB per step, read back by four GEMM launches beside the atomic-bound scatter).
+// Weight gradients (round 3): accumulated HERE, per wavefront, over all its tiles -- no operand export, no GEMM launches beside the
+// scatter. K of those GEMMs is the sample index, and every activation of this kernel lives as "8 features of one sample per lane"; what
+// the GEMMs need is "8 samples of one feature per lane". Both are obtained on the matrix cores (3 % busy on this path) instead of through
+// memory: per 64-sample tile, from the two sample-major input tiles X (in) and D (ddin) and dL/dsdf in LDS,
+//   z1^T  = in W0^T      MFMA with the SAMPLES as M and the hidden units as N: D puts 4 samples of one hidden unit in a lane, so two
+//   fr^T  = ddin W0^T    m-tiles are the 8 K-values an A operand of the weight-gradient GEMM needs
+//   dz    = relu'(z1) (.) half(w1 * dL/dsdf),   dz1 = relu'(z1) (.) w1,   front = relu'(z1) (.) half(fr)   (the roundings of k_fwd_bwd)
+//   in^T, ddin^T         the B operands (input column in the lane, 8 samples in registers): MFMA against the identity (exact)
+//   dW0 += dz in^T, dW0' += dz1 ddin^T (64x32 each, MFMA);   dW1[0,:] += dL/dsdf . z1,  dW1'[0,:] += sum front   (VALU)
+//   (first order: fully_fused_mlp.cu:953-1030; second order: fully_fused_mlp.cu:1097-1131)
+// 80 MFMAs per tile, 72 accumulator registers; the workgroup's four wavefronts are summed in LDS at the end and leave ONE partial per
+// workgroup, which k_dw_finish sums in a fixed order (deterministic). Round 2 exported z1, dz1, dz, front, dso and both inputs
+// feature-major (672 B per sample of 2-byte stores, 176 MB per step) to four GEMM launches that ran 190 us beside the atomic-bound scatter.
 // ---------------------------------------------------------------------------------------------
 constexpr int SW_S0 = 0;                    // [64][S32] sdf W0, input columns in tile order (below)
 constexpr int SW_S0T = SW_S0 + 64 * S32;    // [32][S64] sdf W0^T, rows in tile order, columns in chain order
 constexpr int SW_W1 = SW_S0T + 32 * S64;    // [64] sdf W1 row 0 in chain order
-constexpr int SW_END = SW_W1 + 64;
+constexpr int SW_W1N = SW_W1 + 64;          // [64] the same row in natural order (weight-gradient block)
+constexpr int SW_END = SW_W1N + 64;
 constexpr int SW_END_PADDED = (SW_END + 7) / 8 * 8;
 constexpr int FBS_WAVE_HALFS = 2 * TILE * S32 + TILE; // two 32-wide tiles (network input / second-order input) + one half per sample
 constexpr size_t LDS_FBS = (size_t)(SW_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
@@ -634,7 +645,7 @@ __host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (
 __device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
 	for (int i = tid; i < 64 * 32; i += nthreads) { const int o = i >> 5, p = i & 31; w[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
 	for (int i = tid; i < 32 * 64; i += nthreads) { const int q = i >> 6, p = i & 63; w[SW_S0T + q * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + fbs_logical(q)]; }
-	for (int i = tid; i < 64; i += nthreads) w[SW_W1 + i] = net.sdf_w1[chain_logical(i)];
+	for (int i = tid; i < 64; i += nthreads) { w[SW_W1 + i] = net.sdf_w1[chain_logical(i)]; w[SW_W1N + i] = net.sdf_w1[i]; }
 	for (int i = SW_END + tid; i < SW_END_PADDED; i += nthreads) w[i] = (half_t)0.f;
 	// (row padding of the images is never read)
 }
@@ -663,7 +674,7 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 		}
 }
 
-__global__ __launch_bounds__(WG, 3) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
@@ -681,6 +692,12 @@ __global__ __launch_bounds__(WG, 3) void k_fwd_bwd_sdf(const GridMeta G, const N
 	const uint32_t n_tiles = B / TILE;
 	const TrainScratch& T = a.t;
 	float var_sum = 0.f;
+	f4 acc_w0[4][2], acc_w0b[4][2]; // weight-gradient accumulators of this wavefront (all its tiles)
+	float acc_w1[4] = {0.f, 0.f, 0.f, 0.f}, acc_w1b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+		for (int ni = 0; ni < 2; ++ni) { acc_w0[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; acc_w0b[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; }
 	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
 		const uint32_t s = tile * TILE + lane;
 		float c[3];
@@ -728,15 +745,67 @@ __global__ __launch_bounds__(WG, 3) void k_fwd_bwd_sdf(const GridMeta G, const N
 			Drow[14] = pack_h2(n0, n1); Drow[15] = pack_h2(n2, (half_t)0.f);
 		}
 		Z[lane] = dout[3];
-		// dL/dsdf (only that row of dso survives, add_density_gradient), variance gradient
-		T.dso[s] = (half_t)0.f + dout[3];
-		var_sum += h2f(dout[7]);
+		var_sum += h2f(dout[7]); // variance gradient
 		wave_lds_sync();
-		{ // this sample's rows of the two 32-wide inputs, in tile order (fbs_logical), for k_dw_sdf
-			h8* gi = reinterpret_cast<h8*>(T.sdfin + (size_t)s * 32);
-			h8* gd = reinterpret_cast<h8*>(T.ddin + (size_t)s * 32);
+		{ // ---- weight gradients of this tile (see the header) ----
+			h8 ain[4], add[4];
+			h4 d3v[4];
 #pragma unroll
-			for (int q = 0; q < 4; ++q) { gi[q] = *reinterpret_cast<const h8*>(X + lane * S32 + 8 * q); gd[q] = *reinterpret_cast<const h8*>(D + lane * S32 + 8 * q); }
+			for (int mt = 0; mt < 4; ++mt) {
+				ain[mt] = *reinterpret_cast<const h8*>(X + (16 * mt + r16) * S32 + 8 * hq);
+				add[mt] = *reinterpret_cast<const h8*>(D + (16 * mt + r16) * S32 + 8 * hq);
+				d3v[mt] = *reinterpret_cast<const h4*>(Z + 16 * mt + 4 * hq);
+			}
+			const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+			// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
+			h8 b_in[2][2], b_dd[2][2];
+#pragma unroll
+			for (int n2 = 0; n2 < 2; ++n2) {
+				h8 idf;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) idf[j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const f4 ti = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[2 * ks + h], idf, zero4, 0, 0, 0);
+						const f4 td = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[2 * ks + h], idf, zero4, 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) { b_in[n2][ks][4 * h + r] = f2h(ti[r]); b_dd[n2][ks][4 * h + r] = f2h(td[r]); }
+					}
+			}
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
+				const h8 wbn = *reinterpret_cast<const h8*>(wts + SW_S0 + (16 * nt + r16) * S32 + 8 * hq);
+				const half_t w1h = wts[SW_W1N + 16 * nt + r16];
+				const float w1f = h2f(w1h);
+				h8 a_dz[2], a_dz1[2];
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int mt = 2 * ks + h;
+						const f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
+						const f4 fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							const half_t zh = f2h(z[r]);
+							const bool on = zh > (half_t)0.f; // relu' tests the stored half activation (common_device.h:182 ff.)
+							const float d = h2f(d3v[mt][r]);
+							acc_w1[nt] += on ? d * h2f(zh) : 0.f;
+							acc_w1b[nt] += on ? h2f(f2h(fr[r])) : 0.f;
+							a_dz[ks][4 * h + r] = on ? f2h(w1f * d) : (half_t)0.f;
+							a_dz1[ks][4 * h + r] = on ? w1h : (half_t)0.f;
+						}
+					}
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int ni = 0; ni < 2; ++ni) {
+						acc_w0[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz[ks], b_in[ni][ks], acc_w0[nt][ni], 0, 0, 0);
+						acc_w0b[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz1[ks], b_dd[ni][ks], acc_w0b[nt][ni], 0, 0, 0);
+					}
+			}
 		}
 		// z1 = relu(W0 in), kept as next-layer fragments; its relu' mask in fragment order
 		h8 bz[4][2];
@@ -788,6 +857,36 @@ __global__ __launch_bounds__(WG, 3) void k_fwd_bwd_sdf(const GridMeta G, const N
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) var_sum += __shfl_down(var_sum, off, 64);
 	if (lane == 0) T.var_partial[blockIdx.x * WAVES_PER_WG + wave] = var_sum;
+	// The four wavefronts' weight gradients, summed in a fixed order, leave as ONE partial per workgroup in k_dw's layout. The per-wave
+	// tiles are dead: their LDS is the staging area. D layout: lane = input column 16 ni + r16 (tile order), register r = hidden unit 16 mo + 4 hq + r.
+	float* red = reinterpret_cast<float*>(wts + SW_END);
+	static_assert((size_t)WAVES_PER_WG * FBS_WAVE_HALFS * sizeof(half_t) >= (size_t)WAVES_PER_WG * 64 * 32 * sizeof(float), "staging area of the weight-gradient partials");
+	constexpr int N = 64 * 32;
+	for (int pass = 0; pass < 2; ++pass) {
+		__syncthreads();
+#pragma unroll
+		for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+			for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) red[wave * N + (16 * mo + 4 * hq + r) * 32 + fbs_logical(16 * ni + r16)] = pass ? acc_w0b[mo][ni][r] : acc_w0[mo][ni][r];
+		__syncthreads();
+		float* dst = (pass ? a.dw_w0b : a.dw_w0) + (size_t)blockIdx.x * N;
+		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
+	}
+	// row 0 of the two 16x64 gradients of W1: per lane the sum over its samples; 16 lane groups (wave, hq) per hidden unit
+	for (int pass = 0; pass < 2; ++pass) {
+		__syncthreads();
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) red[(wave * 4 + hq) * 64 + 16 * nt + r16] = pass ? acc_w1b[nt] : acc_w1[nt];
+		__syncthreads();
+		float* dst = (pass ? a.dw_w1b : a.dw_w1) + (size_t)blockIdx.x * (16 * 64);
+		for (int q = threadIdx.x; q < 16 * 64; q += WG) {
+			float v = 0.f;
+			if (q < 64) for (int g = 0; g < 16; ++g) v += red[g * 64 + q];
+			dst[q] = v; // rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -857,127 +956,6 @@ __global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
 		case DW_4x4: dw_body<4, 4, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
 		case DW_4x2: dw_body<4, 2, false>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
 		default: dw_body<1, 4, true>(a.YT[g], a.XT[g], a.B, a.chunk, a.partial[g], wg, red); break;
-	}
-}
-
-// --no-albedo: all four weight-gradient GEMMs of the SDF MLP in one kernel that rebuilds its operands (see k_fwd_bwd_sdf's header).
-// Per 64-sample tile, from the exported sample-major rows `in`, `ddin` [B][32] (columns in tile order, fbs_logical) and dL/dsdf [B]:
-//   z1^T  = in W0^T      MFMA with the SAMPLES as M and the hidden units as N: D puts 4 samples of one hidden unit in a lane, so two
-//   fr^T  = ddin W0^T    m-tiles are the 8 K-values (K = samples) an A operand of the weight-gradient GEMM needs -- no transpose
-//   dz    = relu'(z1) (.) half(w1 * dL/dsdf),   front = relu'(z1) (.) half(fr)        (same roundings as k_fwd_bwd_sdf / k_fwd_bwd)
-//   in^T, ddin^T         the B operands (input feature in the lane, 8 samples in registers): MFMA against the identity (exact)
-//   dz1   = relu'(z1) (.) w1                                                         (d sdf / d z1, the double backward's d L / d front)
-//   dW0 += dz in^T (64x32), dW0' += dz1 ddin^T (64x32)     MFMA, K = the tile's samples;   dW1[0,:] += dL/dsdf . z1, dW1'[0,:] += sum front (VALU)
-//   (first order: fully_fused_mlp.cu:953-1030; second order: fully_fused_mlp.cu:1097-1131)
-// Partials per workgroup in k_dw's layout (k_dw_finish sums them in a fixed order). 80 MFMAs and 192 bytes read per tile.
-__global__ __launch_bounds__(WG, 1) void k_dw_sdf(const NetW net, const half_t* __restrict__ in_sm, const half_t* __restrict__ dd_sm, const half_t* __restrict__ dsdf, const uint32_t chunk,
-                                                  float* __restrict__ p_w0, float* __restrict__ p_w0b, float* __restrict__ p_w1, float* __restrict__ p_w1b) {
-	__shared__ __attribute__((aligned(16))) half_t w0[64 * S32];
-	__shared__ half_t w1s[64];
-	__shared__ float red[WAVES_PER_WG * 64 * 32];
-	for (int i = threadIdx.x; i < 64 * 32; i += WG) { const int o = i >> 5, p = i & 31; w0[o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
-	if (threadIdx.x < 64) w1s[threadIdx.x] = net.sdf_w1[threadIdx.x];
-	__syncthreads();
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int r16 = lane & 15, hq = lane >> 4;
-	h8 wb[4], idf[2];
-	float w1v[4];
-#pragma unroll
-	for (int nt = 0; nt < 4; ++nt) { wb[nt] = *reinterpret_cast<const h8*>(w0 + (16 * nt + r16) * S32 + 8 * hq); w1v[nt] = h2f(w1s[16 * nt + r16]); }
-#pragma unroll
-	for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-		for (int j = 0; j < 8; ++j) idf[n2][j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
-	f4 acc_w0[4][2], acc_w0b[4][2];
-	float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc1b[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-	for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-		for (int ni = 0; ni < 2; ++ni) { acc_w0[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; acc_w0b[mo][ni] = f4{0.f, 0.f, 0.f, 0.f}; }
-	const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-	const uint32_t tiles = chunk / TILE, tile0 = blockIdx.x * tiles;
-	for (uint32_t tile = tile0 + wave; tile < tile0 + tiles; tile += WAVES_PER_WG) {
-		const size_t s0 = (size_t)tile * TILE;
-		h8 ain[4], add[4];
-		h4 d3[4];
-#pragma unroll
-		for (int mt = 0; mt < 4; ++mt) {
-			ain[mt] = *reinterpret_cast<const h8*>(in_sm + (s0 + 16 * mt + r16) * 32 + 8 * hq);
-			add[mt] = *reinterpret_cast<const h8*>(dd_sm + (s0 + 16 * mt + r16) * 32 + 8 * hq);
-			d3[mt] = *reinterpret_cast<const h4*>(dsdf + s0 + 16 * mt + 4 * hq);
-		}
-		// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
-		h8 b_in[2][2], b_dd[2][2];
-#pragma unroll
-		for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-			for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const f4 ti = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[2 * ks + h], idf[n2], zero4, 0, 0, 0);
-					const f4 td = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[2 * ks + h], idf[n2], zero4, 0, 0, 0);
-#pragma unroll
-					for (int r = 0; r < 4; ++r) { b_in[n2][ks][4 * h + r] = f2h(ti[r]); b_dd[n2][ks][4 * h + r] = f2h(td[r]); }
-				}
-#pragma unroll
-		for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
-			h8 a_dz[2], a_dz1[2];
-			const half_t w1h = w1s[16 * nt + r16];
-#pragma unroll
-			for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int mt = 2 * ks + h;
-					const f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wb[nt], zero4, 0, 0, 0);
-					const f4 fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wb[nt], zero4, 0, 0, 0);
-#pragma unroll
-					for (int r = 0; r < 4; ++r) {
-						const half_t zh = f2h(z[r]);
-						const bool on = zh > (half_t)0.f; // relu' tests the stored half activation (common_device.h:182 ff.)
-						const float d = h2f(d3[mt][r]);
-						const half_t dzv = on ? f2h(w1v[nt] * d) : (half_t)0.f;
-						const half_t frv = on ? f2h(fr[r]) : (half_t)0.f;
-						acc1[nt] += on ? d * h2f(zh) : 0.f;
-						acc1b[nt] += h2f(frv);
-						a_dz[ks][4 * h + r] = dzv;
-						a_dz1[ks][4 * h + r] = on ? w1h : (half_t)0.f;
-					}
-				}
-#pragma unroll
-			for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-				for (int ni = 0; ni < 2; ++ni) {
-					acc_w0[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz[ks], b_in[ni][ks], acc_w0[nt][ni], 0, 0, 0);
-					acc_w0b[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz1[ks], b_dd[ni][ks], acc_w0b[nt][ni], 0, 0, 0);
-				}
-		}
-	}
-	// the four waves' partials, summed in a fixed order; D layout: lane = input column 16 ni + r16 (tile order), register r = hidden unit 16 mo + 4 hq + r
-	constexpr int N = 64 * 32;
-	for (int pass = 0; pass < 2; ++pass) {
-		__syncthreads();
-#pragma unroll
-		for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-			for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-				for (int r = 0; r < 4; ++r) red[wave * N + (16 * mo + 4 * hq + r) * 32 + fbs_logical(16 * ni + r16)] = pass ? acc_w0b[mo][ni][r] : acc_w0[mo][ni][r];
-		__syncthreads();
-		float* dst = (pass ? p_w0b : p_w0) + (size_t)blockIdx.x * N;
-		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
-	}
-	// row 0 of the two 16x64 gradients of W1: per lane the sum over its samples; 16 lane groups (wave, hq) per hidden unit
-	for (int pass = 0; pass < 2; ++pass) {
-		__syncthreads();
-#pragma unroll
-		for (int nt = 0; nt < 4; ++nt) red[(wave * 4 + hq) * 64 + 16 * nt + r16] = pass ? acc1b[nt] : acc1[nt];
-		__syncthreads();
-		float* dst = (pass ? p_w1b : p_w1) + (size_t)blockIdx.x * (16 * 64);
-		for (int q = threadIdx.x; q < 16 * 64; q += WG) {
-			float v = 0.f;
-			if (q < 64) for (int g = 0; g < 16; ++g) v += red[g * 64 + q];
-			dst[q] = v; // rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
-		}
 	}
 }
 
@@ -1191,33 +1169,40 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 // One L2 atomic per corner. Four adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a
 // cell is the next table entry on dense levels and for even x on hashed ones (hash prime 1), so the four lanes' atomics mostly
 // fall on 16 contiguous bytes of one cache line and travel as one request; each lane issues the 4 (dy, dz) corners.
-__global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, const ScatterArgs a, const uint32_t level0) {
+// Both atomic kernels run as a capped number of workgroups that walk "virtual" workgroups (blockIdx.x, + gridDim.x, ...): the atomic unit
+// is saturated by a few workgroups per CU (tools/probe_atomics4.hip: 64 workgroups reach the rate of 4096), and every further resident
+// wavefront only takes a slot from the kernels of the side streams (march, optimizer chunks), which were starved beside the scatter
+// (k_march_write 48 -> 186 us beside the one-shot grid of 65 k wavefronts, profiles/r03_*).
+__global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) {
 	const uint32_t level = blockIdx.y + level0;
 	if (level > G.valid_level) return;
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t s = t >> 2;
-	if (s >= a.B) return;
-	const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
 	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
 	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
 	const float scale = G.scale[level];
 	const uint32_t res = G.resolution[level];
-	const ScatterSample sm = load_srec(a.srec, s);
-	float pos[3];
-	uint32_t pg[3];
-	pos_fract(sm.x, scale, &pos[0], &pg[0]);
-	pos_fract(sm.y, scale, &pos[1], &pg[1]);
-	pos_fract(sm.z, scale, &pos[2], &pg[2]);
-	const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
-	const float g1 = h2f(unpack_h2(q12.x)[f]);
-	const float g2 = h2f(unpack_h2(q12.y)[f]);
+#pragma unroll 1
+	for (uint32_t vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+		const uint32_t t = vb * blockDim.x + threadIdx.x;
+		const uint32_t s = t >> 2;
+		if (s >= a.B) continue;
+		const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+		const ScatterSample sm = load_srec(a.srec, s);
+		float pos[3];
+		uint32_t pg[3];
+		pos_fract(sm.x, scale, &pos[0], &pg[0]);
+		pos_fract(sm.y, scale, &pos[1], &pg[1]);
+		pos_fract(sm.z, scale, &pos[2], &pg[2]);
+		const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
+		const float g1 = h2f(unpack_h2(q12.x)[f]);
+		const float g2 = h2f(unpack_h2(q12.y)[f]);
 #pragma unroll
-	for (uint32_t yz = 0; yz < 4; ++yz) {
-		const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
-		const float add = corner_addend(g1, g2, scale, sm.dn, pos, c);
-		if (add != 0.f) {
-			const uint32_t e = grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]);
-			atomicAdd(gg + (size_t)e * 2 + f, add);
+		for (uint32_t yz = 0; yz < 4; ++yz) {
+			const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+			const float add = corner_addend(g1, g2, scale, sm.dn, pos, c);
+			if (add != 0.f) {
+				const uint32_t e = grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]);
+				atomicAdd(gg + (size_t)e * 2 + f, add);
+			}
 		}
 	}
 }
@@ -1231,55 +1216,67 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 struct ScatterRlPlan { uint32_t n; uint32_t wg_start[17]; uint64_t k_log2; };
 
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) {
-	uint32_t li = 0;
 #pragma unroll 1
-	for (uint32_t q = 1; q < plan.n; ++q) if (blockIdx.x >= plan.wg_start[q]) li = q;
-	const uint32_t level = level0 + li;
-	const uint32_t K = 1u << ((plan.k_log2 >> (4 * li)) & 15u);
-	if (level > G.valid_level) return;
-	const uint32_t t = (blockIdx.x - plan.wg_start[li]) * blockDim.x + threadIdx.x;
-	const uint32_t s0 = (t >> 2) * K;
-	if (s0 >= a.B) return;
-	const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
-	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
-	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
-	const float scale = G.scale[level];
-	const uint32_t res = G.resolution[level];
-	float acc[4] = {0.f, 0.f, 0.f, 0.f};
-	uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-	auto flush = [&]() {
+	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) { // virtual workgroups (see k_grid_scatter_quad)
+		uint32_t li = 0;
+#pragma unroll 1
+		for (uint32_t q = 1; q < plan.n; ++q) if (vb >= plan.wg_start[q]) li = q;
+		const uint32_t level = level0 + li;
+		const uint32_t K = 1u << ((plan.k_log2 >> (4 * li)) & 15u);
+		if (level > G.valid_level) continue;
+		const uint32_t t = (vb - plan.wg_start[li]) * blockDim.x + threadIdx.x;
+		const uint32_t s0 = (t >> 2) * K;
+		if (s0 >= a.B) continue;
+		const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+		float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+		const float scale = G.scale[level];
+		const uint32_t res = G.resolution[level];
+		float acc[4] = {0.f, 0.f, 0.f, 0.f};
+		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+		auto flush = [&]() {
 #pragma unroll
-		for (uint32_t yz = 0; yz < 4; ++yz) {
-			if (acc[yz] != 0.f) {
-				const uint32_t e = grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1));
-				atomicAdd(gg + (size_t)e * 2 + f, acc[yz]);
-				acc[yz] = 0.f;
+			for (uint32_t yz = 0; yz < 4; ++yz) {
+				if (acc[yz] != 0.f) {
+					const uint32_t e = grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1));
+					atomicAdd(gg + (size_t)e * 2 + f, acc[yz]);
+					acc[yz] = 0.f;
+				}
+			}
+		};
+		const uint32_t s_end = min(s0 + K, a.B);
+		const uint2* g12l = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+		// the loads of a walk are issued four samples ahead (a dependent load per sample made the walk latency-bound: 107 us for a 68 us floor)
+		constexpr uint32_t C = 4;
+#pragma unroll 1
+		for (uint32_t sc = s0; sc < s_end; sc += C) {
+			ScatterSample sm[C];
+			uint2 q12[C];
+#pragma unroll
+			for (uint32_t j = 0; j < C; ++j) { const uint32_t s = min(sc + j, s_end - 1); sm[j] = load_srec(a.srec, s); q12[j] = g12l[s]; }
+#pragma unroll
+			for (uint32_t j = 0; j < C; ++j) {
+				if (sc + j >= s_end) break;
+				float pos[3];
+				uint32_t pg[3];
+				pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
+				pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
+				pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
+				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+					if (cur[0] != 0xffffffffu) flush();
+					cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+				}
+				const float g1 = h2f(unpack_h2(q12[j].x)[f]);
+				const float g2 = h2f(unpack_h2(q12[j].y)[f]);
+#pragma unroll
+				for (uint32_t yz = 0; yz < 4; ++yz) {
+					const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+					acc[yz] += corner_addend(g1, g2, scale, sm[j].dn, pos, c);
+				}
 			}
 		}
-	};
-	const uint32_t s_end = min(s0 + K, a.B);
-#pragma unroll 1
-	for (uint32_t s = s0; s < s_end; ++s) {
-		const ScatterSample sm = load_srec(a.srec, s);
-		float pos[3];
-		uint32_t pg[3];
-		pos_fract(sm.x, scale, &pos[0], &pg[0]);
-		pos_fract(sm.y, scale, &pos[1], &pg[1]);
-		pos_fract(sm.z, scale, &pos[2], &pg[2]);
-		if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-			if (cur[0] != 0xffffffffu) flush();
-			cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-		}
-		const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
-		const float g1 = h2f(unpack_h2(q12.x)[f]);
-		const float g2 = h2f(unpack_h2(q12.y)[f]);
-#pragma unroll
-		for (uint32_t yz = 0; yz < 4; ++yz) {
-			const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
-			acc[yz] += corner_addend(g1, g2, scale, sm.dn, pos, c);
-		}
+		flush();
 	}
-	flush();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -151,7 +151,8 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool march_narrow = false, fwd_bwd_generic = false, loss_wave_per_ray = false;
-		uint32_t fbs_wg_per_cu = 3; // RNB_FBS_WG_PER_CU: workgroups of k_fwd_bwd_sdf per CU (122 VGPRs, 51 KB of LDS: three fit; round 2's 242-register form ran two)
+		uint32_t scatter_wg_per_cu = 0; // RNB_SCATTER_WG_PER_CU: resident workgroups of the atomic scatter kernels per CU (0 = one workgroup per 64 samples, round 2's launch)
+		uint32_t fbs_wg_per_cu = 2; // RNB_FBS_WG_PER_CU: workgroups of k_fwd_bwd_sdf per CU (its launch bounds allow two)
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -499,6 +500,20 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	a.wimg = !c->wimg_valid ? nullptr : (c->cfg.apply_no_albedo && !c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
+	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own
+	const size_t slab = sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
+	float* p_rgb2; float* p_rgb1; float* p_rgb0; float* p_sdf1; float* p_sdf0; float* p_sdf0b; float* p_sdf1b;
+	{
+		float* p = c->dw_partial.p;
+		p_rgb2 = p;  p += slab * 16 * 64;
+		p_rgb1 = p;  p += slab * 64 * 64;
+		p_rgb0 = p;  p += slab * 64 * 32;
+		p_sdf1 = p;  p += slab * 16 * 64;
+		p_sdf0 = p;  p += slab * 64 * 32;
+		p_sdf0b = p; p += slab * 64 * 32;
+		p_sdf1b = p; p += slab * 16 * 64;
+	}
+	a.dw_w0 = p_sdf0; a.dw_w0b = p_sdf0b; a.dw_w1 = p_sdf1; a.dw_w1b = p_sdf1b;
 	const bool side_streams = c->overlap();
 	c->prof.mark(s, P_NONE);
 	hipEvent_t ev_fb = side_streams ? c->ev_fb : nullptr; // the weight-gradient GEMMs start on the side stream when this kernel is done
@@ -511,15 +526,6 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	// ---- weight-gradient GEMMs (MFMA / streaming)
 	auto launch_dw = [&](hipStream_t sd, hipEvent_t done) {
 		const uint32_t nwg = c->dw_nwg, chunk = c->dw_chunk;
-		const size_t slab = (size_t)nwg; // one partial per workgroup
-		float* p = c->dw_partial.p;
-		float* p_rgb2 = p;                      p += slab * 16 * 64;
-		float* p_rgb1 = p;                      p += slab * 64 * 64;
-		float* p_rgb0 = p;                      p += slab * 64 * 32;
-		float* p_sdf1 = p;                      p += slab * 16 * 64;
-		float* p_sdf0 = p;                      p += slab * 64 * 32;
-		float* p_sdf0b = p;                     p += slab * 64 * 32;
-		float* p_sdf1b = p;                     p += slab * 16 * 64;
 		DwAllArgs d;
 		d.n = 0; d.nwg = nwg; d.B = B; d.chunk = chunk;
 		auto add = [&](uint32_t kind, const half_t* yt, const half_t* xt, float* part) { d.kind[d.n] = kind; d.YT[d.n] = yt; d.XT[d.n] = xt; d.partial[d.n] = part; ++d.n; };
@@ -533,8 +539,9 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		add(DW_1x4, T.dso, T.z1, p_sdf1);
 		add(DW_1x4_ONES, nullptr, T.front, p_sdf1b);
 		for (uint32_t q = d.n; q < 7; ++q) { d.kind[q] = DW_1x4; d.YT[q] = nullptr; d.XT[q] = nullptr; d.partial[q] = nullptr; }
-		if (!sdf_only) hipLaunchKernelGGL(k_dw_all, dim3(nwg * d.n), dim3(WG), 0, sd, d); // the generic kernel's feature-major operands: seven (four with --no-albedo) GEMMs in one launch (0.852 -> 0.831 ms/step)
-		else hipLaunchKernelGGL(k_dw_sdf, dim3(nwg), dim3(WG), 0, sd, c->net(false), T.sdfin, T.ddin, T.dso, chunk, p_sdf0, p_sdf0b, p_sdf1, p_sdf1b); // k_fwd_bwd_sdf's sample-major rows
+		// the generic kernel's feature-major operands: seven (four with --no-albedo) GEMMs in one launch (0.852 -> 0.831 ms/step); k_fwd_bwd_sdf has
+		// accumulated its weight gradients itself and left one partial per workgroup
+		if (!sdf_only) hipLaunchKernelGGL(k_dw_all, dim3(nwg * d.n), dim3(WG), 0, sd, d);
 		DwFinishArgs f;
 		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 		f.n_partials = (uint32_t)slab;
@@ -553,7 +560,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
-		if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3((B * 4 + 255) / 256, l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0);
+		const uint32_t n_vb = (B * 4 + 255) / 256, cap = c->knobs.scatter_wg_per_cu ? std::max(1u, (uint32_t)c->n_cus * c->knobs.scatter_wg_per_cu / (l1 - l0)) : n_vb;
+		if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
@@ -563,7 +571,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		uint32_t wg = 0;
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + sg.Ks[e_c + q] - 1) / sg.Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
-		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(wg), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+		const uint32_t cap_rl = c->knobs.scatter_wg_per_cu ? (uint32_t)c->n_cus * c->knobs.scatter_wg_per_cu : wg;
+		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
 		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -919,7 +928,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		c->dw_nwg = nwg;
 		c->dw_chunk = B / nwg;
 		const size_t per_wave = (size_t)16 * 64 * 3 + 64 * 64 + (size_t)64 * 32 * 3;
-		ALLOC(c->dw_partial, (size_t)nwg * WAVES_PER_WG * per_wave);
+		ALLOC(c->dw_partial, (size_t)std::max<uint32_t>(nwg * WAVES_PER_WG, (uint32_t)c->n_cus * 2) * per_wave); // one slab per producing workgroup: k_dw's, or k_fwd_bwd_sdf's own (<= 2 per CU)
 	}
 #undef ALLOC
 	HIP_TRY_C(hipMemset(c->params_fp32.p, 0, c->params_fp32.bytes()));
@@ -961,7 +970,8 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
-		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = std::max(1, std::min(3, atoi(e)));
+		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = (uint32_t)std::max(0, atoi(e));
+		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
