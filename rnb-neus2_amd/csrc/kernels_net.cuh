@@ -1299,7 +1299,7 @@ struct AdamArgs {
 // parameter it was most of k_adam_ema: two powf per live parameter made the kernel VALU-bound (3.6 k wave instructions per wavefront, 110 us
 // of issue time for a 240 MB stream, profiles/r02_pmc_sq.json). The table holds the same expression, evaluated by the same device functions,
 // for t < lr_table_n; a step count beyond the table is computed in place.
-__device__ __forceinline__ float adam_bias_correction(const float beta1, const float beta2, const uint32_t t) {
+__device__ __noinline__ float adam_bias_correction(const float beta1, const float beta2, const uint32_t t) {
 	return sqrtf(1 - powf(beta2, (float)t)) / (1 - powf(beta1, (float)t));
 }
 __global__ void k_adam_lr_table(float* __restrict__ table, const uint32_t n, const float beta1, const float beta2) {
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 		bool any = is_matrix;
 		float gradient[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { gradient[k] = rh(graw[k]) / LOSS_SCALE; any = any || gradient[k] != 0.f; } // the reference's gradient vector is half (trainer.h:78-84)
+		for (int k = 0; k < 4; ++k) { gradient[k] = rh(graw[k]) * (1.0f / LOSS_SCALE); any = any || gradient[k] != 0.f; } // the reference's gradient vector is half (trainer.h:78-84)
 		if (i0 >= a.skip_lo && i0 < a.skip_hi) any = false;
 		if (any) {
 			f4 w32 = reinterpret_cast<const f4*>(a.w32)[q];
@@ -1340,7 +1340,10 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 				const float second_moment = v[k] = a.beta2 * v[k] + (1 - a.beta2) * gradient_sq;
 				float learning_rate = a.base_lr;
 				const uint32_t cs = ++stp[k];
-				learning_rate *= cs < a.lr_table_n ? a.lr_table[cs] : adam_bias_correction(a.beta1, a.beta2, cs);
+				float correction;
+				if (__builtin_expect(cs < a.lr_table_n, 1)) correction = a.lr_table[cs];
+				else correction = adam_bias_correction(a.beta1, a.beta2, cs); // (a call: the two powf expansions stay out of the loop body)
+				learning_rate *= correction;
 				const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), 0.f), 3.402823466e+38f);
 				const float decayed_weight = (1 - 0.f * learning_rate) * weight_fp - copysignf(0.f * learning_rate, weight_fp);
 				const float new_weight = decayed_weight - effective_learning_rate * first_moment;
