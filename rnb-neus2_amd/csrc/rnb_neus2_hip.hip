@@ -371,11 +371,11 @@ static LossFlags loss_flags(const rnb_ctx* c) {
 // 26 k / 50 k / 85 k / 95 k rays per step, i.e. 13.8 / 9.9 / 5.2 / 3.1 / 2.8 compacted samples per ray): the best head is ~4.5 x the
 // compacted samples per ray -- 48: 0.712 / 0.764 / 0.796 / 0.822 / 0.842; 32: 0.732 / 0.759 / 0.765 / 0.803 / 0.827; 24: 0.789 / 0.784 /
 // 0.754 / 0.788 / 0.816; 16: 0.840 / 0.849 / 0.769 / 0.782 / 0.796 -- and the controller holds the compacted batch at B, so that is
-// 4.5 B / n_rays, kept within [16, 48]. The results do not depend on it (tests/test_gpu_fullsize.py).
+// 4.5 B / n_rays, kept within [12, 48]. The results do not depend on it (tests/test_gpu_fullsize.py).
 static uint32_t k1_for(const rnb_ctx* c, uint32_t n_rays) {
 	if (c->fwd_k1 == 0 || c->fwd_k1_fixed) return c->fwd_k1;
 	const uint32_t k = (uint32_t)(4.5f * (float)c->cfg.target_batch_size / (float)std::max(1u, n_rays));
-	return std::min(c->fwd_k1, std::max(16u, k));
+	return std::min(c->fwd_k1, std::max(12u, k)); // floor 12 (round 3: 0.680 vs 0.687 ms/step at 95 k rays per step; 8: 0.689)
 }
 
 MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
