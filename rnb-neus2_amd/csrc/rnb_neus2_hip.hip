@@ -151,7 +151,10 @@ struct rnb_ctx {
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
 		bool march_narrow = false, fwd_bwd_generic = false, loss_wave_per_ray = false;
-		uint32_t scatter_wg_per_cu = 0; // RNB_SCATTER_WG_PER_CU: resident workgroups of the atomic scatter kernels per CU (0 = one workgroup per 64 samples, round 2's launch)
+		// RNB_SCATTER_WG_PER_CU: resident workgroups of the atomic scatter kernels per CU (0 = one workgroup per 64 samples, round 2's launch). Default
+		// by mode, measured in round 3 (window, ms/step): --no-albedo 0: 0.650, 2: 0.666, 4: 0.667, 8: 0.664; albedo 0: 0.826, 2: 0.796, 4: 0.808, 8: 0.828
+		// (there the weight-gradient GEMMs of the side stream are the long pole and need the wave slots)
+		int scatter_wg_per_cu = -1;
 		uint32_t fbs_wg_per_cu = 2; // RNB_FBS_WG_PER_CU: workgroups of k_fwd_bwd_sdf per CU (its launch bounds allow two)
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
@@ -556,11 +559,12 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	//   B  middle  [e_c, l_fine) run-length quad kernel: a cell spans several march steps (~590 / resolution); same bound + the latency of the walk
 	//   C  coarse  [0, e_c)      LDS-privatised tables (beside the atomic groups on the optimizer's stream it stretches 42 -> 158 us and the
 	//                            step loses 4 %, measured in round 2: it stays last on the caller's stream)
+	const uint32_t scatter_cap = c->knobs.scatter_wg_per_cu >= 0 ? (uint32_t)c->knobs.scatter_wg_per_cu : (sdf_only ? 0u : 2u);
 	ScatterArgs sa;
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
-		const uint32_t n_vb = (B * 4 + 255) / 256, cap = c->knobs.scatter_wg_per_cu ? std::max(1u, (uint32_t)c->n_cus * c->knobs.scatter_wg_per_cu / (l1 - l0)) : n_vb;
+		const uint32_t n_vb = (B * 4 + 255) / 256, cap = scatter_cap ? std::max(1u, (uint32_t)c->n_cus * scatter_cap / std::max(1u, l1 - l0)) : n_vb;
 		if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (done) (void)hipEventRecord(done, st);
 	};
@@ -571,7 +575,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		uint32_t wg = 0;
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + sg.Ks[e_c + q] - 1) / sg.Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
-		const uint32_t cap_rl = c->knobs.scatter_wg_per_cu ? (uint32_t)c->n_cus * c->knobs.scatter_wg_per_cu : wg;
+		const uint32_t cap_rl = scatter_cap ? (uint32_t)c->n_cus * scatter_cap : wg;
 		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
@@ -970,7 +974,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
-		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = (uint32_t)std::max(0, atoi(e));
+		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 	}
 	plan_scatter_groups(c);
