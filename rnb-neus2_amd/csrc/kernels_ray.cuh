@@ -264,6 +264,7 @@ struct MarchArgs {
 	const uint8_t* bitfield;
 	const uint32_t* coarse; // k_coarse_bitfield of cascade 0
 	uint32_t n_blocks_lds;  // how many of its blocks the launch's LDS holds
+	uint32_t lattice_ok;    // the march lattice t_{k+1} = fl(t_k + MIN_CONE_STEPSIZE) is linear inside every binade of [0.25, 8) (no rounding ties): closed form allowed
 	// per-ray scratch
 	float* setup;       // [n_rays][8]: o(3) dir(3) startt alive
 	float* ray_t;       // [n_rays][RNB_MAX_STEPS]: t of every sample found by the counting pass
@@ -420,14 +421,35 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 	float* tt = a.ray_t + (size_t)(ray_exists ? i : 0) * RNB_MAX_STEPS;
 	const float cone = a.A.cone_angle;
 	while (__any(!term)) {
-		// the next MG positions of the ray (every lane of the group computes the same values)
+		// The next MG positions of the ray. Closed form of the lattice t_{k+1} = fl(t_k + C) (C = the constant step of the single-cascade scenes):
+		// while t stays inside one binade [2^(e-1), 2^e) every t_k is a multiple of that binade's ulp, so fl(t_k + C) = t_k + d with
+		// d = C rounded to a multiple of the ulp -- the same d for every k (a.lattice_ok: the host has checked that C is not a rounding tie in
+		// the binades used, rnb_neus2_hip.hip lattice_is_linear). Then t_{k+m} = t_k + m d EXACTLY (m d and the sum are exact: multiples of the
+		// ulp below 2^e), and "the first position at or beyond a target" is a division plus one exact comparison instead of a scan over 16
+		// running sums. A round whose 17 positions straddle a binade boundary takes the running sums (below), as does the multi-cascade march.
 		float T[MG + 1];
-		T[0] = t_cur;
 		float my_t = t_cur;
+		float dlt = 0.f, inv_dlt = 0.f;
+		bool fast = false;
+		if (SC && a.lattice_ok) {
+			int e;
+			(void)frexpf(t_cur, &e); // t_cur in [2^(e-1), 2^e)
+			const float base = scalbnf(0.5f, e), hi = scalbnf(1.0f, e);
+			dlt = (base + MIN_CONE_STEPSIZE) - base;
+			const bool ok = term || (t_cur >= 0.25f && t_cur < 8.0f && t_cur + (float)MG * dlt < hi);
+			fast = !__any(!ok);
+		}
+		if (fast) {
+			my_t = t_cur + (float)g * dlt;
+			T[MG] = t_cur + (float)MG * dlt;
+			inv_dlt = __builtin_amdgcn_rcpf(dlt); // an estimate is enough: the candidate it yields is checked exactly
+		} else {
+			T[0] = t_cur;
 #pragma unroll
-		for (int m = 0; m < MG; ++m) {
-			T[m + 1] = T[m] + (SC ? MIN_CONE_STEPSIZE : calc_dt(T[m], cone));
-			if (m + 1 == g) my_t = T[m + 1];
+			for (int m = 0; m < MG; ++m) {
+				T[m + 1] = T[m] + (SC ? MIN_CONE_STEPSIZE : calc_dt(T[m], cone));
+				if (m + 1 == g) my_t = T[m + 1];
+			}
 		}
 		// my position
 		const Vec3 pos = o + my_t * dir;
@@ -442,9 +464,15 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 			if (!occ) {
 				const uint32_t res = GRIDSIZE >> mip;
 				t_target = my_t + distance_to_next_voxel(pos, dir, idir, res);
+				if (fast) { // smallest m in (g, MG) with t_cur + m d >= t_target, else MG
+					int m0 = (int)floorf(fminf((t_target - t_cur) * inv_dlt, 64.f));
+					m0 += (t_cur + (float)m0 * dlt < t_target) ? 1 : 0;
+					nxt = (uint32_t)min(max(m0, g + 1), MG);
+				} else {
 #pragma unroll
-				for (int m = MG - 1; m >= 1; --m) {
-					if (m > g && T[m] >= t_target) nxt = (uint32_t)m;
+					for (int m = MG - 1; m >= 1; --m) {
+						if (m > g && T[m] >= t_target) nxt = (uint32_t)m;
+					}
 				}
 			}
 		}
@@ -457,9 +485,15 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 		if (!term) {
 			int cur = 0;
 			if (have_pending) { // continue the reference's do { t += dt } while (t < t_target) across the round boundary
-				cur = MG;
+				if (fast) { // smallest m in [0, MG) with t_cur + m d >= pending_target, else MG
+					int m0 = (int)floorf(fminf(fmaxf((pending_target - t_cur) * inv_dlt, -2.f), 64.f));
+					m0 += (t_cur + (float)m0 * dlt < pending_target) ? 1 : 0;
+					cur = min(max(m0, 0), MG);
+				} else {
+					cur = MG;
 #pragma unroll
-				for (int m = MG - 1; m >= 0; --m) if (T[m] >= pending_target) cur = m;
+					for (int m = MG - 1; m >= 0; --m) if (T[m] >= pending_target) cur = m;
+				}
 				if (cur < MG) have_pending = false;
 			}
 			while (cur < MG) {

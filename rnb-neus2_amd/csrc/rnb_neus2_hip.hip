@@ -156,6 +156,7 @@ struct rnb_ctx {
 		// (there the weight-gradient GEMMs of the side stream are the long pole and need the wave slots)
 		int scatter_wg_per_cu = -1;
 		uint32_t fbs_wg_per_cu = 2; // RNB_FBS_WG_PER_CU: workgroups of k_fwd_bwd_sdf per CU (its launch bounds allow two)
+		bool march_running_sums = false; // RNB_MARCH_RUNNING_SUMS: the 16-lanes-per-ray march with the 16 running sums per round everywhere (round 2), no closed form
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
@@ -381,8 +382,26 @@ static uint32_t k1_for(const rnb_ctx* c, uint32_t n_rays) {
 	return std::min(c->fwd_k1, std::max(12u, k)); // floor 12 (round 3: 0.680 vs 0.687 ms/step at 95 k rays per step; 8: 0.689)
 }
 
+// Is t -> fl(t + C) the addition of ONE constant inside each binade of [0.25, 8)? It is unless C sits exactly half way between two
+// multiples of the binade's ulp (a tie, rounded to even: the increment would then alternate with the parity of t). Checked on an even and
+// an odd multiple of the ulp at both ends of every binade; k_march_count_wide's closed form relies on it.
+static bool lattice_is_linear() {
+	const volatile float C = STEPSIZE;
+	for (int e = -1; e <= 3; ++e) { // binades [2^(e-1), 2^e)
+		const float base = std::ldexp(0.5f, e), ulp = std::ldexp(1.0f, e - 1 - 23);
+		const volatile float d0 = (base + C) - base;
+		for (const float t : {base, base + ulp, base + 2 * ulp, base + 3 * ulp, std::ldexp(1.0f, e) - 64 * d0, std::ldexp(1.0f, e) - 64 * d0 + ulp}) {
+			const volatile float sum = t + C;
+			if (sum - t != d0) return false;
+		}
+	}
+	return true;
+}
+
 MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
 	MarchArgs a;
+	static const bool linear = lattice_is_linear();
+	a.lattice_ok = (linear && !c->knobs.march_running_sums) ? 1u : 0u;
 	a.n_rays = n_rays;
 	a.n_rays_global = n_rays * c->cfg.world_size;
 	a.ray_offset = c->cfg.rank * n_rays;
@@ -973,6 +992,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		k.loss_wave_per_ray = getenv("RNB_LOSS_WAVE_PER_RAY") != nullptr; // the loss passes with one wavefront per ray whatever the batch (A/B, tests)
 		k.dp_order = getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr;
 		k.march_late = getenv("RNB_MARCH_LATE") != nullptr;
+		k.march_running_sums = getenv("RNB_MARCH_RUNNING_SUMS") != nullptr;
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
