@@ -513,6 +513,15 @@ struct Testbed {
 		snap.set("nerf", nerf);
 		snap.set("training_step", mpk::Value::uint(training_step));
 		snap.set("loss", mpk::Value::real(loss_scalar));
+		{ // The reference's loader also reads the accumulated global movement and the delta network (load_global_movement / load_local_movement,
+			// nerf_network.h:1017-1081): half buffers, identity here (static scenes; nerf_network.h:852-905, transform_network.h:30-38, 209-235).
+			const uint16_t one = f32_to_f16(1.0f);
+			const uint16_t rot[12] = {one, 0, 0, 0, one, 0, 0, 0, one, 0, 0, 0}, tr[4] = {0, 0, 0, 0}, lrot[8] = {one, 0, 0, 0, one, 0, 0, 0};
+			snap.set("rotation", mpk::Value::binary(rot, sizeof(rot)));
+			snap.set("transition", mpk::Value::binary(tr, sizeof(tr)));
+			snap.set("local_rotation", mpk::Value::binary(lrot, sizeof(lrot)));
+			snap.set("local_transition", mpk::Value::binary(tr, sizeof(tr)));
+		}
 		root.set("snapshot", snap);
 		// the whole network configuration travels with the snapshot (m_network_config, src/testbed.cu:3282-3313): optimizer, loss, both
 		// encodings and networks as parsed, so that a resumed run steps with the hyper-parameters of the run that wrote the file

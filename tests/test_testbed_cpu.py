@@ -328,3 +328,48 @@ def test_config_1_single_256x256_view_200_steps(install, tmp_path):
     assert snap["training_step"] == 200 and np.isfinite(snap["loss"])
     n_v = sum(1 for l in open(out / "mesh_200.obj") if l.startswith("v "))
     assert n_v > 50
+
+
+# ---------------------------------------------------------------- snapshot interoperability with the reference (missing #3)
+def test_snapshot_carries_every_key_the_reference_loader_reads(trained):
+    """Testbed::load_snapshot (src/testbed.cu:3333-3390), Trainer::deserialize (trainer.h:292-301) and load_global/local_movement
+    (nerf_network.h:1017-1081) read exactly these entries of the msgpack file; binaries are plain msgpack `bin` (nlohmann binary_t without
+    a subtype, gpu_memory_json.h:36-56). The parameter block is [density MLP | rgb MLP | hash grid | variance] (nerf_network.h:539-583)."""
+    with open(trained["scene"] / "output" / "snapshot_4.msgpack", "rb") as f:
+        root = msgpack.unpackb(f.read(), raw=False)
+    snap = root["snapshot"]
+    assert snap["density_grid_size"] == 128                                                   # testbed.cu:3347
+    for k in ("rays_per_batch", "measured_batch_size", "measured_batch_size_before_compaction"):
+        assert isinstance(snap["nerf"]["rgb"][k], int)                                        # testbed.cu:3351-3353
+    assert snap["nerf"]["aabb_scale"] == 1                                                    # testbed.cu:3361-3363
+    assert isinstance(snap["density_grid_binary"], bytes) and len(snap["density_grid_binary"]) == 128 ** 3 * 2   # testbed.cu:3366
+    assert isinstance(snap["training_step"], int) and isinstance(snap["loss"], float)         # testbed.cu:3383-3384
+    assert isinstance(snap["params_binary"], bytes) and len(snap["params_binary"]) == 2 * snap["n_params"]      # trainer.h:293-294
+    one = np.float16(1.0).tobytes()
+    z = np.float16(0.0).tobytes()
+    assert snap["rotation"] == (one + z * 3) * 2 + one + z * 3 and snap["transition"] == z * 4   # nerf_network.h:1020-1038 (identity, 852-905)
+    assert snap["local_rotation"] == one + z * 3 + one + z * 3 and snap["local_transition"] == z * 4   # nerf_network.h:1062-1080
+    for block in ("encoding", "network", "optimizer", "loss"):                                # reset_network reads the config blocks of the same file
+        assert block in root, block
+
+
+def test_resume_from_a_reference_style_snapshot(install, trained, tmp_path):
+    """A file as the reference writes it: nlohmann's to_msgpack encodings (float32 where exact, str8, map16), the extra `nerf.dataset`
+    block and optimizer state this build does not read, keys in another order -- `--snapshot` restores it and trains on."""
+    scene = trained["scene"]
+    with open(scene / "output" / "snapshot_4.msgpack", "rb") as f:
+        root = msgpack.unpackb(f.read(), raw=False)
+    snap = root["snapshot"]
+    ref = {k: root[k] for k in sorted(root, reverse=True) if k != "snapshot"}
+    ref["snapshot"] = {k: snap[k] for k in sorted(snap, reverse=True)}
+    ref["snapshot"]["nerf"]["dataset"] = {"n_images": 4, "aabb_scale": 1, "scale": 1.0, "offset": [0.0, 0.0, 0.0], "paths": ["a" * 300]}   # testbed.cu:3313, ignored with --scene
+    ref["snapshot"]["optimizer"] = {"nested": {"nested": {"current_step": 4, "base_learning_rate": np.float32(1e-3).item()}}}                # trainer.h:296-298: not written by main.cu (include_optimizer_state = false)
+    path = tmp_path / "reference_style.msgpack"
+    with open(path, "wb") as f:
+        f.write(msgpack.packb(ref, use_single_float=True, use_bin_type=True))
+    r = run(install, "--scene", scene, "--maxiter", 5, "--no-gui", "--mask-weight", 1.0, "--no-albedo", "--save-snapshot", "--snapshot", path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Loaded snapshot succeed" in r.stdout
+    with open(scene / "output" / "snapshot_5.msgpack", "rb") as f:
+        after = msgpack.unpackb(f.read(), raw=False)["snapshot"]
+    assert after["training_step"] == 5 and after["params_binary"] != snap["params_binary"]
