@@ -134,7 +134,7 @@ typedef enum rnb_buffer_id {
 	RNB_BUF_ADAM_M = 4,        /* float[n_params] */
 	RNB_BUF_ADAM_V = 5,        /* float[n_params] */
 	RNB_BUF_ADAM_STEPS = 6,    /* uint32[n_params] */
-	RNB_BUF_DENSITY_GRID = 7,  /* float[128^3 * (max_cascade+1)] */
+	RNB_BUF_DENSITY_GRID = 7,  /* float[128^3 * (max_cascade+1)]; a caller that writes it other than through rnb_memcpy follows with rnb_update_density_bitfield */
 	RNB_BUF_DENSITY_BITFIELD = 8, /* uint8[128^3/8 * 8 mips] */
 	RNB_BUF_DENSITY_MEAN = 9,  /* float[1] */
 	RNB_BUF_RAY_INDICES = 10,  /* uint32[rays] */
@@ -153,6 +153,8 @@ typedef enum rnb_buffer_id {
 	RNB_BUF_GRID_SAMPLE_IDX = 23,  /* uint32[n] */
 	RNB_BUF_STEP_VECTOR = 24,  /* double[7]: this rank's {counters[0..3], loss sums[0..2]} of the running step, final once the loss pass is
 	                              (rnb_train_step_local has returned); data-parallel callers all-reduce it in place */
+	RNB_BUF_GRID_SAMPLE_POS_EVAL = 25, /* float[n*3] / uint32[n]: the same samples in the order the last update evaluated them (cell order, prepared an */
+	RNB_BUF_GRID_SAMPLE_IDX_EVAL = 26, /* update interval ahead); 0 bytes when it evaluated them in the reference's order (GRID_SAMPLE_POS / _IDX). HIP library only */
 	RNB_BUF_COUNT
 } rnb_buffer_id;
 

@@ -41,8 +41,9 @@ __device__ __forceinline__ void ray_intersect(const SceneAabb& A, const Vec3& po
 // Occupancy grid
 // ---------------------------------------------------------------------------------------------
 // generate_grid_samples_nerf_nonuniform (testbed_nerf.cu:585-614)
+// `hist` (optional): the number of samples per block of 2^key_shift Morton-consecutive cells, for k_grid_samples_place below.
 __global__ void k_grid_samples(const uint32_t n_elements, Pcg32 rng, const uint32_t step, const SceneAabb A, const float* __restrict__ grid_in,
-                               float* __restrict__ pos_out, uint32_t* __restrict__ idx_out, const float thresh) {
+                               float* __restrict__ pos_out, uint32_t* __restrict__ idx_out, const float thresh, uint32_t* __restrict__ hist, const uint32_t key_shift) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	const uint32_t n_cascades = A.max_cascade + 1;
@@ -62,6 +63,23 @@ __global__ void k_grid_samples(const uint32_t n_elements, Pcg32 rng, const uint3
 	const Vec3 w = warp_position(A, pos);
 	pos_out[(size_t)i * 3 + 0] = w.x; pos_out[(size_t)i * 3 + 1] = w.y; pos_out[(size_t)i * 3 + 2] = w.z;
 	idx_out[i] = idx;
+	if (hist) atomicAdd(hist + (idx >> key_shift), 1u);
+}
+
+// The samples of an occupancy update in cell order (Morton blocks of 2^key_shift cells; any order inside a block). The network is evaluated
+// on a SET of points and splatted with atomicMax (testbed_nerf.cu:616-635), so the order of the samples is free: the reference's order
+// (a multiplicative congruence of the thread index) sends consecutive lanes to unrelated cells, cell order lets the gathers of the coarse
+// and middle levels share cache lines (k_point_query_chained 0.50 -> 0.34 ms). `cursor` = exclusive prefix sums of k_grid_samples'
+// histogram, consumed here. Generated a whole update interval ahead on a side stream: the samples depend on the PREVIOUS update's grid and
+// on the RNG only, not on the weights.
+__global__ void k_grid_samples_place(const uint32_t n, const float* __restrict__ pos_in, const uint32_t* __restrict__ idx_in, uint32_t* __restrict__ cursor, const uint32_t key_shift,
+                                     float* __restrict__ pos_out, uint32_t* __restrict__ idx_out) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const uint32_t idx = idx_in[i];
+	const uint32_t p = atomicAdd(cursor + (idx >> key_shift), 1u);
+	pos_out[(size_t)p * 3 + 0] = pos_in[(size_t)i * 3 + 0]; pos_out[(size_t)p * 3 + 1] = pos_in[(size_t)i * 3 + 1]; pos_out[(size_t)p * 3 + 2] = pos_in[(size_t)i * 3 + 2];
+	idx_out[p] = idx;
 }
 
 // ema_grid_samples_nerf (testbed_nerf.cu:655-685)

@@ -124,6 +124,12 @@ struct rnb_ctx {
 	DevBuf<float> grid_sample_pos;
 	DevBuf<uint32_t> grid_sample_idx;
 	uint32_t n_grid_samples = 0;
+	// the next update's samples in cell order (pregenerate_grid_samples): what they were generated from, their buffers, the placement scratch
+	struct { bool valid = false; uint32_t ema_step = 0, n_uniform = 0, n_nonuniform = 0; uint64_t rng_state = 0, rng_inc = 0; } gs_pre;
+	bool last_update_sorted = false;
+	DevBuf<float> gs_sorted_pos, gs_stage_pos, gs_eval_pos;   // sorted / stage: being prepared for the next update; eval: what the last update evaluated
+	DevBuf<uint32_t> gs_sorted_idx, gs_stage_idx, gs_eval_idx, gs_hist;
+	hipEvent_t ev_grid = nullptr, ev_gs = nullptr;
 
 	// dataset
 	uint32_t n_views = 0;
@@ -160,6 +166,7 @@ struct rnb_ctx {
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
+		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
 	DevBuf<McTable> mc_table; // marching-cubes case table, uploaded on first use
@@ -315,6 +322,62 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 }
 
 // ---- K1-K5 ----
+// K1 for one update: the uniform and the non-uniform pass (testbed_nerf.cu:3385-3409) from the generator state `rng` (advanced twice).
+static int launch_grid_samples(rnb_ctx* c, hipStream_t s, Pcg32& rng, uint32_t ema_step, uint32_t n_uniform, uint32_t n_nonuniform, float* pos, uint32_t* idx, uint32_t* hist, uint32_t key_shift) {
+	if (n_uniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_uniform + 127) / 128), dim3(128), 0, s, n_uniform, rng, ema_step, c->aabb, c->density_grid.p,
+	                                  pos, idx, -0.01f, hist, key_shift);
+	rng.advance();
+	if (n_nonuniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_nonuniform + 127) / 128), dim3(128), 0, s, n_nonuniform, rng, ema_step, c->aabb, c->density_grid.p,
+	                                     pos + (size_t)n_uniform * 3, idx + n_uniform, MIN_OPTICAL_THICKNESS, hist, key_shift);
+	rng.advance();
+	HIP_TRY(hipGetLastError());
+	return RNB_OK;
+}
+
+// The samples of the NEXT occupancy update, generated and put into cell order (k_grid_samples_place) as soon as this update's grid is final:
+// they depend on that grid, the generator state and the update counter only. In the overlapped schedule this runs on a side stream beside
+// the step's march, off the critical path; the next update (16 steps later) finds them ready, checks that nothing they depend on has changed
+// (ema step, generator state, sizes; entry points through which a caller can change the grid invalidate them) and evaluates the network in
+// that order. Same sample SET as the reference's order, same atomicMax splat, same grid.
+static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main, uint32_t n_uniform, uint32_t n_nonuniform) {
+	c->gs_pre.valid = false;
+	if (!c->knobs.grid_presort || c->training_step < 256 || n_nonuniform == 0) return RNB_OK; // the first 256 steps sample every cell each step: nothing to gain
+	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
+	const uint32_t n = n_uniform + n_nonuniform;
+	uint32_t shift = 3;
+	while ((n_elements >> shift) > (1u << 20)) ++shift; // the two-level scan below covers 2^20 keys
+	const uint32_t n_keys = n_elements >> shift;
+	if (!c->gs_sorted_pos.p) {
+		if (c->gs_sorted_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_sorted_idx.alloc(n) != hipSuccess || c->gs_hist.alloc((size_t)(1u << 20) + 2048) != hipSuccess ||
+		    c->gs_stage_pos.alloc(c->grid_sample_pos.n) != hipSuccess || c->gs_stage_idx.alloc(c->grid_sample_idx.n) != hipSuccess ||
+		    c->gs_eval_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_eval_idx.alloc(n) != hipSuccess) {
+			c->knobs.grid_presort = false; // not essential: the update then keeps the reference's order
+			return RNB_OK;
+		}
+	}
+	hipStream_t s = s_main;
+	if (c->overlap()) { // after this update's k_ema_grid (s_main), beside what follows on s_main
+		s = c->s_dw;
+		HIP_TRY(hipEventRecord(c->ev_grid, s_main));
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_grid, 0));
+	}
+	HIP_TRY(hipMemsetAsync(c->gs_hist.p, 0, sizeof(uint32_t) * n_keys, s));
+	Pcg32 rng = c->density_grid_rng;
+	c->gs_pre.rng_state = rng.state; c->gs_pre.rng_inc = rng.inc;
+	int rc = launch_grid_samples(c, s, rng, c->density_grid_ema_step, n_uniform, n_nonuniform, c->gs_stage_pos.p, c->gs_stage_idx.p, c->gs_hist.p, shift);
+	if (rc != RNB_OK) return rc;
+	const uint32_t nb = (n_keys + 1023) / 1024;
+	uint32_t* sums = c->gs_hist.p + (1u << 20);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, s, c->gs_hist.p, (uint64_t)n_keys, sums);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, (uint64_t)nb, sums + 1024);
+	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, c->gs_hist.p, (uint64_t)n_keys, sums);
+	hipLaunchKernelGGL(k_grid_samples_place, dim3((n + 127) / 128), dim3(128), 0, s, n, c->gs_stage_pos.p, c->gs_stage_idx.p, c->gs_hist.p, shift, c->gs_sorted_pos.p, c->gs_sorted_idx.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev_gs, s));
+	c->gs_pre.valid = true; c->gs_pre.ema_step = c->density_grid_ema_step; c->gs_pre.n_uniform = n_uniform; c->gs_pre.n_nonuniform = n_nonuniform;
+	return RNB_OK;
+}
+
 int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t n_nonuniform) { // testbed_nerf.cu:3424-3495
 	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
@@ -322,18 +385,28 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	if (c->training_step == 0) {
 		c->density_grid_ema_step = 0;
 		HIP_TRY(hipMemsetAsync(c->density_grid.p, 0, sizeof(float) * n_elements, s));
+		c->gs_pre.valid = false;
 	}
 	HIP_TRY(hipMemsetAsync(c->density_grid_tmp.p, 0, sizeof(float) * n_elements, s));
-	if (n_uniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_uniform + 127) / 128), dim3(128), 0, s, n_uniform, c->density_grid_rng, c->density_grid_ema_step, c->aabb, c->density_grid.p,
-	                                  c->grid_sample_pos.p, c->grid_sample_idx.p, -0.01f);
-	c->density_grid_rng.advance();
-	if (n_nonuniform) hipLaunchKernelGGL(k_grid_samples, dim3((n_nonuniform + 127) / 128), dim3(128), 0, s, n_nonuniform, c->density_grid_rng, c->density_grid_ema_step, c->aabb, c->density_grid.p,
-	                                     c->grid_sample_pos.p + (size_t)n_uniform * 3, c->grid_sample_idx.p + n_uniform, MIN_OPTICAL_THICKNESS);
-	c->density_grid_rng.advance();
-	HIP_TRY(hipGetLastError());
+	const bool sorted = c->gs_pre.valid && c->gs_pre.ema_step == c->density_grid_ema_step && c->gs_pre.n_uniform == n_uniform && c->gs_pre.n_nonuniform == n_nonuniform &&
+	                    c->gs_pre.rng_state == c->density_grid_rng.state && c->gs_pre.rng_inc == c->density_grid_rng.inc;
+	c->gs_pre.valid = false;
+	c->last_update_sorted = sorted;
+	if (sorted) { // generated after the previous update (pregenerate_grid_samples): the staging pair holds the reference's order, gs_sorted_* the cell order
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_gs, 0));
+		std::swap(c->grid_sample_pos, c->gs_stage_pos); // RNB_BUF_GRID_SAMPLE_POS / _IDX: the samples of the LAST update, as always
+		std::swap(c->grid_sample_idx, c->gs_stage_idx);
+		std::swap(c->gs_sorted_pos, c->gs_eval_pos);     // the next pregenerate_grid_samples writes the other pair
+		std::swap(c->gs_sorted_idx, c->gs_eval_idx);
+		c->density_grid_rng.advance();
+		c->density_grid_rng.advance();
+	} else {
+		int rc = launch_grid_samples(c, s, c->density_grid_rng, c->density_grid_ema_step, n_uniform, n_nonuniform, c->grid_sample_pos.p, c->grid_sample_idx.p, nullptr, 0);
+		if (rc != RNB_OK) return rc;
+	}
 	c->prof.mark(s, P_GRID_SAMPLES);
 	c->n_grid_samples = n_samples;
-	int rc = launch_point_query(c, s, c->grid_sample_pos.p, n_samples, nullptr, c->grid_sample_idx.p, c->density_grid_tmp.p, 1, false);
+	int rc = launch_point_query(c, s, sorted ? c->gs_eval_pos.p : c->grid_sample_pos.p, n_samples, nullptr, sorted ? c->gs_eval_idx.p : c->grid_sample_idx.p, c->density_grid_tmp.p, 1, false);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_POINT_QUERY);
 	c->prof.units[P_POINT_QUERY] += n_samples;
@@ -342,7 +415,8 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	++c->density_grid_ema_step;
 	rc = update_bitfield(c, s);
 	c->prof.mark(s, P_EMA_BITFIELD);
-	return rc;
+	if (rc != RNB_OK) return rc;
+	return pregenerate_grid_samples(c, s, n_uniform, n_nonuniform);
 }
 
 int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
@@ -853,6 +927,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
+	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
@@ -861,7 +936,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_all, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	delete c;
 	return RNB_OK;
@@ -996,6 +1071,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_NARROW_FROM")) k.march_narrow_from = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
+		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1005,7 +1081,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them.
 	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	*out = c;
@@ -1111,7 +1187,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_ADAM_M: BUF(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
-		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
+		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid); // written through rnb_memcpy, or followed by rnb_update_density_bitfield: samples prepared from the old grid are dropped there
 		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield); // a caller that writes through the pointer says so with rnb_bitfield_changed
 		case RNB_BUF_DENSITY_MEAN: BUF(c->density_mean);
 		case RNB_BUF_RAY_INDICES: BUF(c->ray_indices);
@@ -1129,6 +1205,8 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_DENSITY_GRID_TMP: BUF(c->density_grid_tmp);
 		case RNB_BUF_GRID_SAMPLE_POS: *ptr = c->grid_sample_pos.p; *n_bytes = (uint64_t)c->n_grid_samples * 12; return RNB_OK;
 		case RNB_BUF_GRID_SAMPLE_IDX: *ptr = c->grid_sample_idx.p; *n_bytes = (uint64_t)c->n_grid_samples * 4; return RNB_OK;
+		case RNB_BUF_GRID_SAMPLE_POS_EVAL: *ptr = c->gs_eval_pos.p; *n_bytes = c->last_update_sorted ? (uint64_t)c->n_grid_samples * 12 : 0; return RNB_OK;
+		case RNB_BUF_GRID_SAMPLE_IDX_EVAL: *ptr = c->gs_eval_idx.p; *n_bytes = c->last_update_sorted ? (uint64_t)c->n_grid_samples * 4 : 0; return RNB_OK;
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
@@ -1144,6 +1222,7 @@ int rnb_bitfield_changed(rnb_ctx* c) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c); // a batch generated ahead of time marched through the old bits
 	c->coarse_valid = false;
+	c->gs_pre.valid = false;
 	return RNB_OK;
 }
 
@@ -1160,8 +1239,12 @@ int rnb_device_free(rnb_ctx* c, void* ptr) {
 	return RNB_OK;
 }
 
-int rnb_memcpy(rnb_ctx*, void* dst, const void* src, uint64_t n_bytes, int kind) {
+int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kind) {
 	if (!dst || !src) return fail(RNB_ERR_INVALID, "null argument");
+	if (c && kind != RNB_D2H) { // a write into the occupancy grid: the next update's samples, prepared from the old grid, are generated afresh
+		const char *d = static_cast<const char*>(dst), *g = reinterpret_cast<const char*>(c->density_grid.p);
+		if (g && d < g + c->density_grid.bytes() && d + n_bytes > g) c->gs_pre.valid = false;
+	}
 	hipMemcpyKind k = kind == RNB_H2D ? hipMemcpyHostToDevice : kind == RNB_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 	HIP_TRY(hipDeviceSynchronize());
 	HIP_TRY(hipMemcpy(dst, src, n_bytes, k));
@@ -1215,6 +1298,7 @@ int rnb_update_density_grid(rnb_ctx* c, void* stream) {
 int rnb_update_density_bitfield(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
+	c->gs_pre.valid = false; // called after the grid was written from outside
 	return update_bitfield(c, as_stream(stream));
 }
 

@@ -113,6 +113,60 @@ def test_density_grid_update(pair):
     assert np.array_equal(gpu.get("DENSITY_BITFIELD"), cpu.get("DENSITY_BITFIELD"))
 
 
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+def test_density_grid_update_in_cell_order_equals_reference_order(aabb_scale):
+    """From step 256 on the library generates an update's samples an interval ahead and evaluates them in cell order
+    (pregenerate_grid_samples / k_grid_samples_place): the network sees the same SET of points and the splat is an atomicMax
+    (testbed_nerf.cu:616-635), so the grid must equal, bit for bit, the one of a library that keeps the reference's order
+    (RNB_GRID_PRESORT=0), and the samples must still be the oracle's. Three updates in a row: the first generates in line, the
+    second and third find their samples ready; then a grid written from outside must invalidate the prepared samples."""
+    gpu, cpu = _pair(aabb_scale=aabb_scale)
+    ref, cpu2 = _pair(env={"RNB_GRID_PRESORT": "0"}, aabb_scale=aabb_scale)
+    cpu2.close()
+    try:
+        _randomize(gpu, cpu)
+        ref.set_params(cpu.get("PARAMS_FP32"))
+        for c in (gpu, ref, cpu):
+            c.set_training_step(0)
+            c.update_density_grid()       # a first grid with structure (every cell sampled)
+            c.set_training_step(304)
+        for k in range(3):
+            for c in (gpu, ref, cpu):
+                c.update_density_grid()
+            assert np.array_equal(gpu.get("GRID_SAMPLE_IDX"), cpu.get("GRID_SAMPLE_IDX")), k
+            assert np.array_equal(gpu.get("GRID_SAMPLE_POS").view(np.uint32), cpu.get("GRID_SAMPLE_POS").view(np.uint32)), k
+            a, b = gpu.get("DENSITY_GRID"), ref.get("DENSITY_GRID")
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, int((a != b).sum()))
+            assert np.array_equal(gpu.get("DENSITY_BITFIELD"), ref.get("DENSITY_BITFIELD")), k
+            ev = gpu.get("GRID_SAMPLE_IDX_EVAL")
+            assert ev.size == (0 if k == 0 else gpu.get("GRID_SAMPLE_IDX").size), (k, ev.size)  # in line first, prepared ahead afterwards
+            assert ref.get("GRID_SAMPLE_IDX_EVAL").size == 0
+            if k:  # the same samples (cell, position), in cell-block order
+                idx, pos = gpu.get("GRID_SAMPLE_IDX"), gpu.get("GRID_SAMPLE_POS").view(np.uint32).reshape(-1, 3)
+                pe = gpu.get("GRID_SAMPLE_POS_EVAL").view(np.uint32).reshape(-1, 3)
+                assert np.all(np.diff((ev >> 3).astype(np.int64)) >= 0)
+                rec = lambda i, p: np.sort((i.astype(np.uint64) << np.uint64(32) | p[:, 0].astype(np.uint64)) ^ (p[:, 1].astype(np.uint64) << np.uint64(20)) ^ (p[:, 2].astype(np.uint64) << np.uint64(40)))
+                assert np.array_equal(rec(idx, pos), rec(ev, pe))
+            _half_close(a, cpu.get("DENSITY_GRID"), rel=4e-3, abs_=1e-3, name="density grid %d" % k)
+            # keep the three grids identical so that the non-uniform pass of the next update picks the same cells everywhere
+            for c in (ref, cpu):
+                c.put("DENSITY_GRID", a)
+                c.update_density_bitfield()
+        # a caller writes the grid: samples prepared from the old one must not be used
+        g = gpu.get("DENSITY_GRID").copy()
+        g[::3] = 0.0
+        for c in (gpu, ref, cpu):
+            c.put("DENSITY_GRID", g)
+            c.update_density_bitfield()
+            c.update_density_grid()
+        assert np.array_equal(gpu.get("GRID_SAMPLE_IDX"), cpu.get("GRID_SAMPLE_IDX"))
+        assert gpu.get("GRID_SAMPLE_IDX_EVAL").size == 0
+        assert np.array_equal(gpu.get("DENSITY_GRID").view(np.uint32), ref.get("DENSITY_GRID").view(np.uint32))
+    finally:
+        for c in (gpu, ref, cpu):
+            c.close()
+
+
 def test_point_queries(rpair):
     gpu, cpu = pair = rpair
     rng = np.random.default_rng(0)
