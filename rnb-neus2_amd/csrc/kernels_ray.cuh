@@ -129,7 +129,7 @@ constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup:
 template <uint32_t NW = 16>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
 // One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
-__global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks) {
+__global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks, uint32_t* __restrict__ n_blocks_host) {
 	__shared__ uint32_t wsum[16];
 	const uint32_t w = threadIdx.x, lane = w & 63u, wave = w >> 6;
 	uint32_t bits = 0;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restr
 		if (r < COARSE_MAX_BLOCKS) blocks[r] = reinterpret_cast<const uint2*>(bitfield)[morton3D(b & 31u, (b >> 5) & 31u, b >> 10)];
 		++r;
 	}
-	if (w == 0) *n_blocks = total;
+	if (w == 0) { *n_blocks = total; if (n_blocks_host) *n_blocks_host = total; } // the host copy sizes the LDS of later march launches (any size is exact)
 }
 // the first 2 * COARSE_WORDS + 2 * n_blocks_lds words of k_coarse_bitfield's output
 __device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t n_blocks_lds, const uint32_t tid, const uint32_t n_threads) {
@@ -199,6 +199,43 @@ __global__ void k_bitfield_max_pool(const uint32_t n_elements, const uint8_t* __
 	const uint32_t y = morton3D_invert(i >> 1) + GRIDSIZE / 8;
 	const uint32_t z = morton3D_invert(i >> 2) + GRIDSIZE / 8;
 	next_level[morton3D(x, y, z)] |= bits;
+}
+// The same for levels first_level .. N_CASCADES-1 in ONE launch of one workgroup, when level first_level-1 has no bits of its own (it is above
+// the scene's last cascade): such a level is zero outside what was pooled into its central 64^3 cells, its pooled image is zero outside the
+// central 32^3 cells of the next level, and so on. In bytes (= 2x2x2-cell blocks, a 64^3 lattice per level) the support of level
+// first_level-1 is [16, 48)^3 = 32 KB: it is read once into LDS and the levels follow each other there -- 4096, 512, 64, 8, 8 ... outputs
+// instead of 32768 per level and no trip through memory between them -- so the seven launches of a single-cascade scene (~4.7 us each,
+// launch-bound, on the critical path of every occupancy update) become two. What these loops do not write was zero-filled by
+// k_grid_to_bitfield and stays zero, exactly as `|= 0` leaves it in the full kernel; what they write had no bits of its own to keep.
+__global__ __launch_bounds__(1024) void k_bitfield_max_pool_tail(const uint32_t first_level, uint8_t* __restrict__ bitfield) {
+	__shared__ uint8_t buf[2][32 * 32 * 32];
+	uint32_t lo = GRIDSIZE / 8, hi = GRIDSIZE / 8 * 3; // support of the level being read, byte coordinates
+	{
+		const uint8_t* prev_level = bitfield + (size_t)(GRID_CELLS / 8) * (first_level - 1);
+		for (uint32_t q = threadIdx.x; q < 32 * 32 * 32; q += blockDim.x) buf[0][q] = prev_level[morton3D(lo + (q & 31u), lo + ((q >> 5) & 31u), lo + (q >> 10))];
+	}
+	__syncthreads();
+	uint32_t cur = 0;
+	for (uint32_t level = first_level; level < N_CASCADES; ++level) {
+		uint8_t* next_level = bitfield + (size_t)(GRID_CELLS / 8) * level;
+		const uint32_t wi = hi - lo; // width of the support held in buf[cur]
+		const uint32_t o_lo = lo / 2, o_hi = (hi + 1) / 2, w = o_hi - o_lo; // outputs whose 2x2x2 input bytes touch the support
+		for (uint32_t q = threadIdx.x; q < w * w * w; q += blockDim.x) {
+			const uint32_t ox = o_lo + q % w, oy = o_lo + (q / w) % w, oz = o_lo + q / (w * w);
+			uint8_t bits = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) { // input byte i * 8 + j of the full kernel = Morton neighbour j of (2 ox, 2 oy, 2 oz)
+				const uint32_t x = 2 * ox + (j & 1u), y = 2 * oy + ((j >> 1) & 1u), z = 2 * oz + (j >> 2);
+				const bool in = x >= lo && x < hi && y >= lo && y < hi && z >= lo && z < hi;
+				if (in && buf[cur][(x - lo) + wi * ((y - lo) + wi * (z - lo))] > 0) bits |= (uint8_t)(1u << j);
+			}
+			next_level[morton3D(ox + GRIDSIZE / 8, oy + GRIDSIZE / 8, oz + GRIDSIZE / 8)] = bits;
+			buf[cur ^ 1u][q] = bits; // = index (ox - o_lo) + w ((oy - o_lo) + w (oz - o_lo)) of the next support
+		}
+		lo = o_lo + GRIDSIZE / 8; hi = o_hi + GRIDSIZE / 8;
+		cur ^= 1u;
+		__syncthreads();
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,6 +337,7 @@ struct MarchArgs {
 	float* ray_const;   // [n_rays kept][RAY_CONST_FLOATS]
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
+	uint32_t* fwd_counts; // [4] sizes of the two evaluation rounds (k_scan_rays / k_march_write<.., true> write [0] and clear the rest)
 };
 
 // SC: one cascade and no cone (aabb_scale 1, every RNb scene): dt is the constant step and every position inside the box is in
@@ -925,12 +963,91 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 // ONE thread per ray -- the first MARCH_WRITE_WG / LR threads of the workgroup, one for each of its rays -- and not by every
 // lane of the ray's group (that was most of this kernel: 65 -> see DESIGN.md section 6).
 constexpr uint32_t MARCH_WRITE_WG = 1024;
-template <int LR>
+// sum of three counters over the workgroup's 16 wavefronts; result in every thread
+__device__ __forceinline__ void block_sum3(uint32_t (&v)[3], uint32_t (*sh)[16], const uint32_t tid) {
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+		if (lane == 0) sh[k][wave] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		uint32_t t = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < 16; ++w) t += sh[k][w];
+		v[k] = t;
+	}
+	__syncthreads();
+}
+// FUSED: the exclusive scans over the rays (k_scan_rays) are worked out by every workgroup for its own rays -- the sample counts of the rays in
+// front of it are <= 18 k integers in the L2, one or two 16-byte loads per thread and a block sum -- and the last workgroup writes the step
+// counters. k_scan_rays is ONE workgroup of 16 wavefronts that must be co-resident on a CU: beside the gradient scatter's 65 k wavefronts it
+// waited 45 us for the slots (67 us for 21 us of work, profiles/r03_timeline_*), in the middle of the chain march -> scan -> write that the
+// next step's network evaluation waits for. Integer work, same numbers. ok(ray) = steps > 0 && prefix + steps <= max_samples
+// (testbed_nerf.cu:1348-1355): the prefix only grows, so once a ray fails every later one does, and if the samples in front of a workgroup
+// fit (P <= max_samples) every ray in front of it with samples was kept -- their count is the slot offset, no second scan needed.
+template <int LR, bool FUSED = false>
 __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs a) {
 	constexpr uint32_t RAYS = MARCH_WRITE_WG / LR;
+	__shared__ uint32_t sh_sum[3][16];
+	__shared__ uint32_t sh_ray[3][RAYS]; // slot, base, base1 of the workgroup's rays
+	__shared__ uint32_t sh_own[3];
+	if (FUSED) {
+		static_assert(RAYS <= 64 && RAYS % 4 == 0, "the workgroup's rays are scanned by one wavefront");
+		const uint32_t tid = threadIdx.x, r0 = blockIdx.x * RAYS;
+		uint32_t v[3] = {0, 0, 0}; // over the rays in front of the workgroup: samples, rays with samples, first-round samples
+		for (uint32_t q = tid * 4; q < r0; q += MARCH_WRITE_WG * 4) { // r0 is a multiple of 4
+			const uint4 w = *reinterpret_cast<const uint4*>(a.steps + q);
+			const uint32_t st[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) { v[0] += st[e]; v[1] += st[e] > 0 ? 1u : 0u; v[2] += min(st[e], a.k1); }
+		}
+		block_sum3(v, sh_sum, tid);
+		if (tid < 64) { // this workgroup's rays: one wavefront; sh_own = their samples, kept rays, kept first-round samples
+			const uint32_t i = r0 + tid;
+			const uint32_t st = (tid < RAYS && i < a.n_rays) ? a.steps[i] : 0u;
+			const uint32_t incl = wave_inclusive_scan(st, tid);
+			const bool ok = st > 0 && v[0] + incl <= a.max_samples;
+			const uint32_t okc = wave_inclusive_scan(ok ? 1u : 0u, tid), okf = wave_inclusive_scan(ok ? min(st, a.k1) : 0u, tid);
+			if (tid < RAYS) {
+				sh_ray[0][tid] = ok ? v[1] + okc - 1u : 0xffffffffu; // front_fits whenever ok
+				sh_ray[1][tid] = v[0] + incl - st;
+				sh_ray[2][tid] = v[2] + okf - (ok ? min(st, a.k1) : 0u);
+			}
+			if (tid == 63) { sh_own[0] = incl; sh_own[1] = okc; sh_own[2] = okf; }
+		}
+		__syncthreads();
+		if (blockIdx.x == gridDim.x - 1) { // the step counters (k_scan_rays' last lines); every thread takes the same branch
+			const uint32_t own[3] = {sh_own[0], sh_own[1], sh_own[2]};
+			uint32_t kept[3] = {0, 0, 0}; // kept rays, their samples, their first-round samples
+			const uint32_t total = v[0] + own[0];
+			if (total <= a.max_samples) { kept[0] = v[1] + own[1]; kept[1] = total; kept[2] = v[2] + own[2]; }
+			else { // the batch does not fit (the ray controller avoids it): count what does, chunk by chunk
+				__shared__ uint32_t wsum[16];
+				uint32_t carry = 0, acc[3] = {0, 0, 0};
+				for (uint32_t t0 = 0; t0 < a.n_rays; t0 += MARCH_WRITE_WG) {
+					const uint32_t st = t0 + tid < a.n_rays ? a.steps[t0 + tid] : 0u;
+					uint32_t tot;
+					const uint32_t excl = block_exclusive_scan<16>(st, tid & 63u, tid >> 6, wsum, tot);
+					if (st > 0 && carry + excl + st <= a.max_samples) { acc[0] += 1u; acc[1] += st; acc[2] += min(st, a.k1); }
+					carry += tot;
+				}
+				block_sum3(acc, sh_sum, tid);
+#pragma unroll
+				for (int k = 0; k < 3; ++k) kept[k] = acc[k];
+			}
+			if (tid == 0) {
+				a.counters[0] = total; a.counters[2] = kept[0]; a.counters[3] = kept[1];
+				a.fwd_counts[0] = kept[2]; a.fwd_counts[1] = 0; a.fwd_counts[2] = 0; a.fwd_counts[3] = 0;
+			}
+		}
+	}
 	if (a.ray_const && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
 		const uint32_t i = blockIdx.x * RAYS + threadIdx.x;
-		const uint32_t s = i < a.n_rays ? a.slot[i] : 0xffffffffu;
+		const uint32_t s = i < a.n_rays ? (FUSED ? sh_ray[0][threadIdx.x] : a.slot[i]) : 0xffffffffu;
 		if (s != 0xffffffffu) {
 			RayConstIn in;
 			in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
@@ -948,11 +1065,11 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 	const uint32_t i = blockIdx.x * RAYS + threadIdx.x / LR;
 	const uint32_t lane = threadIdx.x & (LR - 1);
 	if (i >= a.n_rays) return;
-	const uint32_t s = a.slot[i];
+	const uint32_t s = FUSED ? sh_ray[0][threadIdx.x / LR] : a.slot[i];
 	if (s == 0xffffffffu) return;
 	const float* st = a.setup + (size_t)i * 8;
 	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
-	const uint32_t steps = a.steps[i], base = a.base[i];
+	const uint32_t steps = a.steps[i], base = FUSED ? sh_ray[1][threadIdx.x / LR] : a.base[i];
 	if (lane == 0) {
 		a.ray_indices[s] = i;
 		float* ro = a.rays + (size_t)s * 6;
@@ -962,7 +1079,7 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 		a.numsteps[(size_t)s * 2 + 1] = base;
 	}
 	if (a.k1) {
-		const uint32_t b1 = a.base1[i];
+		const uint32_t b1 = FUSED ? sh_ray[2][threadIdx.x / LR] : a.base1[i];
 		for (uint32_t j = lane; j < min(steps, a.k1); j += LR) a.idx1[b1 + j] = base + j;
 	}
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415

@@ -120,13 +120,15 @@ struct rnb_ctx {
 	DevBuf<uint8_t> bitfield;
 	DevBuf<uint32_t> coarse_bits, coarse_count; // k_coarse_bitfield: cascade 0's occupancy in the form the march kernels keep in LDS; its number of non-empty blocks
 	bool coarse_valid = false;
-	uint32_t coarse_n_blocks = 0; // host copy of coarse_count
+	uint32_t* host_coarse = nullptr; // mapped host memory: k_coarse_bitfield's block count as last written by the device (0xffffffff: never)
+	uint32_t* host_coarse_dev = nullptr;
 	DevBuf<float> grid_sample_pos;
 	DevBuf<uint32_t> grid_sample_idx;
 	uint32_t n_grid_samples = 0;
 	// the next update's samples in cell order (pregenerate_grid_samples): what they were generated from, their buffers, the placement scratch
 	struct { bool valid = false; uint32_t ema_step = 0, n_uniform = 0, n_nonuniform = 0; uint64_t rng_state = 0, rng_inc = 0; } gs_pre;
 	bool last_update_sorted = false;
+	struct { bool pending = false; uint32_t n_uniform = 0, n_nonuniform = 0; } gs_todo; // an update has run: prepare the next one's samples
 	DevBuf<float> gs_sorted_pos, gs_stage_pos, gs_eval_pos;   // sorted / stage: being prepared for the next update; eval: what the last update evaluated
 	DevBuf<uint32_t> gs_sorted_idx, gs_stage_idx, gs_eval_idx, gs_hist;
 	hipEvent_t ev_grid = nullptr, ev_gs = nullptr;
@@ -166,6 +168,7 @@ struct rnb_ctx {
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
+		bool scan_kernel = false; // RNB_MARCH_SCAN_KERNEL: the ray scans of small batches as their own launch (k_scan_rays, rounds 1-3) instead of inside k_march_write
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -286,28 +289,35 @@ int reset_optimizer_state(rnb_ctx* c) {
 // ---- K5 ----
 // The LDS form of the occupancy for the march kernels (kernels_ray.cuh) + its block count on the host (the launches size their LDS
 // by it). Runs after an occupancy update (every 16th step, which synchronises anyway) or when a caller may have written the bitfield.
-static int rebuild_coarse(rnb_ctx* c, hipStream_t s) {
-	hipLaunchKernelGGL(k_coarse_bitfield, dim3(1), dim3(1024), 0, s, c->bitfield.p, c->coarse_bits.p, c->coarse_count.p);
+static int rebuild_coarse(rnb_ctx* c, hipStream_t s, bool wait = true) {
+	// ev_grid = this kernel's completion: an occupancy update is over (pregenerate_grid_samples starts behind it, beside the march)
+	LAUNCH_EV(k_coarse_bitfield, dim3(1), dim3(1024), 0, s, (c->overlap() && !wait) ? c->ev_grid : nullptr, c->bitfield.p, c->coarse_bits.p, c->coarse_count.p, c->host_coarse_dev);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(&c->coarse_n_blocks, c->coarse_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
 	c->coarse_valid = true;
+	// The block count only sizes the LDS image of later march launches; a launch with any other size takes the same decisions (blocks beyond its
+	// budget are read from the bitfield, load_coarse / occupied_mip0). The training loop therefore does not wait for it: the kernel writes the count
+	// into mapped host memory and march_args reads whatever has arrived (the previous update's count until then) plus a margin. A caller-written
+	// bitfield (rnb_bitfield_changed) can be of any shape, so that path waits as before.
+	if (wait || *c->host_coarse == 0xffffffffu) HIP_TRY(hipStreamSynchronize(s));
 	return RNB_OK;
 }
 
-int update_bitfield(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3497-3517
+int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true) { // testbed_nerf.cu:3497-3517
 	const uint32_t n_blocks = 1024;
 	hipLaunchKernelGGL(k_mean_partial, dim3(n_blocks), dim3(256), 0, s, c->density_grid.p, c->mean_partial.p);
 	hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, c->mean_partial.p, n_blocks, c->density_mean.p);
 	const uint32_t n_bytes_per_mip = GRID_CELLS / 8;
 	const uint32_t n_el = n_bytes_per_mip * N_CASCADES;
 	hipLaunchKernelGGL(k_grid_to_bitfield, dim3((n_el + 127) / 128), dim3(128), 0, s, n_el, n_bytes_per_mip * (c->aabb.max_cascade + 1), c->density_grid.p, c->bitfield.p, c->density_mean.p);
-	for (uint32_t level = 1; level < N_CASCADES; ++level) {
+	// levels that pool a level with bits of its own (the scene's cascades): the full kernel; the levels above them in one small launch
+	const uint32_t first_tail = std::min<uint32_t>(c->aabb.max_cascade + 2, N_CASCADES);
+	for (uint32_t level = 1; level < first_tail; ++level) {
 		hipLaunchKernelGGL(k_bitfield_max_pool, dim3((GRID_CELLS / 64 + 127) / 128), dim3(128), 0, s, GRID_CELLS / 64,
 		                   c->bitfield.p + (size_t)n_bytes_per_mip * (level - 1), c->bitfield.p + (size_t)n_bytes_per_mip * level);
 	}
+	if (first_tail < N_CASCADES) hipLaunchKernelGGL(k_bitfield_max_pool_tail, dim3(1), dim3(1024), 0, s, first_tail, c->bitfield.p);
 	HIP_TRY(hipGetLastError());
-	return rebuild_coarse(c, s);
+	return rebuild_coarse(c, s, wait);
 }
 
 int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference) {
@@ -339,8 +349,11 @@ static int launch_grid_samples(rnb_ctx* c, hipStream_t s, Pcg32& rng, uint32_t e
 // the step's march, off the critical path; the next update (16 steps later) finds them ready, checks that nothing they depend on has changed
 // (ema step, generator state, sizes; entry points through which a caller can change the grid invalidate them) and evaluates the network in
 // that order. Same sample SET as the reference's order, same atomicMax splat, same grid.
-static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main, uint32_t n_uniform, uint32_t n_nonuniform) {
+static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
+	if (!c->gs_todo.pending) return RNB_OK;
+	c->gs_todo.pending = false;
 	c->gs_pre.valid = false;
+	const uint32_t n_uniform = c->gs_todo.n_uniform, n_nonuniform = c->gs_todo.n_nonuniform;
 	if (!c->knobs.grid_presort || c->training_step < 256 || n_nonuniform == 0) return RNB_OK; // the first 256 steps sample every cell each step: nothing to gain
 	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
 	const uint32_t n = n_uniform + n_nonuniform;
@@ -356,9 +369,8 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main, uint32_t n_u
 		}
 	}
 	hipStream_t s = s_main;
-	if (c->overlap()) { // after this update's k_ema_grid (s_main), beside what follows on s_main
+	if (c->overlap()) { // after this update's k_ema_grid (ev_grid), beside what follows it on s_main
 		s = c->s_dw;
-		HIP_TRY(hipEventRecord(c->ev_grid, s_main));
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_grid, 0));
 	}
 	HIP_TRY(hipMemsetAsync(c->gs_hist.p, 0, sizeof(uint32_t) * n_keys, s));
@@ -413,10 +425,10 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
 	HIP_TRY(hipGetLastError());
 	++c->density_grid_ema_step;
-	rc = update_bitfield(c, s);
+	rc = update_bitfield(c, s, !c->overlap());
 	c->prof.mark(s, P_EMA_BITFIELD);
-	if (rc != RNB_OK) return rc;
-	return pregenerate_grid_samples(c, s, n_uniform, n_nonuniform);
+	c->gs_todo.pending = true; c->gs_todo.n_uniform = n_uniform; c->gs_todo.n_nonuniform = n_nonuniform; // queued by the caller once the kernels that wait for THIS update are in their queue
+	return rc;
 }
 
 int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
@@ -486,10 +498,15 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.rng = c->rng;
 	a.A = c->aabb;
 	a.views = c->views.p;
-	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p; a.n_blocks_lds = c->coarse_n_blocks <= COARSE_MAX_BLOCKS ? c->coarse_n_blocks : 0u; // a volume rather than a surface (early training): coarse bits only, the cell bits from the bitfield
+	a.bitfield = c->bitfield.p; a.coarse = c->coarse_bits.p;
+	{ // LDS image: the count the device last reported + 1/8 + 64 blocks (the update in flight may have grown the surface; any size is exact)
+		const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(c->host_coarse);
+		const uint32_t budget = seen == 0xffffffffu ? 0u : (seen + seen / 8 + 64 + 63) / 64 * 64;
+		a.n_blocks_lds = seen <= COARSE_MAX_BLOCKS ? std::min(budget, COARSE_MAX_BLOCKS) : 0u; // a volume rather than a surface (early training): coarse bits only, the cell bits from the bitfield
+	}
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
-	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays);
+	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays); a.fwd_counts = c->fwd_counts.p;
 	a.F = loss_flags(c);
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.ray_const = c->ray_const.p;
@@ -521,11 +538,12 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
 		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
 		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
-	} else
+	} else if (c->knobs.scan_kernel)
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, done, a);
-	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
+	else if (c->knobs.scan_kernel) LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
+	else LAUNCH_EV((k_march_write<64, true>), dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a); // the ray scans inside (no k_scan_rays launch)
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -938,6 +956,7 @@ int rnb_destroy(rnb_ctx* c) {
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
+	if (c->host_coarse) (void)hipHostFree(c->host_coarse);
 	delete c;
 	return RNB_OK;
 }
@@ -1072,6 +1091,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
+		k.scan_kernel = getenv("RNB_MARCH_SCAN_KERNEL") != nullptr;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1084,6 +1104,9 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
+	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_coarse), 64, hipHostMallocMapped));
+	*c->host_coarse = 0xffffffffu;
+	HIP_TRY_C(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_coarse_dev), c->host_coarse, 0));
 	*out = c;
 	return RNB_OK;
 #undef HIP_TRY_C
@@ -1293,7 +1316,9 @@ uint32_t rnb_valid_level(const rnb_ctx* c) { return c ? c->valid_level : 0; }
 int rnb_update_density_grid(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
-	return training_prep(c, as_stream(stream));
+	const int rc = training_prep(c, as_stream(stream));
+	if (rc != RNB_OK) return rc;
+	return pregenerate_grid_samples(c, as_stream(stream));
 }
 int rnb_update_density_bitfield(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
@@ -1482,7 +1507,10 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 		auto t0 = std::chrono::steady_clock::now();
 		rc = training_prep(c, s);
 		if (rc != RNB_OK) return rc;
-		HIP_TRY(hipStreamSynchronize(s)); // testbed.cu:2820
+		// testbed.cu:2820 waits here (it times the update). The overlapped schedule does not: the march, the network evaluation and the loss pass of
+		// this step are queued behind the update while it runs (the wait left the queue empty for ~0.1 ms after every update, profiles/r03_timeline_update_*);
+		// prep_ms is then the time it took to queue the update.
+		if (!c->overlap()) HIP_TRY(hipStreamSynchronize(s));
 		c->grid_updated = true;
 		c->prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_prep_to_skip;
 	}
@@ -1513,7 +1541,9 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
-	return compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
+	rc = compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
+	if (rc != RNB_OK) return rc;
+	return pregenerate_grid_samples(c, s); // after an update: the next one's samples, behind everything this step's front needed from the host
 }
 
 static int step_back(rnb_ctx* c, hipStream_t s) {
