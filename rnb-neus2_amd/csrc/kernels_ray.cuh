@@ -203,31 +203,32 @@ __global__ void k_bitfield_max_pool(const uint32_t n_elements, const uint8_t* __
 // The same for levels first_level .. N_CASCADES-1 in ONE launch of one workgroup, when level first_level-1 has no bits of its own (it is above
 // the scene's last cascade): such a level is zero outside what was pooled into its central 64^3 cells, its pooled image is zero outside the
 // central 32^3 cells of the next level, and so on. In bytes (= 2x2x2-cell blocks, a 64^3 lattice per level) the support of level
-// first_level-1 is [16, 48)^3 = 32 KB: it is read once into LDS and the levels follow each other there -- 4096, 512, 64, 8, 8 ... outputs
+// first_level-1 is [16, 48)^3: its first pooled image (16^3 outputs, one 8-byte word each) is kept in LDS and the levels follow each other there -- 4096, 512, 64, 8, 8 ... outputs
 // instead of 32768 per level and no trip through memory between them -- so the seven launches of a single-cascade scene (~4.7 us each,
 // launch-bound, on the critical path of every occupancy update) become two. What these loops do not write was zero-filled by
 // k_grid_to_bitfield and stays zero, exactly as `|= 0` leaves it in the full kernel; what they write had no bits of its own to keep.
 __global__ __launch_bounds__(1024) void k_bitfield_max_pool_tail(const uint32_t first_level, uint8_t* __restrict__ bitfield) {
-	__shared__ uint8_t buf[2][32 * 32 * 32];
+	__shared__ uint8_t buf[2][16 * 16 * 16];
 	uint32_t lo = GRIDSIZE / 8, hi = GRIDSIZE / 8 * 3; // support of the level being read, byte coordinates
-	{
-		const uint8_t* prev_level = bitfield + (size_t)(GRID_CELLS / 8) * (first_level - 1);
-		for (uint32_t q = threadIdx.x; q < 32 * 32 * 32; q += blockDim.x) buf[0][q] = prev_level[morton3D(lo + (q & 31u), lo + ((q >> 5) & 31u), lo + (q >> 10))];
-	}
-	__syncthreads();
 	uint32_t cur = 0;
 	for (uint32_t level = first_level; level < N_CASCADES; ++level) {
 		uint8_t* next_level = bitfield + (size_t)(GRID_CELLS / 8) * level;
-		const uint32_t wi = hi - lo; // width of the support held in buf[cur]
+		const uint32_t wi = hi - lo; // width of the support held in buf[cur] (levels after the first)
 		const uint32_t o_lo = lo / 2, o_hi = (hi + 1) / 2, w = o_hi - o_lo; // outputs whose 2x2x2 input bytes touch the support
 		for (uint32_t q = threadIdx.x; q < w * w * w; q += blockDim.x) {
 			const uint32_t ox = o_lo + q % w, oy = o_lo + (q / w) % w, oz = o_lo + q / (w * w);
 			uint8_t bits = 0;
+			if (level == first_level) { // from memory: the 8 input bytes i * 8 + j of the full kernel are one aligned word (16^3 outputs, 4 per thread)
+				const uint64_t v = reinterpret_cast<const uint64_t*>(bitfield + (size_t)(GRID_CELLS / 8) * (level - 1))[morton3D(ox, oy, oz)];
 #pragma unroll
-			for (uint32_t j = 0; j < 8; ++j) { // input byte i * 8 + j of the full kernel = Morton neighbour j of (2 ox, 2 oy, 2 oz)
-				const uint32_t x = 2 * ox + (j & 1u), y = 2 * oy + ((j >> 1) & 1u), z = 2 * oz + (j >> 2);
-				const bool in = x >= lo && x < hi && y >= lo && y < hi && z >= lo && z < hi;
-				if (in && buf[cur][(x - lo) + wi * ((y - lo) + wi * (z - lo))] > 0) bits |= (uint8_t)(1u << j);
+				for (uint32_t j = 0; j < 8; ++j) bits |= ((v >> (8 * j)) & 0xffull) ? (uint8_t)(1u << j) : (uint8_t)0;
+			} else {
+#pragma unroll
+				for (uint32_t j = 0; j < 8; ++j) { // input byte i * 8 + j of the full kernel = Morton neighbour j of (2 ox, 2 oy, 2 oz)
+					const uint32_t x = 2 * ox + (j & 1u), y = 2 * oy + ((j >> 1) & 1u), z = 2 * oz + (j >> 2);
+					const bool in = x >= lo && x < hi && y >= lo && y < hi && z >= lo && z < hi;
+					if (in && buf[cur][(x - lo) + wi * ((y - lo) + wi * (z - lo))] > 0) bits |= (uint8_t)(1u << j);
+				}
 			}
 			next_level[morton3D(ox + GRIDSIZE / 8, oy + GRIDSIZE / 8, oz + GRIDSIZE / 8)] = bits;
 			buf[cur ^ 1u][q] = bits; // = index (ox - o_lo) + w ((oy - o_lo) + w (oz - o_lo)) of the next support
