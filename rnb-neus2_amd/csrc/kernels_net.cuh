@@ -85,6 +85,8 @@ struct FwdArgs {
 	float sdf_bias;
 	const uint32_t* idx;       // optional: evaluate the samples idx[0 .. n) (slots into coords / out) instead of 0 .. n
 	const half_t* wimg;        // optional: the LDS weight image (load_weights_chained layout) prepared once per step by k_prepare_weight_images
+	half_t* cin_out;           // optional [slot][32]: the colour MLP's input row of every evaluated sample, [sdf_out 16 | x y z | grad sdf 3 | 0 x 10] (the compact
+	                           // column order of W_C0), for k_rgb_fwd_bwd: the training pass does not evaluate the SDF MLP a second time to obtain it
 };
 
 // K7, register-chained flavour (mlp.cuh): per wavefront one 32-wide exchange tile X (sdf_in rows -> d sdf / d in rows -> r
@@ -256,6 +258,20 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 		}
 		wave_lds_sync();
 		const half_t sdf0 = Z[lane];
+		if (a.cin_out) { // rows of the colour MLP's input (natural column order); lane (r16, hq) holds sdf_out[4 hq .. 4 hq + 3] of sample 16 nt + r16
+			if (valid) {
+				h8* row = reinterpret_cast<h8*>(a.cin_out + (size_t)s * 32);
+				row[2] = *reinterpret_cast<const h8*>(Y + lane * 8);
+				row[3] = h8{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			}
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				const uint32_t s_nt = (uint32_t)__shfl((int)s, 16 * nt + r16, 64);
+				const bool v_nt = __shfl((int)valid, 16 * nt + r16, 64) != 0;
+				const h4 o = {f2h(acc_so[0][nt][0]), f2h(acc_so[0][nt][1]), f2h(acc_so[0][nt][2]), f2h(acc_so[0][nt][3])};
+				if (v_nt) *reinterpret_cast<h4*>(a.cin_out + (size_t)s_nt * 32 + 4 * hq) = o;
+			}
+		}
 		h8 bh[4][2];
 		{
 			h8 bin[4][1];
@@ -325,6 +341,7 @@ struct TrainArgs {
 	                   // colour MLP receives and propagates exact zeros: its forward/backward are skipped, not approximated
 	const half_t* wimg; // optional: k_fwd_bwd_sdf's LDS weight image prepared by k_prepare_weight_images
 	float *dw_w0, *dw_w0b, *dw_w1, *dw_w1b; // k_fwd_bwd_sdf: one partial per workgroup of the four SDF-MLP weight gradients (k_dw's layout)
+	const half_t* dcin;    // k_fwd_bwd_sdf_full: [B][32] dL/d(colour-MLP input row) from k_rgb_fwd_bwd
 	TrainScratch t;
 };
 
@@ -638,6 +655,10 @@ constexpr int SW_END = SW_W1N + 64;
 constexpr int SW_END_PADDED = (SW_END + 7) / 8 * 8;
 constexpr int FBS_WAVE_HALFS = 2 * TILE * S32 + TILE; // two 32-wide tiles (network input / second-order input) + one half per sample
 constexpr size_t LDS_FBS = (size_t)(SW_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
+// albedo mode (k_fwd_bwd_sdf_full): dL/d sdf_out has all 16 rows, so W1^T is a matrix again: [64][S32], row = hidden unit, columns = the 16 outputs + zeros
+constexpr int SW_W1T = SW_END_PADDED;
+constexpr int SWF_END = SW_W1T + 64 * S32;
+constexpr size_t LDS_FBS_FULL = (size_t)(SWF_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
 // Column order of the 32-wide input tiles: the 28 hash features first (a level's pair is one aligned 4-byte LDS access),
 // then x y z, then the pad -- the input index is a summation index of W0 . in, the weight images follow the same order.
 __host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (p < 31 ? p - 28 : 31); }
@@ -649,12 +670,18 @@ __device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net,
 	for (int i = SW_END + tid; i < SW_END_PADDED; i += nthreads) w[i] = (half_t)0.f;
 	// (row padding of the images is never read)
 }
+__device__ inline void load_weights_fbs_full(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
+	load_weights_fbs(w, net, tid, nthreads);
+	for (int i = tid; i < 64 * 32; i += nthreads) { const int u = i >> 5, o = i & 31; w[SW_W1T + u * S32 + o] = o < 16 ? net.sdf_w1[o * 64 + u] : (half_t)0.f; }
+}
 
-// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf; 2: image of k_fwd_bwd. All from the training weights.
-__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train) {
+__device__ inline void load_weights_rgb(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads);
+// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf(_full); 2: image of k_fwd_bwd; 3: image of k_rgb_fwd_bwd. All from the training weights.
+__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train, half_t* __restrict__ img_rgb) {
 	if (blockIdx.x == 0) load_weights_chained(img_fwd, net, threadIdx.x, WG);
-	else if (blockIdx.x == 1) load_weights_fbs(img_fbs, net, threadIdx.x, WG);
-	else load_weights<true>(img_train, net, threadIdx.x, WG);
+	else if (blockIdx.x == 1) load_weights_fbs_full(img_fbs, net, threadIdx.x, WG);
+	else if (blockIdx.x == 2) load_weights<true>(img_train, net, threadIdx.x, WG);
+	else load_weights_rgb(img_rgb, net, threadIdx.x, WG);
 }
 
 // dst[idx] with a wave-uniform base and a 32-bit element index (scalar base + vector byte offset addressing)
@@ -674,17 +701,22 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 		}
 }
 
-__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// FULL (albedo mode, part 2 of 2 behind k_rgb_fwd_bwd): dL/d sdf_out = rows 0..15 of dL/d(colour input) (+ dL/dsdf on row 0) and
+// dL/d(grad sdf) gains the colour MLP's rows 19..21 -- both known before the encode, so everything else is the kernel above with
+//   dz = (W1^T dso) (.) relu'(z1)  as a K = 16 MFMA (both orientations) instead of one product per element, and
+//   dW1 += dso z1^T                as a 16 x 64 MFMA (dso^T by an identity MFMA) instead of row 0 on the VALU.
+template <bool FULL>
+__device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& net, const TrainArgs& a, char* smem_raw, LevelMeta* lm) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
-	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	constexpr int W_END = FULL ? SWF_END : SW_END;
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_live = min(G.n_levels, G.valid_level + 1u); // levels [0, n_live) are encoded, the others are zeros (grid.h:192-210)
-	if (a.wimg) copy_weight_image(wts, a.wimg, SW_END, threadIdx.x, WG);
+	if (a.wimg) copy_weight_image(wts, a.wimg, W_END, threadIdx.x, WG);
+	else if (FULL) load_weights_fbs_full(wts, net, threadIdx.x, WG);
 	else load_weights_fbs(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	half_t* X = wts + SW_END + wave * FBS_WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in
+	half_t* X = wts + W_END + wave * FBS_WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in
 	half_t* D = X + TILE * S32;                        // second-order input rows (ddin)
 	half_t* Z = D + TILE * S32;
 	const int r16 = lane & 15, hq = lane >> 4;
@@ -694,6 +726,9 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 	float var_sum = 0.f;
 	f4 acc_w0[4][2], acc_w0b[4][2]; // weight-gradient accumulators of this wavefront (all its tiles)
 	float acc_w1[4] = {0.f, 0.f, 0.f, 0.f}, acc_w1b[4] = {0.f, 0.f, 0.f, 0.f};
+	f4 acc_w1f[FULL ? 4 : 1]; // FULL: dW1[o = 4 hq + r][u = 16 nt + r16]
+#pragma unroll
+	for (int nt = 0; nt < (FULL ? 4 : 1); ++nt) acc_w1f[nt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 	for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
@@ -715,12 +750,16 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		// nothing per level stays in registers, the level loop is not unrolled, and occupancy rather than unrolling hides
 		// the gather latency.
 		float dn[3];
+		{
+			h8 a2 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			if (FULL) a2 = *reinterpret_cast<const h8*>(a.dcin + (size_t)s * 32 + 16); // dL_drgb_network_input rows 35..37 = compact columns 19..21
 #pragma unroll
-		for (int d = 0; d < 3; ++d) {
-			float v = 0.f;                             // dL_drgb_network_input rows 35..37 are zero here
-			v += h2f(dout[4 + d]) / (float)a.B_global;          // add_positions_view_ekloss (common_operation.cuh:283-296)
-			v += h2f(dout[8 + d]);                     // add_positions_view (nerf_network.h:343-373)
-			dn[d] = v;
+			for (int d = 0; d < 3; ++d) {
+				float v = FULL ? h2f(a2[3 + d]) : 0.f;     // (zero without the colour MLP)
+				v += h2f(dout[4 + d]) / (float)a.B_global;          // add_positions_view_ekloss (common_operation.cuh:283-296)
+				v += h2f(dout[8 + d]);                     // add_positions_view (nerf_network.h:343-373)
+				dn[d] = v;
+			}
 		}
 		reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 0] = f4{c[0], c[1], c[2], dn[0]};
 		reinterpret_cast<f4*>(T.srec)[(size_t)s * 2 + 1] = f4{dn[1], dn[2], 0.f, 0.f};
@@ -747,7 +786,20 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		Z[lane] = dout[3];
 		var_sum += h2f(dout[7]); // variance gradient
 		wave_lds_sync();
+		// FULL: dso = dL/d(colour input)[0:16], row 0 += dL/dsdf (add_density_gradient), as fragments: lane (r16, hq) holds rows 8 hq .. 8 hq + 7 of sample
+		// 16 nt + r16 (zeros beyond row 15) -- the B operand of W1^T dso and, with the roles swapped, the A operand of its transpose
+		auto load_fso = [&](const int nt) { // (loaded where it is used, twice per tile: 16 registers less across the encode-free middle of the tile)
+			h8 v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+			if (hq < 2) v = *reinterpret_cast<const h8*>(a.dcin + (size_t)(tile * TILE + 16 * nt + r16) * 32 + 8 * hq);
+			if (hq == 0) v[0] = v[0] + Z[16 * nt + r16];
+			return v;
+		};
 		{ // ---- weight gradients of this tile (see the header) ----
+			h8 fso[4];
+			if (FULL) {
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) fso[nt] = load_fso(nt);
+			}
 			h8 ain[4], add[4];
 			h4 d3v[4];
 #pragma unroll
@@ -757,6 +809,20 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 				d3v[mt] = *reinterpret_cast<const h4*>(Z + 16 * mt + 4 * hq);
 			}
 			const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+			h8 a_so[2]; // FULL: dso^T, lane = output row o = r16, registers <-> samples (A operand of dW1 += dso z1^T)
+			if (FULL) {
+				h8 idf;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) idf[j] = (8 * hq + j == r16) ? (half_t)1.f : (half_t)0.f;
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const f4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(fso[2 * ks + h], idf, zero4, 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) a_so[ks][4 * h + r] = f2h(t[r]);
+					}
+			}
 			// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
 			h8 b_in[2][2], b_dd[2][2];
 #pragma unroll
@@ -779,7 +845,9 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 				const h8 wbn = *reinterpret_cast<const h8*>(wts + SW_S0 + (16 * nt + r16) * S32 + 8 * hq);
 				const half_t w1h = wts[SW_W1N + 16 * nt + r16];
 				const float w1f = h2f(w1h);
-				h8 a_dz[2], a_dz1[2];
+				h8 wb1t;
+				if (FULL) wb1t = *reinterpret_cast<const h8*>(wts + SW_W1T + (16 * nt + r16) * S32 + 8 * hq);
+				h8 a_dz[2], a_dz1[2], b_z1[2];
 #pragma unroll
 				for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -787,17 +855,24 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 						const int mt = 2 * ks + h;
 						const f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
 						const f4 fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
+						f4 dzt = zero4;
+						if (FULL) dzt = __builtin_amdgcn_mfma_f32_16x16x32_f16(fso[mt], wb1t, zero4, 0, 0, 0); // (W1^T dso)^T: lane = hidden unit, registers = samples
 #pragma unroll
 						for (int r = 0; r < 4; ++r) {
 							const half_t zh = f2h(z[r]);
 							const bool on = zh > (half_t)0.f; // relu' tests the stored half activation (common_device.h:182 ff.)
 							const float d = h2f(d3v[mt][r]);
-							acc_w1[nt] += on ? d * h2f(zh) : 0.f;
+							if (!FULL) acc_w1[nt] += on ? d * h2f(zh) : 0.f;
 							acc_w1b[nt] += on ? h2f(f2h(fr[r])) : 0.f;
-							a_dz[ks][4 * h + r] = on ? f2h(w1f * d) : (half_t)0.f;
+							a_dz[ks][4 * h + r] = on ? (FULL ? f2h(dzt[r]) : f2h(w1f * d)) : (half_t)0.f;
 							a_dz1[ks][4 * h + r] = on ? w1h : (half_t)0.f;
+							if (FULL) b_z1[ks][4 * h + r] = on ? zh : (half_t)0.f;
 						}
 					}
+				if (FULL) {
+#pragma unroll
+					for (int ks = 0; ks < 2; ++ks) acc_w1f[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_so[ks], b_z1[ks], acc_w1f[nt], 0, 0, 0);
+				}
 #pragma unroll
 				for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -820,6 +895,23 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		for (int nt = 0; nt < 4; ++nt) d3[nt] = Z[16 * nt + r16];
 		// dz1 = W1[0,:] (.) relu'(z1) (the stored half activation is tested, common_device.h:182 ff.); dz = dL/dsdf * dz1
 		h8 bdz[4][2];
+		if (FULL) { // W1^T dso (K = 16) sample tile by sample tile, masked below
+			h8 w1t[4];
+#pragma unroll
+			for (int mt = 0; mt < 4; ++mt) w1t[mt] = *reinterpret_cast<const h8*>(wts + SW_W1T + (16 * mt + r16) * S32 + 8 * hq);
+			const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt) {
+				const h8 v = load_fso(nt);
+				f4 ac[4];
+#pragma unroll
+				for (int mt = 0; mt < 4; ++mt) ac[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1t[mt], v, zero4, 0, 0, 0);
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) bdz[nt][ks][j] = f2h(ac[2 * ks + (j >> 2)][j & 3]); // chain_pack's mapping
+			}
+		}
 #pragma unroll
 		for (int ks = 0; ks < 2; ++ks) {
 			const h8 w1 = *reinterpret_cast<const h8*>(wts + SW_W1 + 32 * ks + 8 * hq);
@@ -829,7 +921,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 				for (int j = 0; j < 8; ++j) {
 					const bool on = bz[nt][ks][j] > (half_t)0.f;
 					bz[nt][ks][j] = on ? w1[j] : (half_t)0.f;                                   // bz now holds dz1
-					bdz[nt][ks][j] = on ? f2h(h2f(w1[j]) * h2f(d3[nt])) : (half_t)0.f;
+					bdz[nt][ks][j] = on ? (FULL ? bdz[nt][ks][j] : f2h(h2f(w1[j]) * h2f(d3[nt]))) : (half_t)0.f;
 				}
 		}
 		wave_lds_sync(); // X (network input) consumed by the first GEMM
@@ -859,7 +951,7 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 	if (lane == 0) T.var_partial[blockIdx.x * WAVES_PER_WG + wave] = var_sum;
 	// The four wavefronts' weight gradients, summed in a fixed order, leave as ONE partial per workgroup in k_dw's layout. The per-wave
 	// tiles are dead: their LDS is the staging area. D layout: lane = input column 16 ni + r16 (tile order), register r = hidden unit 16 mo + 4 hq + r.
-	float* red = reinterpret_cast<float*>(wts + SW_END);
+	float* red = reinterpret_cast<float*>(wts + W_END);
 	static_assert((size_t)WAVES_PER_WG * FBS_WAVE_HALFS * sizeof(half_t) >= (size_t)WAVES_PER_WG * 64 * 32 * sizeof(float), "staging area of the weight-gradient partials");
 	constexpr int N = 64 * 32;
 	for (int pass = 0; pass < 2; ++pass) {
@@ -874,8 +966,18 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		float* dst = (pass ? a.dw_w0b : a.dw_w0) + (size_t)blockIdx.x * N;
 		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
 	}
+	if (FULL) { // dW1 (first order), all 16 rows: D layout lane = hidden unit 16 nt + r16, register r = row 4 hq + r
+		__syncthreads();
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) red[wave * (16 * 64) + (4 * hq + r) * 64 + 16 * nt + r16] = acc_w1f[nt][r];
+		__syncthreads();
+		float* dst = a.dw_w1 + (size_t)blockIdx.x * (16 * 64);
+		for (int q = threadIdx.x; q < 16 * 64; q += WG) dst[q] = ((red[q] + red[16 * 64 + q]) + red[2 * 16 * 64 + q]) + red[3 * 16 * 64 + q];
+	}
 	// row 0 of the two 16x64 gradients of W1: per lane the sum over its samples; 16 lane groups (wave, hq) per hidden unit
-	for (int pass = 0; pass < 2; ++pass) {
+	for (int pass = FULL ? 1 : 0; pass < 2; ++pass) {
 		__syncthreads();
 #pragma unroll
 		for (int nt = 0; nt < 4; ++nt) red[(wave * 4 + hq) * 64 + 16 * nt + r16] = pass ? acc_w1b[nt] : acc_w1[nt];
@@ -884,8 +986,274 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 		for (int q = threadIdx.x; q < 16 * 64; q += WG) {
 			float v = 0.f;
 			if (q < 64) for (int g = 0; g < 16; ++g) v += red[g * 64 + q];
-			dst[q] = v; // rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
+			dst[q] = v; // rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb); the second-order gradient of W1 has row 0 only in either mode
 		}
+	}
+}
+
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<false>(G, net, a, smem_raw, lm);
+}
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<true>(G, net, a, smem_raw, lm);
+}
+// the same with one workgroup per CU: no register spills (the two-per-CU instance keeps ~80 values in scratch), half the wavefronts to hide the gathers
+__global__ __launch_bounds__(WG, 1) void k_fwd_bwd_sdf_full_wg1(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<true>(G, net, a, smem_raw, lm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10 + K11 with the colour MLP (albedo mode, nerf_network.h:257-452), part 1 of 2: the colour MLP alone -- forward, backward to its
+// input, and its three weight gradients -- on the compacted batch. Its input rows [sdf_out 16 | x y z | grad sdf | 0] were written by the
+// network evaluation of this step (FwdArgs::cin_out: same weights, so the training pass need not evaluate the SDF MLP twice, and --
+// the point -- need not keep 84 dy/dx values per sample alive across the colour MLP: part 2, k_fwd_bwd_sdf_full, receives
+// dL/d(input row) from here and consumes dy/dx level by level like the --no-albedo kernel). No hash-grid access, no LDS tiles:
+//   h1 = relu(W0 cin)   h2 = relu(W1 h1)   (rgb = W2 h2 is not needed: no output activation, fully_fused_mlp.cu:936-940)
+//   dh2 = (W2^T dr) (.) relu'(h2), dr = rows 0..2 of dL/doutput     dh1 = (W1^T dh2) (.) relu'(h1)     dcin = W0^T dh1
+//   dW2 += dr h2^T   dW1 += dh2 h1^T   dW0 += dh1 cin^T            (fully_fused_mlp.cu:953-1030)
+// The data path is register-chained (mlp.cuh: "8 features of one sample per lane"). The weight-gradient GEMMs have K = samples and take
+// "8 samples of one feature per lane": every operand they need is the TRANSPOSE of a chained fragment, made by an MFMA against the identity
+// (exact: one non-zero product per output) -- the matrix pipe is 3 % busy on this path, the vector ALU is what the kernel shares with the
+// march of the next step that runs beside it, so everything that can be a matrix instruction is one (the first version recomputed the
+// transposed copies with swapped operands and repeated the relu / mask / W2^T dr arithmetic on the VALU: 3500 vector instructions per
+// tile, 211 us beside the march; this one: see DESIGN.md). A transposed fragment holds the features in CHAIN order (lane r16 of fragment q =
+// chained position 16 q + r16), so the gradients come out with rows / columns permuted by chain_logical, undone when the partials are stored.
+// One partial per workgroup in k_dw's layout for k_dw_finish.
+// ---------------------------------------------------------------------------------------------
+constexpr int RW_C0 = 0;                      // [64][S32] rgb W0, compact columns in natural order
+constexpr int RW_C1 = RW_C0 + 64 * S32;       // [64][S64] rgb W1, columns in chain order
+constexpr int RW_C1T = RW_C1 + 64 * S64;      // [64][S64] rgb W1^T (row = h1 unit), columns = h2 units in chain order
+constexpr int RW_C0T = RW_C1T + 64 * S64;     // [32][S64] rgb W0^T (compact rows), columns = h1 units in chain order
+constexpr int RW_C2T = RW_C0T + 32 * S64;     // [64][S32] rgb W2^T (row = h2 unit), columns = the 16 outputs + zeros
+constexpr int RW_END = RW_C2T + 64 * S32;     // 16 640 halfs
+static_assert(RW_END % 8 == 0, "16-byte copies of the image");
+constexpr size_t LDS_RGB = std::max((size_t)RW_END * sizeof(half_t), (size_t)WAVES_PER_WG * 64 * 64 * sizeof(float));
+
+__device__ inline void load_weights_rgb(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
+	auto col = [](int c) { return c < 16 ? c : c + 16; }; // compact input index -> column of the 48-wide W0 (the 16 direction columns receive zeros)
+	for (int i = tid; i < 64 * 32; i += nthreads) {
+		const int o = i >> 5, c = i & 31;
+		w[RW_C0 + o * S32 + c] = net.rgb_w0[o * 48 + col(c)];
+		w[RW_C2T + o * S32 + c] = c < 16 ? net.rgb_w2[c * 64 + o] : (half_t)0.f;
+	}
+	for (int i = tid; i < 64 * 64; i += nthreads) {
+		const int o = i >> 6, p = i & 63;
+		w[RW_C1 + o * S64 + p] = net.rgb_w1[o * 64 + chain_logical(p)];
+		w[RW_C1T + o * S64 + p] = net.rgb_w1[chain_logical(p) * 64 + o];
+	}
+	for (int i = tid; i < 32 * 64; i += nthreads) { const int c = i >> 6, p = i & 63; w[RW_C0T + c * S64 + p] = net.rgb_w0[chain_logical(p) * 48 + col(c)]; }
+	// (row padding of the images is never read)
+}
+
+struct RgbArgs {
+	const half_t* cin;        // [slot][32] FwdArgs::cin_out
+	const uint32_t* src_slot; // [B] slot of every compacted sample (null: sample s is slot s)
+	const half_t* dout;       // [B][16]
+	half_t* dcin;             // [B][32] dL/d(input row): columns 0..15 -> dL/d sdf_out, 19..21 -> dL/d(grad sdf)
+	uint32_t B;
+	const half_t* wimg;       // optional: load_weights_rgb's image prepared by k_prepare_weight_images
+	float *dw_c0, *dw_c1, *dw_c2; // one partial per workgroup: [64][32] compact, [64][64], [16][64]
+};
+
+// Transpose of chained fragments: in[ms][ks] (lane = sample 16 ms + r16, K slot 8 hq + j = chained position 32 ks + 8 hq + j) ->
+// out[q][ks2] (lane = chained position 16 q + r16, register 4 h + r <-> sample 32 ks2 + 16 h + 4 hq + r), KS k-steps of 32 positions.
+template <int KS>
+__device__ __forceinline__ void transpose_frags(const h8 (&in)[4][KS], h8 (&out)[2 * KS][2], const int r16, const int hq) {
+	const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int n2 = 0; n2 < 2; ++n2) {
+		h8 idf;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) idf[j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
+#pragma unroll
+		for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+			for (int ms = 0; ms < 4; ++ms) {
+				const f4 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(in[ms][ks], idf, zero4, 0, 0, 0);
+#pragma unroll
+				for (int r = 0; r < 4; r += 2) {
+					out[2 * ks + n2][ms >> 1][4 * (ms & 1) + r] = f2h(t[r]);
+					out[2 * ks + n2][ms >> 1][4 * (ms & 1) + r + 1] = f2h(t[r + 1]);
+				}
+			}
+	}
+}
+
+__global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const RgbArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
+	if (a.wimg) copy_weight_image(wts, a.wimg, RW_END, threadIdx.x, WG);
+	else load_weights_rgb(wts, net, threadIdx.x, WG);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int r16 = lane & 15, hq = lane >> 4;
+	const uint32_t n_tiles = a.B / TILE;
+	const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+	const h8 zero8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+	f4 acc_w1[4][4], acc_w0[4][2], acc_w2[4]; // rows / columns in chain order (see the header), dW2: rows = outputs 4 hq + r
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+#pragma unroll
+		for (int ni = 0; ni < 4; ++ni) acc_w1[q][ni] = zero4;
+		acc_w0[q][0] = zero4; acc_w0[q][1] = zero4; acc_w2[q] = zero4;
+	}
+	// this tile's rows: input fragments (lane (r16, hq): columns 8 hq .. + 7 of sample 16 nt + r16) and dr fragments (rows 0..2 of dL/doutput in K slots
+	// 0..2 of the hq == 0 lanes, zeros elsewhere); the next tile's are requested before this tile's arithmetic (one wavefront per SIMD hides nothing)
+	auto load_tile = [&](const uint32_t tile, h8 (&cf)[4][1], h8 (&drf)[4][1]) {
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) {
+			const uint32_t sidx = tile * TILE + 16 * nt + r16;
+			const uint32_t slot = a.src_slot ? a.src_slot[sidx] : sidx;
+			cf[nt][0] = *reinterpret_cast<const h8*>(a.cin + (size_t)slot * 32 + 8 * hq);
+			h8 d = zero8;
+			if (hq == 0) { const h4 v = *reinterpret_cast<const h4*>(a.dout + (size_t)sidx * 16); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+			drf[nt][0] = d;
+		}
+	};
+	const uint32_t tile0 = blockIdx.x * WAVES_PER_WG + wave, tstride = gridDim.x * WAVES_PER_WG;
+	h8 cf_n[4][1], drf_n[4][1];
+	if (tile0 < n_tiles) load_tile(tile0, cf_n, drf_n);
+	for (uint32_t tile = tile0; tile < n_tiles; tile += tstride) {
+		const uint32_t s0 = tile * TILE;
+		h8 cf[4][1], drf[4][1];
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt) { cf[nt][0] = cf_n[nt][0]; drf[nt][0] = drf_n[nt][0]; }
+		if (tile + tstride < n_tiles) load_tile(tile + tstride, cf_n, drf_n);
+		// ---- forward
+		h8 bh1[4][2], bh2[4][2];
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 1>(wts + RW_C0, S32, cf, acc, lane);
+			chain_pack<true>(acc, bh1);
+		}
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 2>(wts + RW_C1, S64, bh1, acc, lane);
+			chain_pack<true>(acc, bh2);
+		}
+		// ---- dW2 += dr h2^T (the transposes of h2 and dr)
+		{
+			h8 th2[4][2], tdr[2][2];
+			transpose_frags<2>(bh2, th2, r16, hq);
+			transpose_frags<1>(drf, tdr, r16, hq); // tdr[0]: lane = output row r16; tdr[1] (columns 16..31) is zero
+#pragma unroll
+			for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks) acc_w2[qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tdr[0][ks], th2[qi][ks], acc_w2[qi], 0, 0, 0);
+		}
+		// ---- dh2 = (W2^T dr) (.) relu'(h2) (a K = 16 MFMA whose rows 3..15 meet zeros), in place of h2
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 1>(wts + RW_C2T, S32, drf, acc, lane);
+			h8 d[4][2];
+			chain_pack<false>(acc, d);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) bh2[nt][ks][j] = (bh2[nt][ks][j] > (half_t)0.f) ? d[nt][ks][j] : (half_t)0.f;
+		}
+		// ---- dW1 += dh2 h1^T
+		{
+			h8 th1[4][2], tdh2[4][2];
+			transpose_frags<2>(bh1, th1, r16, hq);
+			transpose_frags<2>(bh2, tdh2, r16, hq);
+#pragma unroll
+			for (int qo = 0; qo < 4; ++qo)
+#pragma unroll
+				for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+					for (int ks = 0; ks < 2; ++ks) acc_w1[qo][qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tdh2[qo][ks], th1[qi][ks], acc_w1[qo][qi], 0, 0, 0);
+		}
+		// ---- dh1 = (W1^T dh2) (.) relu'(h1), in place of h1
+		{
+			f4 acc[4][4];
+			zero_acc<4>(acc);
+			mfma_layer_regs<4, 2>(wts + RW_C1T, S64, bh2, acc, lane);
+			h8 d[4][2];
+			chain_pack<false>(acc, d);
+#pragma unroll
+			for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) bh1[nt][ks][j] = (bh1[nt][ks][j] > (half_t)0.f) ? d[nt][ks][j] : (half_t)0.f;
+		}
+		// ---- dcin = W0^T dh1 -> memory (rows of 32 halfs; this lane: columns 16 mt + 4 hq .. + 3 of sample 16 nt + r16)
+		{
+			f4 acc[2][4];
+			zero_acc<2>(acc);
+			mfma_layer_regs<2, 2>(wts + RW_C0T, S64, bh1, acc, lane);
+#pragma unroll
+			for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) {
+					const h4 v = {f2h(acc[mt][nt][0]), f2h(acc[mt][nt][1]), f2h(acc[mt][nt][2]), f2h(acc[mt][nt][3])};
+					*reinterpret_cast<h4*>(a.dcin + (size_t)(s0 + 16 * nt + r16) * 32 + 16 * mt + 4 * hq) = v;
+				}
+		}
+		// ---- dW0 += dh1 cin^T (cin is in natural column order, so its transpose is too)
+		{
+			h8 tdh1[4][2], tc[2][2];
+			transpose_frags<2>(bh1, tdh1, r16, hq);
+			transpose_frags<1>(cf, tc, r16, hq);
+#pragma unroll
+			for (int qo = 0; qo < 4; ++qo)
+#pragma unroll
+				for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+					for (int ks = 0; ks < 2; ++ks) acc_w0[qo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tdh1[qo][ks], tc[ni][ks], acc_w0[qo][ni], 0, 0, 0);
+		}
+	}
+	// The four wavefronts' weight gradients, summed in a fixed order, leave as ONE partial per workgroup in k_dw's layout; the weight image is dead.
+	// D layout of the accumulators: lane r16 = column of the B operand, register r = row 4 hq + r of the A operand, both possibly in chain order.
+	float* red = reinterpret_cast<float*>(smem_raw);
+	{
+		constexpr int N = 64 * 64;
+		__syncthreads();
+#pragma unroll
+		for (int qo = 0; qo < 4; ++qo)
+#pragma unroll
+			for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) red[wave * N + chain_logical(16 * qo + 4 * hq + r) * 64 + chain_logical(16 * qi + r16)] = acc_w1[qo][qi][r];
+		__syncthreads();
+		float* dst = a.dw_c1 + (size_t)blockIdx.x * N;
+		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
+	}
+	{
+		constexpr int N = 64 * 32;
+		__syncthreads();
+#pragma unroll
+		for (int qo = 0; qo < 4; ++qo)
+#pragma unroll
+			for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) red[wave * N + chain_logical(16 * qo + 4 * hq + r) * 32 + 16 * ni + r16] = acc_w0[qo][ni][r];
+		__syncthreads();
+		float* dst = a.dw_c0 + (size_t)blockIdx.x * N;
+		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
+	}
+	{ // dW2 [16][64]: rows 3..15 are sums of exact zeros
+		constexpr int N = 16 * 64;
+		__syncthreads();
+#pragma unroll
+		for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) red[wave * N + (4 * hq + r) * 64 + chain_logical(16 * qi + r16)] = acc_w2[qi][r];
+		__syncthreads();
+		float* dst = a.dw_c2 + (size_t)blockIdx.x * N;
+		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
 	}
 }
 

@@ -811,6 +811,7 @@ struct LossArgs {
 	uint32_t* ncomp;  // [n_rays]
 	uint32_t* cbase;  // [n_rays]
 	float* coords_compacted;
+	uint32_t* src_slot; // optional [B]: the marched-sample slot of every compacted sample (k_rgb_fwd_bwd reads that slot's colour-MLP input row, written by the network evaluation)
 	half_t* dloss;
 	float *loss, *ek_loss, *mask_loss;
 	const float* ray_const; // per-ray constants precomputed by k_march_write (null: compute them here)
@@ -1385,6 +1386,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		if (valid) {
 #pragma unroll
 			for (int q = 0; q < 7; ++q) coords_out[(size_t)j * 7 + q] = coords_in[(size_t)j * 7 + q];
+			if (a.src_slot) a.src_slot[compacted_base + j] = base + j;
 			load_out16(net + (size_t)j * 16, o);
 			dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
 			albedo_from_output(F, o, albedo);
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)
 // fill_rollover_and_rescale / fill_rollover (common_device.h:514-535): pad the compacted batch to B by wrapping.
 __device__ __forceinline__ void rollover_body(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords,
-                                              const uint64_t first, const uint64_t stride) {
+                                              const uint64_t first, const uint64_t stride, uint32_t* __restrict__ src_slot = nullptr) {
 	const uint32_t n_in = counters[1];
 	if (n_in == 0 || n_in >= B) return;
 	const uint64_t n_out16 = (uint64_t)B * 16, n_in16 = (uint64_t)n_in * 16;
@@ -1495,10 +1497,11 @@ __device__ __forceinline__ void rollover_body(const uint32_t B, const uint32_t* 
 			dloss[q] = f2h(v * n_in / B);
 		}
 		if (q >= n_in7 && q < n_out7) coords[q] = coords[q % n_in7];
+		if (src_slot && q >= n_in && q < B) src_slot[q] = src_slot[q % n_in]; // the wrapped samples are the same samples: same input rows
 	}
 }
-__global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords) {
-	rollover_body(B, counters, dloss, coords, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+__global__ void k_rollover(const uint32_t B, const uint32_t* __restrict__ counters, half_t* __restrict__ dloss, float* __restrict__ coords, uint32_t* __restrict__ src_slot) {
+	rollover_body(B, counters, dloss, coords, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x, src_slot);
 }
 
 // per-tile (4096 rays) fp64 sums of the three loss rows, for batches too large for one workgroup to walk (fixed order: deterministic)
@@ -1554,9 +1557,9 @@ __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const u
 // both need nothing but the second loss pass, and one launch on the critical stream instead of two saves a kernel boundary.
 __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1,
                                                                  const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
-                                                                 const double* __restrict__ partial, const uint32_t n_partial, const uint32_t B, half_t* __restrict__ dloss, float* __restrict__ coords) {
+                                                                 const double* __restrict__ partial, const uint32_t n_partial, const uint32_t B, half_t* __restrict__ dloss, float* __restrict__ coords, uint32_t* __restrict__ src_slot) {
 	if (blockIdx.x == 0) reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial);
-	else rollover_body(B, counters, dloss, coords, (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - 1) * blockDim.x);
+	else rollover_body(B, counters, dloss, coords, (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - 1) * blockDim.x, src_slot);
 }
 
 } // namespace rnb

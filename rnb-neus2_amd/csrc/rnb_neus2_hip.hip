@@ -149,7 +149,13 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase, scan_tiles; // scan_tiles: [64] tile sums + [64][3] dependent tile sums of the multi-workgroup ray scan
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
-	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train; // LDS weight images of the training weights, rebuilt after every optimizer step
+	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train, wimg_rgb; // LDS weight images of the training weights, rebuilt after every optimizer step
+	// albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full (kernels_net.cuh). cin_eval = the colour MLP's input row of every evaluated sample (written by the
+	// network evaluation), src_slot = the slot of every compacted sample (loss pass 2), dcin = dL/d(input row) between the two training kernels
+	DevBuf<half_t> cin_eval, dcin, rgb_out_scratch;
+	DevBuf<uint32_t> src_slot;
+	bool cin_flow = false; // this step's network evaluation has exported cin_eval and the loss pass src_slot (rnb_train_step_begin); stage entry points clear it
+	bool rgb_split() const { return !cfg.apply_no_albedo && !knobs.fwd_bwd_generic; }
 	bool wimg_valid = false;
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
 	DevBuf<uint32_t> unfinished;
@@ -169,6 +175,7 @@ struct rnb_ctx {
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		bool scan_kernel = false; // RNB_MARCH_SCAN_KERNEL: the ray scans of small batches as their own launch (k_scan_rays, rounds 1-3) instead of inside k_march_write
+		bool fbs_full_wg1 = false; // RNB_FBS_FULL_WG1: the albedo mode's k_fwd_bwd_sdf_full with one workgroup per CU (no register spills) instead of two
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -437,10 +444,19 @@ int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
 	return update_density_grid(c, s, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
 }
 
-int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference, const uint32_t* idx = nullptr) {
+// The buffers of the albedo mode's training kernels, on first use (the mode can be switched on by rnb_update_config).
+static int ensure_rgb_buffers(rnb_ctx* c) {
+	if (c->cin_eval.p) return RNB_OK;
+	const size_t B = c->cfg.target_batch_size;
+	if (c->cin_eval.alloc(B * 16 * 32) != hipSuccess || c->dcin.alloc(B * 32) != hipSuccess || c->rgb_out_scratch.alloc(B * 16) != hipSuccess || c->src_slot.alloc(B) != hipSuccess)
+		return fail(RNB_ERR_NOMEM, "hipMalloc failed for the colour-MLP training buffers");
+	return RNB_OK;
+}
+
+int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference, const uint32_t* idx = nullptr, half_t* cin_out = nullptr) {
 	if (n_max == 0) return RNB_OK;
 	FwdArgs a;
-	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx;
+	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx; a.cin_out = cin_out;
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
@@ -562,6 +578,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.views = c->views.p; a.counters = c->counters.p; a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p;
 	a.coords = c->coords.p; a.mlp_out = c->mlp_out.p; a.ray_loss = c->ray_loss.p; a.ncomp = c->ncomp.p; a.cbase = c->cbase.p;
 	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss; a.mask_loss = c->mask_loss;
+	a.src_slot = c->cin_flow ? c->src_slot.p : nullptr;
 	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
 	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
@@ -578,7 +595,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		a.cap = c->cur_k1;
 		launch_heads();
 		c->prof.mark(s, P_LOSS_PASS1);
-		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 2, two_round_n_max, c->mlp_out.p, false, c->idx2.p);
+		int rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p + 2, two_round_n_max, c->mlp_out.p, false, c->idx2.p, c->cin_flow ? c->cin_eval.p : nullptr);
 		if (rc != RNB_OK) return rc;
 		c->prof.mark(s, P_FORWARD);
 		a.phase = 1;
@@ -595,7 +612,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	c->prof.mark(s, P_SCAN_COMPACT);
 	if (rows) hipLaunchKernelGGL(k_loss_pass2<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 	else hipLaunchKernelGGL(k_loss_pass2<64>, dim3(blocks), dim3(256), 0, s, a);
-	if (!defer_rollover) hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p);
+	if (!defer_rollover) hipLaunchKernelGGL(k_rollover, dim3(1024), dim3(256), 0, s, c->cfg.target_batch_size, c->counters.p, c->dloss_dout.p, c->coords_compacted.p, a.src_slot);
 	c->prof.mark(s, P_LOSS_PASS2);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -611,9 +628,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.B_global = B * c->cfg.world_size; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
-	a.wimg = !c->wimg_valid ? nullptr : (c->cfg.apply_no_albedo && !c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
-	const bool sdf_only = a.skip_rgb && !c->knobs.fwd_bwd_generic;
-	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
+	const bool split = c->rgb_split(); // albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full instead of the generic kernel and its weight-gradient GEMMs
+	a.wimg = !c->wimg_valid ? nullptr : (!c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
+	const bool sdf_only = (a.skip_rgb && !c->knobs.fwd_bwd_generic) || split; // the training kernels leave one weight-gradient partial per workgroup themselves
+	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * (split && c->knobs.fbs_full_wg1 ? 1u : c->knobs.fbs_wg_per_cu)) : c->fwd_grid;
 	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own
 	const size_t slab = sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
 	float* p_rgb2; float* p_rgb1; float* p_rgb0; float* p_sdf1; float* p_sdf0; float* p_sdf0b; float* p_sdf1b;
@@ -631,7 +649,24 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const bool side_streams = c->overlap();
 	c->prof.mark(s, P_NONE);
 	hipEvent_t ev_fb = side_streams ? c->ev_fb : nullptr; // the weight-gradient GEMMs start on the side stream when this kernel is done
-	if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+	if (split) {
+		int rc = ensure_rgb_buffers(c);
+		if (rc != RNB_OK) return rc;
+		const bool flow = c->cin_flow; // the step's network evaluation exported the input rows; a stage call evaluates the compacted batch for them
+		c->cin_flow = false;
+		if (!flow) {
+			rc = launch_forward(c, s, c->coords_compacted.p, nullptr, B, c->rgb_out_scratch.p, false, nullptr, c->cin_eval.p);
+			if (rc != RNB_OK) return rc;
+		}
+		RgbArgs r;
+		r.cin = c->cin_eval.p; r.src_slot = flow ? c->src_slot.p : nullptr; r.dout = c->dloss_dout.p; r.dcin = c->dcin.p; r.B = B;
+		r.wimg = c->wimg_valid ? c->wimg_rgb.p : nullptr;
+		r.dw_c0 = p_rgb0; r.dw_c1 = p_rgb1; r.dw_c2 = p_rgb2;
+		hipLaunchKernelGGL(k_rgb_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
+		a.dcin = c->dcin.p;
+		if (c->knobs.fbs_full_wg1) LAUNCH_EV(k_fwd_bwd_sdf_full_wg1, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+		else LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+	} else if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
@@ -670,7 +705,9 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	//   B  middle  [e_c, l_fine) run-length quad kernel: a cell spans several march steps (~590 / resolution); same bound + the latency of the walk
 	//   C  coarse  [0, e_c)      LDS-privatised tables (beside the atomic groups on the optimizer's stream it stretches 42 -> 158 us and the
 	//                            step loses 4 %, measured in round 2: it stays last on the caller's stream)
-	const uint32_t scatter_cap = c->knobs.scatter_wg_per_cu >= 0 ? (uint32_t)c->knobs.scatter_wg_per_cu : (sdf_only ? 0u : 2u);
+	// albedo mode, round 4 (k_rgb_fwd_bwd + k_fwd_bwd_sdf_full, march held back behind them): 0: 0.806, 1: 0.783, 2: 0.760, 3: 0.774, 4: 0.800 -- there the march is the
+	// long pole beside the scatter and gets the wave slots a capped scatter leaves
+	const uint32_t scatter_cap = c->knobs.scatter_wg_per_cu >= 0 ? (uint32_t)c->knobs.scatter_wg_per_cu : ((sdf_only && !split) ? 0u : 2u);
 	ScatterArgs sa;
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
@@ -809,7 +846,7 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 	c->opt.begun = false;
 	c->opt.early_done = false;
 	c->sc.valid = false;
-	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(3), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p);
+	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(4), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
 	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
@@ -868,7 +905,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
-			LAUNCH_EV(k_prepare_weight_images, dim3(3), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p);
+			LAUNCH_EV(k_prepare_weight_images, dim3(4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
 			images_done = true;
 			adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
@@ -948,7 +985,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
+	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->mc_table.free(); c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -1021,7 +1058,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
-	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SW_END_PADDED); ALLOC(c->wimg_train, W_TRAIN_END);
+	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SWF_END); ALLOC(c->wimg_train, W_TRAIN_END); ALLOC(c->wimg_rgb, RW_END);
 	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
@@ -1065,6 +1102,9 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	{
 		const int march_lds_max = (int)((2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS) * sizeof(uint32_t));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
@@ -1092,6 +1132,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
 		k.scan_kernel = getenv("RNB_MARCH_SCAN_KERNEL") != nullptr;
+		k.fbs_full_wg1 = getenv("RNB_FBS_FULL_WG1") != nullptr;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1537,8 +1578,11 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->cur_n_rays_total = n_rays_total;
 	c->prof.mark(s, P_NONE);
 	const bool two_round = c->cur_k1 != 0;
-	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p);
-	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false);
+	c->cin_flow = c->rgb_split();
+	if (c->cin_flow) { rc = ensure_rgb_buffers(c); if (rc != RNB_OK) return rc; }
+	half_t* cin_out = c->cin_flow ? c->cin_eval.p : nullptr;
+	if (two_round) rc = launch_forward(c, s, c->coords.p, c->fwd_counts.p, max_inference, c->mlp_out.p, false, c->idx1.p, cin_out);
+	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false, nullptr, cin_out);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
 	rc = compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
@@ -1560,7 +1604,7 @@ static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	const uint32_t n_tiles = (c->cur_n_rays + SCAN_TILE - 1) / SCAN_TILE;
 	if (tiled) hipLaunchKernelGGL(k_reduce_losses_tiles, dim3(n_tiles), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_partial.p);
 	LAUNCH_EV(k_reduce_losses_rollover, dim3(1 + 255), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
-	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles, c->cfg.target_batch_size, c->dloss_dout.p, c->coords_compacted.p);
+	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles, c->cfg.target_batch_size, c->dloss_dout.p, c->coords_compacted.p, c->cin_flow ? c->src_slot.p : nullptr);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1582,7 +1626,10 @@ static int launch_premarch(rnb_ctx* c) {
 	// No fill in front of the march: every step counter is written with a plain store by the scans (k_scan_rays*, k_scan_compact*), and the
 	// loss rows are written for every kept ray by k_loss_pass2 (zeros for a ray without compacted samples) -- k_reduce_losses reads nothing
 	// else. (Round 2 queued a k_clear_step here: 62 us behind k_fwd_bwd_sdf's workgroups at the head of the march chain.)
-	if (c->knobs.march_late) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
+	// Albedo mode: always. Its two training kernels (k_rgb_fwd_bwd: one wavefront per SIMD with ~470 registers; k_fwd_bwd_sdf_full: two with 256) and the march
+	// exclude each other on a SIMD; a march that has started beside the first keeps the second at half occupancy (253 instead of 113 us, the step 0.79 instead of
+	// 0.76 ms). Behind them it runs beside the scatter, as it effectively does with --no-albedo, where k_fwd_bwd_sdf claims the registers first.
+	if (c->knobs.march_late || c->rgb_split()) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
 	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
 	if (rc != RNB_OK) return rc;
 	c->pre.loss_cleared = true;
