@@ -381,6 +381,79 @@ def test_sdf_only_training_kernel_matches_generic(scene, trained):
         spe.close()
 
 
+def test_albedo_training_kernels_match_generic_and_oracle(scene, trained):
+    """Albedo mode (configs 3 and 5) at full size. The colour MLP trains in k_rgb_fwd_bwd on input rows the step's network evaluation
+    exported (slots through the compaction and the batch padding), the SDF MLP and the hash grid in k_fwd_bwd_sdf_full;
+    RNB_FWD_BWD_GENERIC=1 is rounds 1-3's single kernel with its feature-major operand export and GEMM launches. (a) One training step of
+    each from the same state: the loss pass is identical, every gradient block agrees up to the summation order and the one-half-ulp
+    freedom of the two forward passes' K order. (b) The same kernels through the stage interface on the oracle's compacted batch and
+    dL/doutput (nerf_network.h:257-452), all seven weight gradients, the hash grid and the variance against the CPU oracle."""
+    from tests import oracle_lib
+    ctx, state = trained
+    # 1000 steps of --no-albedo training leave the colour MLP without signal (zero gradients, weight decay): give it weights of the initial scale
+    lay0 = ctx.param_layout()
+    state = dict(state)
+    state["params"] = state["params"].copy()
+    state["params"][lay0["rgb"]:lay0["grid"]] = np.random.default_rng(5).uniform(-0.2, 0.2, lay0["grid"] - lay0["rgb"]).astype(np.float32)
+    gen = _clone(scene, state, env={"RNB_FWD_BWD_GENERIC": "1"}, overlap=0, apply_no_albedo=0)
+    spl = _clone(scene, state, overlap=0, apply_no_albedo=0)
+    kw = dict(KW)
+    kw["apply_no_albedo"] = 0
+    cpu = oracle_lib.context(**kw)
+    try:
+        cpu.init_params()
+        cpu.set_dataset(*scene)
+        cpu.set_params(state["params"])
+        cpu.put("DENSITY_GRID", state["grid"])
+        cpu.update_density_bitfield()
+        cpu.set_controller(state["step"], state["rays"], state["before"], 0)
+        lay = gen.param_layout()
+        blocks = {"sdf_mlp": (lay["sdf"], lay["rgb"]), "rgb_mlp": (lay["rgb"], lay["grid"]), "hash_grid": (lay["grid"], lay["variance"])}
+
+        def compare(g0, g1, tol_mlp, tol_grid, what):
+            for name, (lo, hi) in blocks.items():
+                x, y = g0[lo:hi].astype(np.float64), g1[lo:hi].astype(np.float64)
+                sc = np.abs(y).max()
+                assert sc > 0, (what, name)
+                tol = tol_grid if name == "hash_grid" else tol_mlp
+                assert np.abs(x - y).max() <= tol * sc, (what, name, np.abs(x - y).max() / sc)
+                assert x @ y / (np.linalg.norm(x) * np.linalg.norm(y)) > 0.9999, (what, name)
+            v0, v1 = float(g0[lay["variance"]]), float(g1[lay["variance"]])
+            assert abs(v0 - v1) <= 5e-3 * abs(v1) + 1e-6, (what, v0, v1)
+
+        # (a) a whole step, the training flow (rows exported by the network evaluation, slots from the loss pass)
+        for c in (gen, spl):
+            c.train_step_begin()
+        assert np.array_equal(gen.get("DLOSS_DOUT").view(np.uint16), spl.get("DLOSS_DOUT").view(np.uint16))
+        assert np.array_equal(gen.get("COORDS_COMPACTED").view(np.uint32), spl.get("COORDS_COMPACTED").view(np.uint32))
+        compare(spl.get("GRADS_FP32"), gen.get("GRADS_FP32"), 5e-3, 2e-3, "split vs generic")
+        for c in (gen, spl):
+            cnt, sums = c.train_step_local()
+            c.train_step_finish(cnt, sums)
+            c.train_step_apply()
+        # (b) the stage interface against the oracle, on the oracle's batch (a fresh context: the step above has moved the generators on)
+        spl.close()
+        spl = _clone(scene, state, overlap=0, apply_no_albedo=0)
+        R = state["rays"]
+        for c in (spl, cpu):
+            c.set_controller(state["step"] | 1, R, state["before"], 0)
+            c.generate_training_samples(R, 4096)
+        written = int(cpu.get("COUNTERS")[3])
+        for c in (spl, cpu):
+            c.forward_infer_staged(written)
+        spl.put("MLP_OUT", cpu.get("MLP_OUT", written * 16))
+        for c in (spl, cpu):
+            c.compute_loss(R, 4096)
+        assert np.array_equal(spl.get("COORDS_COMPACTED").view(np.uint32), cpu.get("COORDS_COMPACTED").view(np.uint32))
+        spl.put("DLOSS_DOUT", cpu.get("DLOSS_DOUT"))
+        for c in (spl, cpu):
+            c.forward_backward()
+        compare(spl.get("GRADS_FP32"), cpu.get("GRADS_FP32"), 5e-3, 2e-3, "split vs oracle")
+    finally:
+        for c in (gen, spl, cpu):
+            c.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # One config-4 step at full size against the oracle, from the trained state: at the controller's own ray count (~12 k,
 # the 16-lanes-per-ray march and single-workgroup scans) and at 40 000 rays (>= 18 432: thread-per-ray march, tiled scans,
