@@ -338,7 +338,6 @@ struct MarchArgs {
 	float* ray_const;   // [n_rays kept][RAY_CONST_FLOATS]
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
-	uint32_t* fwd_counts; // [4] sizes of the two evaluation rounds (k_scan_rays / k_march_write<.., true> write [0] and clear the rest)
 };
 
 // SC: one cascade and no cone (aabb_scale 1, every RNb scene): dt is the constant step and every position inside the box is in
@@ -965,91 +964,12 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 // ONE thread per ray -- the first MARCH_WRITE_WG / LR threads of the workgroup, one for each of its rays -- and not by every
 // lane of the ray's group (that was most of this kernel: 65 -> see DESIGN.md section 6).
 constexpr uint32_t MARCH_WRITE_WG = 1024;
-// sum of three counters over the workgroup's 16 wavefronts; result in every thread
-__device__ __forceinline__ void block_sum3(uint32_t (&v)[3], uint32_t (*sh)[16], const uint32_t tid) {
-	const uint32_t lane = tid & 63u, wave = tid >> 6;
-#pragma unroll
-	for (int k = 0; k < 3; ++k) {
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-		if (lane == 0) sh[k][wave] = v[k];
-	}
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < 3; ++k) {
-		uint32_t t = 0;
-#pragma unroll
-		for (uint32_t w = 0; w < 16; ++w) t += sh[k][w];
-		v[k] = t;
-	}
-	__syncthreads();
-}
-// FUSED: the exclusive scans over the rays (k_scan_rays) are worked out by every workgroup for its own rays -- the sample counts of the rays in
-// front of it are <= 18 k integers in the L2, one or two 16-byte loads per thread and a block sum -- and the last workgroup writes the step
-// counters. k_scan_rays is ONE workgroup of 16 wavefronts that must be co-resident on a CU: beside the gradient scatter's 65 k wavefronts it
-// waited 45 us for the slots (67 us for 21 us of work, profiles/r03_timeline_*), in the middle of the chain march -> scan -> write that the
-// next step's network evaluation waits for. Integer work, same numbers. ok(ray) = steps > 0 && prefix + steps <= max_samples
-// (testbed_nerf.cu:1348-1355): the prefix only grows, so once a ray fails every later one does, and if the samples in front of a workgroup
-// fit (P <= max_samples) every ray in front of it with samples was kept -- their count is the slot offset, no second scan needed.
-template <int LR, bool FUSED = false>
+template <int LR>
 __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs a) {
 	constexpr uint32_t RAYS = MARCH_WRITE_WG / LR;
-	__shared__ uint32_t sh_sum[3][16];
-	__shared__ uint32_t sh_ray[3][RAYS]; // slot, base, base1 of the workgroup's rays
-	__shared__ uint32_t sh_own[3];
-	if (FUSED) {
-		static_assert(RAYS <= 64 && RAYS % 4 == 0, "the workgroup's rays are scanned by one wavefront");
-		const uint32_t tid = threadIdx.x, r0 = blockIdx.x * RAYS;
-		uint32_t v[3] = {0, 0, 0}; // over the rays in front of the workgroup: samples, rays with samples, first-round samples
-		for (uint32_t q = tid * 4; q < r0; q += MARCH_WRITE_WG * 4) { // r0 is a multiple of 4
-			const uint4 w = *reinterpret_cast<const uint4*>(a.steps + q);
-			const uint32_t st[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-			for (int e = 0; e < 4; ++e) { v[0] += st[e]; v[1] += st[e] > 0 ? 1u : 0u; v[2] += min(st[e], a.k1); }
-		}
-		block_sum3(v, sh_sum, tid);
-		if (tid < 64) { // this workgroup's rays: one wavefront; sh_own = their samples, kept rays, kept first-round samples
-			const uint32_t i = r0 + tid;
-			const uint32_t st = (tid < RAYS && i < a.n_rays) ? a.steps[i] : 0u;
-			const uint32_t incl = wave_inclusive_scan(st, tid);
-			const bool ok = st > 0 && v[0] + incl <= a.max_samples;
-			const uint32_t okc = wave_inclusive_scan(ok ? 1u : 0u, tid), okf = wave_inclusive_scan(ok ? min(st, a.k1) : 0u, tid);
-			if (tid < RAYS) {
-				sh_ray[0][tid] = ok ? v[1] + okc - 1u : 0xffffffffu; // front_fits whenever ok
-				sh_ray[1][tid] = v[0] + incl - st;
-				sh_ray[2][tid] = v[2] + okf - (ok ? min(st, a.k1) : 0u);
-			}
-			if (tid == 63) { sh_own[0] = incl; sh_own[1] = okc; sh_own[2] = okf; }
-		}
-		__syncthreads();
-		if (blockIdx.x == gridDim.x - 1) { // the step counters (k_scan_rays' last lines); every thread takes the same branch
-			const uint32_t own[3] = {sh_own[0], sh_own[1], sh_own[2]};
-			uint32_t kept[3] = {0, 0, 0}; // kept rays, their samples, their first-round samples
-			const uint32_t total = v[0] + own[0];
-			if (total <= a.max_samples) { kept[0] = v[1] + own[1]; kept[1] = total; kept[2] = v[2] + own[2]; }
-			else { // the batch does not fit (the ray controller avoids it): count what does, chunk by chunk
-				__shared__ uint32_t wsum[16];
-				uint32_t carry = 0, acc[3] = {0, 0, 0};
-				for (uint32_t t0 = 0; t0 < a.n_rays; t0 += MARCH_WRITE_WG) {
-					const uint32_t st = t0 + tid < a.n_rays ? a.steps[t0 + tid] : 0u;
-					uint32_t tot;
-					const uint32_t excl = block_exclusive_scan<16>(st, tid & 63u, tid >> 6, wsum, tot);
-					if (st > 0 && carry + excl + st <= a.max_samples) { acc[0] += 1u; acc[1] += st; acc[2] += min(st, a.k1); }
-					carry += tot;
-				}
-				block_sum3(acc, sh_sum, tid);
-#pragma unroll
-				for (int k = 0; k < 3; ++k) kept[k] = acc[k];
-			}
-			if (tid == 0) {
-				a.counters[0] = total; a.counters[2] = kept[0]; a.counters[3] = kept[1];
-				a.fwd_counts[0] = kept[2]; a.fwd_counts[1] = 0; a.fwd_counts[2] = 0; a.fwd_counts[3] = 0;
-			}
-		}
-	}
 	if (a.ray_const && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
 		const uint32_t i = blockIdx.x * RAYS + threadIdx.x;
-		const uint32_t s = i < a.n_rays ? (FUSED ? sh_ray[0][threadIdx.x] : a.slot[i]) : 0xffffffffu;
+		const uint32_t s = i < a.n_rays ? a.slot[i] : 0xffffffffu;
 		if (s != 0xffffffffu) {
 			RayConstIn in;
 			in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
@@ -1067,11 +987,11 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 	const uint32_t i = blockIdx.x * RAYS + threadIdx.x / LR;
 	const uint32_t lane = threadIdx.x & (LR - 1);
 	if (i >= a.n_rays) return;
-	const uint32_t s = FUSED ? sh_ray[0][threadIdx.x / LR] : a.slot[i];
+	const uint32_t s = a.slot[i];
 	if (s == 0xffffffffu) return;
 	const float* st = a.setup + (size_t)i * 8;
 	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
-	const uint32_t steps = a.steps[i], base = FUSED ? sh_ray[1][threadIdx.x / LR] : a.base[i];
+	const uint32_t steps = a.steps[i], base = a.base[i];
 	if (lane == 0) {
 		a.ray_indices[s] = i;
 		float* ro = a.rays + (size_t)s * 6;
@@ -1081,7 +1001,7 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 		a.numsteps[(size_t)s * 2 + 1] = base;
 	}
 	if (a.k1) {
-		const uint32_t b1 = FUSED ? sh_ray[2][threadIdx.x / LR] : a.base1[i];
+		const uint32_t b1 = a.base1[i];
 		for (uint32_t j = lane; j < min(steps, a.k1); j += LR) a.idx1[b1 + j] = base + j;
 	}
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415

@@ -174,7 +174,6 @@ struct rnb_ctx {
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
-		bool scan_kernel = false; // RNB_MARCH_SCAN_KERNEL: the ray scans of small batches as their own launch (k_scan_rays, rounds 1-3) instead of inside k_march_write
 		bool fbs_full_wg1 = false; // RNB_FBS_FULL_WG1: the albedo mode's k_fwd_bwd_sdf_full with one workgroup per CU (no register spills) instead of two
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
@@ -522,7 +521,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	}
 	a.setup = c->ray_setup.p; a.ray_t = c->ray_t.p; a.d_unnorm = c->ray_dunnorm.p; a.steps = c->ray_steps.p; a.base = c->ray_base.p; a.slot = c->ray_slot.p;
 	a.ray_indices = c->ray_indices.p; a.rays = c->rays.p; a.numsteps = c->numsteps.p; a.coords = c->coords.p; a.counters = c->counters.p;
-	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays); a.fwd_counts = c->fwd_counts.p;
+	a.base1 = c->ray_base1.p; a.idx1 = c->idx1.p; a.k1 = k1_for(c, n_rays);
 	a.F = loss_flags(c);
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.ray_const = c->ray_const.p;
@@ -554,12 +553,11 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
 		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
 		hipLaunchKernelGGL(k_scan_rays_slots, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->ray_base.p, c->scan_tiles.p + 64, c->ray_slot.p, c->ray_base1.p, c->counters.p, c->fwd_counts.p);
-	} else if (c->knobs.scan_kernel)
+	} else
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, done, a);
-	else if (c->knobs.scan_kernel) LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
-	else LAUNCH_EV((k_march_write<64, true>), dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a); // the ray scans inside (no k_scan_rays launch)
+	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -589,7 +587,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		if (rows) hipLaunchKernelGGL(k_loss_pass1_heads<16>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
 		else hipLaunchKernelGGL(k_loss_pass1_heads<64>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
 	};
-	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
+	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p;
 	c->prof.mark(s, P_NONE);
 	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
 		a.cap = c->cur_k1;
@@ -1131,7 +1129,6 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
-		k.scan_kernel = getenv("RNB_MARCH_SCAN_KERNEL") != nullptr;
 		k.fbs_full_wg1 = getenv("RNB_FBS_FULL_WG1") != nullptr;
 	}
 	plan_scatter_groups(c);
