@@ -658,7 +658,9 @@ constexpr size_t LDS_FBS = (size_t)(SW_END + WAVES_PER_WG * FBS_WAVE_HALFS) * si
 // albedo mode (k_fwd_bwd_sdf_full): dL/d sdf_out has all 16 rows, so W1^T is a matrix again: [64][S32], row = hidden unit, columns = the 16 outputs + zeros
 constexpr int SW_W1T = SW_END_PADDED;
 constexpr int SWF_END = SW_W1T + 64 * S32;
-constexpr size_t LDS_FBS_FULL = (size_t)(SWF_END + WAVES_PER_WG * FBS_WAVE_HALFS) * sizeof(half_t);
+constexpr int SO_STRIDE = 24;                                          // halfs per row of the dso tile (16 + 8: conflict-free 16-byte fragment reads)
+constexpr int FBS_FULL_WAVE_HALFS = FBS_WAVE_HALFS + TILE * SO_STRIDE; // + dso rows [64][16] staged at the top of the tile
+constexpr size_t LDS_FBS_FULL = (size_t)(SWF_END + WAVES_PER_WG * FBS_FULL_WAVE_HALFS) * sizeof(half_t);
 // Column order of the 32-wide input tiles: the 28 hash features first (a level's pair is one aligned 4-byte LDS access),
 // then x y z, then the pad -- the input index is a summation index of W0 . in, the weight images follow the same order.
 __host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (p < 31 ? p - 28 : 31); }
@@ -716,9 +718,11 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 	else load_weights_fbs(wts, net, threadIdx.x, WG);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	half_t* X = wts + W_END + wave * FBS_WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in
+	constexpr int WAVE_HALFS = FULL ? FBS_FULL_WAVE_HALFS : FBS_WAVE_HALFS;
+	half_t* X = wts + W_END + wave * WAVE_HALFS; // network input rows, later d sdf / d in, later dL / d in
 	half_t* D = X + TILE * S32;                        // second-order input rows (ddin)
 	half_t* Z = D + TILE * S32;
+	half_t* SO = Z + TILE; // FULL: dso rows
 	const int r16 = lane & 15, hq = lane >> 4;
 	const uint32_t B = a.B;
 	const uint32_t n_tiles = B / TILE;
@@ -752,7 +756,14 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		float dn[3];
 		{
 			h8 a2 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-			if (FULL) a2 = *reinterpret_cast<const h8*>(a.dcin + (size_t)s * 32 + 16); // dL_drgb_network_input rows 35..37 = compact columns 19..21
+			if (FULL) {
+				const h8* row = reinterpret_cast<const h8*>(a.dcin + (size_t)s * 32);
+				a2 = row[2]; // dL_drgb_network_input rows 35..37 = compact columns 19..21
+				h8 o0 = row[0];
+				o0[0] = o0[0] + dout[3]; // dso: row 0 += dL/dsdf (add_density_gradient)
+				*reinterpret_cast<h8*>(SO + lane * SO_STRIDE) = o0; // (read as fragments behind the encode's wave_lds_sync; requested here, beside the gathers)
+				*reinterpret_cast<h8*>(SO + lane * SO_STRIDE + 8) = row[1];
+			}
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
 				float v = FULL ? h2f(a2[3 + d]) : 0.f;     // (zero without the colour MLP)
@@ -790,8 +801,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		// 16 nt + r16 (zeros beyond row 15) -- the B operand of W1^T dso and, with the roles swapped, the A operand of its transpose
 		auto load_fso = [&](const int nt) { // (loaded where it is used, twice per tile: 16 registers less across the encode-free middle of the tile)
 			h8 v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-			if (hq < 2) v = *reinterpret_cast<const h8*>(a.dcin + (size_t)(tile * TILE + 16 * nt + r16) * 32 + 8 * hq);
-			if (hq == 0) v[0] = v[0] + Z[16 * nt + r16];
+			if (hq < 2) v = *reinterpret_cast<const h8*>(SO + (16 * nt + r16) * SO_STRIDE + 8 * hq);
 			return v;
 		};
 		{ // ---- weight gradients of this tile (see the header) ----
@@ -997,12 +1007,6 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf(const GridMeta G, const N
 	fwd_bwd_sdf_body<false>(G, net, a, smem_raw, lm);
 }
 __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full(const GridMeta G, const NetW net, const TrainArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
-	fwd_bwd_sdf_body<true>(G, net, a, smem_raw, lm);
-}
-// the same with one workgroup per CU: no register spills (the two-per-CU instance keeps ~80 values in scratch), half the wavefronts to hide the gathers
-__global__ __launch_bounds__(WG, 1) void k_fwd_bwd_sdf_full_wg1(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fwd_bwd_sdf_body<true>(G, net, a, smem_raw, lm);

@@ -174,7 +174,6 @@ struct rnb_ctx {
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
-		bool fbs_full_wg1 = false; // RNB_FBS_FULL_WG1: the albedo mode's k_fwd_bwd_sdf_full with one workgroup per CU (no register spills) instead of two
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -587,7 +586,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 		if (rows) hipLaunchKernelGGL(k_loss_pass1_heads<16>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
 		else hipLaunchKernelGGL(k_loss_pass1_heads<64>, dim3(blocks_heads), dim3(LOSS1_WG), 0, s, a);
 	};
-	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p;
+	a.cap = 0xffffffffu; a.phase = 0; a.unfinished = c->unfinished.p; a.idx2 = c->idx2.p; a.fwd_counts = c->fwd_counts.p;
 	c->prof.mark(s, P_NONE);
 	if (two_round_n_max) { // the caller has evaluated the head (fwd_k1 samples) of every ray; settle what that allows, evaluate the queued tails, redo those rays
 		a.cap = c->cur_k1;
@@ -629,7 +628,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const bool split = c->rgb_split(); // albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full instead of the generic kernel and its weight-gradient GEMMs
 	a.wimg = !c->wimg_valid ? nullptr : (!c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = (a.skip_rgb && !c->knobs.fwd_bwd_generic) || split; // the training kernels leave one weight-gradient partial per workgroup themselves
-	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * (split && c->knobs.fbs_full_wg1 ? 1u : c->knobs.fbs_wg_per_cu)) : c->fwd_grid;
+	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
 	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own
 	const size_t slab = sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
 	float* p_rgb2; float* p_rgb1; float* p_rgb0; float* p_sdf1; float* p_sdf0; float* p_sdf0b; float* p_sdf1b;
@@ -662,8 +661,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		r.dw_c0 = p_rgb0; r.dw_c1 = p_rgb1; r.dw_c2 = p_rgb2;
 		hipLaunchKernelGGL(k_rgb_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
 		a.dcin = c->dcin.p;
-		if (c->knobs.fbs_full_wg1) LAUNCH_EV(k_fwd_bwd_sdf_full_wg1, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
-		else LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+		// (one workgroup per CU -- no register spills, the two-per-CU instance keeps ~80 values in scratch -- lost: 0.88 vs 0.80 ms/step, half the wavefronts to hide the gathers)
+		LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
 	} else if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
@@ -1101,7 +1100,6 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
-	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_wg1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	{
 		const int march_lds_max = (int)((2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS) * sizeof(uint32_t));
@@ -1129,7 +1127,6 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
-		k.fbs_full_wg1 = getenv("RNB_FBS_FULL_WG1") != nullptr;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
