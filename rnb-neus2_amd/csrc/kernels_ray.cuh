@@ -778,6 +778,88 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_slots(const uint32_t n, c
 	if (blockIdx.x == gridDim.x - 1 && tid == 0) { counters[2] = pre[0] + t0; counters[3] = pre[1] + t1; fwd_counts[0] = pre[2] + t2; fwd_counts[1] = 0; fwd_counts[2] = 0; fwd_counts[3] = 0; }
 }
 
+// The three tiled kernels above in ONE launch. A tile's sums do not depend on the tiles in front of it, so every workgroup publishes them at once
+// (value + the launch's ticket in one 64-bit word) and then adds up the words of the tiles in front of it as they arrive -- no chain from tile to
+// tile, two such exchanges per launch (the sample offsets first, then the three sums that depend on which rays fit). Workgroups start in index
+// order, so a workgroup that waits only waits for workgroups that are already running. The words are polled with returning atomics: a load, agent
+// scope included, is answered by the polling XCD's own L2 once the line is there (profiles/r03_ab_tickets.txt). Integer work: the numbers of
+// k_scan_rays. Why: the scans sit in the middle of the chain march -> scans -> write that the next step's network evaluation waits for; as one
+// 1024-thread workgroup (small batches) the scan waited for 16 free wavefront slots on one CU beside the scatter (65 us for 21 us of work), as three
+// launches (large batches) it took 48 us for 23.
+struct ScanChainArgs {
+	uint32_t n, max_samples, k1;
+	const uint32_t* steps;
+	uint32_t *base, *slot, *base1, *counters, *fwd_counts;
+	unsigned long long* words; // [n_tiles][4]: ticket << 32 | {samples, kept rays, kept samples, kept first-round samples} of the tile
+	uint32_t ticket;
+	uint32_t* error; // mapped host word: a wait gave up
+};
+__device__ __forceinline__ uint32_t chain_prefix(unsigned long long* __restrict__ words, const uint32_t k, const uint32_t tile, const uint32_t ticket, const uint32_t mine,
+                                                 const uint32_t tid, uint32_t* __restrict__ sh, uint32_t* __restrict__ error) {
+	if (tid == 0) atomicExch(words + tile * 4 + k, ((unsigned long long)ticket << 32) | mine);
+	if (tid < 64) { // tiles in front of this one: one lane each (<= 63)
+		uint32_t v = 0;
+		if (tid < tile) {
+			unsigned long long w;
+			uint32_t spins = 0;
+			do { w = atomicAdd(words + tid * 4 + k, 0ull); if ((uint32_t)(w >> 32) == ticket) break; __builtin_amdgcn_s_sleep(2); } while (++spins < 20000000u); // (bounded: a lost workgroup must not hang the device)
+			if ((uint32_t)(w >> 32) != ticket && error) atomicExch(error, 1u);
+			v = (uint32_t)w;
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+		if (tid == 0) *sh = v;
+	}
+	__syncthreads();
+	const uint32_t r = *sh;
+	__syncthreads();
+	return r;
+}
+__global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs a) {
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
+	const uint32_t i0 = tile * SCAN_TILE + tid * SCAN_EPT;
+	uint32_t st[SCAN_EPT], mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { st[e] = i0 + e < a.n ? a.steps[i0 + e] : 0u; mine += st[e]; }
+	uint32_t total;
+	const uint32_t excl = block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
+	const uint32_t tile_base = chain_prefix(a.words, 0, tile, a.ticket, total, tid, &sh, a.error);
+	uint32_t run = tile_base + excl;
+	uint32_t v[3] = {0, 0, 0};
+	uint32_t okmask = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
+		if (i0 + e < a.n) a.base[i0 + e] = run;
+		const bool ok = st[e] > 0 && run + st[e] <= a.max_samples; // testbed_nerf.cu:1348-1355
+		run += st[e];
+		if (ok) { okmask |= 1u << e; v[0] += 1u; v[1] += st[e]; v[2] += min(st[e], a.k1); }
+	}
+	uint32_t t0, t1, t2;
+	const uint32_t e0 = block_exclusive_scan<SCAN_NW>(v[0], lane, wave, wsum, t0);
+	const uint32_t e2 = block_exclusive_scan<SCAN_NW>(v[2], lane, wave, wsum, t2);
+	(void)block_exclusive_scan<SCAN_NW>(v[1], lane, wave, wsum, t1);
+	const uint32_t p0 = chain_prefix(a.words, 1, tile, a.ticket, t0, tid, &sh, a.error);
+	const uint32_t p1 = chain_prefix(a.words, 2, tile, a.ticket, t1, tid, &sh, a.error);
+	const uint32_t p2 = chain_prefix(a.words, 3, tile, a.ticket, t2, tid, &sh, a.error);
+	uint32_t srun = p0 + e0, frun = p2 + e2;
+#pragma unroll
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
+		const bool ok = (okmask >> e) & 1u;
+		if (i0 + e < a.n) {
+			a.slot[i0 + e] = ok ? srun : 0xffffffffu;
+			if (a.k1) a.base1[i0 + e] = frun;
+		}
+		srun += ok ? 1u : 0u;
+		frun += ok ? min(st[e], a.k1) : 0u;
+	}
+	if (tile == gridDim.x - 1 && tid == 0) {
+		a.counters[0] = tile_base + total; a.counters[2] = p0 + t0; a.counters[3] = p1 + t1;
+		a.fwd_counts[0] = p2 + t2; a.fwd_counts[1] = 0; a.fwd_counts[2] = 0; a.fwd_counts[3] = 0;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8: loss + output gradients (testbed_nerf.cu:1396-2097)
 // ---------------------------------------------------------------------------------------------

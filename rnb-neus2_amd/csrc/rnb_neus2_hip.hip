@@ -149,6 +149,8 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase, scan_tiles; // scan_tiles: [64] tile sums + [64][3] dependent tile sums of the multi-workgroup ray scan
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
+	DevBuf<unsigned long long> scan_words; // k_scan_rays_chain: [64 tiles][4] sums with the launch's ticket
+	uint32_t scan_ticket = 0;
 	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train, wimg_rgb; // LDS weight images of the training weights, rebuilt after every optimizer step
 	// albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full (kernels_net.cuh). cin_eval = the colour MLP's input row of every evaluated sample (written by the
 	// network evaluation), src_slot = the slot of every compacted sample (loss pass 2), dcin = dL/d(input row) between the two training kernels
@@ -174,6 +176,7 @@ struct rnb_ctx {
 		bool march_late = false; // RNB_MARCH_LATE: the next step's march waits for k_fwd_bwd instead of starting after the loss pass
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
+		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -547,7 +550,13 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
 	}
 	c->prof.mark(s, P_MARCH_COUNT);
-	if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
+	const uint32_t n_scan_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
+	if (c->knobs.scan_chain && n_scan_tiles <= 64) { // one launch, one workgroup per 4096-ray tile (k_scan_rays_chain)
+		ScanChainArgs q;
+		q.n = n_rays; q.max_samples = max_samples; q.k1 = a.k1; q.steps = c->ray_steps.p; q.base = c->ray_base.p; q.slot = c->ray_slot.p; q.base1 = c->ray_base1.p;
+		q.counters = c->counters.p; q.fwd_counts = c->fwd_counts.p; q.words = c->scan_words.p; q.ticket = ++c->scan_ticket; q.error = c->host_coarse_dev + 5;
+		hipLaunchKernelGGL(k_scan_rays_chain, dim3(n_scan_tiles), dim3(SCAN_WG), 0, s, q);
+	} else if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
 		hipLaunchKernelGGL(k_scan_rays_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ray_steps.p, c->scan_tiles.p);
 		hipLaunchKernelGGL(k_scan_rays_base, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, max_samples, a.k1, c->ray_steps.p, c->scan_tiles.p, c->ray_base.p, c->scan_tiles.p + 64, c->counters.p);
@@ -982,7 +991,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
-	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
+	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->scan_words.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->mc_table.free(); c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
 	c->prof.destroy();
@@ -1056,7 +1065,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SWF_END); ALLOC(c->wimg_train, W_TRAIN_END); ALLOC(c->wimg_rgb, RW_END);
-	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
+	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->scan_words, 64 * 4); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g12, (size_t)B * 14 * 2); ALLOC(c->srec, (size_t)B * 8);
@@ -1127,6 +1136,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1140,7 +1150,9 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_coarse), 64, hipHostMallocMapped));
+	std::memset(c->host_coarse, 0, 64); // [0] block count of the LDS occupancy, [5] k_scan_rays_chain gave up a wait
 	*c->host_coarse = 0xffffffffu;
+	HIP_TRY_C(hipMemset(c->scan_words.p, 0, c->scan_words.bytes()));
 	HIP_TRY_C(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_coarse_dev), c->host_coarse, 0));
 	*out = c;
 	return RNB_OK;
@@ -1660,6 +1672,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
+	if (c->host_coarse[5]) { c->host_coarse[5] = 0; return fail(RNB_ERR_DEVICE, "k_scan_rays_chain: a tile's sums did not arrive (lost workgroup)"); }
 	const uint32_t* counters = c->host_rb->counters;
 	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += c->cur_k1 ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];
