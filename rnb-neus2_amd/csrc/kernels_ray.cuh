@@ -860,6 +860,25 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 	}
 }
 
+// The compaction offsets (k_scan_compact_sums + k_scan_compact_offsets) the same way, one exchange: on the critical stream of the large-batch regime.
+__global__ __launch_bounds__(SCAN_WG) void k_scan_compact_chain(const uint32_t n, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters,
+                                                             unsigned long long* __restrict__ words, const uint32_t ticket, uint32_t* __restrict__ error) {
+	__shared__ uint32_t wsum[16];
+	__shared__ uint32_t sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
+	const uint32_t i0 = tile * SCAN_TILE + tid * SCAN_EPT;
+	uint32_t v[SCAN_EPT], mine = 0;
+#pragma unroll
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { v[e] = i0 + e < n ? ncomp[i0 + e] : 0u; mine += v[e]; }
+	uint32_t total;
+	const uint32_t excl = block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
+	const uint32_t tile_base = chain_prefix(words, 0, tile, ticket, total, tid, &sh, error);
+	uint32_t run = tile_base + excl;
+#pragma unroll
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { if (i0 + e < n) cbase[i0 + e] = run; run += v[e]; }
+	if (tile == gridDim.x - 1 && tid == 0) counters[1] = tile_base + total; // numsteps_counter_compacted
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8: loss + output gradients (testbed_nerf.cu:1396-2097)
 // ---------------------------------------------------------------------------------------------

@@ -149,7 +149,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> ray_steps, ray_base, ray_slot, ncomp, cbase, scan_tiles; // scan_tiles: [64] tile sums + [64][3] dependent tile sums of the multi-workgroup ray scan
 	// two-round network evaluation (step_front): head of every ray first, tails of the rays that need them second
 	DevBuf<uint32_t> ray_base1, idx1, idx2, fwd_counts;
-	DevBuf<unsigned long long> scan_words; // k_scan_rays_chain: [64 tiles][4] sums with the launch's ticket
+	DevBuf<unsigned long long> scan_words; // k_scan_rays_chain / k_scan_compact_chain: [64 tiles][4] sums with the launch's ticket, one block each
 	uint32_t scan_ticket = 0;
 	DevBuf<half_t> wimg_fwd, wimg_fbs, wimg_train, wimg_rgb; // LDS weight images of the training weights, rebuilt after every optimizer step
 	// albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full (kernels_net.cuh). cin_eval = the colour MLP's input row of every evaluated sample (written by the
@@ -609,7 +609,10 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	if (a.phase) hipLaunchKernelGGL(k_loss_pass1, dim3(std::min(blocks, 1024u)), dim3(256), 0, s, a);
 	else launch_heads();
 	c->prof.mark(s, P_LOSS_PASS1);
-	if (n_rays >= c->knobs.march_narrow_from) {
+	if (n_rays >= c->knobs.march_narrow_from && c->knobs.scan_chain && (n_rays + SCAN_TILE - 1) / SCAN_TILE <= 64) {
+		hipLaunchKernelGGL(k_scan_compact_chain, dim3((n_rays + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p,
+		                   c->scan_words.p + 64 * 4, ++c->scan_ticket, c->host_coarse_dev + 5);
+	} else if (n_rays >= c->knobs.march_narrow_from) {
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
 		hipLaunchKernelGGL(k_scan_compact_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256);
 		hipLaunchKernelGGL(k_scan_compact_offsets, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256, c->cbase.p, c->counters.p);
@@ -1065,7 +1068,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SWF_END); ALLOC(c->wimg_train, W_TRAIN_END); ALLOC(c->wimg_rgb, RW_END);
-	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->scan_words, 64 * 4); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
+	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->scan_words, 2 * 64 * 4); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g12, (size_t)B * 14 * 2); ALLOC(c->srec, (size_t)B * 8);
