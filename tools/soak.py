@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 import rnb_neus2_amd as rnb
 from rnb_neus2_amd import synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-ctx = rnb.Context(apply_no_albedo=1, mask_loss_weight=1.0)
+ctx = rnb.Context(apply_no_albedo=0 if (len(sys.argv) > 2 and sys.argv[2] == "albedo") else 1, mask_loss_weight=1.0)
 ctx.init_params(); ctx.set_dataset(*synthetic.make_scene(64, 800))
 t0 = time.perf_counter(); rays = 0
 for i in range(1, n + 1):
