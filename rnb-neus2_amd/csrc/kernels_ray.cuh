@@ -91,6 +91,34 @@ __global__ void k_ema_grid(const uint32_t n_elements, const float decay, float* 
 	grid_out[i] = (prev_val < 0.f) ? prev_val : fmaxf(prev_val * decay, importance);
 }
 
+// k_ema_grid + k_mean_partial in one launch (round 4: an occupancy update is a chain of small dependent launches on the critical path of every 16th
+// step, ~5 us each). Block b owns cells [2048 b, 2048 (b + 1)): the update of k_ema_grid, and -- for the blocks of the first mip -- k_mean_partial's
+// sum of exactly those cells in exactly its order (thread t: cells t, t + 256, ...; the same tree), so `partial` holds the same 1024 doubles.
+__global__ __launch_bounds__(256) void k_ema_mean(const uint32_t n_elements, const float decay, float* __restrict__ grid_out, const float* __restrict__ grid_in, double* __restrict__ partial) {
+	__shared__ double sh[256];
+	const uint32_t base = blockIdx.x * 2048u;
+	static_assert(GRID_CELLS / 1024u == 2048u, "k_mean_partial's blocks");
+	const bool first_mip = base < GRID_CELLS;
+	double acc = 0.0;
+	for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) {
+		const uint32_t idx = base + i;
+		if (idx >= n_elements) break;
+		const float importance = grid_in[idx];
+		const float prev_val = grid_out[idx];
+		const float v = (prev_val < 0.f) ? prev_val : fmaxf(prev_val * decay, importance);
+		grid_out[idx] = v;
+		if (first_mip) acc += (double)(fmaxf(v, 0.f) / (float)GRID_CELLS);
+	}
+	if (!first_mip) return; // (uniform over the block)
+	sh[threadIdx.x] = acc;
+	__syncthreads();
+	for (int off = 128; off > 0; off >>= 1) {
+		if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
 // mean of max(v,0)/n over the first mip (testbed_nerf.cu:3509), summed in fp64 in a fixed order (2 kernels).
 __global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ grid, double* __restrict__ partial) {
 	__shared__ double sh[256];
@@ -106,12 +134,16 @@ __global__ __launch_bounds__(256) void k_mean_partial(const float* __restrict__ 
 	}
 	if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ void k_mean_final(const double* __restrict__ partial, const uint32_t n, float* __restrict__ mean_out) {
-	// one wavefront: strided partial sums, then a shuffle tree (a fixed order; fp64, so the float result does not depend on it)
+// one wavefront: strided partial sums, then a shuffle tree (a fixed order; fp64, so the float result does not depend on it); result in lane 0
+__device__ __forceinline__ double mean_final_wave(const double* __restrict__ partial, const uint32_t n, const uint32_t lane) {
 	double s = 0.0;
-	for (uint32_t i = threadIdx.x; i < n; i += 64) s += partial[i];
+	for (uint32_t i = lane; i < n; i += 64) s += partial[i];
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+	return s;
+}
+__global__ void k_mean_final(const double* __restrict__ partial, const uint32_t n, float* __restrict__ mean_out) {
+	const double s = mean_final_wave(partial, n, threadIdx.x);
 	if (threadIdx.x == 0) *mean_out = (float)s;
 }
 // Occupancy of cascade 0 in a form a workgroup keeps in LDS (the march's loop is one occupancy test per visited cell; as a
@@ -129,8 +161,7 @@ constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup:
 template <uint32_t NW = 16>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
 // One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
-__global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks, uint32_t* __restrict__ n_blocks_host) {
-	__shared__ uint32_t wsum[16];
+__device__ __forceinline__ void coarse_bitfield_body(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks, uint32_t* __restrict__ n_blocks_host, uint32_t* __restrict__ wsum) {
 	const uint32_t w = threadIdx.x, lane = w & 63u, wave = w >> 6;
 	uint32_t bits = 0;
 	for (uint32_t k = 0; k < 32; ++k) {
@@ -151,6 +182,10 @@ __global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restr
 		++r;
 	}
 	if (w == 0) { *n_blocks = total; if (n_blocks_host) *n_blocks_host = total; } // the host copy sizes the LDS of later march launches (any size is exact)
+}
+__global__ __launch_bounds__(1024) void k_coarse_bitfield(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out, uint32_t* __restrict__ n_blocks, uint32_t* __restrict__ n_blocks_host) {
+	__shared__ uint32_t wsum[16];
+	coarse_bitfield_body(bitfield, out, n_blocks, n_blocks_host, wsum);
 }
 // the first 2 * COARSE_WORDS + 2 * n_blocks_lds words of k_coarse_bitfield's output
 __device__ __forceinline__ void load_coarse(uint32_t* __restrict__ lds, const uint32_t* __restrict__ g, const uint32_t n_blocks_lds, const uint32_t tid, const uint32_t n_threads) {
@@ -188,6 +223,36 @@ __global__ void k_grid_to_bitfield(const uint32_t n_elements, const uint32_t n_n
 	for (uint8_t j = 0; j < 8; ++j) bits |= grid[(size_t)i * 8 + j] > thresh ? ((uint8_t)1 << j) : 0;
 	bitfield[i] = bits;
 }
+// Single-cascade scenes (aabb_scale 1: every RNb scene): k_mean_final + k_grid_to_bitfield + the first k_bitfield_max_pool in one launch. Every
+// block forms the mean from the 1024 partial sums the way k_mean_final does (same order, same bits), thread i makes byte i of level 0, and the
+// 8 consecutive threads of a 64-cell block make its pooled byte of level 1 from one ballot. Levels >= 1 have no bits of their own here and are
+// written with plain stores where the pooling reaches (level 1: its central 32^3 bytes, from here; levels 2.. : k_pool_tail_coarse); the rest
+// of those levels is zero from the creation of the context on and stays zero -- a caller-written bitfield takes the general kernels once, which
+// zero-fill (update_bitfield, rnb_ctx::bitfield_foreign). Same bytes as the three kernels.
+__global__ __launch_bounds__(256) void k_bitfield_sc(const float* __restrict__ grid, uint8_t* __restrict__ bitfield, const double* __restrict__ partial, float* __restrict__ mean_out) {
+	__shared__ float sh_mean;
+	if (threadIdx.x < 64) {
+		const double s = mean_final_wave(partial, 1024u, threadIdx.x);
+		if (threadIdx.x == 0) { sh_mean = (float)s; if (blockIdx.x == 0) *mean_out = (float)s; }
+	}
+	__syncthreads();
+	const float thresh = fminf(MIN_OPTICAL_THICKNESS, sh_mean);
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; // < GRID_CELLS / 8 (the launch covers level 0 exactly)
+	const f4 g0 = reinterpret_cast<const f4*>(grid)[(size_t)i * 2 + 0], g1 = reinterpret_cast<const f4*>(grid)[(size_t)i * 2 + 1];
+	uint8_t bits = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < 4; ++j) { bits |= g0[j] > thresh ? (uint8_t)(1u << j) : (uint8_t)0; bits |= g1[j] > thresh ? (uint8_t)(16u << j) : (uint8_t)0; }
+	bitfield[i] = bits;
+	const unsigned long long nz = __ballot(bits > 0);
+	const uint32_t lane = threadIdx.x & 63u;
+	if ((lane & 7u) == 0u) {
+		const uint8_t pooled = (uint8_t)((nz >> lane) & 0xffull); // bit j = "byte 8 q + j of level 0 is non-zero" (k_bitfield_max_pool)
+		const uint32_t q = i >> 3;
+		const uint32_t x = morton3D_invert(q >> 0) + GRIDSIZE / 8, y = morton3D_invert(q >> 1) + GRIDSIZE / 8, z = morton3D_invert(q >> 2) + GRIDSIZE / 8;
+		bitfield[GRID_CELLS / 8 + morton3D(x, y, z)] = pooled;
+	}
+}
+
 // bitfield_max_pool (testbed_nerf.cu:719-740)
 __global__ void k_bitfield_max_pool(const uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -207,8 +272,7 @@ __global__ void k_bitfield_max_pool(const uint32_t n_elements, const uint8_t* __
 // instead of 32768 per level and no trip through memory between them -- so the seven launches of a single-cascade scene (~4.7 us each,
 // launch-bound, on the critical path of every occupancy update) become two. What these loops do not write was zero-filled by
 // k_grid_to_bitfield and stays zero, exactly as `|= 0` leaves it in the full kernel; what they write had no bits of its own to keep.
-__global__ __launch_bounds__(1024) void k_bitfield_max_pool_tail(const uint32_t first_level, uint8_t* __restrict__ bitfield) {
-	__shared__ uint8_t buf[2][16 * 16 * 16];
+__device__ __forceinline__ void max_pool_tail_body(const uint32_t first_level, uint8_t* __restrict__ bitfield, uint8_t (*buf)[16 * 16 * 16]) {
 	uint32_t lo = GRIDSIZE / 8, hi = GRIDSIZE / 8 * 3; // support of the level being read, byte coordinates
 	uint32_t cur = 0;
 	for (uint32_t level = first_level; level < N_CASCADES; ++level) {
@@ -237,6 +301,18 @@ __global__ __launch_bounds__(1024) void k_bitfield_max_pool_tail(const uint32_t 
 		cur ^= 1u;
 		__syncthreads();
 	}
+}
+__global__ __launch_bounds__(1024) void k_bitfield_max_pool_tail(const uint32_t first_level, uint8_t* __restrict__ bitfield) {
+	__shared__ uint8_t buf[2][16 * 16 * 16];
+	max_pool_tail_body(first_level, bitfield, buf);
+}
+// The upper pool levels and the march kernels' LDS form of level 0 in one launch of two workgroups (each is one workgroup of 1024 threads, and both
+// only read what the launch in front of them wrote: level first_level - 1 resp. level 0).
+__global__ __launch_bounds__(1024) void k_pool_tail_coarse(const uint32_t first_level, uint8_t* __restrict__ bitfield, uint32_t* __restrict__ coarse_out, uint32_t* __restrict__ n_blocks, uint32_t* __restrict__ n_blocks_host) {
+	__shared__ uint8_t buf[2][16 * 16 * 16];
+	__shared__ uint32_t wsum[16];
+	if (blockIdx.x == 0) coarse_bitfield_body(bitfield, coarse_out, n_blocks, n_blocks_host, wsum);
+	else if (first_level < N_CASCADES) max_pool_tail_body(first_level, bitfield, buf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,13 +498,15 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 // reference's sequential visit order over those outcomes with integer bit operations: occupied -> sample, next
 // position; empty -> jump to the first position at or beyond the voxel exit. Visited set and t values are identical.
 // MG = lanes per ray (16 or 32): more lanes = fewer dependent rounds per ray, more redundant t-chain work per round.
-template <int MG, bool SC>
-__global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
-	static_assert(MG == 8 || MG == 16 || MG == 32, "lanes per ray");
+// WGS = threads per workgroup. (Round 4 measured one WAVEFRONT per ray, <64, true, 1024>, for the march that has the GPU to itself behind an occupancy update:
+// 660 us against 184 -- the rounds are not what a ray costs; the sequential replay below is, and every lane of a ray's group executes it.)
+template <int MG, bool SC, int WGS = 256>
+__global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
+	static_assert(MG == 8 || MG == 16 || MG == 32 || MG == 64, "lanes per ray");
 	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
 	if (SC) { load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x); __syncthreads(); }
-	constexpr uint64_t GM = (1ull << MG) - 1ull;  // a group's lanes inside a 64-bit ballot
-	const uint32_t i = blockIdx.x * (256 / MG) + (threadIdx.x / MG);
+	constexpr uint64_t GM = MG == 64 ? ~0ull : (1ull << (MG & 63)) - 1ull;  // a group's lanes inside a 64-bit ballot
+	const uint32_t i = blockIdx.x * (WGS / MG) + (threadIdx.x / MG);
 	const int lane = threadIdx.x & 63;
 	const int g = lane & (MG - 1);
 	const int gb = lane & ~(MG - 1); // first lane of the group inside the wavefront
@@ -556,10 +634,10 @@ __global__ __launch_bounds__(256) void k_march_count_wide(const MarchArgs a) {
 				if (!((in16 >> cur) & 1ull)) { term = true; break; } // left the box (testbed_nerf.cu:1337)
 				if ((occ16 >> cur) & 1ull) {
 					const uint64_t run_mask = (occ16 & in16) >> cur;
-					int run = __builtin_ctzll(~run_mask); // bits above the group are zero in run_mask: the complement always has a set bit
+					int run = (MG == 64 && run_mask == ~0ull) ? 64 : __builtin_ctzll(~run_mask); // bits above the group are zero in run_mask: the complement has a set bit unless the group is the whole ballot
 					run = min(run, MG - cur);
 					const int allowed = min(run, (int)(RNB_MAX_STEPS - j));
-					vis |= ((1ull << allowed) - 1ull) << cur;
+					vis |= (allowed >= 64 ? ~0ull : ((1ull << allowed) - 1ull)) << cur;
 					j += (uint32_t)allowed;
 					cur += allowed;
 					if (j >= RNB_MAX_STEPS) { term = true; break; }
@@ -794,30 +872,39 @@ struct ScanChainArgs {
 	uint32_t ticket;
 	uint32_t* error; // mapped host word: a wait gave up
 };
+// `bad` (in/out, uniform over the workgroup): a wait of this tile or of a tile in front of it gave up. The HIP programming model does not promise that
+// lower-numbered workgroups are scheduled first (they are on this hardware, one dispatcher per queue handing out workgroups in order), so the
+// spin is bounded; a tile that gives up would otherwise go on with a stale word of an earlier launch. Instead it marks the word it publishes
+// (bit 31: sums stay below 2^23), the mark travels with the sums to the tiles behind, the last tile reports zero counters (the step then ends
+// with RNB_ERR_NO_SAMPLES instead of training on garbage) and the mapped host word `error` names the launch for the next synchronising call.
+constexpr uint32_t CHAIN_POISON = 0x80000000u;
 __device__ __forceinline__ uint32_t chain_prefix(unsigned long long* __restrict__ words, const uint32_t k, const uint32_t tile, const uint32_t ticket, const uint32_t mine,
-                                                 const uint32_t tid, uint32_t* __restrict__ sh, uint32_t* __restrict__ error) {
-	if (tid == 0) atomicExch(words + tile * 4 + k, ((unsigned long long)ticket << 32) | mine);
+                                                 const uint32_t tid, uint32_t* __restrict__ sh, uint32_t* __restrict__ error, bool& bad) {
+	if (tid == 0) atomicExch(words + tile * 4 + k, ((unsigned long long)ticket << 32) | mine | (bad ? CHAIN_POISON : 0u));
 	if (tid < 64) { // tiles in front of this one: one lane each (<= 63)
-		uint32_t v = 0;
+		uint32_t v = 0, flag = bad ? 1u : 0u;
 		if (tid < tile) {
 			unsigned long long w;
 			uint32_t spins = 0;
 			do { w = atomicAdd(words + tid * 4 + k, 0ull); if ((uint32_t)(w >> 32) == ticket) break; __builtin_amdgcn_s_sleep(2); } while (++spins < 20000000u); // (bounded: a lost workgroup must not hang the device)
-			if ((uint32_t)(w >> 32) != ticket && error) atomicExch(error, 1u);
-			v = (uint32_t)w;
+			if ((uint32_t)(w >> 32) != ticket) { flag = 1u; w = 0; if (error) atomicExch(error, 1u); }
+			if ((uint32_t)w & CHAIN_POISON) flag = 1u;
+			v = (uint32_t)w & ~CHAIN_POISON;
 		}
 #pragma unroll
-		for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-		if (tid == 0) *sh = v;
+		for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); flag |= __shfl_xor(flag, off, 64); }
+		if (tid == 0) { sh[0] = v; sh[1] = flag; }
 	}
 	__syncthreads();
-	const uint32_t r = *sh;
+	const uint32_t r = sh[0];
+	bad = sh[1] != 0u;
 	__syncthreads();
 	return r;
 }
 __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs a) {
 	__shared__ uint32_t wsum[16];
-	__shared__ uint32_t sh;
+	__shared__ uint32_t sh[2];
+	bool bad = false;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
 	const uint32_t i0 = tile * SCAN_TILE + tid * SCAN_EPT;
 	uint32_t st[SCAN_EPT], mine = 0;
@@ -825,7 +912,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) { st[e] = i0 + e < a.n ? a.steps[i0 + e] : 0u; mine += st[e]; }
 	uint32_t total;
 	const uint32_t excl = block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
-	const uint32_t tile_base = chain_prefix(a.words, 0, tile, a.ticket, total, tid, &sh, a.error);
+	const uint32_t tile_base = chain_prefix(a.words, 0, tile, a.ticket, total, tid, sh, a.error, bad);
 	uint32_t run = tile_base + excl;
 	uint32_t v[3] = {0, 0, 0};
 	uint32_t okmask = 0;
@@ -840,9 +927,9 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 	const uint32_t e0 = block_exclusive_scan<SCAN_NW>(v[0], lane, wave, wsum, t0);
 	const uint32_t e2 = block_exclusive_scan<SCAN_NW>(v[2], lane, wave, wsum, t2);
 	(void)block_exclusive_scan<SCAN_NW>(v[1], lane, wave, wsum, t1);
-	const uint32_t p0 = chain_prefix(a.words, 1, tile, a.ticket, t0, tid, &sh, a.error);
-	const uint32_t p1 = chain_prefix(a.words, 2, tile, a.ticket, t1, tid, &sh, a.error);
-	const uint32_t p2 = chain_prefix(a.words, 3, tile, a.ticket, t2, tid, &sh, a.error);
+	const uint32_t p0 = chain_prefix(a.words, 1, tile, a.ticket, t0, tid, sh, a.error, bad);
+	const uint32_t p1 = chain_prefix(a.words, 2, tile, a.ticket, t1, tid, sh, a.error, bad);
+	const uint32_t p2 = chain_prefix(a.words, 3, tile, a.ticket, t2, tid, sh, a.error, bad);
 	uint32_t srun = p0 + e0, frun = p2 + e2;
 #pragma unroll
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
@@ -855,8 +942,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 		frun += ok ? min(st[e], a.k1) : 0u;
 	}
 	if (tile == gridDim.x - 1 && tid == 0) {
-		a.counters[0] = tile_base + total; a.counters[2] = p0 + t0; a.counters[3] = p1 + t1;
-		a.fwd_counts[0] = p2 + t2; a.fwd_counts[1] = 0; a.fwd_counts[2] = 0; a.fwd_counts[3] = 0;
+		a.counters[0] = bad ? 0u : tile_base + total; a.counters[2] = bad ? 0u : p0 + t0; a.counters[3] = bad ? 0u : p1 + t1; // bad: nothing is evaluated, the step reports no samples
+		a.fwd_counts[0] = bad ? 0u : p2 + t2; a.fwd_counts[1] = 0; a.fwd_counts[2] = 0; a.fwd_counts[3] = 0;
 	}
 }
 
@@ -864,7 +951,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 __global__ __launch_bounds__(SCAN_WG) void k_scan_compact_chain(const uint32_t n, const uint32_t* __restrict__ ncomp, uint32_t* __restrict__ cbase, uint32_t* __restrict__ counters,
                                                              unsigned long long* __restrict__ words, const uint32_t ticket, uint32_t* __restrict__ error) {
 	__shared__ uint32_t wsum[16];
-	__shared__ uint32_t sh;
+	__shared__ uint32_t sh[2];
+	bool bad = false;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
 	const uint32_t i0 = tile * SCAN_TILE + tid * SCAN_EPT;
 	uint32_t v[SCAN_EPT], mine = 0;
@@ -872,11 +960,11 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_compact_chain(const uint32_t n
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) { v[e] = i0 + e < n ? ncomp[i0 + e] : 0u; mine += v[e]; }
 	uint32_t total;
 	const uint32_t excl = block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
-	const uint32_t tile_base = chain_prefix(words, 0, tile, ticket, total, tid, &sh, error);
+	const uint32_t tile_base = chain_prefix(words, 0, tile, ticket, total, tid, sh, error, bad);
 	uint32_t run = tile_base + excl;
 #pragma unroll
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) { if (i0 + e < n) cbase[i0 + e] = run; run += v[e]; }
-	if (tile == gridDim.x - 1 && tid == 0) counters[1] = tile_base + total; // numsteps_counter_compacted
+	if (tile == gridDim.x - 1 && tid == 0) counters[1] = bad ? 0u : tile_base + total; // numsteps_counter_compacted (bad: the step reports no samples)
 }
 
 // ---------------------------------------------------------------------------------------------

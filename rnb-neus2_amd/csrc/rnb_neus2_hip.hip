@@ -113,9 +113,16 @@ struct rnb_ctx {
 	DevBuf<float> params_fp32, grads, adam_m, adam_v;
 	DevBuf<half_t> params_fp16, params_ema;
 	DevBuf<uint32_t> adam_steps;
+	// Optimizer state as k_adam_ema keeps it: one 64-byte record {fp32 weight, m, v, step count} per 4-parameter group (kernels_net.cuh). params_fp32 /
+	// adam_m / adam_v / adam_steps above are the staging views rnb_buffer hands out: unpacked from the records when a caller asks for one
+	// (opt_plain_current), packed back in front of the next optimizer launch (opt_rec_current = false: the caller may have written through the pointer).
+	DevBuf<float> opt_rec;
+	bool opt_plain_current = true, opt_rec_current = false;
 	DevBuf<float> adam_lr_table; // k_adam_lr_table
 	float lr_table_beta1 = -1.f, lr_table_beta2 = -1.f; // the betas the table was filled for
-	DevBuf<float> density_grid, density_grid_tmp, density_mean;
+	DevBuf<float> density_grid, density_grid_tmp, density_grid_tmp_alt, density_mean; // _alt: cleared on a side stream for the NEXT update (tmp_alt_clear), the two swap roles
+	bool tmp_alt_clear = false;
+	bool bitfield_foreign = false; // a caller may have written the bitfield: levels >= 1 are not known to be zero outside the pooled supports (update_bitfield takes the zero-filling kernels once)
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
 	DevBuf<uint32_t> coarse_bits, coarse_count; // k_coarse_bitfield: cascade 0's occupancy in the form the march kernels keep in LDS; its number of non-empty blocks
@@ -156,7 +163,7 @@ struct rnb_ctx {
 	// network evaluation), src_slot = the slot of every compacted sample (loss pass 2), dcin = dL/d(input row) between the two training kernels
 	DevBuf<half_t> cin_eval, dcin, rgb_out_scratch;
 	DevBuf<uint32_t> src_slot;
-	bool cin_flow = false; // this step's network evaluation has exported cin_eval and the loss pass src_slot (rnb_train_step_begin); stage entry points clear it
+	bool cin_flow = false; // this step's network evaluation has exported cin_eval and the loss pass src_slot (rnb_train_step_begin); consumed by its backward pass, cleared by the stage entry points and when the step's front fails
 	bool rgb_split() const { return !cfg.apply_no_albedo && !knobs.fwd_bwd_generic; }
 	bool wimg_valid = false;
 	DevBuf<float> ray_const; // per kept ray: loss constants worked out beside the march (k_march_write)
@@ -177,6 +184,7 @@ struct rnb_ctx {
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
+		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -238,6 +246,16 @@ struct rnb_ctx {
 
 static void discard_premarch(rnb_ctx* c);
 
+// The one-launch scans (kernels_ray.cuh, chain_prefix) report a wait that gave up through two mapped host words; read after a synchronisation.
+// The launch itself has poisoned its result (zero counters), so nothing was trained on it.
+static int check_scan_errors(rnb_ctx* c) {
+	const bool rays = c->host_coarse[5] != 0, compact = c->host_coarse[6] != 0;
+	if (!rays && !compact) return RNB_OK;
+	c->host_coarse[5] = 0; c->host_coarse[6] = 0;
+	g_err = std::string(rays ? "k_scan_rays_chain" : "k_scan_compact_chain") + ": a tile's sums did not arrive (workgroup not scheduled); the launch reported zero counters";
+	return RNB_ERR_DEVICE;
+}
+
 namespace {
 
 constexpr size_t LDS_TRAIN = (size_t)(W_TRAIN_END + WAVES_PER_WG * 3 * ACT_TILE_HALFS) * sizeof(half_t);
@@ -284,6 +302,28 @@ int derive_half_params(rnb_ctx* c, hipStream_t s) { // trainer.h:103-107
 	return RNB_OK;
 }
 
+// Brings the optimizer records up to date with the staging views (after rnb_init_params / rnb_set_params / a caller's rnb_buffer) -- in front of
+// an optimizer launch -- or the views with the records (rnb_buffer). Both are whole-array copies behind a device synchronisation: rare events.
+static int ensure_opt_records(rnb_ctx* c) {
+	if (c->opt_rec_current) return RNB_OK;
+	HIP_TRY(hipDeviceSynchronize());
+	hipLaunchKernelGGL(k_opt_records_pack, dim3(4096), dim3(256), 0, 0, c->param_capacity / 4, c->params_fp32.p, c->adam_m.p, c->adam_v.p, c->adam_steps.p, c->opt_rec.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	c->opt_rec_current = true;
+	return RNB_OK;
+}
+static int ensure_opt_views(rnb_ctx* c) {
+	if (c->opt_plain_current) return RNB_OK;
+	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
+	hipLaunchKernelGGL(k_opt_records_unpack, dim3(4096), dim3(256), 0, 0, c->param_capacity / 4, c->opt_rec.p, c->params_fp32.p, c->adam_m.p, c->adam_v.p, c->adam_steps.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipDeviceSynchronize());
+	c->opt_plain_current = true;
+	return RNB_OK;
+}
+
+// (callers have written, or are about to overwrite, the whole fp32 master array of the staging views)
 int reset_optimizer_state(rnb_ctx* c) {
 	HIP_TRY(hipMemset(c->adam_m.p, 0, c->adam_m.bytes()));
 	HIP_TRY(hipMemset(c->adam_v.p, 0, c->adam_v.bytes()));
@@ -291,6 +331,7 @@ int reset_optimizer_state(rnb_ctx* c) {
 	HIP_TRY(hipMemset(c->grads.p, 0, c->grads.bytes()));
 	c->grads_clean = true;
 	c->optimizer_step_count = 0;
+	c->opt_plain_current = true; c->opt_rec_current = false; // the views are the truth until the next optimizer launch packs them
 	return RNB_OK;
 }
 
@@ -310,11 +351,21 @@ static int rebuild_coarse(rnb_ctx* c, hipStream_t s, bool wait = true) {
 	return RNB_OK;
 }
 
-int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true) { // testbed_nerf.cu:3497-3517
+// have_partials: k_ema_mean has left the 1024 partial sums of the mean (update_density_grid); otherwise they are formed here.
+int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true, bool have_partials = false) { // testbed_nerf.cu:3497-3517
 	const uint32_t n_blocks = 1024;
-	hipLaunchKernelGGL(k_mean_partial, dim3(n_blocks), dim3(256), 0, s, c->density_grid.p, c->mean_partial.p);
-	hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, c->mean_partial.p, n_blocks, c->density_mean.p);
+	if (!have_partials) hipLaunchKernelGGL(k_mean_partial, dim3(n_blocks), dim3(256), 0, s, c->density_grid.p, c->mean_partial.p);
 	const uint32_t n_bytes_per_mip = GRID_CELLS / 8;
+	if (c->aabb.max_cascade == 0 && !c->bitfield_foreign && c->knobs.fused_update) {
+		// single-cascade scene: mean + level 0 + level 1 in one launch, the upper levels + the march's LDS form in a second one (kernels_ray.cuh)
+		hipLaunchKernelGGL(k_bitfield_sc, dim3(n_bytes_per_mip / 256), dim3(256), 0, s, c->density_grid.p, c->bitfield.p, c->mean_partial.p, c->density_mean.p);
+		LAUNCH_EV(k_pool_tail_coarse, dim3(2), dim3(1024), 0, s, (c->overlap() && !wait) ? c->ev_grid : nullptr, 2u, c->bitfield.p, c->coarse_bits.p, c->coarse_count.p, c->host_coarse_dev);
+		HIP_TRY(hipGetLastError());
+		c->coarse_valid = true;
+		if (wait || *c->host_coarse == 0xffffffffu) HIP_TRY(hipStreamSynchronize(s)); // (see rebuild_coarse)
+		return RNB_OK;
+	}
+	hipLaunchKernelGGL(k_mean_final, dim3(1), dim3(64), 0, s, c->mean_partial.p, n_blocks, c->density_mean.p);
 	const uint32_t n_el = n_bytes_per_mip * N_CASCADES;
 	hipLaunchKernelGGL(k_grid_to_bitfield, dim3((n_el + 127) / 128), dim3(128), 0, s, n_el, n_bytes_per_mip * (c->aabb.max_cascade + 1), c->density_grid.p, c->bitfield.p, c->density_mean.p);
 	// levels that pool a level with bits of its own (the scene's cascades): the full kernel; the levels above them in one small launch
@@ -325,6 +376,7 @@ int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true) { // testbed_ne
 	}
 	if (first_tail < N_CASCADES) hipLaunchKernelGGL(k_bitfield_max_pool_tail, dim3(1), dim3(1024), 0, s, first_tail, c->bitfield.p);
 	HIP_TRY(hipGetLastError());
+	c->bitfield_foreign = false; // k_grid_to_bitfield has zero-filled every level
 	return rebuild_coarse(c, s, wait);
 }
 
@@ -382,6 +434,10 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_grid, 0));
 	}
 	HIP_TRY(hipMemsetAsync(c->gs_hist.p, 0, sizeof(uint32_t) * n_keys, s));
+	if (c->density_grid_tmp_alt.p) { // the next update's splat target, cleared here instead of in front of its network evaluation (ordered by ev_gs like the samples)
+		HIP_TRY(hipMemsetAsync(c->density_grid_tmp_alt.p, 0, sizeof(float) * n_elements, s));
+		c->tmp_alt_clear = true;
+	}
 	Pcg32 rng = c->density_grid_rng;
 	c->gs_pre.rng_state = rng.state; c->gs_pre.rng_inc = rng.inc;
 	int rc = launch_grid_samples(c, s, rng, c->density_grid_ema_step, n_uniform, n_nonuniform, c->gs_stage_pos.p, c->gs_stage_idx.p, c->gs_hist.p, shift);
@@ -407,11 +463,13 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 		HIP_TRY(hipMemsetAsync(c->density_grid.p, 0, sizeof(float) * n_elements, s));
 		c->gs_pre.valid = false;
 	}
-	HIP_TRY(hipMemsetAsync(c->density_grid_tmp.p, 0, sizeof(float) * n_elements, s));
 	const bool sorted = c->gs_pre.valid && c->gs_pre.ema_step == c->density_grid_ema_step && c->gs_pre.n_uniform == n_uniform && c->gs_pre.n_nonuniform == n_nonuniform &&
 	                    c->gs_pre.rng_state == c->density_grid_rng.state && c->gs_pre.rng_inc == c->density_grid_rng.inc;
 	c->gs_pre.valid = false;
 	c->last_update_sorted = sorted;
+	if (sorted && c->tmp_alt_clear) std::swap(c->density_grid_tmp, c->density_grid_tmp_alt); // cleared behind the previous update, ordered by ev_gs below
+	else HIP_TRY(hipMemsetAsync(c->density_grid_tmp.p, 0, sizeof(float) * n_elements, s));
+	c->tmp_alt_clear = false;
 	if (sorted) { // generated after the previous update (pregenerate_grid_samples): the staging pair holds the reference's order, gs_sorted_* the cell order
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_gs, 0));
 		std::swap(c->grid_sample_pos, c->gs_stage_pos); // RNB_BUF_GRID_SAMPLE_POS / _IDX: the samples of the LAST update, as always
@@ -430,10 +488,11 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_POINT_QUERY);
 	c->prof.units[P_POINT_QUERY] += n_samples;
-	hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
+	if (c->knobs.fused_update) hipLaunchKernelGGL(k_ema_mean, dim3(n_elements / 2048), dim3(256), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p, c->mean_partial.p);
+	else hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
 	HIP_TRY(hipGetLastError());
 	++c->density_grid_ema_step;
-	rc = update_bitfield(c, s, !c->overlap());
+	rc = update_bitfield(c, s, !c->overlap(), c->knobs.fused_update);
 	c->prof.mark(s, P_EMA_BITFIELD);
 	c->gs_todo.pending = true; c->gs_todo.n_uniform = n_uniform; c->gs_todo.n_nonuniform = n_nonuniform; // queued by the caller once the kernels that wait for THIS update are in their queue
 	return rc;
@@ -611,7 +670,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	c->prof.mark(s, P_LOSS_PASS1);
 	if (n_rays >= c->knobs.march_narrow_from && c->knobs.scan_chain && (n_rays + SCAN_TILE - 1) / SCAN_TILE <= 64) {
 		hipLaunchKernelGGL(k_scan_compact_chain, dim3((n_rays + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p,
-		                   c->scan_words.p + 64 * 4, ++c->scan_ticket, c->host_coarse_dev + 5);
+		                   c->scan_words.p + 64 * 4, ++c->scan_ticket, c->host_coarse_dev + 6);
 	} else if (n_rays >= c->knobs.march_narrow_from) {
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
 		hipLaunchKernelGGL(k_scan_compact_sums, dim3(n_tiles), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->scan_tiles.p + 256);
@@ -789,9 +848,11 @@ static void fill_lr_table(rnb_ctx* c, hipStream_t s) { // stream-ordered in fron
 	c->lr_table_beta1 = c->cfg.beta1; c->lr_table_beta2 = c->cfg.beta2;
 }
 
-static void optimizer_begin(rnb_ctx* c) {
-	if (c->opt.begun) return;
+static int optimizer_begin(rnb_ctx* c) {
+	if (c->opt.begun) return RNB_OK;
 	const rnb_config& cfg = c->cfg;
+	{ const int rc = ensure_opt_records(c); if (rc != RNB_OK) return rc; }
+	c->opt_plain_current = false; // the records move on; the staging views are refreshed when a caller asks for one (rnb_buffer)
 	fill_lr_table(c, nullptr);
 	const uint32_t step0 = c->optimizer_step_count;
 	if (step0 == 0) c->lr_factor = 1.0f;
@@ -799,8 +860,8 @@ static void optimizer_begin(rnb_ctx* c) {
 	const uint32_t current_step = ++c->optimizer_step_count;
 	AdamArgs& a = c->opt.args;
 	a.n = c->n_params; a.n_matrix = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
-	a.w32 = c->params_fp32.p; a.w16 = c->params_fp16.p; a.ema = c->params_ema.p;
-	a.grads = c->grads.p; a.m = c->adam_m.p; a.v = c->adam_v.p; a.steps = c->adam_steps.p;
+	a.rec = c->opt_rec.p; a.w16 = c->params_fp16.p; a.ema = c->params_ema.p;
+	a.grads = c->grads.p;
 	a.base_lr = cfg.learning_rate * c->lr_factor; a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.epsilon = cfg.epsilon; a.l2_reg = cfg.l2_reg;
 	a.ema_decay = cfg.ema_decay;
 	a.skip_lo = cfg.only_sdf_training ? (uint64_t)c->off_rgb : 0; a.skip_hi = cfg.only_sdf_training ? (uint64_t)c->off_grid : 0;
@@ -809,6 +870,7 @@ static void optimizer_begin(rnb_ctx* c) {
 	a.lr_table = c->adam_lr_table.p; a.lr_table_n = (uint32_t)c->adam_lr_table.n;
 	c->opt.begun = true;
 	c->opt.early_done = false;
+	return RNB_OK;
 }
 
 static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi, hipEvent_t done = nullptr) {
@@ -822,7 +884,7 @@ static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi, hi
 // Optimizer on the early gradient block only (rnb_gradient_parts block 0), on the caller's stream.
 int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
 	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
-	optimizer_begin(c);
+	{ const int rc = optimizer_begin(c); if (rc != RNB_OK) return rc; }
 	if (c->sc.dp) adam_launch(c, st, 0, c->sc.split[0], c->ev_adam);
 	else adam_launch(c, st, c->sc.split[1], c->sc.split[0], c->ev_adam);
 	c->opt.early_done = true;
@@ -882,7 +944,7 @@ static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_
 }
 
 int optimizer_step(rnb_ctx* c, hipStream_t s) {
-	optimizer_begin(c);
+	{ const int rc = optimizer_begin(c); if (rc != RNB_OK) return rc; }
 	c->prof.mark(s, P_NONE);
 	const bool chunked = !c->opt.early_done && c->overlap() && !c->sc.dp && c->sc.valid && !c->sc.exchanged;
 	if (!c->sc.dw_joined && !chunked) {
@@ -935,7 +997,7 @@ int optimizer_step_shard(rnb_ctx* c, uint32_t part, hipStream_t st) {
 	shard_layout(c, parts, &n);
 	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");
 	const rnb_shard_part& p = parts[part];
-	optimizer_begin(c);
+	{ const int rc = optimizer_begin(c); if (rc != RNB_OK) return rc; }
 	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(st, c->ev_dw, 0)); // any block may hold MLP parameters
 	if (p.own_lo > p.lo) HIP_TRY(hipMemsetAsync(c->grads.p + p.lo, 0, (p.own_lo - p.lo) * sizeof(float), st));
 	if (p.hi > p.own_hi) HIP_TRY(hipMemsetAsync(c->grads.p + p.own_hi, 0, (p.hi - p.own_hi) * sizeof(float), st));
@@ -988,8 +1050,8 @@ int rnb_default_config(rnb_config* cfg) {
 
 int rnb_destroy(rnb_ctx* c) {
 	if (!c) return RNB_OK;
-	c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
-	c->density_grid.free(); c->density_grid_tmp.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
+	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
+	c->density_grid.free(); c->density_grid_tmp.free(); c->density_grid_tmp_alt.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
@@ -1056,9 +1118,10 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		if ((buf).alloc_padded(c->n_params, c->param_capacity) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
 	} while (0)
 	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
+	ALLOC(c->opt_rec, c->param_capacity * 4);
 	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
-	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
+	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_grid_tmp_alt, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
@@ -1139,6 +1202,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_WG_PER_CU")) k.scatter_wg_per_cu = std::max(0, atoi(e));
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
+		if (const char* e = getenv("RNB_FUSED_UPDATE")) k.fused_update = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
@@ -1153,7 +1217,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_coarse), 64, hipHostMallocMapped));
-	std::memset(c->host_coarse, 0, 64); // [0] block count of the LDS occupancy, [5] k_scan_rays_chain gave up a wait
+	std::memset(c->host_coarse, 0, 64); // [0] block count of the LDS occupancy, [5] / [6] k_scan_rays_chain / k_scan_compact_chain gave up a wait
 	*c->host_coarse = 0xffffffffu;
 	HIP_TRY_C(hipMemset(c->scan_words.p, 0, c->scan_words.bytes()));
 	HIP_TRY_C(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_coarse_dev), c->host_coarse, 0));
@@ -1189,6 +1253,7 @@ int rnb_grid_tables(const rnb_ctx* c, uint32_t* offsets, uint32_t* resolution, f
 int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
 	if (!c || !sdf_w) return fail(RNB_ERR_INVALID, "null argument");
 	discard_premarch(c);
+	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer (side streams)
 	std::seed_seq seq{c->cfg.seed}; // Trainer ctor, trainer.h:54-61
 	std::vector<uint32_t> seeds(2);
 	seq.generate(std::begin(seeds), std::end(seeds));
@@ -1252,16 +1317,29 @@ int rnb_set_params(rnb_ctx* c, const float* params) {
 int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
 #define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
+	const bool read_only = (id & RNB_BUF_READONLY) != 0;
+	id &= ~RNB_BUF_READONLY;
+	if (id == RNB_BUF_PARAMS_FP32 || id == RNB_BUF_ADAM_M || id == RNB_BUF_ADAM_V || id == RNB_BUF_ADAM_STEPS) {
+		// staging views of the optimizer records (rnb_ctx::opt_rec): brought up to date here, read back in front of the next optimizer launch
+		const int rc = ensure_opt_views(c);
+		if (rc != RNB_OK) return rc;
+		if (!read_only) c->opt_rec_current = false;
+	}
+	if (!read_only) { // a possible write before the caller's next call: drop the cached forms now (a kept pointer written later: rnb_params_changed / rnb_bitfield_changed)
+		if (id == RNB_BUF_PARAMS_FP16) c->wimg_valid = false;
+		else if (id == RNB_BUF_DENSITY_BITFIELD) { discard_premarch(c); c->coarse_valid = false; c->gs_pre.valid = false; c->bitfield_foreign = true; }
+		else if (id == RNB_BUF_DENSITY_GRID) c->gs_pre.valid = false;
+	}
 	switch (id) {
 		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
-		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16); // a caller that writes through the pointer says so with rnb_params_changed
+		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16);
 		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
 		case RNB_BUF_GRADS_FP32: BUF(c->grads);
 		case RNB_BUF_ADAM_M: BUF(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);
-		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid); // written through rnb_memcpy, or followed by rnb_update_density_bitfield: samples prepared from the old grid are dropped there
-		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield); // a caller that writes through the pointer says so with rnb_bitfield_changed
+		case RNB_BUF_DENSITY_GRID: BUF(c->density_grid);
+		case RNB_BUF_DENSITY_BITFIELD: BUF(c->bitfield);
 		case RNB_BUF_DENSITY_MEAN: BUF(c->density_mean);
 		case RNB_BUF_RAY_INDICES: BUF(c->ray_indices);
 		case RNB_BUF_RAYS: BUF(c->rays);
@@ -1296,6 +1374,7 @@ int rnb_bitfield_changed(rnb_ctx* c) {
 	discard_premarch(c); // a batch generated ahead of time marched through the old bits
 	c->coarse_valid = false;
 	c->gs_pre.valid = false;
+	c->bitfield_foreign = true;
 	return RNB_OK;
 }
 
@@ -1320,6 +1399,7 @@ int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kin
 	}
 	hipMemcpyKind k = kind == RNB_H2D ? hipMemcpyHostToDevice : kind == RNB_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 	HIP_TRY(hipDeviceSynchronize());
+	if (c) { const int rc = check_scan_errors(c); if (rc != RNB_OK) return rc; } // stage API: the scans of rnb_generate_training_samples / rnb_compute_loss are read through here
 	HIP_TRY(hipMemcpy(dst, src, n_bytes, k));
 	return RNB_OK;
 }
@@ -1505,6 +1585,7 @@ int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uin
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
 	if (max_samples > c->cfg.target_batch_size * 16) return fail(RNB_ERR_INVALID, "max_samples exceeds 16*target_batch_size");
+	c->cin_flow = false; // stage calls never use the rows a (failed) training step may have left behind
 	return generate_training_samples(c, as_stream(stream), n_rays, n_rays_total, max_samples);
 }
 
@@ -1512,11 +1593,13 @@ int rnb_compute_loss(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
+	c->cin_flow = false;
 	return compute_loss(c, as_stream(stream), n_rays, n_rays_total);
 }
 
 int rnb_forward_backward(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->cin_flow = false; // the stage pass evaluates the compacted batch itself for the colour MLP's input rows
 	return forward_backward(c, as_stream(stream));
 }
 
@@ -1578,7 +1661,8 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	} else {
 		n_rays_total = c->n_rays_total;
 		c->n_rays_total += n_rays * c->cfg.world_size;
-		HIP_TRY(hipMemsetAsync(c->counters.p, 0, c->counters.bytes(), s)); // Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530
+		// (Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530, zeroes the counters here; every one of them is written with a plain store by
+		// the scans of this step -- k_scan_rays*: [0] [2] [3], k_scan_compact*: [1] -- so the fill, a launch on the critical path of the update steps, is left out)
 		rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
 		if (rc != RNB_OK) return rc;
 		c->cur_k1 = c->gen_k1;
@@ -1653,7 +1737,7 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	hipStream_t s = as_stream(stream);
 	c->cur_step = c->training_step;
 	int rc = step_front(c, s);
-	if (rc != RNB_OK) return rc;
+	if (rc != RNB_OK) { c->cin_flow = false; return rc; }
 	// the step's counters and loss sums are final here: hand them to the host now, so that the ray controller (and the next
 	// step's march) does not have to wait for the backward pass
 	rc = launch_reduce_losses(c, s);
@@ -1675,7 +1759,7 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
 	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
-	if (c->host_coarse[5]) { c->host_coarse[5] = 0; return fail(RNB_ERR_DEVICE, "k_scan_rays_chain: a tile's sums did not arrive (lost workgroup)"); }
+	{ const int rc = check_scan_errors(c); if (rc != RNB_OK) return rc; }
 	const uint32_t* counters = c->host_rb->counters;
 	if (c->prof.on) { c->prof.collect(); c->prof.units[P_FORWARD] += c->cur_k1 ? c->host_rb->fwd[0] + c->host_rb->fwd[1] : counters[3]; }
 	for (int k = 0; k < 4; ++k) counters_out[k] = counters[k];

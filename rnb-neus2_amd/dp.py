@@ -47,6 +47,7 @@ def grads_tensor(ctx):
 
 
 # parameter-shaped buffers and the element type their exchange uses (uint32 counters travel as int32)
+_STAGING_VIEWS = ("PARAMS_FP32", "ADAM_M", "ADAM_V", "ADAM_STEPS")  # include/rnb_neus2.h, rnb_buffer
 _PARAM_BUFFERS = {"GRADS_FP32": "<f4", "PARAMS_FP16": "<f2", "PARAMS_FP32": "<f4", "PARAMS_EMA": "<f2", "ADAM_M": "<f4", "ADAM_V": "<f4", "ADAM_STEPS": "<i4"}
 
 
@@ -63,9 +64,11 @@ class TorchShardCollectives:
     def view(self, name):
         import torch
         v = self._views.get(name)
-        if v is None:
+        if v is None or name in _STAGING_VIEWS:
+            # the optimizer-state arrays are staging views: every rnb_buffer call brings them up to date (and announces a possible write)
             ptr, _ = self.ctx.buffer(name)  # allocated up to `capacity` elements (rnb_shard_layout)
-            v = self._views[name] = torch.as_tensor(_DeviceArray(ptr, self.capacity, _PARAM_BUFFERS[name]), device="cuda")
+            if v is None:
+                v = self._views[name] = torch.as_tensor(_DeviceArray(ptr, self.capacity, _PARAM_BUFFERS[name]), device="cuda")
         return v
 
     def reduce_scatter(self, name, part):

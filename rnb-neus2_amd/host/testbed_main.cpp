@@ -461,7 +461,7 @@ struct Testbed {
 	// ---- snapshot (src/testbed.cu:3280-3390; tiny-cuda-nn/trainer.h:263-305) ----
 	template <typename T> std::vector<T> download(int buf) {
 		void* p; uint64_t nb;
-		RNB_CHECK(rnb_buffer(ctx, buf, &p, &nb));
+		RNB_CHECK(rnb_buffer(ctx, buf | RNB_BUF_READONLY, &p, &nb));
 		std::vector<T> h(nb / sizeof(T));
 		if (nb) RNB_CHECK(rnb_memcpy(ctx, h.data(), p, nb, RNB_D2H));
 		return h;
