@@ -678,12 +678,16 @@ __device__ inline void load_weights_fbs_full(half_t* __restrict__ w, const NetW&
 }
 
 __device__ inline void load_weights_rgb(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads);
-// blockIdx.x == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf(_full); 2: image of k_fwd_bwd; 3: image of k_rgb_fwd_bwd. All from the training weights.
+// blockIdx.y == 0: image of k_forward_chained; 1: image of k_fwd_bwd_sdf(_full); 2: image of k_fwd_bwd; 3: image of k_rgb_fwd_bwd. All from the training weights.
+// gridDim.x workgroups per image (round 4: 16, one element per thread and array; one workgroup per image walked ~50 dependent 2-byte loads per thread, 15 us
+// alone and 70-90 us beside the scatter, at the end of the side stream that the next step's network evaluation waits for).
+constexpr uint32_t WIMG_WGS = 16;
 __global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train, half_t* __restrict__ img_rgb) {
-	if (blockIdx.x == 0) load_weights_chained(img_fwd, net, threadIdx.x, WG);
-	else if (blockIdx.x == 1) load_weights_fbs_full(img_fbs, net, threadIdx.x, WG);
-	else if (blockIdx.x == 2) load_weights<true>(img_train, net, threadIdx.x, WG);
-	else load_weights_rgb(img_rgb, net, threadIdx.x, WG);
+	const int tid = blockIdx.x * WG + threadIdx.x, nthreads = gridDim.x * WG;
+	if (blockIdx.y == 0) load_weights_chained(img_fwd, net, tid, nthreads);
+	else if (blockIdx.y == 1) load_weights_fbs_full(img_fbs, net, tid, nthreads);
+	else if (blockIdx.y == 2) load_weights<true>(img_train, net, tid, nthreads);
+	else load_weights_rgb(img_rgb, net, tid, nthreads);
 }
 
 // dst[idx] with a wave-uniform base and a 32-bit element index (scalar base + vector byte offset addressing)
@@ -1341,43 +1345,47 @@ struct DwFinishArgs {
 	uint32_t n_var_partials;
 	float* grads;            // GRADS_FP32
 	uint32_t off_sdf, off_rgb, off_var;
-	uint32_t skip_rgb;       // colour-MLP gradients are exactly zero (see TrainArgs::skip_rgb)
+	uint32_t skip_rgb;       // colour-MLP gradients are exactly zero (see TrainArgs::skip_rgb): their accumulators are clear already and no workgroup is launched for them
 };
 
-// 64 parameters per workgroup x 16 slices of the partial list (fixed summation order -> deterministic). Mirrors the
+// DWF_PARAMS parameters per workgroup x DWF_SLICES slices of the partial list (fixed summation order -> deterministic). Mirrors the
 // reference's precision staging: each GEMM result is narrowed to half (beta = 0), the second-order GEMMs accumulate onto
 // it (beta = 1) and narrow again (fully_fused_mlp.cu:948, 966, 1001, 1012, 1127).
-__device__ __forceinline__ float dw_sum(const float* __restrict__ base, const uint32_t stride, const uint32_t idx, const uint32_t n_partials, const uint32_t slice, float (*sh)[64], const uint32_t e) {
+// Workgroups of 256 threads = 16 parameters x 16 slices (round 4; 64 x 16 = 1024 threads until then): the kernel runs on the side stream beside the gradient
+// scatter, whose short workgroups hold every CU's wave slots -- a 16-wavefront workgroup waits for 16 slots to fall free at once (21 us of work took 130-160 us,
+// profiles/r04_timeline_*), 4 are found at once. (64 parameters x 4 slices in 256 threads: 198 us -- a quarter of the threads, each walking 128 partials.)
+constexpr uint32_t DWF_SLICES = 16, DWF_PARAMS = 16, DWF_WG = DWF_PARAMS * DWF_SLICES;
+__device__ __forceinline__ float dw_sum(const float* __restrict__ base, const uint32_t stride, const uint32_t idx, const uint32_t n_partials, const uint32_t slice, float (*sh)[DWF_PARAMS], const uint32_t e) {
 	float s = 0.f;
-	for (uint32_t p = slice; p < n_partials; p += 16) s += base[(size_t)p * stride + idx];
+	for (uint32_t p = slice; p < n_partials; p += DWF_SLICES) s += base[(size_t)p * stride + idx];
 	__syncthreads();
 	sh[slice][e] = s;
 	__syncthreads();
 	float t = 0.f;
 #pragma unroll
-	for (int q = 0; q < 16; ++q) t += sh[q][e];
+	for (uint32_t q = 0; q < DWF_SLICES; ++q) t += sh[q][e];
 	return t;
 }
 
-__global__ __launch_bounds__(1024) void k_dw_finish(const DwFinishArgs a) {
-	__shared__ float sh[16][64];
-	const uint32_t e = threadIdx.x & 63, slice = threadIdx.x >> 6;
-	const uint32_t n_mlp = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
-	const uint32_t i = blockIdx.x * 64 + e;
-	if (blockIdx.x * 64 >= n_mlp) { // last workgroup: the variance gradient (nerf_network.h:327-340)
+__global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
+	__shared__ float sh[DWF_SLICES][DWF_PARAMS];
+	const uint32_t e = threadIdx.x % DWF_PARAMS, slice = threadIdx.x / DWF_PARAMS;
+	const uint32_t n_mlp = a.skip_rgb ? RNB_N_SDF_MLP_PARAMS : RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
+	const uint32_t i = blockIdx.x * DWF_PARAMS + e;
+	if (blockIdx.x * DWF_PARAMS >= n_mlp) { // last workgroup: the variance gradient (nerf_network.h:327-340)
 		float v = 0.f;
-		for (uint32_t p = threadIdx.x; p < a.n_var_partials; p += 1024) v += a.var_partial[p];
-		__shared__ float shv[1024];
+		for (uint32_t p = threadIdx.x; p < a.n_var_partials; p += DWF_WG) v += a.var_partial[p];
+		__shared__ float shv[DWF_WG];
 		shv[threadIdx.x] = v;
 		__syncthreads();
-		for (int off = 512; off > 0; off >>= 1) {
+		for (int off = DWF_WG / 2; off > 0; off >>= 1) {
 			if ((int)threadIdx.x < off) shv[threadIdx.x] += shv[threadIdx.x + off];
 			__syncthreads();
 		}
 		if (threadIdx.x == 0) { a.grads[a.off_var + 0] = shv[0]; a.grads[a.off_var + 1] = 0.f; a.grads[a.off_var + 2] = 0.f; a.grads[a.off_var + 3] = 0.f; }
 		return;
 	}
-	// all 64 parameters of a workgroup lie in the same matrix (matrix sizes are multiples of 64)
+	// all parameters of a workgroup lie in the same matrix and, for the colour MLP's first matrix, in the same row (matrix sizes and 48 are multiples of 16)
 	float g;
 	if (i < 64 * 32) { // sdf W0
 		g = rh(dw_sum(a.partial[4], 64 * 32, i, a.n_partials, slice, sh, e));
@@ -1390,9 +1398,7 @@ __global__ __launch_bounds__(1024) void k_dw_finish(const DwFinishArgs a) {
 		if (slice == 0) a.grads[a.off_sdf + i] = g;
 	} else {
 		const uint32_t j = i - RNB_N_SDF_MLP_PARAMS;
-		if (a.skip_rgb) {
-			g = 0.f;
-		} else if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
+		if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
 			const uint32_t o = j / 48, col = j % 48;
 			const uint32_t cc = col < 16 ? col : (col >= 32 ? col - 16 : 0);
 			const float v = rh(dw_sum(a.partial[2], 64 * 32, o * 32 + cc, a.n_partials, slice, sh, e));
@@ -1743,6 +1749,8 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 		reinterpret_cast<h4*>(a.ema)[q] = e;
 	}
 }
+// (Round 4 measured the hash grid's EMA as a launch of its own behind the step's last Adam chunk -- nothing of the next step reads the EMA weights, so its
+// 63 MB need not share the memory system with the scatter: 0.629 vs 0.627 ms/step over the window with it; dropped, profiles/r04_ab_sync.txt.)
 
 // The staging views of rnb_buffer <-> the records: group q = parameters 4 q .. 4 q + 3. Bit copies (the step counts travel as raw words).
 __global__ __launch_bounds__(256) void k_opt_records_pack(const uint64_t n_groups, const float* __restrict__ w32, const float* __restrict__ m, const float* __restrict__ v,

@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_tiles(const uint32_t n_m
 
 // loss scalars of Counters::update_after_training (testbed_nerf.cu:3549-3551): fp64 sums over the kept rays
 __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1, const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
-                                                        const double* __restrict__ partial, const uint32_t n_partial) {
+                                                        const double* __restrict__ partial, const uint32_t n_partial, const uint32_t host_seq = 0) {
 	__shared__ double sh[3][1024];
 	const uint32_t n = min(counters[2], n_max);
 	double s0 = 0, s1 = 0, s2 = 0;
@@ -1658,6 +1658,13 @@ __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const u
 		if (threadIdx.x == 0) { host_out[0] = sh[0][0]; host_out[1] = sh[1][0]; host_out[2] = sh[2][0]; }
 		if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(host_out + 3)[threadIdx.x] = counters[threadIdx.x];
 		if (threadIdx.x < 2) reinterpret_cast<uint32_t*>(host_out + 5)[threadIdx.x] = fwd_counts ? fwd_counts[threadIdx.x * 2] : 0u;
+		// host_seq != 0: the host does not wait for this kernel's completion but polls the word behind the 56 bytes for the step's sequence number
+		// (rnb_train_step_local): no completion event with a system-scope fence on the critical stream, and everything this workgroup reads
+		// (counters, loss rows, fwd_counts) has been read by then, so the next step's march may overwrite it.
+		if (host_seq) {
+			__syncthreads();
+			if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(host_out + 6), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 }
 
@@ -1666,8 +1673,9 @@ __device__ __forceinline__ void reduce_losses_body(const uint32_t n_max, const u
 // both need nothing but the second loss pass, and one launch on the critical stream instead of two saves a kernel boundary.
 __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t n_max, const uint32_t* __restrict__ counters, const float* __restrict__ l0, const float* __restrict__ l1,
                                                                  const float* __restrict__ l2, double* __restrict__ out, const uint32_t* __restrict__ fwd_counts, double* __restrict__ host_out,
-                                                                 const double* __restrict__ partial, const uint32_t n_partial, const uint32_t B, half_t* __restrict__ dloss, float* __restrict__ coords, uint32_t* __restrict__ src_slot) {
-	if (blockIdx.x == 0) reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial);
+                                                                 const double* __restrict__ partial, const uint32_t n_partial, const uint32_t B, half_t* __restrict__ dloss, float* __restrict__ coords, uint32_t* __restrict__ src_slot,
+                                                                 const uint32_t host_seq) {
+	if (blockIdx.x == 0) reduce_losses_body(n_max, counters, l0, l1, l2, out, fwd_counts, host_out, partial, n_partial, host_seq);
 	else rollover_body(B, counters, dloss, coords, (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - 1) * blockDim.x, src_slot);
 }
 

@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -184,6 +185,9 @@ struct rnb_ctx {
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
+		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
+		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
+		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
@@ -213,10 +217,14 @@ struct rnb_ctx {
 	// generation + march — which depends on the occupancy bitfield and the RNG, not on the weights — runs beside this step's
 	// backward pass and optimizer (s_march). Results are identical to the serial order; see DESIGN.md §5.
 	hipStream_t s_march = nullptr, s_dw = nullptr, s_adam = nullptr; // with the caller's stream: the 4 hardware queues HIP multiplexes streams onto
+	// The step's side stream s_dw ends with the MLPs' Adam and the LDS weight images (ev_tail). Every barrier packet in front of the next network evaluation
+	// costs the critical stream ~5 us (tools/probe_barriers.hip), so when the next step's march is about to be queued, the wait for ev_tail goes onto ITS stream,
+	// in front of k_march_write (slack there), and the critical stream reaches it through ev_march. tail_pending: nobody has waited for ev_tail yet.
+	bool tail_pending = false;
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
 	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
 	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; } sc;
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0; } sc;
 	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
 	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
@@ -225,7 +233,10 @@ struct rnb_ctx {
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
 	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; } pre; // samples already generated for the next step
-	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t pad[2]; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills
+	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t seq, pad; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills; seq: see poll_loss()
+	uint32_t rb_seq = 0;     // sequence number of the last step whose readback was launched in polling mode
+	bool loss_polled = true; // the host has seen that step's readback (or the step publishes through ev_loss instead)
+	bool poll_loss() const { return overlap() && !dp_order() && knobs.poll_loss; }
 	void* host_rb_dev = nullptr;
 	bool overlap() const { return cfg.overlap != 0 && !prof.on && s_march != nullptr; }
 
@@ -245,6 +256,12 @@ struct rnb_ctx {
 };
 
 static void discard_premarch(rnb_ctx* c);
+static bool prep_due(uint32_t step) { // testbed.cu:2805
+	const uint32_t n_prep_to_skip = std::min(std::max(step / 16u, 1u), 16u);
+	return step % n_prep_to_skip == 0;
+}
+// Safety net of the deferred join (rnb_ctx::tail_pending) for launches outside the training step's own sequence: wait on the host.
+static void join_tail_host(rnb_ctx* c) { if (c->tail_pending) { (void)hipEventSynchronize(c->ev_tail); c->tail_pending = false; } }
 
 // The one-launch scans (kernels_ray.cuh, chain_prefix) report a wait that gave up through two mapped host words; read after a synchronisation.
 // The launch itself has poisoned its result (zero counters), so nothing was trained on it.
@@ -382,6 +399,7 @@ int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true, bool have_parti
 
 int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference) {
 	if (n == 0) return RNB_OK;
+	if (!inference) join_tail_host(c);
 	PointArgs a;
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
@@ -515,6 +533,7 @@ static int ensure_rgb_buffers(rnb_ctx* c) {
 
 int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference, const uint32_t* idx = nullptr, half_t* cin_out = nullptr) {
 	if (n_max == 0) return RNB_OK;
+	if (!inference) join_tail_host(c);
 	FwdArgs a;
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx; a.cin_out = cin_out;
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
@@ -589,7 +608,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	return a;
 }
 
-int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr) {
+int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr, hipEvent_t wait_before_write = nullptr) {
 	if (!c->coarse_valid) { const int rc0 = rebuild_coarse(c, s); if (rc0 != RNB_OK) return rc0; } // a caller may have written the bitfield (rnb_buffer)
 	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	c->gen_k1 = a.k1;
@@ -623,6 +642,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	} else
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
+	if (wait_before_write) HIP_TRY(hipStreamWaitEvent(s, wait_before_write, 0)); // (rnb_ctx::tail_pending)
 	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, done, a);
 	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
 	c->prof.mark(s, P_MARCH_WRITE);
@@ -691,6 +711,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const rnb_ctx::ScatterGroups& sg = c->sg;
 	const uint32_t L = c->cfg.n_levels;
 	const uint32_t e_c = sg.e_c, l_fine = sg.l_fine;
+	join_tail_host(c);
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
 	c->grads_clean = false;
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
@@ -764,8 +785,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		f.n_partials = (uint32_t)slab;
 		f.var_partial = c->var_partial.p; f.n_var_partials = fb_grid * WAVES_PER_WG;
 		f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
-		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS) / 64 + 1; // + the variance workgroup
-		LAUNCH_EV(k_dw_finish, dim3(n_fin_blocks), dim3(1024), 0, sd, done, f);
+		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + (a.skip_rgb ? 0 : RNB_N_RGB_MLP_PARAMS)) / DWF_PARAMS + 1; // + the variance workgroup
+		LAUNCH_EV(k_dw_finish, dim3(n_fin_blocks), dim3(DWF_WG), 0, sd, done, f);
 	};
 
 	// ---- hash-grid gradient scatter, three groups of levels (kernels_net.cuh); the addends commute up to fp32 rounding, as with any atomic order:
@@ -819,9 +840,22 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// Data parallel: C, B, then A, so that the parameters in front of A's levels (MLPs, C, B: one contiguous block) are final at
 		// ev_sc[0] + ev_dw and their exchange runs beside the scatter of A; A's levels + variance are the second block.
 		if (c->sc.dp) launch_c(s, nullptr);
-		launch_b(s, c->ev_sc[0]);
-		launch_a(s, c->ev_sc[1], l_fine, a_mid);
-		launch_a(s, c->ev_sc[3], a_mid, L);
+		// Order of the groups by batch shape (round 4, ms/step over 160 steps, one box, B-A1-A2-C / A1-A2-B-C / A-B-C): step 1000, 14 k rays: 0.6446 / 0.6473 / 0.6325;
+		// 1200, 18.5 k: 0.6435 / 0.6594 / 0.6394; 1400, 24 k: 0.6304 / 0.6324 / 0.6388; 1800, 41 k: 0.6132 / 0.6142 / 0.6161; 6000, 94 k: 0.6452 / 0.6482 / 0.6470
+		// (profiles/r04_sweep_scatter_order.txt): the fine levels first and in one launch while the batch is few long rays (the regime of the 16-lanes-per-ray march).
+		c->sc.order = c->sc.dp ? 0 : c->knobs.scatter_order >= 0 ? c->knobs.scatter_order : (c->cur_n_rays < c->knobs.march_narrow_from ? 2 : 0);
+		if (c->sc.order == 0) { // B, A1, A2 (, C)
+			launch_b(s, c->ev_sc[0]);
+			launch_a(s, c->ev_sc[1], l_fine, a_mid);
+			launch_a(s, c->ev_sc[3], a_mid, L);
+		} else if (c->sc.order == 1) { // A1, A2, B, C: the fine levels' atomics before any optimizer chunk shares the memory side with them
+			launch_a(s, c->ev_sc[1], l_fine, a_mid);
+			launch_a(s, c->ev_sc[3], a_mid, L);
+			launch_b(s, c->ev_sc[0]);
+		} else { // A (one launch), B, C
+			launch_a(s, c->ev_sc[1], l_fine, L);
+			launch_b(s, c->ev_sc[0]);
+		}
 		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
 		if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
 		if (c->sc.dp || join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
@@ -880,7 +914,6 @@ static void adam_launch(rnb_ctx* c, hipStream_t st, uint64_t lo, uint64_t hi, hi
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>(4096, ((hi - lo) / 4 + 255) / 256);
 	LAUNCH_EV(k_adam_ema, dim3(blocks), dim3(256), 0, st, done, a);
 }
-
 // Optimizer on the early gradient block only (rnb_gradient_parts block 0), on the caller's stream.
 int optimizer_step_early(rnb_ctx* c, hipStream_t st) {
 	if (!c->sc.valid || c->opt.early_done) return RNB_OK;
@@ -917,7 +950,7 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 	c->opt.begun = false;
 	c->opt.early_done = false;
 	c->sc.valid = false;
-	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(4), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
+	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
 	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
@@ -961,12 +994,26 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
 		// on the side stream, beside the scatter of the next group; only the last half of group A is left for the end.
 		hipStream_t sa = c->s_adam;
-		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
-		adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
-		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
-		adam_launch(c, sa, c->sc.split[0], c->sc.split_mid);        // group A's levels, first half beside the second half's scatter
-		HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[3], 0));
-		adam_launch(c, sa, c->sc.split_mid, c->off_var, c->ev_adam);
+		if (c->sc.order == 0) {
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
+			adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
+			adam_launch(c, sa, c->sc.split[0], c->sc.split_mid);        // group A's levels, first half beside the second half's scatter
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[3], 0));
+			adam_launch(c, sa, c->sc.split_mid, c->off_var, c->ev_adam);
+		} else if (c->sc.order == 1) {
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
+			adam_launch(c, sa, c->sc.split[0], c->sc.split_mid);
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[3], 0));
+			adam_launch(c, sa, c->sc.split_mid, c->off_var);
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
+			adam_launch(c, sa, c->sc.split[1], c->sc.split[0], c->ev_adam);
+		} else {
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[1], 0));
+			adam_launch(c, sa, c->sc.split[0], c->off_var);
+			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
+			adam_launch(c, sa, c->sc.split[1], c->sc.split[0], c->ev_adam);
+		}
 		if (c->sc.dw_joined) {
 			adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
 			adam_launch(c, s, c->off_var, c->n_params);
@@ -976,10 +1023,12 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
-			LAUNCH_EV(k_prepare_weight_images, dim3(4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
+			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
 			images_done = true;
 			adam_launch(c, s, c->off_grid, c->sc.split[1]);
-			HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
+			// the join with the side stream: on the next step's march stream if that march is queued after this call (launch_premarch), else here
+			if (c->knobs.defer_tail && !c->pre.valid && !prep_due(c->cur_step + 1)) c->tail_pending = true;
+			else HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
 			c->sc.dw_joined = true;
 		}
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
@@ -1203,6 +1252,9 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_FBS_WG_PER_CU")) k.fbs_wg_per_cu = (uint32_t)std::max(1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_GRID_PRESORT")) k.grid_presort = atoi(e) != 0;
 		if (const char* e = getenv("RNB_FUSED_UPDATE")) k.fused_update = atoi(e) != 0;
+		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
+		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
@@ -1325,6 +1377,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		if (rc != RNB_OK) return rc;
 		if (!read_only) c->opt_rec_current = false;
 	}
+	if (id == RNB_BUF_PARAMS_FP16) join_tail_host(c);
 	if (!read_only) { // a possible write before the caller's next call: drop the cached forms now (a kept pointer written later: rnb_params_changed / rnb_bitfield_changed)
 		if (id == RNB_BUF_PARAMS_FP16) c->wimg_valid = false;
 		else if (id == RNB_BUF_DENSITY_BITFIELD) { discard_premarch(c); c->coarse_valid = false; c->gs_pre.valid = false; c->bitfield_foreign = true; }
@@ -1399,6 +1452,7 @@ int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kin
 	}
 	hipMemcpyKind k = kind == RNB_H2D ? hipMemcpyHostToDevice : kind == RNB_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 	HIP_TRY(hipDeviceSynchronize());
+	if (c) c->tail_pending = false;
 	if (c) { const int rc = check_scan_errors(c); if (rc != RNB_OK) return rc; } // stage API: the scans of rnb_generate_training_samples / rnb_compute_loss are read through here
 	HIP_TRY(hipMemcpy(dst, src, n_bytes, k));
 	return RNB_OK;
@@ -1623,14 +1677,11 @@ static uint32_t next_max_inference(rnb_ctx* c) { // testbed_nerf.cu:3891-3896
 	return next_multiple_u32(std::min(c->measured_batch_size_before_compaction, max_samples), 128u);
 }
 
-static bool prep_due(uint32_t step) { // testbed.cu:2805
-	const uint32_t n_prep_to_skip = std::min(std::max(step / 16u, 1u), 16u);
-	return step % n_prep_to_skip == 0;
-}
 
 // Occupancy update (when due), ray generation + march, network evaluation of all samples, loss + compaction.
 static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->valid_level = compute_valid_level(c->cfg, (int)c->training_step); // testbed.cu:2792
+	if (c->tail_pending) { HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; } // no march was queued behind the optimizer to take the join
 	c->grid_updated = false;
 	c->prep_ms = 0.f;
 	int rc;
@@ -1690,14 +1741,35 @@ static int step_back(rnb_ctx* c, hipStream_t s) {
 	return RNB_OK;
 }
 
+// Polling mode (launch_reduce_losses): spin on the sequence word of the pinned readback block until the step's k_reduce_losses has published it.
+static int wait_loss_readback(rnb_ctx* c, hipStream_t s) {
+	if (c->loss_polled) return RNB_OK;
+	const volatile uint32_t* seq = &c->host_rb->seq;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (uint64_t spins = 0; *seq != c->rb_seq; ++spins) {
+		if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { // the kernel never ran, or failed: let the runtime say why
+			HIP_TRY(hipStreamSynchronize(s));
+			if (*seq != c->rb_seq) return fail(RNB_ERR_DEVICE, "the loss readback of the step did not arrive");
+		}
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	c->loss_polled = true;
+	return RNB_OK;
+}
+
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
 	c->prof.mark(s, P_NONE);
 	// the 48-byte readback goes straight into the pinned host block (no copy kernel, no marker packet); ev_loss is the kernel's completion
 	const bool tiled = c->cur_n_rays >= c->knobs.march_narrow_from;
 	const uint32_t n_tiles = (c->cur_n_rays + SCAN_TILE - 1) / SCAN_TILE;
 	if (tiled) hipLaunchKernelGGL(k_reduce_losses_tiles, dim3(n_tiles), dim3(1024), 0, s, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_partial.p);
-	LAUNCH_EV(k_reduce_losses_rollover, dim3(1 + 255), dim3(1024), 0, s, c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
-	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles, c->cfg.target_batch_size, c->dloss_dout.p, c->coords_compacted.p, c->cin_flow ? c->src_slot.p : nullptr);
+	// Single GPU, overlapped schedule: no completion event (ev_loss carries a system-scope fence and has a waiter on the march's stream: ~5 us between this kernel
+	// and k_fwd_bwd, tools/probe_barriers.hip); the host polls the readback's sequence word instead (wait_loss_readback). Data parallel / serial: the event, as before.
+	const bool poll = c->poll_loss();
+	if (poll) { if (++c->rb_seq == 0) ++c->rb_seq; c->loss_polled = false; }
+	LAUNCH_EV(k_reduce_losses_rollover, dim3(1 + 255), dim3(1024), 0, s, poll ? nullptr : c->ev_loss, c->cur_n_rays, c->counters.p, c->loss.p, c->ek_loss, c->mask_loss, c->loss_sums.p, c->fwd_counts.p,
+	          reinterpret_cast<double*>(c->host_rb_dev), tiled ? c->loss_partial.p : nullptr, n_tiles, c->cfg.target_batch_size, c->dloss_dout.p, c->coords_compacted.p, c->cin_flow ? c->src_slot.p : nullptr,
+	          poll ? c->rb_seq : 0u);
 	c->prof.mark(s, P_REDUCE);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1715,7 +1787,8 @@ static int launch_premarch(rnb_ctx* c) {
 	// the generic kernel of the albedo mode -- a sample set that the same launch on an idle GPU does not produce. Without packed
 	// fp32 (rnb-neus2_amd/build.py) and with that index read through one cross-lane shuffle instead: 0 of 2000 launches beside
 	// k_fwd_bwd (0 of 1300 for the one-thread-per-ray kernel of the large batches). DESIGN.md section 6.
-	HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
+	if (c->poll_loss()) { const int rc0 = wait_loss_readback(c, nullptr); if (rc0 != RNB_OK) return rc0; } // the host has SEEN the loss pass end: nothing to wait for on the device
+	else HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
 	// No fill in front of the march: every step counter is written with a plain store by the scans (k_scan_rays*, k_scan_compact*), and the
 	// loss rows are written for every kept ray by k_loss_pass2 (zeros for a ray without compacted samples) -- k_reduce_losses reads nothing
 	// else. (Round 2 queued a k_clear_step here: 62 us behind k_fwd_bwd_sdf's workgroups at the head of the march chain.)
@@ -1723,8 +1796,9 @@ static int launch_premarch(rnb_ctx* c) {
 	// exclude each other on a SIMD; a march that has started beside the first keeps the second at half occupancy (253 instead of 113 us, the step 0.79 instead of
 	// 0.76 ms). Behind them it runs beside the scatter, as it effectively does with --no-albedo, where k_fwd_bwd_sdf claims the registers first.
 	if (c->knobs.march_late || c->rgb_split()) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
-	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march);
+	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march, c->tail_pending ? c->ev_tail : nullptr);
 	if (rc != RNB_OK) return rc;
+	c->tail_pending = false; // the next step reaches ev_tail through ev_march
 	c->pre.loss_cleared = true;
 	c->n_rays_total += n_rays * c->cfg.world_size;
 	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference; c->pre.k1 = c->gen_k1;
@@ -1757,7 +1831,8 @@ int rnb_train_step_apply(rnb_ctx* c, void* stream) {
 // Counters + loss sums of the step started by the last rnb_train_step_begin. May be called before or after _apply.
 int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], double loss_sums_out[3]) {
 	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
-	if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss)); // the backward pass / optimizer may still be running
+	if (c->poll_loss()) { const int rc = wait_loss_readback(c, as_stream(stream)); if (rc != RNB_OK) return rc; } // the backward pass / optimizer may still be running
+	else if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss));
 	else HIP_TRY(hipStreamSynchronize(as_stream(stream)));      // testbed.cu:2866
 	{ const int rc = check_scan_errors(c); if (rc != RNB_OK) return rc; }
 	const uint32_t* counters = c->host_rb->counters;
