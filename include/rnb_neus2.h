@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 2 (round 4): RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS became staging views (see rnb_buffer); buffer ids 25, 26 and
- * rnb_bitfield_changed / rnb_update_density_grid_shard were added after 1 without a bump -- a binary built against 1 must not link silently. */
+ * rnb_bitfield_changed were added after 1 without a bump -- a binary built against 1 must not link silently. */
 #define RNB_ABI_VERSION 2
 
 typedef enum rnb_status {
@@ -291,6 +291,11 @@ int rnb_profile_count(const rnb_ctx* ctx);
 int rnb_profile_get(const rnb_ctx* ctx, int idx, const char** name, double* total_ms, uint64_t* launches, double* units);
 uint32_t rnb_training_step(const rnb_ctx* ctx);
 uint32_t rnb_rays_per_batch(const rnb_ctx* ctx);
+/* Re-seat the optimizer's step counter: what AdamOptimizer / ExponentialDecayOptimizer::deserialize restore from a snapshot that carries the
+ * optimizer state (adam.h:486-495 "current_step", exponential_decay.h:143-147 "learning_rate_factor"). `step` = optimizer steps taken so far; the
+ * learning-rate factor becomes lr_decay_base ^ (number of decay events the steps [0, step) have seen, exponential_decay.h:61-72), multiplied up
+ * in the same order as the running optimizer does. The per-parameter state (moments, step counts) is written through rnb_buffer. */
+int rnb_set_optimizer_step(rnb_ctx* ctx, uint32_t step);
 /* Re-seat the controller state (snapshot resume, testbed.cu:3333-3390). */
 int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_batch,
                        uint32_t measured_batch_size_before_compaction, uint32_t n_rays_total);

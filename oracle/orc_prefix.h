@@ -46,6 +46,7 @@
 #define rnb_profile_get orc_profile_get
 #define rnb_rays_per_batch orc_rays_per_batch
 #define rnb_set_controller orc_set_controller
+#define rnb_set_optimizer_step orc_set_optimizer_step
 #define rnb_gradient_parts orc_gradient_parts
 #define rnb_gradient_part_wait orc_gradient_part_wait
 #define rnb_train_step_apply_early orc_train_step_apply_early

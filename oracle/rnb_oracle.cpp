@@ -1943,6 +1943,15 @@ int rnb_profile_get(const orc_ctx_s*, int, const char**, double*, uint64_t*, dou
 uint32_t rnb_training_step(const orc_ctx_s* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch : 0; }
 
+int rnb_set_optimizer_step(orc_ctx_s* c, uint32_t step) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->opt_begun = false;
+	c->optimizer_step_count = step;
+	c->lr_factor = 1.0f;
+	for (uint64_t s0 = c->cfg.lr_decay_start; s0 < step && s0 <= 10000000u; s0 += std::max(1u, c->cfg.lr_decay_interval)) c->lr_factor *= c->cfg.lr_decay_base; // exponential_decay.h:61-72, one factor per event
+	return RNB_OK;
+}
+
 int rnb_set_controller(orc_ctx_s* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (rays_per_batch == 0 || rays_per_batch > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "rays_per_batch out of range");

@@ -158,6 +158,7 @@ PROTOTYPES = {
     "training_step": (_u32, [_ctx]),
     "rays_per_batch": (_u32, [_ctx]),
     "set_controller": (_i, [_ctx, _u32, _u32, _u32, _u32]),
+    "set_optimizer_step": (_i, [_ctx, _u32]),
     "gradient_parts": (_i, [_ctx, C.POINTER(_u64 * 2 * 3), C.POINTER(_u32)]),
     "gradient_part_wait": (_i, [_ctx, _u32, _stream]),
     "train_step_apply_early": (_i, [_ctx, _stream]),

@@ -239,6 +239,10 @@ class Context:
     def set_controller(self, training_step, rays_per_batch, measured_before_compaction=0, n_rays_total=0):
         self._check(self.f.set_controller(self._h, int(training_step), int(rays_per_batch), int(measured_before_compaction), int(n_rays_total)))
 
+    def set_optimizer_step(self, step):
+        """Optimizer steps taken so far (adam.h:486-495, exponential_decay.h:143-147): step counter + learning-rate factor."""
+        self._check(self.f.set_optimizer_step(self._h, int(step)))
+
     def gradient_parts(self):
         """[(first, last+1), ...] blocks of GRADS_FP32 in the order they become final during the queued backward pass."""
         arr = (C.c_uint64 * 2 * 3)()

@@ -1921,6 +1921,16 @@ int rnb_profile_get(const rnb_ctx* c, int idx, const char** name, double* total_
 uint32_t rnb_training_step(const rnb_ctx* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0; }
 
+int rnb_set_optimizer_step(rnb_ctx* c, uint32_t step) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
+	c->opt.begun = false;
+	c->optimizer_step_count = step;
+	c->lr_factor = 1.0f;
+	for (uint64_t s0 = c->cfg.lr_decay_start; s0 < step && s0 <= 10000000u; s0 += std::max(1u, c->cfg.lr_decay_interval)) c->lr_factor *= c->cfg.lr_decay_base; // exponential_decay.h:61-72, one factor per event
+	return RNB_OK;
+}
+
 int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (rays_per_batch == 0 || rays_per_batch > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "rays_per_batch out of range");

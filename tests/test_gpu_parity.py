@@ -485,6 +485,57 @@ def test_optimizer_step(pair):
     assert not gpu.get("GRADS_FP32").any()
 
 
+def test_optimizer_bias_correction_table_fallback_and_lr_decay():
+    """a12 beyond t <= 3 (adam.h:182-190, exponential_decay.h:61-72): per-parameter step counts preset so that this step's count is 1, 7, 999,
+    65 535 (last entry of the device's 2^16-entry bias-correction table), 65 536 (first one computed in place) and 100 000, non-zero moments,
+    and the optimizer's own step counter at 25 000 and 45 000 (one and three learning-rate decay events behind it): masters, moments, step counts
+    and EMA weights against the oracle; and the decay is seen to act (update sizes scale by 0.33 and 0.33^3 against step 100)."""
+    gpu, cpu = _pair()
+    try:
+        rng = np.random.default_rng(11)
+        n = cpu.n_params
+        pre = np.array([0, 6, 998, 65534, 65535, 99999], dtype=np.uint32)
+        steps = pre[rng.integers(0, len(pre), n)]
+        m0 = (rng.standard_normal(n) * 1e-3).astype(np.float32)
+        v0 = (rng.random(n) * 1e-6 + 1e-9).astype(np.float32)
+        w0 = cpu.get("PARAMS_FP32").copy()
+        grads = np.zeros(n, dtype=np.float32)
+        idx = rng.choice(n, size=600000, replace=False)
+        z = rng.standard_normal(idx.size).astype(np.float32)
+        grads[idx] = np.sign(z) * (0.01 + np.abs(z) * 0.05)  # away from zero: the half-narrowed gradient decides whether a parameter is stepped
+        grads[:11264] = rng.standard_normal(11264).astype(np.float32) * 0.01
+        deltas = {}
+        for opt_step in (100, 25000, 45000):
+            for c in (gpu, cpu):
+                c.set_params(w0)
+                c.put("ADAM_STEPS", steps)
+                c.put("ADAM_M", m0)
+                c.put("ADAM_V", v0)
+                c.set_optimizer_step(opt_step)
+                c.put("GRADS_FP32", grads)
+                c.optimizer_step()
+            a, b = gpu.get("PARAMS_FP32"), cpu.get("PARAMS_FP32")
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9, err_msg="PARAMS_FP32 at optimizer step %d" % opt_step)
+            for name in ("ADAM_M", "ADAM_V"):
+                np.testing.assert_allclose(gpu.get(name), cpu.get(name), rtol=1e-6, atol=1e-12, err_msg="%s at optimizer step %d" % (name, opt_step))
+            sg = gpu.get("ADAM_STEPS")
+            assert np.array_equal(sg, cpu.get("ADAM_STEPS"))
+            live = grads != 0
+            live[:11264] = True
+            assert np.array_equal(sg[live], steps[live] + 1) and np.array_equal(sg[~live], steps[~live])
+            for t in (1, 7, 999, 65535, 65536, 100000):  # every class of step count took part, the table's edge and the fallback included
+                assert np.count_nonzero(sg[live] == t) > 1000, t
+            _half_close(gpu.get("PARAMS_EMA"), cpu.get("PARAMS_EMA"), rel=1.1e-3, abs_=1e-7, frac=0.9999, name="ema at optimizer step %d" % opt_step)
+            assert not gpu.get("GRADS_FP32").any()
+            deltas[opt_step] = (a.astype(np.float64) - w0)[11264:][live[11264:]]
+        for opt_step, factor in ((25000, 0.33), (45000, 0.33 ** 3)):
+            ratio = np.median(np.abs(deltas[opt_step]) / np.maximum(np.abs(deltas[100]), 1e-30))
+            assert abs(ratio - factor) < 2e-3 * factor, (opt_step, ratio, factor)
+    finally:
+        gpu.close()
+        cpu.close()
+
+
 def test_train_steps_track_oracle():
     gpu, cpu = _pair()
     try:
