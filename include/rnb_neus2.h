@@ -300,6 +300,21 @@ int rnb_set_optimizer_step(rnb_ctx* ctx, uint32_t step);
 int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_batch,
                        uint32_t measured_batch_size_before_compaction, uint32_t n_rays_total);
 
+/* Self-test of the integer / index primitives the path is built on, evaluated by the library's own device functions (one thread per item) --
+ * what tests/golden/int_fixtures.json (outputs of the reference's host-compilable fragments) is compared with. Words are uint32; floats
+ * travel as bit patterns. Items in / out per kind:
+ *   RNB_PRIM_PCG32   in  initstate lo hi, initseq lo hi, delta lo hi           pcg32{initstate, initseq}; advance(delta)  (pcg32.h:44-170)
+ *                    out state hi lo (after the advance), next_uint(), bits(next_float()) (each the draw at that position)
+ *   RNB_PRIM_MORTON  in  x y z          out morton3D, morton3D_invert(code >> 0, 1, 2)                  (tiny-cuda-nn/common_device.h:337-363)
+ *   RNB_PRIM_SRGB    in  bits(v)        out bits(srgb_to_linear(v)), bits(linear_to_srgb(v))              (common_device.cuh:31-61)
+ *   RNB_PRIM_RAY_BOX in  box lo hi, origin 3, direction 3     out tmin, tmax, contains(origin)            (bounding_box.cuh:163-213)
+ *   RNB_PRIM_MARCH   in  cone_angle, max_cascade, pos 3, dir 3, t   out calc_dt(t), mip_from_pos, mip_from_dt(dt), cascaded_grid_idx_at(pos, mip),
+ *                    density_grid_occupied_at (bitfield byte i = pcg32{5} draw i >> 24), distance_to_next_voxel, advance_to_next_voxel at res = 128 >> mip
+ *                                                                                                        (src/testbed_nerf.cu:153-155, 301-323, 439-465, 569-583)
+ * Host pointers; syncs. */
+typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4 } rnb_primitive;
+int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
+
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by
  * rnb_train_step_begin, so that a caller can exchange the early block while the rest is still being accumulated.
  * ranges[k] = {first, last+1} parameter indices into RNB_BUF_GRADS_FP32, k = 0 .. *n_parts-1 (at most 3); the blocks

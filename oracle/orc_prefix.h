@@ -47,6 +47,7 @@
 #define rnb_rays_per_batch orc_rays_per_batch
 #define rnb_set_controller orc_set_controller
 #define rnb_set_optimizer_step orc_set_optimizer_step
+#define rnb_eval_primitives orc_eval_primitives
 #define rnb_gradient_parts orc_gradient_parts
 #define rnb_gradient_part_wait orc_gradient_part_wait
 #define rnb_train_step_apply_early orc_train_step_apply_early

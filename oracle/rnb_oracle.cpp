@@ -1943,6 +1943,58 @@ int rnb_profile_get(const orc_ctx_s*, int, const char**, double*, uint64_t*, dou
 uint32_t rnb_training_step(const orc_ctx_s* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch : 0; }
 
+// rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
+int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
+	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
+	if (kind < 0 || kind > RNB_PRIM_MARCH) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[5] = {6, 3, 1, 8, 9}, OUT_W[5] = {4, 4, 2, 3, 7};
+	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
+	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
+	std::vector<uint8_t> bf;
+	if (kind == RNB_PRIM_MARCH) {
+		bf.resize((size_t)GRID_CELLS / 8 * N_CASCADES);
+		Pcg32 q{5};
+		for (auto& b : bf) b = (uint8_t)(q.next_uint() >> 24);
+	}
+	orc_ctx_s box; // ray_intersect / aabb_contains read the box from a context
+	for (uint32_t i = 0; i < n_items; ++i) {
+		const uint32_t* a = in + (size_t)i * IN_W[kind];
+		uint32_t* o = out + (size_t)i * OUT_W[kind];
+		if (kind == RNB_PRIM_PCG32) {
+			Pcg32 r{(uint64_t)a[0] | (uint64_t)a[1] << 32, (uint64_t)a[2] | (uint64_t)a[3] << 32};
+			r.advance((int64_t)((uint64_t)a[4] | (uint64_t)a[5] << 32));
+			o[0] = (uint32_t)(r.state >> 32); o[1] = (uint32_t)r.state;
+			Pcg32 r2 = r;
+			o[2] = r.next_uint();
+			o[3] = u(r2.next_float());
+		} else if (kind == RNB_PRIM_MORTON) {
+			const uint32_t m = morton3D(a[0], a[1], a[2]);
+			o[0] = m; o[1] = morton3D_invert(m >> 0); o[2] = morton3D_invert(m >> 1); o[3] = morton3D_invert(m >> 2);
+		} else if (kind == RNB_PRIM_SRGB) {
+			o[0] = u(srgb_to_linear(f(a[0]))); o[1] = u(linear_to_srgb(f(a[0])));
+		} else if (kind == RNB_PRIM_RAY_BOX) {
+			box.aabb_min = f(a[0]); box.aabb_max = f(a[1]);
+			const Vec3 p = {f(a[2]), f(a[3]), f(a[4])}, d = {f(a[5]), f(a[6]), f(a[7])};
+			float t0, t1;
+			ray_intersect(&box, p, d, &t0, &t1);
+			o[0] = u(t0); o[1] = u(t1); o[2] = aabb_contains(&box, p) ? 1u : 0u;
+		} else {
+			const float cone = f(a[0]);
+			const uint32_t max_cascade = a[1];
+			const Vec3 p = {f(a[2]), f(a[3]), f(a[4])}, d = {f(a[5]), f(a[6]), f(a[7])};
+			const Vec3 idir = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+			const float t = f(a[8]);
+			const float dt = calc_dt(t, cone);
+			const int mip = mip_from_dt(dt, p, max_cascade);
+			const uint32_t res = GRIDSIZE >> mip;
+			o[0] = u(dt); o[1] = (uint32_t)mip_from_pos(p, max_cascade); o[2] = (uint32_t)mip; o[3] = cascaded_grid_idx_at(p, (uint32_t)mip);
+			o[4] = density_grid_occupied_at(p, bf.data(), (uint32_t)mip) ? 1u : 0u;
+			o[5] = u(distance_to_next_voxel(p, d, idir, res)); o[6] = u(advance_to_next_voxel(t, cone, p, d, idir, res));
+		}
+	}
+	return RNB_OK;
+}
+
 int rnb_set_optimizer_step(orc_ctx_s* c, uint32_t step) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->opt_begun = false;

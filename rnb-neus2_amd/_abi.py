@@ -106,6 +106,8 @@ BUF_DTYPE = dict(
     COUNTERS="u4", DENSITY_GRID_TMP="f4", GRID_SAMPLE_POS="f4", GRID_SAMPLE_IDX="u4", STEP_VECTOR="f8", GRID_SAMPLE_POS_EVAL="f4", GRID_SAMPLE_IDX_EVAL="u4",
 )
 BUF_READONLY = 0x100  # RNB_BUF_READONLY
+PRIM = dict(PCG32=0, MORTON=1, SRGB=2, RAY_BOX=3, MARCH=4)  # rnb_primitive
+PRIM_IN_WORDS, PRIM_OUT_WORDS = (6, 3, 1, 8, 9), (4, 4, 2, 3, 7)
 H2D, D2H, D2D = 0, 1, 2
 
 _ctx = C.c_void_p
@@ -159,6 +161,7 @@ PROTOTYPES = {
     "rays_per_batch": (_u32, [_ctx]),
     "set_controller": (_i, [_ctx, _u32, _u32, _u32, _u32]),
     "set_optimizer_step": (_i, [_ctx, _u32]),
+    "eval_primitives": (_i, [_ctx, _i, C.c_void_p, _u32, C.c_void_p]),
     "gradient_parts": (_i, [_ctx, C.POINTER(_u64 * 2 * 3), C.POINTER(_u32)]),
     "gradient_part_wait": (_i, [_ctx, _u32, _stream]),
     "train_step_apply_early": (_i, [_ctx, _stream]),

@@ -239,6 +239,14 @@ class Context:
     def set_controller(self, training_step, rays_per_batch, measured_before_compaction=0, n_rays_total=0):
         self._check(self.f.set_controller(self._h, int(training_step), int(rays_per_batch), int(measured_before_compaction), int(n_rays_total)))
 
+    def eval_primitives(self, kind, items):
+        """rnb_eval_primitives: uint32 items [n, words_in(kind)] -> uint32 [n, words_out(kind)] (floats as bit patterns)."""
+        k = _abi.PRIM[kind]
+        a = np.ascontiguousarray(items, dtype=np.uint32).reshape(-1, _abi.PRIM_IN_WORDS[k])
+        out = np.empty((a.shape[0], _abi.PRIM_OUT_WORDS[k]), dtype=np.uint32)
+        self._check(self.f.eval_primitives(self._h, k, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def set_optimizer_step(self, step):
         """Optimizer steps taken so far (adam.h:486-495, exponential_decay.h:143-147): step counter + learning-rate factor."""
         self._check(self.f.set_optimizer_step(self._h, int(step)))

@@ -1679,4 +1679,56 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 	else rollover_body(B, counters, dloss, coords, (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x, (uint64_t)(gridDim.x - 1) * blockDim.x, src_slot);
 }
 
+// ---------------------------------------------------------------------------------------------
+// rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
+// holds what the reference's own host-compilable fragments return for the same items.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t PRIM_IN_WORDS[5] = {6, 3, 1, 8, 9}, PRIM_OUT_WORDS[5] = {4, 4, 2, 3, 7};
+__global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	Pcg32 q{5};
+	q.advance((int64_t)i);
+	bitfield[i] = (uint8_t)(q.next_uint() >> 24);
+}
+__global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, const uint32_t n, uint32_t* __restrict__ out, const uint8_t* __restrict__ bitfield) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t* a = in + (size_t)i * PRIM_IN_WORDS[kind];
+	uint32_t* o = out + (size_t)i * PRIM_OUT_WORDS[kind];
+	auto f = [](uint32_t u) { return __uint_as_float(u); };
+	auto u = [](float v) { return __float_as_uint(v); };
+	if (kind == RNB_PRIM_PCG32) {
+		Pcg32 r{(uint64_t)a[0] | (uint64_t)a[1] << 32, (uint64_t)a[2] | (uint64_t)a[3] << 32};
+		r.advance((int64_t)((uint64_t)a[4] | (uint64_t)a[5] << 32));
+		o[0] = (uint32_t)(r.state >> 32); o[1] = (uint32_t)r.state;
+		Pcg32 r2 = r;
+		o[2] = r.next_uint();
+		o[3] = u(r2.next_float());
+	} else if (kind == RNB_PRIM_MORTON) {
+		const uint32_t m = morton3D(a[0], a[1], a[2]);
+		o[0] = m; o[1] = morton3D_invert(m >> 0); o[2] = morton3D_invert(m >> 1); o[3] = morton3D_invert(m >> 2);
+	} else if (kind == RNB_PRIM_SRGB) {
+		o[0] = u(srgb_to_linear(f(a[0]))); o[1] = u(linear_to_srgb(f(a[0])));
+	} else if (kind == RNB_PRIM_RAY_BOX) {
+		SceneAabb A; A.mn = f(a[0]); A.mx = f(a[1]); A.cone_angle = 0.f; A.max_cascade = 0;
+		const Vec3 p = {f(a[2]), f(a[3]), f(a[4])}, d = {f(a[5]), f(a[6]), f(a[7])};
+		float t0, t1;
+		ray_intersect(A, p, d, &t0, &t1);
+		o[0] = u(t0); o[1] = u(t1); o[2] = aabb_contains(A, p) ? 1u : 0u;
+	} else {
+		const float cone = f(a[0]);
+		const uint32_t max_cascade = a[1];
+		const Vec3 p = {f(a[2]), f(a[3]), f(a[4])}, d = {f(a[5]), f(a[6]), f(a[7])};
+		const Vec3 idir = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+		const float t = f(a[8]);
+		const float dt = calc_dt(t, cone);
+		const int mip = mip_from_dt(dt, p, max_cascade);
+		const uint32_t res = GRIDSIZE >> mip;
+		o[0] = u(dt); o[1] = (uint32_t)mip_from_pos(p, max_cascade); o[2] = (uint32_t)mip; o[3] = cascaded_grid_idx_at(p, (uint32_t)mip);
+		o[4] = density_grid_occupied_at(p, bitfield, (uint32_t)mip) ? 1u : 0u;
+		o[5] = u(distance_to_next_voxel(p, d, idir, res)); o[6] = u(advance_to_next_voxel(t, cone, p, d, idir, res));
+	}
+}
+
 } // namespace rnb

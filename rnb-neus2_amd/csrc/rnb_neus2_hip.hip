@@ -1921,6 +1921,29 @@ int rnb_profile_get(const rnb_ctx* c, int idx, const char** name, double* total_
 uint32_t rnb_training_step(const rnb_ctx* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0; }
 
+int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
+	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
+	if (kind < 0 || kind > RNB_PRIM_MARCH) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (n_items == 0) return RNB_OK;
+	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
+	uint32_t *in = nullptr, *out = nullptr;
+	uint8_t* bf = nullptr;
+	int rc = RNB_OK;
+	if (hipMalloc((void**)&in, n_in * 4) != hipSuccess || hipMalloc((void**)&out, n_out * 4) != hipSuccess || (kind == RNB_PRIM_MARCH && hipMalloc((void**)&bf, n_bf) != hipSuccess))
+		rc = fail(RNB_ERR_NOMEM, "hipMalloc failed for the primitive self-test");
+	if (rc == RNB_OK && hipMemcpy(in, in_host, n_in * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: copy in failed");
+	if (rc == RNB_OK) {
+		if (bf) hipLaunchKernelGGL(k_prim_bitfield, dim3((uint32_t)((n_bf + 255) / 256)), dim3(256), 0, 0, bf, (uint32_t)n_bf);
+		hipLaunchKernelGGL(k_primitives, dim3((n_items + 127) / 128), dim3(128), 0, 0, kind, in, n_items, out, bf);
+		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_host, out, n_out * 4, hipMemcpyDeviceToHost) != hipSuccess)
+			rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: kernel or copy out failed");
+	}
+	if (in) (void)hipFree(in);
+	if (out) (void)hipFree(out);
+	if (bf) (void)hipFree(bf);
+	return rc;
+}
+
 int rnb_set_optimizer_step(rnb_ctx* c, uint32_t step) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer

@@ -96,6 +96,16 @@ def test_init_params_bit_exact(pair):
     assert np.array_equal(gpu.grid_tables()[0], cpu.grid_tables()[0])
 
 
+def test_device_primitives_match_the_reference_fragments(pair):
+    """PCG32 streams, Morton codes, ray / box, the march helpers (dt, mip, cell index, occupancy bit, voxel stepping): the library's own
+    device functions against what the reference's host-compilable fragments return (tests/golden/int_fixtures.json), bit for bit; the sRGB
+    transfer within 4 ulp (device powf), exact on its linear segment."""
+    from tests import int_fixture_cases
+    gpu, _ = pair
+    n = int_fixture_cases.check(gpu, exact_pow=False)
+    assert n == {"pcg32": 44, "morton": 64, "srgb": 256, "ray_box": 96, "march": 128}
+
+
 def test_density_grid_update(pair):
     gpu, cpu = pair
     for c in pair:
