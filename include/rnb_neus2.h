@@ -234,6 +234,19 @@ int rnb_set_training_step(rnb_ctx* ctx, uint32_t step);
 uint32_t rnb_valid_level(const rnb_ctx* ctx);
 /* Testbed::training_prep_nerf -> update_density_grid_nerf (testbed_nerf.cu:4125-4138, 3424-3495), K1-K5. */
 int rnb_update_density_grid(rnb_ctx* ctx, void* stream);
+/* Data parallel: the occupancy update sharded over the ranks. The update evaluates the network on a SET of 2^20 sample points and splats the densities
+ * with atomicMax into DENSITY_GRID_TMP (testbed_nerf.cu:616-635); with world_size > 1
+ *     rnb_update_density_grid_begin   K1 (all samples: every rank draws the same ones) + K2-K3 on samples [rank n / W, (rank + 1) n / W) of the evaluation order
+ *     element-wise MAX of DENSITY_GRID_TMP over the ranks (float[128^3 (max_cascade + 1)], all values >= 0: the same as a max of the words as int32 / uint32)
+ *     rnb_update_density_grid_end     K4-K5: EMA, mean, bitfield, pools
+ * leaves every rank with the grid a single rank computes, bit for bit, for 1 / W of the network evaluations. rnb_update_density_grid = begin; [the exchange]; end,
+ * where the exchange is the callback of rnb_set_grid_exchange (stream-ordered work on `stream`, e.g. one ncclAllReduce(ncclMax); returns 0 on success) -- which is
+ * also how the training step (rnb_train_step_begin) shards its updates. Without a callback the update stays replicated (every rank evaluates every sample: no
+ * communication). With world_size 1 begin / end are the two halves of rnb_update_density_grid. No reference counterpart (the reference is single-GPU). */
+typedef int (*rnb_grid_exchange_fn)(void* user, void* grid_tmp, uint64_t n_elements, void* stream);
+int rnb_set_grid_exchange(rnb_ctx* ctx, rnb_grid_exchange_fn fn, void* user);
+int rnb_update_density_grid_begin(rnb_ctx* ctx, void* stream);
+int rnb_update_density_grid_end(rnb_ctx* ctx, void* stream);
 /* Testbed::update_density_grid_mean_and_bitfield (testbed_nerf.cu:3497-3517), K5 from the current grid. */
 int rnb_update_density_bitfield(rnb_ctx* ctx, void* stream);
 /* NerfNetwork::density (nerf_network.h:522-537): xyz[n,3] f32 -> density half[n], training weights. */

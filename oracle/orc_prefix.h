@@ -27,6 +27,9 @@
 #define rnb_valid_level orc_valid_level
 #define rnb_update_density_grid orc_update_density_grid
 #define rnb_update_density_bitfield orc_update_density_bitfield
+#define rnb_update_density_grid_begin orc_update_density_grid_begin
+#define rnb_update_density_grid_end orc_update_density_grid_end
+#define rnb_set_grid_exchange orc_set_grid_exchange
 #define rnb_density orc_density
 #define rnb_sdf orc_sdf
 #define rnb_forward_infer orc_forward_infer

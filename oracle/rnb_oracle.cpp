@@ -141,6 +141,8 @@ struct orc_ctx_s {
 	uint32_t measured_batch_size = 0;
 	uint32_t measured_batch_size_before_compaction = 0;
 	uint32_t n_rays_total = 0;
+	rnb_grid_exchange_fn grid_exchange = nullptr; // rnb_set_grid_exchange
+	void* grid_exchange_user = nullptr;
 	uint32_t optimizer_step_count = 0;
 	bool opt_begun = false;
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays (equal data-parallel shards)
@@ -702,8 +704,9 @@ void update_bitfield(orc_ctx_s* c) {
 	}
 }
 
-// update_density_grid_nerf (testbed_nerf.cu:3424-3495)
-void update_density_grid(orc_ctx_s* c, uint32_t n_uniform, uint32_t n_nonuniform) {
+// update_density_grid_nerf (testbed_nerf.cu:3424-3495), first half: samples, network, splat. shard: this rank's 1 / world_size of the samples only
+// (rnb_update_density_grid_begin: the caller takes the element-wise max of DENSITY_GRID_TMP over the ranks before the second half).
+void update_density_grid_front(orc_ctx_s* c, uint32_t n_uniform, uint32_t n_nonuniform, bool shard) {
 	const uint32_t n_elements = GRID_CELLS * (c->max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
 	if (c->training_step == 0) { // testbed_nerf.cu:3446-3452
@@ -722,16 +725,23 @@ void update_density_grid(orc_ctx_s* c, uint32_t n_uniform, uint32_t n_nonuniform
 	NetParams np = net_params(c, false);
 	uint32_t* tmp_bits = reinterpret_cast<uint32_t*>(c->density_grid_tmp.data());
 	std::vector<float> dens(n_samples);
+	const uint64_t W = shard ? c->cfg.world_size : 1u, r = shard ? c->cfg.rank : 0u;
+	const int64_t lo = (int64_t)((uint64_t)n_samples * r / W), hi = (int64_t)((uint64_t)n_samples * (r + 1) / W);
 #pragma omp parallel for schedule(static)
-	for (int64_t i = 0; i < (int64_t)n_samples; ++i) {
+	for (int64_t i = lo; i < hi; ++i) {
 		half_t sdf = sdf_sample(c, np, &c->grid_sample_pos[(size_t)i * 3]);
 		dens[i] = h2f(sdf_to_density(sdf, np.variance));
 	}
-	for (uint32_t i = 0; i < n_samples; ++i) {
+	for (int64_t i = lo; i < hi; ++i) {
 		uint32_t b; std::memcpy(&b, &dens[i], 4);
 		uint32_t& dst = tmp_bits[c->grid_sample_idx[i]];
 		if (b > dst) dst = b; // atomicMax on float bits
 	}
+}
+
+// second half: EMA, mean, bitfield
+void update_density_grid_back(orc_ctx_s* c) {
+	const uint32_t n_elements = GRID_CELLS * (c->max_cascade + 1);
 	// ema_grid_samples_nerf (testbed_nerf.cu:655-685)
 	const float decay = c->cfg.density_grid_decay;
 	for (uint32_t i = 0; i < n_elements; ++i) {
@@ -744,10 +754,18 @@ void update_density_grid(orc_ctx_s* c, uint32_t n_uniform, uint32_t n_nonuniform
 }
 
 // training_prep_nerf (testbed_nerf.cu:4125-4138)
-void training_prep(orc_ctx_s* c) {
+void training_prep_front(orc_ctx_s* c, bool shard) {
 	const uint32_t n_cascades = c->max_cascade + 1;
-	if (c->training_step < 256) update_density_grid(c, GRID_CELLS * n_cascades, 0);
-	else update_density_grid(c, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
+	if (c->training_step < 256) update_density_grid_front(c, GRID_CELLS * n_cascades, 0, shard);
+	else update_density_grid_front(c, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades, shard);
+}
+int training_prep(orc_ctx_s* c) {
+	const bool shard = c->cfg.world_size > 1 && c->grid_exchange != nullptr;
+	training_prep_front(c, shard);
+	if (shard && c->grid_exchange(c->grid_exchange_user, c->density_grid_tmp.data(), (uint64_t)GRID_CELLS * (c->max_cascade + 1), nullptr) != 0)
+		return fail(RNB_ERR_INVALID, "the occupancy grid exchange (rnb_set_grid_exchange) failed");
+	update_density_grid_back(c);
+	return RNB_OK;
 }
 
 // ======================================================================
@@ -1730,7 +1748,21 @@ uint32_t rnb_valid_level(const orc_ctx_s* c) { return c ? c->valid_level : 0; }
 
 int rnb_update_density_grid(orc_ctx_s* c, void*) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	training_prep(c);
+	return training_prep(c);
+}
+int rnb_set_grid_exchange(orc_ctx_s* c, rnb_grid_exchange_fn fn, void* user) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->grid_exchange = fn; c->grid_exchange_user = user;
+	return RNB_OK;
+}
+int rnb_update_density_grid_begin(orc_ctx_s* c, void*) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	training_prep_front(c, c->cfg.world_size > 1);
+	return RNB_OK;
+}
+int rnb_update_density_grid_end(orc_ctx_s* c, void*) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	update_density_grid_back(c);
 	return RNB_OK;
 }
 int rnb_update_density_bitfield(orc_ctx_s* c, void*) {
@@ -1834,7 +1866,7 @@ int rnb_train_step_begin(orc_ctx_s* c, void*) {
 	const uint32_t n_prep_to_skip = std::min(std::max(c->training_step / 16u, 1u), 16u); // testbed.cu:2805
 	if (c->training_step % n_prep_to_skip == 0) {
 		auto t0 = std::chrono::steady_clock::now();
-		training_prep(c);
+		{ const int rc = training_prep(c); if (rc != RNB_OK) return rc; }
 		c->grid_updated = true;
 		c->prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_prep_to_skip;
 	}

@@ -106,6 +106,7 @@ BUF_DTYPE = dict(
     COUNTERS="u4", DENSITY_GRID_TMP="f4", GRID_SAMPLE_POS="f4", GRID_SAMPLE_IDX="u4", STEP_VECTOR="f8", GRID_SAMPLE_POS_EVAL="f4", GRID_SAMPLE_IDX_EVAL="u4",
 )
 BUF_READONLY = 0x100  # RNB_BUF_READONLY
+GRID_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)  # rnb_grid_exchange_fn(user, grid_tmp, n_elements, stream)
 PRIM = dict(PCG32=0, MORTON=1, SRGB=2, RAY_BOX=3, MARCH=4)  # rnb_primitive
 PRIM_IN_WORDS, PRIM_OUT_WORDS = (6, 3, 1, 8, 9), (4, 4, 2, 3, 7)
 H2D, D2H, D2D = 0, 1, 2
@@ -138,6 +139,9 @@ PROTOTYPES = {
     "valid_level": (_u32, [_ctx]),
     "update_density_grid": (_i, [_ctx, _stream]),
     "update_density_bitfield": (_i, [_ctx, _stream]),
+    "update_density_grid_begin": (_i, [_ctx, _stream]),
+    "update_density_grid_end": (_i, [_ctx, _stream]),
+    "set_grid_exchange": (_i, [_ctx, C.c_void_p, C.c_void_p]),
     "density": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),
     "sdf": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),
     "forward_infer": (_i, [_ctx, _stream, C.c_void_p, _u32, C.c_void_p, _i]),

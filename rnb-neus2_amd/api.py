@@ -294,6 +294,32 @@ class Context:
     def update_density_grid(self, stream=None):
         self._check(self.f.update_density_grid(self._h, _stream_handle(stream)))
 
+    def update_density_grid_begin(self, stream=None):
+        """First half of an occupancy update: samples + network on this rank's share (rnb_update_density_grid_begin)."""
+        self._check(self.f.update_density_grid_begin(self._h, _stream_handle(stream)))
+
+    def update_density_grid_end(self, stream=None):
+        self._check(self.f.update_density_grid_end(self._h, _stream_handle(stream)))
+
+    def set_grid_exchange(self, fn):
+        """fn(grid_tmp_ptr, n_elements, stream_handle) -> None takes the element-wise max of DENSITY_GRID_TMP over the data-parallel ranks (stream-ordered);
+        None removes it (replicated occupancy updates). rnb_set_grid_exchange."""
+        if fn is None:
+            self._grid_cb = None
+            self._check(self.f.set_grid_exchange(self._h, None, None))
+            return
+
+        def trampoline(_user, ptr, n, stream):
+            try:
+                fn(ptr, int(n), stream)
+                return 0
+            except Exception:  # no exception may cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._grid_cb = _abi.GRID_EXCHANGE_FN(trampoline)  # kept alive with the context
+        self._check(self.f.set_grid_exchange(self._h, C.cast(self._grid_cb, C.c_void_p), None))
+
     def update_density_bitfield(self, stream=None):
         self._check(self.f.update_density_bitfield(self._h, _stream_handle(stream)))
 

@@ -72,6 +72,7 @@ struct PointArgs {
 	float* grid_tmp;
 	int want_density;          // 0: sdf + bias, 1: density
 	float sdf_bias;
+	const uint32_t* range;     // optional (device): evaluate points range[0] .. range[1] - 1 of xyz / splat_idx instead of 0 .. n - 1 (k_shard_range; n bounds the launch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -122,11 +123,13 @@ __global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G,
 	half_t* Z = X + TILE * S32;
 	const half_t variance = net.variance[0];
 	const half_t bias = f2h(a.sdf_bias);
-	const uint32_t n_tiles = (a.n + TILE - 1) / TILE;
+	uint32_t s_first = 0, s_end = a.n;
+	if (a.range) { s_first = a.range[0]; s_end = min(a.range[1], a.n); }
+	const uint32_t n_tiles = (s_end - s_first + TILE - 1) / TILE;
 	const int r16 = lane & 15, hq = lane >> 4;
 	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
-		const uint32_t s = tile * TILE + lane;
-		const bool valid = s < a.n;
+		const uint32_t s = s_first + tile * TILE + lane;
+		const bool valid = s < s_end;
 		float x = 0.5f, y = 0.5f, z = 0.5f;
 		if (valid) { x = a.xyz[(size_t)s * 3 + 0]; y = a.xyz[(size_t)s * 3 + 1]; z = a.xyz[(size_t)s * 3 + 2]; }
 		uint32_t cell = 0;

@@ -82,6 +82,24 @@ __global__ void k_grid_samples_place(const uint32_t n, const float* __restrict__
 	idx_out[p] = idx;
 }
 
+// Data parallel: this rank's share [out[0], out[1]) of the cell-ordered samples. The order INSIDE a block of cells is whatever k_grid_samples_place's atomics
+// made of it on this rank, so a share must begin and end at block boundaries, where the membership does not depend on the order: boundary r = the first block
+// end at or beyond n r / W (binary search over `ends`, the cursor array as k_grid_samples_place leaves it: ends[k] = number of samples in blocks 0 .. k).
+__global__ void k_shard_range(const uint32_t* __restrict__ ends, const uint32_t n_keys, const uint32_t n, const uint32_t world, const uint32_t rank, uint32_t* __restrict__ out) {
+	if (threadIdx.x >= 2) return;
+	const uint32_t b = rank + threadIdx.x; // boundary index 0 .. world
+	uint32_t v;
+	if (b == 0) v = 0;
+	else if (b >= world) v = n;
+	else {
+		const uint32_t target = (uint32_t)((uint64_t)n * b / world);
+		uint32_t lo = 0, hi = n_keys - 1; // smallest k with ends[k] >= target
+		while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if (ends[mid] >= target) hi = mid; else lo = mid + 1; }
+		v = ends[lo];
+	}
+	out[threadIdx.x] = v;
+}
+
 // ema_grid_samples_nerf (testbed_nerf.cu:655-685)
 __global__ void k_ema_grid(const uint32_t n_elements, const float decay, float* __restrict__ grid_out, const float* __restrict__ grid_in) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;

@@ -123,6 +123,8 @@ struct rnb_ctx {
 	float lr_table_beta1 = -1.f, lr_table_beta2 = -1.f; // the betas the table was filled for
 	DevBuf<float> density_grid, density_grid_tmp, density_grid_tmp_alt, density_mean; // _alt: cleared on a side stream for the NEXT update (tmp_alt_clear), the two swap roles
 	bool tmp_alt_clear = false;
+	rnb_grid_exchange_fn grid_exchange = nullptr; // data parallel: element-wise max of density_grid_tmp over the ranks between the two halves of an occupancy update
+	void* grid_exchange_user = nullptr;
 	bool bitfield_foreign = false; // a caller may have written the bitfield: levels >= 1 are not known to be zero outside the pooled supports (update_bitfield takes the zero-filling kernels once)
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
@@ -138,7 +140,7 @@ struct rnb_ctx {
 	bool last_update_sorted = false;
 	struct { bool pending = false; uint32_t n_uniform = 0, n_nonuniform = 0; } gs_todo; // an update has run: prepare the next one's samples
 	DevBuf<float> gs_sorted_pos, gs_stage_pos, gs_eval_pos;   // sorted / stage: being prepared for the next update; eval: what the last update evaluated
-	DevBuf<uint32_t> gs_sorted_idx, gs_stage_idx, gs_eval_idx, gs_hist;
+	DevBuf<uint32_t> gs_sorted_idx, gs_stage_idx, gs_eval_idx, gs_hist, gs_range; // gs_range: [2] this rank's share of the cell-ordered samples (k_shard_range)
 	hipEvent_t ev_grid = nullptr, ev_gs = nullptr;
 
 	// dataset
@@ -397,11 +399,11 @@ int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true, bool have_parti
 	return rebuild_coarse(c, s, wait);
 }
 
-int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference) {
+int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference, const uint32_t* range = nullptr) {
 	if (n == 0) return RNB_OK;
 	if (!inference) join_tail_host(c);
 	PointArgs a;
-	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias;
+	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
 	hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
@@ -439,7 +441,7 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
 	while ((n_elements >> shift) > (1u << 20)) ++shift; // the two-level scan below covers 2^20 keys
 	const uint32_t n_keys = n_elements >> shift;
 	if (!c->gs_sorted_pos.p) {
-		if (c->gs_sorted_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_sorted_idx.alloc(n) != hipSuccess || c->gs_hist.alloc((size_t)(1u << 20) + 2048) != hipSuccess ||
+		if (c->gs_range.alloc(2) != hipSuccess || c->gs_sorted_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_sorted_idx.alloc(n) != hipSuccess || c->gs_hist.alloc((size_t)(1u << 20) + 2048) != hipSuccess ||
 		    c->gs_stage_pos.alloc(c->grid_sample_pos.n) != hipSuccess || c->gs_stage_idx.alloc(c->grid_sample_idx.n) != hipSuccess ||
 		    c->gs_eval_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_eval_idx.alloc(n) != hipSuccess) {
 			c->knobs.grid_presort = false; // not essential: the update then keeps the reference's order
@@ -466,13 +468,16 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
 	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, sums, (uint64_t)nb, sums + 1024);
 	hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, s, c->gs_hist.p, (uint64_t)n_keys, sums);
 	hipLaunchKernelGGL(k_grid_samples_place, dim3((n + 127) / 128), dim3(128), 0, s, n, c->gs_stage_pos.p, c->gs_stage_idx.p, c->gs_hist.p, shift, c->gs_sorted_pos.p, c->gs_sorted_idx.p);
+	if (c->cfg.world_size > 1) hipLaunchKernelGGL(k_shard_range, dim3(1), dim3(64), 0, s, c->gs_hist.p, n_keys, n, c->cfg.world_size, c->cfg.rank, c->gs_range.p); // this rank's share of the update (rnb_update_density_grid_begin)
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(c->ev_gs, s));
 	c->gs_pre.valid = true; c->gs_pre.ema_step = c->density_grid_ema_step; c->gs_pre.n_uniform = n_uniform; c->gs_pre.n_nonuniform = n_nonuniform;
 	return RNB_OK;
 }
 
-int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t n_nonuniform) { // testbed_nerf.cu:3424-3495
+// First half of an occupancy update (K1-K3). shard: this rank evaluates its 1 / world_size of the samples only (the caller takes the element-wise max of
+// density_grid_tmp over the ranks before update_density_grid_back).
+int update_density_grid_front(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t n_nonuniform, bool shard) { // testbed_nerf.cu:3424-3490
 	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
 	const uint32_t n_samples = n_uniform + n_nonuniform;
 	c->prof.mark(s, P_NONE);
@@ -502,24 +507,50 @@ int update_density_grid(rnb_ctx* c, hipStream_t s, uint32_t n_uniform, uint32_t 
 	}
 	c->prof.mark(s, P_GRID_SAMPLES);
 	c->n_grid_samples = n_samples;
-	int rc = launch_point_query(c, s, sorted ? c->gs_eval_pos.p : c->grid_sample_pos.p, n_samples, nullptr, sorted ? c->gs_eval_idx.p : c->grid_sample_idx.p, c->density_grid_tmp.p, 1, false);
+	int rc;
+	const uint64_t W = shard ? c->cfg.world_size : 1u, r = shard ? c->cfg.rank : 0u;
+	if (sorted) { // cell order: the share's bounds sit at cell-block boundaries and live on the device (k_shard_range, behind the placement)
+		rc = launch_point_query(c, s, c->gs_eval_pos.p, n_samples, nullptr, c->gs_eval_idx.p, c->density_grid_tmp.p, 1, false, W > 1 ? c->gs_range.p : nullptr);
+	} else { // the reference's order: the same on every rank, shares by count
+		const uint32_t lo = (uint32_t)((uint64_t)n_samples * r / W), hi = (uint32_t)((uint64_t)n_samples * (r + 1) / W);
+		rc = launch_point_query(c, s, c->grid_sample_pos.p + (size_t)lo * 3, hi - lo, nullptr, c->grid_sample_idx.p + lo, c->density_grid_tmp.p, 1, false);
+	}
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_POINT_QUERY);
-	c->prof.units[P_POINT_QUERY] += n_samples;
+	c->prof.units[P_POINT_QUERY] += n_samples / W;
+	c->gs_todo.n_uniform = n_uniform; c->gs_todo.n_nonuniform = n_nonuniform; // (pending is set by the second half)
+	return RNB_OK;
+}
+
+// Second half (K4-K5) from density_grid_tmp.
+int update_density_grid_back(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:3491-3517
+	const uint32_t n_elements = GRID_CELLS * (c->aabb.max_cascade + 1);
+	int rc;
 	if (c->knobs.fused_update) hipLaunchKernelGGL(k_ema_mean, dim3(n_elements / 2048), dim3(256), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p, c->mean_partial.p);
 	else hipLaunchKernelGGL(k_ema_grid, dim3((n_elements + 127) / 128), dim3(128), 0, s, n_elements, c->cfg.density_grid_decay, c->density_grid.p, c->density_grid_tmp.p);
 	HIP_TRY(hipGetLastError());
 	++c->density_grid_ema_step;
 	rc = update_bitfield(c, s, !c->overlap(), c->knobs.fused_update);
 	c->prof.mark(s, P_EMA_BITFIELD);
-	c->gs_todo.pending = true; c->gs_todo.n_uniform = n_uniform; c->gs_todo.n_nonuniform = n_nonuniform; // queued by the caller once the kernels that wait for THIS update are in their queue
+	c->gs_todo.pending = true; // queued by the caller once the kernels that wait for THIS update are in their queue
 	return rc;
 }
 
-int training_prep(rnb_ctx* c, hipStream_t s) { // testbed_nerf.cu:4125-4138
+int training_prep_front(rnb_ctx* c, hipStream_t s, bool shard) { // testbed_nerf.cu:4125-4138
 	const uint32_t n_cascades = c->aabb.max_cascade + 1;
-	if (c->training_step < 256) return update_density_grid(c, s, GRID_CELLS * n_cascades, 0);
-	return update_density_grid(c, s, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
+	if (c->training_step < 256) return update_density_grid_front(c, s, GRID_CELLS * n_cascades, 0, shard);
+	return update_density_grid_front(c, s, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades, shard);
+}
+// The whole update; sharded over the data-parallel ranks when the host has given an exchange (rnb_set_grid_exchange).
+int training_prep(rnb_ctx* c, hipStream_t s) {
+	const bool shard = c->cfg.world_size > 1 && c->grid_exchange != nullptr;
+	int rc = training_prep_front(c, s, shard);
+	if (rc != RNB_OK) return rc;
+	if (shard) {
+		const int xrc = c->grid_exchange(c->grid_exchange_user, c->density_grid_tmp.p, (uint64_t)GRID_CELLS * (c->aabb.max_cascade + 1), (void*)s);
+		if (xrc != 0) return fail(RNB_ERR_INVALID, "the occupancy grid exchange (rnb_set_grid_exchange) failed");
+	}
+	return update_density_grid_back(c, s);
 }
 
 // The buffers of the albedo mode's training kernels, on first use (the mode can be switched on by rnb_update_config).
@@ -1102,7 +1133,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_grid_tmp_alt.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
-	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
+	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_range.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
 	c->loss.free(); c->mlp_out.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->scan_words.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
@@ -1501,6 +1532,22 @@ int rnb_update_density_grid(rnb_ctx* c, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	const int rc = training_prep(c, as_stream(stream));
+	if (rc != RNB_OK) return rc;
+	return pregenerate_grid_samples(c, as_stream(stream));
+}
+int rnb_set_grid_exchange(rnb_ctx* c, rnb_grid_exchange_fn fn, void* user) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	c->grid_exchange = fn; c->grid_exchange_user = user;
+	return RNB_OK;
+}
+int rnb_update_density_grid_begin(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	discard_premarch(c);
+	return training_prep_front(c, as_stream(stream), c->cfg.world_size > 1);
+}
+int rnb_update_density_grid_end(rnb_ctx* c, void* stream) {
+	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	const int rc = update_density_grid_back(c, as_stream(stream));
 	if (rc != RNB_OK) return rc;
 	return pregenerate_grid_samples(c, as_stream(stream));
 }

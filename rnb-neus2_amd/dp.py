@@ -11,7 +11,8 @@ parameter block, occupancy grid and dataset; rank r generates the global rays [r
   * one 7-value all-reduce of the step counters / loss sums so all ranks draw the same rays_per_batch next step.
 With the sharded optimizer a rank's fp32 masters, EMA weights and Adam state are current only on its own chunks:
 ``sync_parameters()`` all-gathers them (before snapshots / inference with EMA weights).
-The occupancy update is replicated: identical parameters + identical RNG => identical grids, no communication.
+The occupancy update is sharded (round 4): rank r evaluates its 1/W of the update's 2^20 sample points and the ranks take the element-wise max of
+the splat targets (8 MB every 16 steps) -- the same grid as a single rank computes, bit for bit; ``grid_exchange=None`` keeps it replicated.
 """
 import os
 
@@ -98,9 +99,13 @@ class DataParallelTrainer:
     sums a float64 numpy vector. The defaults use torch.distributed; the CPU tests inject gloo/numpy versions.
     """
 
-    def __init__(self, ctx, all_reduce_grads=None, all_reduce_small=None, stream=None, sharded=None, shard_collectives=None):
+    def __init__(self, ctx, all_reduce_grads=None, all_reduce_small=None, stream=None, sharded=None, shard_collectives=None, grid_exchange="default"):
         """``shard_collectives``: object with reduce_scatter(name, part) / all_gather(name, part) working in place on the
-        context's buffers (default: TorchShardCollectives); the CPU tests inject a gloo version over host buffers."""
+        context's buffers (default: TorchShardCollectives); the CPU tests inject a gloo version over host buffers.
+        ``grid_exchange``: callable(grid_tmp_ptr, n_elements, stream_handle) taking the element-wise max of the occupancy update's splat
+        target over the ranks (rnb_set_grid_exchange: the update's 2^20 network evaluations are then divided over the ranks, every 16th
+        step one max all-reduce of 8 MB); "default" = torch.distributed on the device buffer, None = replicated updates
+        (also RNB_DP_SHARD_GRID=0)."""
         self.ctx = ctx
         self.stream = stream
         if sharded is None:
@@ -116,6 +121,23 @@ class DataParallelTrainer:
         self._collectives = ctx.cfg.world_size > 1 or bool(os.environ.get("RNB_DP_FORCE_COLLECTIVES"))  # the env var exercises the collective path on one rank
         self._reduce_grads = all_reduce_grads or self._torch_reduce_grads
         self._reduce_small = all_reduce_small  # None: all-reduce the library's device block in place
+        if grid_exchange == "default":
+            grid_exchange = self._torch_grid_exchange if (all_reduce_grads is None and shard_collectives is None) else None  # injected transports bring their own
+        if os.environ.get("RNB_DP_SHARD_GRID", "1") == "0" or ctx.cfg.world_size <= 1:
+            grid_exchange = None
+        ctx.set_grid_exchange(grid_exchange)
+        self.grid_sharded = grid_exchange is not None
+
+    def _torch_grid_exchange(self, ptr, n, stream_handle):
+        """Element-wise max of DENSITY_GRID_TMP over the ranks, in place on the device (densities are >= 0: float order = int32 order)."""
+        import torch
+        import torch.distributed as dist
+        t = torch.as_tensor(_DeviceArray(ptr, n, "<i4"), device="cuda")
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     def _torch_reduce_grads(self, ctx):
         """Sum of the fp32 gradient accumulators over the ranks. The block of levels whose scatter finishes first is exchanged

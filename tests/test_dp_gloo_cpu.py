@@ -124,15 +124,39 @@ def _worker_sharded_body(rank, world, port, q):
         ctx.put("GRADS_FP32", t.numpy())
 
     parts, capacity = sh.shard_layout()
-    tr_rep = dp.DataParallelTrainer(rep, all_reduce_grads=reduce_grads)
-    tr_sh = dp.DataParallelTrainer(sh, sharded=True, shard_collectives=_GlooShardCollectives(sh, capacity))
-    assert tr_sh.sharded and not tr_rep.sharded
+    n_exchanges = [0]
+
+    def grid_max(ptr, n, stream):  # rnb_set_grid_exchange over gloo: element-wise max of the checker's host buffer (densities >= 0: int32 order = float order)
+        import ctypes as C
+        v = np.frombuffer((C.c_char * (n * 4)).from_address(ptr), dtype=np.int32)
+        t = torch.from_numpy(v.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        v[:] = t.numpy()
+        n_exchanges[0] += 1
+
+    tr_rep = dp.DataParallelTrainer(rep, all_reduce_grads=reduce_grads)  # replicated optimizer AND replicated occupancy updates
+    tr_sh = dp.DataParallelTrainer(sh, sharded=True, shard_collectives=_GlooShardCollectives(sh, capacity), grid_exchange=grid_max)
+    assert tr_sh.sharded and not tr_rep.sharded and tr_sh.grid_sharded and not tr_rep.grid_sharded
     out = {"rank": rank, "parts": parts, "capacity": capacity, "n_params": sh.n_params, "same_stats": True}
     for i in range(3):
         a, b = tr_rep.step().as_dict(), tr_sh.step().as_dict()
         for k in a:
             if k not in ("prep_ms", "step_ms") and a[k] != b[k]:
                 out["same_stats"] = False
+    # occupancy updates sharded over the ranks (each evaluates half of an update's samples, element-wise max of the splat targets) leave the grid of the
+    # replicated update, bit for bit; the first three steps each begin with an update
+    out["grid_exchanges"] = n_exchanges[0]
+    out["grid_equal"] = bool(np.array_equal(rep.get("DENSITY_GRID"), sh.get("DENSITY_GRID")) and np.array_equal(rep.get("DENSITY_BITFIELD"), sh.get("DENSITY_BITFIELD")))
+    # ... and so does the stage form: begin -> max -> end against one rnb_update_density_grid of the replicated context
+    rep.update_density_grid()
+    sh.set_grid_exchange(None)
+    sh.update_density_grid_begin()
+    half = sh.get("DENSITY_GRID_TMP").copy()
+    ptr, nb = sh.buffer("DENSITY_GRID_TMP")
+    grid_max(ptr, nb // 4, None)
+    out["half_is_partial"] = bool(np.count_nonzero(half) < np.count_nonzero(sh.get("DENSITY_GRID_TMP")))
+    sh.update_density_grid_end()
+    out["grid_equal_stage"] = bool(np.array_equal(rep.get("DENSITY_GRID"), sh.get("DENSITY_GRID")) and np.array_equal(rep.get("DENSITY_GRID_TMP"), sh.get("DENSITY_GRID_TMP")))
     # the training weights are whole on every rank after each step; masters / EMA / Adam state only on the own chunks
     out["w16_equal"] = bool(np.array_equal(rep.get("PARAMS_FP16"), sh.get("PARAMS_FP16")))
     own = np.zeros(sh.n_params, dtype=bool)
@@ -167,6 +191,7 @@ def test_two_rank_sharded_optimizer_equals_replicated():
         assert p.exitcode == 0
     for r in res:
         assert r["same_stats"] and r["w16_equal"]
+        assert r["grid_exchanges"] == 3 and r["grid_equal"] and r["grid_equal_stage"] and r["half_is_partial"], r
         assert all(r["own_equal"].values()), r["own_equal"]
         assert all(r["synced_equal"].values()), r["synced_equal"]
         assert r["foreign_stale"]  # the other rank's chunks really were skipped here

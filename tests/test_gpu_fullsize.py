@@ -579,6 +579,41 @@ def test_full_size_step_against_oracle(scene, states, oracle_full, regime, n_ray
         gpu.close()
 
 
+def test_sharded_occupancy_update_equals_single_rank(scene, trained):
+    """rnb_update_density_grid_begin / _end on ranks 0 and 1 of a world of 2 (two contexts on the one GPU, the element-wise max of their splat
+    targets taken by hand) against rnb_update_density_grid of a single rank: splat target, density grid, mean and bitfield bit for bit. Two
+    updates: the first evaluates the samples in the reference's order (shares by count), the second the cell order prepared behind the first
+    (shares bounded at cell-block boundaries, k_shard_range: the order inside a block differs from context to context)."""
+    _, state = trained
+    one = _clone(scene, state, overlap=0)
+    ranks = [_clone(scene, state, overlap=0, world_size=2, rank=r) for r in range(2)]
+    try:
+        for upd in range(2):
+            one.update_density_grid()
+            for c in ranks:
+                c.update_density_grid_begin()
+            tmps = [c.get("DENSITY_GRID_TMP") for c in ranks]
+            full = one.get("DENSITY_GRID_TMP")
+            assert np.all(tmps[0] >= 0) and np.all(tmps[1] >= 0)
+            mx = np.maximum(tmps[0], tmps[1])
+            assert np.array_equal(mx.view(np.uint32), full.view(np.uint32)), upd
+            n_full = np.count_nonzero(full)
+            for t in tmps:  # each rank evaluated a share only (in the reference's order rank 0 holds the uniform half: few of its samples meet the surface)
+                assert 0 < np.count_nonzero(t) < n_full, (upd, np.count_nonzero(t), n_full)
+            for c in ranks:
+                c.put("DENSITY_GRID_TMP", mx)
+                c.update_density_grid_end()
+            for c in ranks:
+                for name in ("DENSITY_GRID", "DENSITY_BITFIELD", "DENSITY_MEAN"):
+                    assert np.array_equal(c.get(name).view(np.uint8), one.get(name).view(np.uint8)), (upd, name)
+            evaluated_in_cell_order = one.buffer("GRID_SAMPLE_IDX_EVAL", read_only=True)[1] > 0
+            assert evaluated_in_cell_order == (upd == 1)
+    finally:
+        one.close()
+        for c in ranks:
+            c.close()
+
+
 @pytest.mark.parametrize("regime", ["window", "late"])
 def test_whole_step_against_the_default_oracle(scene, states, regime):
     """One WHOLE training step at full size, HIP against the oracle in its default mode, both from the cloned trained state and with no stage
