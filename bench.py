@@ -76,6 +76,9 @@ def parse(argv=None):
                     "controller's ray count); every rank takes 1/N of its rays and samples (dp.strong_scaling_sizes). Default: weak scaling, 2^18 samples per rank. "
                     "With N > 1 the other mode is measured as a second leg of the same job and reported beside `value`")
     ap.add_argument("--other-leg-steps", type=int, default=200, help="timed steps of that second leg (0 = skip it)")
+    ap.add_argument("--fixed-cost-world", type=int, default=8, help="single-GPU runs: time the step ONE rank of a strong-scaling job of this many GPUs would run (B / W compacted "
+                    "samples, R / W rays: dp.strong_scaling_sizes) on this GPU -- the part of the step that does not shrink with the job size and bounds strong scaling; 0 = skip")
+    ap.add_argument("--fixed-cost-steps", type=int, default=400)
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
     return ap.parse_args(argv)
@@ -262,6 +265,39 @@ def main(argv=None, engine=None):
                  "samples_per_step_per_gpu": ctx2.cfg.target_batch_size, "samples_per_s_compacted": round(o_smp / o_el, 1), "loss": round(float(o_last.loss), 6)}
         ctx2.close()
 
+    # ---- one GPU: the fixed cost of strong scaling (tools/strong_scaling_bound.py is the stand-alone form) ----
+    fixed = None
+    if world == 1 and rank == 0 and args.fixed_cost_world > 1 and args.fixed_cost_steps > 0 and not args.strong and B % (128 * args.fixed_cost_world) == 0:
+        Wf = args.fixed_cost_world
+        fctx = engine.context(world_size=1, rank=0, **flags, **dp.strong_scaling_sizes(Wf, B, min(1 << 18, B), min(1 << 12, B)))
+        fctx.init_params()
+        fctx.set_dataset(*scene)
+        ftr = engine.trainer(fctx)
+        for _ in range(args.burn_in + args.warmup):
+            ftr.step()
+        f_el, f_rays, _, _, f_ms, f_last = timed_run(ftr, args.fixed_cost_steps)
+        fctx.profile_enable(True)
+        n_prof = 64
+        for _ in range(n_prof):
+            ftr.step()
+        barrier()
+        fprof = {p["kernel"]: p["total_ms"] / n_prof for p in fctx.profile() if p["launches"]}
+        fctx.profile_enable(False)
+        fctx.close()
+        f_step = 1e3 * f_el / args.fixed_cost_steps
+        f_adam, f_pq = fprof.get("k_adam_ema", 0.0), fprof.get("k_point_query", 0.0)
+        f_sharded = f_step - (1.0 - 1.0 / Wf) * (f_adam + f_pq)
+        fixed = {"what": "the step one rank of a %d-GPU strong-scaling job runs (2^%d / %d compacted samples, rays / %d), timed on this one GPU without any exchange: what does not "
+                         "shrink when the step is divided; the single-GPU step / this = the compute-side bound of the strong-scaling speed-up" % (Wf, args.batch_log2, Wf, Wf),
+                 "world": Wf, "first_step": int(f_last.training_step) - args.fixed_cost_steps, "steps": args.fixed_cost_steps, "ms_per_step": round(f_step, 4),
+                 "p50_ms_per_step": round(float(np.median(f_ms)), 4), "rays_per_step": round(f_rays / args.fixed_cost_steps, 1),
+                 "replicated_in_this_measurement": {"k_adam_ema_ms_per_step": round(f_adam, 4), "k_point_query_ms_per_step": round(f_pq, 4),
+                                                    "note": "serialised HIP-event times of the two kernels a real job divides by W: the sharded optimizer (rnb_train_step_apply_shard) and the "
+                                                            "sharded occupancy update (rnb_update_density_grid_begin / _end); this single context runs both whole"},
+                 "ms_per_step_with_both_divided_estimate": round(f_step - (1.0 - 1.0 / Wf) * (f_adam + f_pq), 4),
+                 "strong_scaling_bound": {"measured": round(1e3 * elapsed / args.steps / f_step, 2), "with_both_divided_estimate": round(1e3 * elapsed / args.steps / max(f_sharded, 1e-6), 2),
+                                          "note": "speed-up <= single-GPU ms_per_step / this, before any exchange; weak scaling (bench.py --gpus N: N x 2^18 samples per step) is the mode the >= 6x at 8 GPUs is claimed for (DESIGN.md section 7)"}}
+
     result = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -341,6 +377,7 @@ def main(argv=None, engine=None):
             "communicator": comm,
             "window_1000_2000": window,
             "late_regime": late,
+            "fixed_cost": fixed,
             "roofline": roofline,
             "rooflines_next": rooflines_next,
             "kernels_ms_per_step": kernels,

@@ -5,7 +5,7 @@ tag=$1; shift
 mkdir -p gpurun_out/$tag
 for env in "$@"; do
   for rep in 1 2; do
-    out=$(env $env python bench.py --steps 200 --no-cpu-baseline --profile-steps 0 --late-steps 100 2>/dev/null | grep "^{")
+    out=$(env $env python bench.py --steps 200 --no-cpu-baseline --profile-steps 0 --late-steps 100 --fixed-cost-steps 0 2>/dev/null | grep "^{")
     python - "$env" "$out" <<'PY' >> gpurun_out/$tag/ab.txt
 import json, sys
 d = json.loads(sys.argv[2])

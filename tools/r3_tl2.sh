@@ -5,7 +5,7 @@ tag=$1; burn=$2; shift; shift
 mkdir -p gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf /tmp/kt_tl
-env "$@" rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_tl -- python bench.py $BENCH_ARGS --burn-in $burn --steps 60 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 > /tmp/kt_tl.log 2>&1
+env "$@" rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_tl -- python bench.py $BENCH_ARGS --burn-in $burn --steps 60 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 > /tmp/kt_tl.log 2>&1
 # steps burn+20 .. burn+80; the cycle `back` from the end runs from the second loss pass of step burn+79-back to that of step burn+80-back
 for back in 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20; do
   python tools/timeline.py /tmp/kt_tl $back > /tmp/tl_$back.txt

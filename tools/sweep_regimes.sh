@@ -6,7 +6,7 @@ mkdir -p gpurun_out/$tag; rm -f gpurun_out/$tag/sweep_raw.txt
 for burn in 980 1180 1380 1580 1780 2380 3180 4380 5980; do
   for rep in 1 2; do
   for env in "$@"; do
-    out=$(env $env python bench.py --burn-in $burn --steps 160 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 2>/dev/null | grep "^{")
+    out=$(env $env python bench.py --burn-in $burn --steps 160 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 2>/dev/null | grep "^{")
     python - "$env" "$burn" "$out" <<'PY' >> gpurun_out/$tag/sweep_raw.txt
 import json, sys
 d = json.loads(sys.argv[3])
