@@ -106,10 +106,9 @@ __device__ __forceinline__ void copy_weight_image(half_t* __restrict__ dst, cons
 constexpr int PQ2_WAVE_HALFS = TILE * S32 + TILE;
 constexpr size_t LDS_POINT2 = (size_t)(W_S0T + WAVES_PER_WG * PQ2_WAVE_HALFS) * sizeof(half_t);
 
-__global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+template <bool EMU>
+__device__ __forceinline__ void point_query_chained_body(const GridMeta& G, const NetW& net, const PointArgs& a, const half_t* __restrict__ wimg, char* smem_raw, LevelMeta* lm) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
-	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
 	if (wimg) copy_weight_image(wts, wimg, W_S0T, threadIdx.x, WG);
@@ -143,12 +142,12 @@ __global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G,
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + W_S0, S32, X, S32, acc, lane);
+			mfma_layer<4, 1, EMU>(wts + W_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
 		f4 acc_so[1][4];
 		zero_acc<1>(acc_so);
-		mfma_layer_regs<1, 2>(wts + W_S1, S64, bz, acc_so, lane);
+		mfma_layer_regs<1, 2, EMU>(wts + W_S1, S64, bz, acc_so, lane);
 		if (hq == 0) { // D layout: row 0 (the sdf) of sample 16 nt + r16
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt) Z[16 * nt + r16] = f2h(acc_so[0][nt][0]);
@@ -163,14 +162,24 @@ __global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G,
 		wave_lds_sync(); // X, Z are rewritten by the next tile
 	}
 }
+__global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	point_query_chained_body<false>(G, net, a, wimg, smem_raw, lm);
+}
+// test-only instance with the reference's half accumulators emulated (mlp.cuh, mfma_emul16)
+__global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	point_query_chained_body<true>(G, net, a, wimg, smem_raw, lm);
+}
 
 constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
 constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
 
-__global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, const NetW net, const FwdArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+template <bool EMU>
+__device__ __forceinline__ void forward_chained_body(const GridMeta& G, const NetW& net, const FwdArgs& a, char* smem_raw, LevelMeta* lm) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
-	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
 	if (a.wimg) copy_weight_image(wts, a.wimg, W_FWD_END, threadIdx.x, WG);
@@ -206,12 +215,12 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + W_S0, S32, X, S32, acc, lane);
+			mfma_layer<4, 1, EMU>(wts + W_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
 		f4 acc_so[1][4];
 		zero_acc<1>(acc_so);
-		mfma_layer_regs<1, 2>(wts + W_S1, S64, bz, acc_so, lane); // sdf_out = W1 z1
+		mfma_layer_regs<1, 2, EMU>(wts + W_S1, S64, bz, acc_so, lane); // sdf_out = W1 z1
 		{
 			// the backward transfer tests the stored half activation (common_device.h:182 ff.)
 #pragma unroll
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 		{
 			f4 acc[2][4];
 			zero_acc<2>(acc);
-			mfma_layer_regs<2, 2>(wts + W_S0T, S64, bz, acc, lane); // d sdf / d in = W0^T dz1
+			mfma_layer_regs<2, 2, EMU>(wts + W_S0T, S64, bz, acc, lane); // d sdf / d in = W0^T dz1
 			store_acc<2, false>(acc, X, S32, 0, lane);
 		}
 		wave_lds_sync();
@@ -287,19 +296,19 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 			}
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 1>(wts + W_C0, S32, bin, acc, lane);
+			mfma_layer_regs<4, 1, EMU>(wts + W_C0, S32, bin, acc, lane);
 			chain_pack<true>(acc, bh);
 		}
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 2>(wts + W_C1, S64, bh, acc, lane);
+			mfma_layer_regs<4, 2, EMU>(wts + W_C1, S64, bh, acc, lane);
 			chain_pack<true>(acc, bh);
 		}
 		{
 			f4 acc[1][4];
 			zero_acc<1>(acc);
-			mfma_layer_regs<1, 2>(wts + W_C2, S64, bh, acc, lane);
+			mfma_layer_regs<1, 2, EMU>(wts + W_C2, S64, bh, acc, lane);
 			store_acc<1, false>(acc, X, S32, 0, lane); // X rows were last read before the previous sync
 		}
 		wave_lds_sync();
@@ -319,6 +328,17 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 		}
 		wave_lds_sync();
 	}
+}
+__global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, const NetW net, const FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	forward_chained_body<false>(G, net, a, smem_raw, lm);
+}
+// test-only instance with the reference's half accumulators emulated (mlp.cuh, mfma_emul16)
+__global__ __launch_bounds__(WG, 1) void k_forward_chained_emul(const GridMeta G, const NetW net, const FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	forward_chained_body<true>(G, net, a, smem_raw, lm);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,8 +52,33 @@ __device__ inline void load_weights(half_t* __restrict__ w, const NetW& net, int
 	}
 }
 
+// EMU (test-only, RNB_EMULATE_FP16_ACCUM=1): the reference's tensor-core path accumulates in HALF -- wmma 16x16x16 fragments of __half
+// (fully_fused_mlp.cu:59-68, 198) -- where these kernels accumulate in fp32 (deviation D1). The emulation follows the model of the
+// CPU checker (oracle/rnb_oracle.cpp dot_h, ORC_EMULATE_FP16_ACCUM): products exact, the 16 products of one logical k-step summed in fp32, the running
+// accumulator rounded to half after every k-step. One 32-wide MFMA covers TWO logical k-steps: it is issued twice with the other step's operand lanes
+// zeroed and the accumulator rounded in between. Which lanes / elements belong to which step depends on the operand's K order:
+//   NATURAL (tile read from LDS, k = 8 hq + j): step 0 = lanes hq < 2;      chained fragments (k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3)): step 0 = j < 4.
+__device__ __forceinline__ f4 round_acc_half(f4 a) {
+#pragma unroll
+	for (int r = 0; r < 4; ++r) a[r] = h2f(f2h(a[r]));
+	return a;
+}
+template <bool NATURAL>
+__device__ __forceinline__ f4 mfma_emul16(const h8 a, const h8 b, f4 acc, const int hq) {
+	const h8 zero = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+	h8 lo = zero, hi = zero;
+	if (NATURAL) { if (hq < 2) lo = b; else hi = b; }
+	else {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { lo[j] = b[j]; hi[4 + j] = b[4 + j]; }
+	}
+	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, lo, acc, 0, 0, 0));
+	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, hi, acc, 0, 0, 0));
+	return acc;
+}
+
 // acc[mt][nt] += W[16mt.., :] * X[16nt.., :]^T over K = 32*K_STEPS.
-template <int M_TILES, int K_STEPS>
+template <int M_TILES, int K_STEPS, bool EMU = false>
 __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const int w_stride, const half_t* __restrict__ X, const int x_stride, f4 (&acc)[M_TILES][4], const int lane) {
 	const int r16 = lane & 15, hq = lane >> 4;
 	h8 b[4][K_STEPS];
@@ -67,7 +92,7 @@ __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const i
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<true>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
 		}
 	}
 }
@@ -158,7 +183,7 @@ __device__ inline void load_weights_chained(half_t* __restrict__ w, const NetW& 
 }
 
 // acc[mt][nt] += W[16mt.., :] * B over K = 32*K_STEPS, B fragments in registers.
-template <int M_TILES, int K_STEPS>
+template <int M_TILES, int K_STEPS, bool EMU = false>
 __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, const int w_stride, const h8 (&b)[4][K_STEPS], f4 (&acc)[M_TILES][4], const int lane) {
 	const int r16 = lane & 15, hq = lane >> 4;
 #pragma unroll
@@ -167,7 +192,7 @@ __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, co
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<false>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
 		}
 	}
 }

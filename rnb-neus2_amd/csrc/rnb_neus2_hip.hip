@@ -187,6 +187,8 @@ struct rnb_ctx {
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
+		bool emulate_fp16_accum = false; // RNB_EMULATE_FP16_ACCUM=1 (tests only, never benchmarked): the network evaluations (k_forward_chained, k_point_query_chained) round their
+		                                  // accumulators to half after every 16-wide k-step, as the reference's WMMA path does (fully_fused_mlp.cu:59-68) and ORC_EMULATE_FP16_ACCUM models
 		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
@@ -406,7 +408,8 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
-	hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	if (c->knobs.emulate_fp16_accum) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -572,7 +575,8 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
-	hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	if (c->knobs.emulate_fp16_accum) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
 }
@@ -1254,6 +1258,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	int rc = reset_optimizer_state(c);
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_emul), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
@@ -1287,6 +1292,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_FUSED_UPDATE")) k.fused_update = atoi(e) != 0;
 		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
+		if (const char* e = getenv("RNB_EMULATE_FP16_ACCUM")) k.emulate_fp16_accum = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
 	}

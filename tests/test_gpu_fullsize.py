@@ -681,8 +681,14 @@ def test_whole_step_against_the_default_oracle(scene, states, regime):
         cpu.close()
 
 
-def test_hip_against_the_reference_as_coded_emulation(scene, states):
-    """Deviations D1 / D2 as a tested number: the HIP path accumulates the MLP dot products and the grid
+@pytest.mark.parametrize("hip_mode", ["fp32_accumulate", "emulated_fp16_accumulate"])
+def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
+    """emulated_fp16_accumulate (round 4): the HIP library's network evaluations run with RNB_EMULATE_FP16_ACCUM=1 -- accumulators rounded to half
+    after every 16-wide k-step like the reference's WMMA fragments (fully_fused_mlp.cu:59-68; mlp.cuh mfma_emul16, a test-only instance of
+    k_forward_chained / k_point_query_chained) -- and the losses of a whole step must then meet the north star's 1e-4 against the oracle's emulation
+    of the reference as coded (the losses depend on the network evaluation only; the backward kernels and the grid atomics stay fp32, so the
+    gradient bounds below are those of the fp32 mode). fp32_accumulate, the product as benchmarked:
+    Deviations D1 / D2 as a tested number: the HIP path accumulates the MLP dot products and the grid
     gradients in fp32, the reference in half (fully_fused_mlp.cu:68 WMMA half accumulators, grid.h:410-430 half2 atomics). The oracle
     emulates the reference as coded (ORC_EMULATE_FP16_ACCUM, ORC_EMULATE_HALF_ATOMICS); one whole config-4 training step of the HIP
     library at step 1009 (all 14 levels, 2^18 samples) must stay within: marched sample set identical, compaction count 1e-3,
@@ -694,19 +700,20 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states):
     gpurun_out/ for DESIGN.md's table."""
     import json
     state = states["window"]
+    emulated = hip_mode == "emulated_fp16_accumulate"
     cpu = _oracle_clone(scene, state, env={"ORC_EMULATE_FP16_ACCUM": "1", "ORC_EMULATE_HALF_ATOMICS": "1"})
-    gpu = _clone(scene, state, overlap=0)
+    gpu = _clone(scene, state, env={"RNB_EMULATE_FP16_ACCUM": "1"} if emulated else None, overlap=0)
     try:
         for c in (gpu, cpu):
             c.set_controller(state["step"] | 1, state["rays"], state["before"], 0)  # not an occupancy-update step
             c.train_step_begin()
         (cg, sg), (cc, sc) = gpu.train_step_local(), cpu.train_step_local()
         assert cg[0] == cc[0] and cg[2] == cc[2] and cg[3] == cc[3], (cg, cc)      # the march does not depend on the network
-        assert abs(int(cg[1]) - int(cc[1])) <= 1e-3 * int(cc[1]) + 1, (cg, cc)     # compaction: T < 1e-4 cuts flip on a few rays (measured: 3 ... 87 of 265 k samples)
+        assert abs(int(cg[1]) - int(cc[1])) <= (2e-4 if emulated else 1e-3) * int(cc[1]) + 1, (cg, cc)     # compaction: T < 1e-4 cuts flip on a few rays (fp32 mode, measured: 3 ... 87 of 265 k samples)
         rel = [abs(x - y) / abs(y) for x, y in zip(sg, sc)]
         g, r = gpu.get("GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
         lay = cpu.param_layout()
-        out = {"step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_emulated": [int(x) for x in cc],
+        out = {"hip_mode": hip_mode, "step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_emulated": [int(x) for x in cc],
                "loss_sums_rel_dev": [float(x) for x in rel]}
         for name, (lo, hi) in {"sdf_mlp": (lay["sdf"], lay["rgb"]), "hash_grid": (lay["grid"], lay["variance"])}.items():
             x, y = g[lo:hi], r[lo:hi]
@@ -719,14 +726,17 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states):
         try:
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(root, "gpurun_out", "r03_emulated_reference_bound.json"), "w") as f:
+            with open(os.path.join(root, "gpurun_out", "r04_emulated_reference_bound_%s.json" % hip_mode), "w") as f:
                 json.dump(out, f, indent=1)
         except OSError:
             pass
         # Measured over the trained states of rounds 3 (training is not reproducible bit for bit, so every run tests another state):
         # colour 0.6e-3 ... 2.4e-3, Eikonal 4e-6 ... 6e-4, mask 2e-6 ... 3.4e-4 -- the two small terms move with the handful of rays whose
         # T < 1e-4 cut flips under half accumulation (each changes that ray's compacted count, by which its Eikonal term is divided).
-        assert rel[0] <= 5e-3 and rel[1] <= 2e-3 and rel[2] <= 1e-3, rel
+        if emulated:
+            assert max(rel) <= 1e-4, rel  # the north star's tolerance, against the reference AS CODED (emulated on both sides)
+        else:
+            assert rel[0] <= 5e-3 and rel[1] <= 2e-3 and rel[2] <= 1e-3, rel
         for name in ("sdf_mlp", "hash_grid"):
             assert out[name]["cosine"] >= 0.98, (name, out[name])
             assert out[name]["rms_dev_over_rms"] <= 0.06, (name, out[name])
