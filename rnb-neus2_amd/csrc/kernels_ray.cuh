@@ -518,6 +518,9 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 // MG = lanes per ray (16 or 32): more lanes = fewer dependent rounds per ray, more redundant t-chain work per round.
 // WGS = threads per workgroup. (Round 4 measured one WAVEFRONT per ray, <64, true, 1024>, for the march that has the GPU to itself behind an occupancy update:
 // 660 us against 184 -- the rounds are not what a ray costs; the sequential replay below is, and every lane of a ray's group executes it.)
+// (Round 4 also measured the replay as a fixed, branch-free scan over the round's 16 positions -- every lane reads its group's 16 jump targets back from LDS and
+// propagates "visited" through 16 unrolled steps; bit-exact; 166 vs 180 us alone, but 0.642 vs 0.635 ms/step at step 1000: the loop's cost is mostly scalar
+// bookkeeping, the scan's is vector instructions, which is what the kernel shares with the scatter beside it. Dropped, profiles/r04_ab_march_scan_replay.txt.)
 template <int MG, bool SC, int WGS = 256>
 __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 	static_assert(MG == 8 || MG == 16 || MG == 32 || MG == 64, "lanes per ray");

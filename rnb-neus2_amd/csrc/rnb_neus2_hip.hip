@@ -137,7 +137,7 @@ struct rnb_ctx {
 	uint32_t n_grid_samples = 0;
 	// the next update's samples in cell order (pregenerate_grid_samples): what they were generated from, their buffers, the placement scratch
 	struct { bool valid = false; uint32_t ema_step = 0, n_uniform = 0, n_nonuniform = 0; uint64_t rng_state = 0, rng_inc = 0; } gs_pre;
-	bool last_update_sorted = false, gs_after_march = false;
+	bool last_update_sorted = false;
 	struct { bool pending = false; uint32_t n_uniform = 0, n_nonuniform = 0; } gs_todo; // an update has run: prepare the next one's samples
 	DevBuf<float> gs_sorted_pos, gs_stage_pos, gs_eval_pos;   // sorted / stage: being prepared for the next update; eval: what the last update evaluated
 	DevBuf<uint32_t> gs_sorted_idx, gs_stage_idx, gs_eval_idx, gs_hist, gs_range; // gs_range: [2] this rank's share of the cell-ordered samples (k_shard_range)
@@ -452,12 +452,12 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
 		}
 	}
 	hipStream_t s = s_main;
-	if (c->overlap()) { // after this update (ev_grid) -- in a training step after the march chain that follows it (ev_march: the placement's returning atomics
-		// share the memory side's atomic unit with the polls of k_scan_rays_chain, 11 -> 54 us at an eighth of the batch) -- beside what follows on s_main
+	if (c->overlap()) { // after this update's k_ema_grid (ev_grid), beside what follows it on s_main: the march. (Behind the march chain instead -- the placement's
+		// returning atomics slow k_scan_rays_chain's polls, 11 -> 54 us at an eighth of the batch -- it runs beside the network evaluation, which is bound by the same
+		// memory system: k_forward_chained 72 -> 130 us twice, the update step 1134 -> 1265 us; round 4, dropped.)
 		s = c->s_dw;
-		HIP_TRY(hipStreamWaitEvent(s, c->gs_after_march ? c->ev_march : c->ev_grid, 0));
+		HIP_TRY(hipStreamWaitEvent(s, c->ev_grid, 0));
 	}
-	c->gs_after_march = false;
 	HIP_TRY(hipMemsetAsync(c->gs_hist.p, 0, sizeof(uint32_t) * n_keys, s));
 	if (c->density_grid_tmp_alt.p) { // the next update's splat target, cleared here instead of in front of its network evaluation (ordered by ev_gs like the samples)
 		HIP_TRY(hipMemsetAsync(c->density_grid_tmp_alt.p, 0, sizeof(float) * n_elements, s));
@@ -1769,8 +1769,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 		c->n_rays_total += n_rays * c->cfg.world_size;
 		// (Counters::prepare_for_training_steps, testbed_nerf.cu:3519-3530, zeroes the counters here; every one of them is written with a plain store by
 		// the scans of this step -- k_scan_rays*: [0] [2] [3], k_scan_compact*: [1] -- so the fill, a launch on the critical path of the update steps, is left out)
-		c->gs_after_march = c->gs_todo.pending && c->overlap(); // an update has just run: the next one's samples are prepared behind this march (pregenerate_grid_samples)
-		rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference, c->gs_after_march ? c->ev_march : nullptr);
+		rc = generate_training_samples(c, s, n_rays, n_rays_total, max_inference);
 		if (rc != RNB_OK) return rc;
 		c->cur_k1 = c->gen_k1;
 	}
