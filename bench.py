@@ -30,10 +30,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_TRAFFIC, PMC_UNITS = "r03_pmc_traffic.json", "r03_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
-PMC_FALLBACK = {"r03_pmc_traffic.json": "r02_pmc_traffic.json", "r03_pmc_units.json": "r02_pmc_units.json"}
+PMC_TRAFFIC, PMC_UNITS = "r04_pmc_traffic.json", "r04_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
+PMC_FALLBACK = {"r04_pmc_traffic.json": "r03_pmc_traffic.json", "r04_pmc_units.json": "r03_pmc_units.json"}
 # committed rocprofv3 summaries of this same command from which every `frac` of the record can be recomputed (profiles/README.md)
-PROFILE_FILES = {"kernel_trace_serial": "profiles/r03_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r03_steady_overlapped_step1000.json",
+PROFILE_FILES = {"kernel_trace_serial": "profiles/r04_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r04_steady_overlapped_step1000.json",
                  "pmc_traffic": "profiles/" + PMC_TRAFFIC, "pmc_units": "profiles/" + PMC_UNITS}
 # Algorithmic bytes per unit (restated in DESIGN.md §measurement)
 ALGO_BYTES = {

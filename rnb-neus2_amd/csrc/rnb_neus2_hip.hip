@@ -880,7 +880,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// Order of the groups by batch shape (round 4, ms/step over 160 steps, one box, B-A1-A2-C / A1-A2-B-C / A-B-C): step 1000, 14 k rays: 0.6446 / 0.6473 / 0.6325;
 		// 1200, 18.5 k: 0.6435 / 0.6594 / 0.6394; 1400, 24 k: 0.6304 / 0.6324 / 0.6388; 1800, 41 k: 0.6132 / 0.6142 / 0.6161; 6000, 94 k: 0.6452 / 0.6482 / 0.6470
 		// (profiles/r04_sweep_scatter_order.txt): the fine levels first and in one launch while the batch is few long rays (the regime of the 16-lanes-per-ray march).
-		c->sc.order = c->sc.dp ? 0 : c->knobs.scatter_order >= 0 ? c->knobs.scatter_order : (c->cur_n_rays < c->knobs.march_narrow_from ? 2 : 0);
+		c->sc.order = c->sc.dp ? 0 : c->knobs.scatter_order >= 0 ? c->knobs.scatter_order : ((c->cur_n_rays < c->knobs.march_narrow_from && !split) ? 2 : 0); // (albedo mode, step 1000: 0.763 with A-B-C vs 0.755 with B-A1-A2-C: its march is held behind the training kernels)
 		if (c->sc.order == 0) { // B, A1, A2 (, C)
 			launch_b(s, c->ev_sc[0]);
 			launch_a(s, c->ev_sc[1], l_fine, a_mid);

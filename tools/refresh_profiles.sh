@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: everything profiles/ holds for a round -> gpurun_out/<round>p/ (copy what is to be judged into profiles/ afterwards)
 #   bash tools/refresh_profiles.sh r02
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/${R}p
 mkdir -p $O $O/pmc
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
