@@ -548,7 +548,7 @@ int training_prep_front(rnb_ctx* c, hipStream_t s, bool shard) { // testbed_nerf
 }
 // The whole update; sharded over the data-parallel ranks when the host has given an exchange (rnb_set_grid_exchange).
 int training_prep(rnb_ctx* c, hipStream_t s) {
-	const bool shard = c->cfg.world_size > 1 && c->grid_exchange != nullptr;
+	const bool shard = c->grid_exchange != nullptr && c->dp_order(); // (a world of one with RNB_DP_FORCE_COLLECTIVES: the whole update, and the exchange is called: the path is exercised)
 	int rc = training_prep_front(c, s, shard);
 	if (rc != RNB_OK) return rc;
 	if (shard) {

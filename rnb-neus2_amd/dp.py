@@ -123,7 +123,7 @@ class DataParallelTrainer:
         self._reduce_small = all_reduce_small  # None: all-reduce the library's device block in place
         if grid_exchange == "default":
             grid_exchange = self._torch_grid_exchange if (all_reduce_grads is None and shard_collectives is None) else None  # injected transports bring their own
-        if os.environ.get("RNB_DP_SHARD_GRID", "1") == "0" or ctx.cfg.world_size <= 1:
+        if os.environ.get("RNB_DP_SHARD_GRID", "1") == "0" or not self._collectives:
             grid_exchange = None
         ctx.set_grid_exchange(grid_exchange)
         self.grid_sharded = grid_exchange is not None

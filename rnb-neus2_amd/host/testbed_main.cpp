@@ -291,7 +291,7 @@ struct Dist {
 	}
 	void attach(rnb_ctx* ctx) {
 		const char* e = std::getenv("RNB_DP_SHARD_GRID");
-		if (on && world > 1 && !(e && std::atoi(e) == 0) && rnb_set_grid_exchange(ctx, &Dist::grid_exchange, this) != RNB_OK) throw std::runtime_error(rnb_last_error());
+		if (on && !(e && std::atoi(e) == 0) && rnb_set_grid_exchange(ctx, &Dist::grid_exchange, this) != RNB_OK) throw std::runtime_error(rnb_last_error());
 	}
 	int train_step(rnb_ctx* ctx, rnb_step_stats* st) {
 		if (!on) return rnb_train_step(ctx, nullptr, st);

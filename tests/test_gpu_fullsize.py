@@ -324,19 +324,34 @@ def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
+    import time
+    t_phase = [time.perf_counter()]
+
+    def phase(name):  # (printed with -s: where the time of this test goes)
+        t_phase.append(time.perf_counter())
+        print("[rccl single rank] %s: %.2f s" % (name, t_phase[-1] - t_phase[-2]), flush=True)
     monkeypatch.setenv("RNB_DP_FORCE_COLLECTIVES", "1")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    phase("init_process_group")
     plain = _clone(scene, state, overlap=1)
     ctxs = [_clone(scene, state, overlap=1), _clone(scene, state, overlap=1)]  # created with the variable set: data-parallel scatter order
+    phase("three clones")
     try:
         trainers = [dp.DataParallelTrainer(ctxs[0], sharded=True), dp.DataParallelTrainer(ctxs[1], sharded=False)]
         assert trainers[0].sharded and not trainers[1].sharded and all(t._collectives for t in trainers)
+        assert all(t.grid_sharded for t in trainers)  # the occupancy update's exchange (a max all-reduce over RCCL inside train_step_begin) is registered
         ref = plain.train_step()
         got = [t.step() for t in trainers]
         torch.cuda.synchronize()
+        phase("first step x 3")
+        assert ref.density_grid_updated and all(st.density_grid_updated for st in got)  # the first step began with an occupancy update: through the exchange, same grid
+        for c in ctxs:
+            assert np.array_equal(plain.get("DENSITY_GRID").view(np.uint32), c.get("DENSITY_GRID").view(np.uint32))
+            assert np.array_equal(plain.get("DENSITY_BITFIELD"), c.get("DENSITY_BITFIELD"))
         for t in trainers:
             t.sync_parameters()
         torch.cuda.synchronize()
+        phase("sync_parameters")
         pa = plain.get("PARAMS_FP32")
         for st, c in zip(got, ctxs):  # first step from a common state: identical statistics, same update up to the order of the atomics
             assert st.training_step == ref.training_step and st.loss == ref.loss and st.next_rays_per_batch == ref.next_rays_per_batch
@@ -349,12 +364,14 @@ def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch
             ref = plain.train_step()
             got = [t.step() for t in trainers]
             history.append((ref.loss, got[0].loss, got[1].loss, ref.rays_per_batch, got[0].rays_per_batch, got[1].rays_per_batch))
+        phase("20 steps x 3")
         for st in got:
             assert st.training_step == ref.training_step
             assert abs(st.loss - ref.loss) <= 0.05 * abs(ref.loss), history  # measured spread between the variants: 0.3 %
             assert abs(st.rays_per_batch - ref.rays_per_batch) <= max(256, 0.02 * ref.rays_per_batch), history  # the controller rounds to multiples of 128
     finally:
         dist.destroy_process_group()
+        phase("destroy_process_group")
         plain.close()
         for c in ctxs:
             c.close()
