@@ -187,6 +187,8 @@ struct rnb_ctx {
 		uint32_t march_narrow_from = 18432; // rays per step from which the per-ray kernels switch to their large-batch forms (RNB_MARCH_NARROW_FROM). ms/step small / large forms, end of round 2: 16.2 k rays 0.697 / 0.707, 19.1 k 0.713 / 0.704, 22.3 k 0.740 / 0.710
 		bool dp_order = false; // scatter order of the data-parallel exchange even with one rank (RNB_DP_FORCE_COLLECTIVES)
 		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
+		uint32_t march_wave_per_ray_below = 4096; // RNB_MARCH_WAVE_PER_RAY_BELOW=n: one wavefront per ray for batches of at most n rays (single-cascade scenes). At an eighth of the batch
+		                                          // (1.8 k rays per step): 0.2985 -> 0.2890 ms/step with 4096 (2560: 0.2887); bit-exact at every size (the full-size tests were run with n = 100 000)
 		bool emulate_fp16_accum = false; // RNB_EMULATE_FP16_ACCUM=1 (tests only, never benchmarked): the network evaluations (k_forward_chained, k_point_query_chained) round their
 		                                  // accumulators to half after every 16-wide k-step, as the reference's WMMA path does (fully_fused_mlp.cu:59-68) and ORC_EMULATE_FP16_ACCUM models
 		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
@@ -659,6 +661,10 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
 		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
+	} else if (sc && n_rays <= c->knobs.march_wave_per_ray_below) {
+		// a batch so small that 16 lanes per ray leave most SIMDs without a wavefront (a rank of a strong-scaling job: 1.8 k rays = 0.4 wavefronts per SIMD): the kernel
+		// is then one wavefront's dependent chain of ~50 rounds, and a whole wavefront per ray quarters the rounds (at 12.6 k rays the same form lost, 660 vs 184 us: DESIGN.md section 6)
+		hipLaunchKernelGGL((k_march_count_wide<64, true, 256>), dim3((n_rays + 3) / 4), dim3(256), march_lds, s, a);
 	} else {
 		const dim3 grid((n_rays + 15) / 16); // 16 lanes per ray (8: 0.19 ms alone but a slower step; 32: 0.32 ms, measured in round 1)
 		if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), march_lds, s, a);
@@ -1267,6 +1273,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		const int march_lds_max = (int)((2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS) * sizeof(uint32_t));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
@@ -1293,6 +1300,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
 		if (const char* e = getenv("RNB_EMULATE_FP16_ACCUM")) k.emulate_fp16_accum = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
 	}
