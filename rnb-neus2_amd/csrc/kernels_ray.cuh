@@ -425,6 +425,7 @@ struct MarchArgs {
 	uint32_t* base1;    // [n_rays] offset of the ray's first-round samples in idx1 (two-round network evaluation, see k_loss_pass1)
 	uint32_t* idx1;     // sample slots of the first round: the first min(steps, k1) samples of every kept ray
 	uint32_t k1;        // 0 = single round
+	uint32_t part;      // k_march_write: 0 = everything; 1 = what the first network evaluation reads (idx1, the coordinates of the heads); 2 = the rest
 	// per-ray loss constants (target colour, light, masks) depend on the ray and the dataset only: worked out here, off the
 	// step's critical path, for the loss passes to pick up (k_march_write -> k_loss_pass1)
 	LossFlags F;
@@ -889,7 +890,8 @@ struct ScanChainArgs {
 	uint32_t n, max_samples, k1;
 	const uint32_t* steps;
 	uint32_t *base, *slot, *base1, *counters, *fwd_counts;
-	unsigned long long* words; // [n_tiles][4]: ticket << 32 | {samples, kept rays, kept samples, kept first-round samples} of the tile
+	unsigned long long* words;  // [n_tiles][4]: ticket << 32 | {samples, rays with samples, first-round samples} of the tile, were no ray dropped
+	unsigned long long* words2; // [n_tiles][4]: ticket << 32 | {kept rays, kept samples, kept first-round samples}: tiles at and behind an overflow of max_samples only
 	uint32_t ticket;
 	uint32_t* error; // mapped host word: a wait gave up
 };
@@ -922,35 +924,100 @@ __device__ __forceinline__ uint32_t chain_prefix(unsigned long long* __restrict_
 	__syncthreads();
 	return r;
 }
+// Round 4: ONE exchange instead of four. Which rays keep their samples depends on the offsets (a ray is dropped if it would overflow max_samples,
+// testbed_nerf.cu:1348-1355), so rounds 1-3 exchanged the sample sums first and the three dependent sums afterwards, one after the other -- and every
+// exchange is a returning atomic that queues behind the gradient scatter's backlog at the memory side (21 us for 4 tiles beside the scatter, 42 for 23).
+// A tile now publishes its sample sum together with the two sums it would have if none of its rays overflowed (rays with samples, first-round samples;
+// the kept samples then are the sample sum): three words of one 32-byte block, written by three lanes of one instruction and polled with three atomics
+// in flight. A tile whose last offset stays within max_samples has no overflow in or in front of it and is done; only tiles at or behind the first
+// overflowing tile (a batch that marched more than 16 x the target: never in a converged run) exchange their true sums a second time (`words2`), taking
+// the optimistic sums of the tiles in front of the overflow as they are.
 __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs a) {
 	__shared__ uint32_t wsum[16];
-	__shared__ uint32_t sh[2];
-	bool bad = false;
+	__shared__ uint32_t sh[8];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, tile = blockIdx.x;
 	const uint32_t i0 = tile * SCAN_TILE + tid * SCAN_EPT;
-	uint32_t st[SCAN_EPT], mine = 0;
+	uint32_t st[SCAN_EPT], mine = 0, npos = 0, f1 = 0;
 #pragma unroll
-	for (uint32_t e = 0; e < SCAN_EPT; ++e) { st[e] = i0 + e < a.n ? a.steps[i0 + e] : 0u; mine += st[e]; }
-	uint32_t total;
+	for (uint32_t e = 0; e < SCAN_EPT; ++e) { st[e] = i0 + e < a.n ? a.steps[i0 + e] : 0u; mine += st[e]; npos += st[e] > 0 ? 1u : 0u; f1 += min(st[e], a.k1); }
+	uint32_t total, t_pos, t_f1;
 	const uint32_t excl = block_exclusive_scan<SCAN_NW>(mine, lane, wave, wsum, total);
-	const uint32_t tile_base = chain_prefix(a.words, 0, tile, a.ticket, total, tid, sh, a.error, bad);
+	uint32_t e0 = block_exclusive_scan<SCAN_NW>(npos, lane, wave, wsum, t_pos);
+	uint32_t e2 = block_exclusive_scan<SCAN_NW>(f1, lane, wave, wsum, t_f1);
+	// exchange A (wavefront 0: lane q polls tile q < tile)
+	uint32_t fa[3] = {0, 0, 0}, incl_front = 0, flagA = 0; // wavefront 0 keeps the front tiles' sums for exchange B
+	if (tid < 3) atomicExch(a.words + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? total : tid == 1 ? t_pos : t_f1));
+	if (tid < 64) {
+		if (tid < tile) {
+			unsigned long long w0, w1, w2;
+			uint32_t spins = 0;
+			bool got;
+			do {
+				w0 = atomicAdd(a.words + tid * 4 + 0, 0ull); w1 = atomicAdd(a.words + tid * 4 + 1, 0ull); w2 = atomicAdd(a.words + tid * 4 + 2, 0ull);
+				got = (uint32_t)(w0 >> 32) == a.ticket && (uint32_t)(w1 >> 32) == a.ticket && (uint32_t)(w2 >> 32) == a.ticket;
+				if (got) break;
+				__builtin_amdgcn_s_sleep(2);
+			} while (++spins < 20000000u); // (bounded: a lost workgroup must not hang the device; see chain_prefix)
+			if (!got) { flagA = 1u; w0 = w1 = w2 = 0; if (a.error) atomicExch(a.error, 1u); }
+			if ((uint32_t)w0 & CHAIN_POISON) flagA = 1u;
+			fa[0] = (uint32_t)w0 & ~CHAIN_POISON; fa[1] = (uint32_t)w1; fa[2] = (uint32_t)w2;
+		}
+		incl_front = wave_inclusive_scan(fa[0], lane);
+		uint32_t r0 = fa[0], r1 = fa[1], r2 = fa[2], fl = flagA;
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64); fl |= __shfl_xor(fl, off, 64); }
+		if (tid == 0) { sh[0] = r0; sh[1] = r1; sh[2] = r2; sh[3] = fl; }
+		if (tid == 0 && fl) atomicOr(a.words + tile * 4, (unsigned long long)CHAIN_POISON); // best effort for the tiles that poll later; the host word `error` is what reports it
+	}
+	__syncthreads();
+	const uint32_t tile_base = sh[0];
+	uint32_t p0 = sh[1], p1 = tile_base, p2 = sh[2];
+	bool bad = sh[3] != 0u;
+	uint32_t t0 = t_pos, t1 = total, t2 = t_f1;
 	uint32_t run = tile_base + excl;
-	uint32_t v[3] = {0, 0, 0};
 	uint32_t okmask = 0;
+	const bool overflow = tile_base + total > a.max_samples; // uniform over the workgroup; true for every tile behind the first such tile too
 #pragma unroll
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
 		if (i0 + e < a.n) a.base[i0 + e] = run;
 		const bool ok = st[e] > 0 && run + st[e] <= a.max_samples; // testbed_nerf.cu:1348-1355
 		run += st[e];
-		if (ok) { okmask |= 1u << e; v[0] += 1u; v[1] += st[e]; v[2] += min(st[e], a.k1); }
+		if (ok) okmask |= 1u << e;
 	}
-	uint32_t t0, t1, t2;
-	const uint32_t e0 = block_exclusive_scan<SCAN_NW>(v[0], lane, wave, wsum, t0);
-	const uint32_t e2 = block_exclusive_scan<SCAN_NW>(v[2], lane, wave, wsum, t2);
-	(void)block_exclusive_scan<SCAN_NW>(v[1], lane, wave, wsum, t1);
-	const uint32_t p0 = chain_prefix(a.words, 1, tile, a.ticket, t0, tid, sh, a.error, bad);
-	const uint32_t p1 = chain_prefix(a.words, 2, tile, a.ticket, t1, tid, sh, a.error, bad);
-	const uint32_t p2 = chain_prefix(a.words, 3, tile, a.ticket, t2, tid, sh, a.error, bad);
+	if (overflow) { // exchange B: the true sums of the tiles at and behind the first overflow
+		uint32_t v[3] = {0, 0, 0};
+#pragma unroll
+		for (uint32_t e = 0; e < SCAN_EPT; ++e) if ((okmask >> e) & 1u) { v[0] += 1u; v[1] += st[e]; v[2] += min(st[e], a.k1); }
+		__syncthreads(); // sh is rewritten
+		e0 = block_exclusive_scan<SCAN_NW>(v[0], lane, wave, wsum, t0);
+		e2 = block_exclusive_scan<SCAN_NW>(v[2], lane, wave, wsum, t2);
+		(void)block_exclusive_scan<SCAN_NW>(v[1], lane, wave, wsum, t1);
+		if (tid < 3) atomicExch(a.words2 + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? (t0 | (bad ? CHAIN_POISON : 0u)) : tid == 1 ? t1 : t2));
+		if (tid < 64) {
+			uint32_t fb[3] = {fa[1], fa[0], fa[2]}, fl = 0; // a tile in front of the overflow: all of its rays with samples are kept
+			if (tid < tile && incl_front > a.max_samples) {
+				unsigned long long w0, w1, w2;
+				uint32_t spins = 0;
+				bool got;
+				do {
+					w0 = atomicAdd(a.words2 + tid * 4 + 0, 0ull); w1 = atomicAdd(a.words2 + tid * 4 + 1, 0ull); w2 = atomicAdd(a.words2 + tid * 4 + 2, 0ull);
+					got = (uint32_t)(w0 >> 32) == a.ticket && (uint32_t)(w1 >> 32) == a.ticket && (uint32_t)(w2 >> 32) == a.ticket;
+					if (got) break;
+					__builtin_amdgcn_s_sleep(2);
+				} while (++spins < 20000000u);
+				if (!got) { fl = 1u; w0 = w1 = w2 = 0; if (a.error) atomicExch(a.error, 1u); }
+				if ((uint32_t)w0 & CHAIN_POISON) fl = 1u;
+				fb[0] = (uint32_t)w0 & ~CHAIN_POISON; fb[1] = (uint32_t)w1; fb[2] = (uint32_t)w2;
+			}
+			uint32_t r0 = fb[0], r1 = fb[1], r2 = fb[2];
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) { r0 += __shfl_xor(r0, off, 64); r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64); fl |= __shfl_xor(fl, off, 64); }
+			if (tid == 0) { sh[4] = r0; sh[5] = r1; sh[6] = r2; sh[7] = fl; }
+		}
+		__syncthreads();
+		p0 = sh[4]; p1 = sh[5]; p2 = sh[6];
+		bad = bad || sh[7] != 0u;
+	}
 	uint32_t srun = p0 + e0, frun = p2 + e2;
 #pragma unroll
 	for (uint32_t e = 0; e < SCAN_EPT; ++e) {
@@ -1177,7 +1244,8 @@ constexpr uint32_t MARCH_WRITE_WG = 1024;
 template <int LR>
 __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs a) {
 	constexpr uint32_t RAYS = MARCH_WRITE_WG / LR;
-	if (a.ray_const && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
+	const bool head = a.part != 2, rest = a.part != 1;
+	if (a.ray_const && rest && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
 		const uint32_t i = blockIdx.x * RAYS + threadIdx.x;
 		const uint32_t s = i < a.n_rays ? a.slot[i] : 0xffffffffu;
 		if (s != 0xffffffffu) {
@@ -1202,7 +1270,7 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 	const float* st = a.setup + (size_t)i * 8;
 	const Vec3 o = {st[0], st[1], st[2]}, dir = {st[3], st[4], st[5]};
 	const uint32_t steps = a.steps[i], base = a.base[i];
-	if (lane == 0) {
+	if (lane == 0 && rest) {
 		a.ray_indices[s] = i;
 		float* ro = a.rays + (size_t)s * 6;
 		ro[0] = o.x; ro[1] = o.y; ro[2] = o.z;
@@ -1210,14 +1278,18 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 		a.numsteps[(size_t)s * 2 + 0] = steps;
 		a.numsteps[(size_t)s * 2 + 1] = base;
 	}
-	if (a.k1) {
+	if (a.k1 && head) {
 		const uint32_t b1 = a.base1[i];
 		for (uint32_t j = lane; j < min(steps, a.k1); j += LR) a.idx1[b1 + j] = base + j;
 	}
+	// part 1: samples [0, k1) of the ray; part 2: [k1, steps) (every lane keeps the samples it has in the one-launch form)
+	const uint32_t j_lo = a.part == 2 ? min(steps, a.k1) : 0u, j_hi = a.part == 1 ? min(steps, a.k1) : steps;
+	if (j_lo >= j_hi) return;
 	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
 	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
 	float* co = a.coords + (size_t)base * 7;
-	for (uint32_t j = lane; j < steps; j += LR) {
+	for (uint32_t j = j_lo / LR * LR + lane; j < j_hi; j += LR) {
+		if (j < j_lo) continue;
 		const float t = tt[j];
 		const Vec3 pos = o + t * dir;
 		const float dt = calc_dt(t, a.A.cone_angle);

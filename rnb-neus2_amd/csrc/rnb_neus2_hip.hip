@@ -173,6 +173,7 @@ struct rnb_ctx {
 	DevBuf<uint32_t> unfinished;
 	uint32_t fwd_k1 = 48;      // head length of the two-round network evaluation (0 = one round); the longest head of the adaptive rule
 	bool fwd_k1_fixed = false; // RNB_FWD_K1: that value for every step
+	bool gen_split = false; // the last generated batch wrote its sample records in two launches (knobs.march_write_split)
 	uint32_t gen_k1 = 0, cur_k1 = 0; // head length the last generated batch / the running step was laid out with (k1_for)
 	// Tuning / A-B knobs, read from the environment once at creation (measurement aids, not part of the interface).
 	struct Knobs {
@@ -195,6 +196,9 @@ struct rnb_ctx {
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
+		bool march_write_split = true; // RNB_MARCH_WRITE_SPLIT=0: k_march_write of a march generated ahead as one launch (rounds 1-3). Split: what the first network evaluation reads (idx1, the heads'
+		                               // coordinates) in a first launch, whose completion the critical stream waits for; the rest (ray constants, ray records, the tails' coordinates) in a second one
+		                               // that runs beside that evaluation and is joined in front of the loss pass
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -227,7 +231,7 @@ struct rnb_ctx {
 	// costs the critical stream ~5 us (tools/probe_barriers.hip), so when the next step's march is about to be queued, the wait for ev_tail goes onto ITS stream,
 	// in front of k_march_write (slack there), and the critical stream reaches it through ev_march. tail_pending: nobody has waited for ev_tail yet.
 	bool tail_pending = false;
-	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_march_rest = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
 	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
 	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
 	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0; } sc;
@@ -238,7 +242,7 @@ struct rnb_ctx {
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
-	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; } pre; // samples already generated for the next step
+	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; bool split = false; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t seq, pad; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills; seq: see poll_loss()
 	uint32_t rb_seq = 0;     // sequence number of the last step whose readback was launched in polling mode
 	bool loss_polled = true; // the host has seen that step's readback (or the step publishes through ev_loss instead)
@@ -644,12 +648,13 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.F = loss_flags(c);
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.ray_const = c->ray_const.p;
+	a.part = 0;
 	return a;
 }
 
-int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr, hipEvent_t wait_before_write = nullptr) {
+int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr, hipEvent_t wait_before_write = nullptr, hipEvent_t rest_done = nullptr) {
 	if (!c->coarse_valid) { const int rc0 = rebuild_coarse(c, s); if (rc0 != RNB_OK) return rc0; } // a caller may have written the bitfield (rnb_buffer)
-	const MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
+	MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	c->gen_k1 = a.k1;
 	const uint32_t blocks = (n_rays + 127) / 128;
 	c->prof.mark(s, P_NONE);
@@ -675,7 +680,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	if (c->knobs.scan_chain && n_scan_tiles <= 64) { // one launch, one workgroup per 4096-ray tile (k_scan_rays_chain)
 		ScanChainArgs q;
 		q.n = n_rays; q.max_samples = max_samples; q.k1 = a.k1; q.steps = c->ray_steps.p; q.base = c->ray_base.p; q.slot = c->ray_slot.p; q.base1 = c->ray_base1.p;
-		q.counters = c->counters.p; q.fwd_counts = c->fwd_counts.p; q.words = c->scan_words.p; q.ticket = ++c->scan_ticket; q.error = c->host_coarse_dev + 5;
+		q.counters = c->counters.p; q.fwd_counts = c->fwd_counts.p; q.words = c->scan_words.p; q.words2 = c->scan_words.p + 2 * 64 * 4; q.ticket = ++c->scan_ticket; q.error = c->host_coarse_dev + 5;
 		hipLaunchKernelGGL(k_scan_rays_chain, dim3(n_scan_tiles), dim3(SCAN_WG), 0, s, q);
 	} else if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
@@ -686,8 +691,13 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (wait_before_write) HIP_TRY(hipStreamWaitEvent(s, wait_before_write, 0)); // (rnb_ctx::tail_pending)
-	if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, done, a);
-	else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, done, a);
+	c->gen_split = rest_done != nullptr && a.k1 != 0 && c->knobs.march_write_split;
+	for (uint32_t part = c->gen_split ? 1u : 0u; part <= (c->gen_split ? 2u : 0u); ++part) {
+		a.part = part;
+		hipEvent_t ev = part == 2 ? rest_done : done;
+		if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
+		else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
+	}
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -1154,7 +1164,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_march_rest, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	if (c->host_coarse) (void)hipHostFree(c->host_coarse);
 	delete c;
@@ -1223,7 +1233,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
 	ALLOC(c->ncomp, maxr); ALLOC(c->cbase, maxr); ALLOC(c->ray_loss, maxr);
 	ALLOC(c->wimg_fwd, W_FWD_END); ALLOC(c->wimg_fbs, SWF_END); ALLOC(c->wimg_train, W_TRAIN_END); ALLOC(c->wimg_rgb, RW_END);
-	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->scan_words, 2 * 64 * 4); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
+	ALLOC(c->ray_const, (size_t)maxr * RAY_CONST_FLOATS); ALLOC(c->ray_base1, maxr); ALLOC(c->scan_words, 3 * 64 * 4); ALLOC(c->unfinished, maxr); ALLOC(c->fwd_counts, 4); ALLOC(c->idx1, (size_t)B * 16); ALLOC(c->idx2, (size_t)B * 16);
 	// feature-major operand arrays: h2 h1 z1 dz1 dh2 dh1 dz front (64 rows), cin sdfin ddin (32 rows), dr dso (16 rows)
 	ALLOC(c->fm, (size_t)B * (8 * 64 + 3 * 32 + 2 * 16));
 	ALLOC(c->g12, (size_t)B * 14 * 2); ALLOC(c->srec, (size_t)B * 8);
@@ -1303,6 +1313,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1312,7 +1323,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them.
 	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
+	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_march_rest, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_coarse), 64, hipHostMallocMapped));
@@ -1767,10 +1778,12 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	const uint32_t n_rays = c->rays_per_batch;
 	if (c->pre.valid && (c->pre.n_rays != n_rays || c->pre.max_inference != max_inference)) discard_premarch(c);
 	uint32_t n_rays_total;
+	bool join_rest = false; // the second k_march_write of a march generated ahead is still to be waited for (knobs.march_write_split)
 	if (c->pre.valid) { // generated beside the previous step's backward pass
 		n_rays_total = c->pre.n_rays_total;
 		c->pre.valid = false;
 		c->cur_k1 = c->pre.k1;
+		join_rest = c->pre.split;
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
 	} else {
 		n_rays_total = c->n_rays_total;
@@ -1792,6 +1805,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	else rc = launch_forward(c, s, c->coords.p, c->counters.p + 3, max_inference, c->mlp_out.p, false, nullptr, cin_out);
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
+	if (join_rest) HIP_TRY(hipStreamWaitEvent(s, c->ev_march_rest, 0));
 	rc = compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
 	if (rc != RNB_OK) return rc;
 	return pregenerate_grid_samples(c, s); // after an update: the next one's samples, behind everything this step's front needed from the host
@@ -1859,12 +1873,12 @@ static int launch_premarch(rnb_ctx* c) {
 	// exclude each other on a SIMD; a march that has started beside the first keeps the second at half occupancy (253 instead of 113 us, the step 0.79 instead of
 	// 0.76 ms). Behind them it runs beside the scatter, as it effectively does with --no-albedo, where k_fwd_bwd_sdf claims the registers first.
 	if (c->knobs.march_late || c->rgb_split()) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
-	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march, c->tail_pending ? c->ev_tail : nullptr);
+	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march, c->tail_pending ? c->ev_tail : nullptr, c->ev_march_rest);
 	if (rc != RNB_OK) return rc;
 	c->tail_pending = false; // the next step reaches ev_tail through ev_march
 	c->pre.loss_cleared = true;
 	c->n_rays_total += n_rays * c->cfg.world_size;
-	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference; c->pre.k1 = c->gen_k1;
+	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference; c->pre.k1 = c->gen_k1; c->pre.split = c->gen_split;
 	return RNB_OK;
 }
 

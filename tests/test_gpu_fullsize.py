@@ -553,6 +553,24 @@ def test_full_size_step_against_oracle(scene, states, oracle_full, regime, n_ray
         assert np.array_equal(gpu.get("NUMSTEPS", kept * 2), cpu.get("NUMSTEPS", kept * 2))
         assert np.array_equal(gpu.get("RAYS", kept * 6).view(np.uint32), cpu.get("RAYS", kept * 6).view(np.uint32))
         assert np.array_equal(gpu.get("COORDS", written * 7).view(np.uint32), cpu.get("COORDS", written * 7).view(np.uint32))
+        if regime == "late" or n_rays:
+            # the same batch with max_samples at 60 % of what it marches (testbed_nerf.cu:1348-1355): the first dropped ray sits in the middle of the tiles of
+            # k_scan_rays_chain, the tiles behind it exchange their sums a second time
+            for c in (gpu, cpu):
+                c.generate_training_samples(R, 4096, int(0.6 * written))
+            og, oc = gpu.get("COUNTERS"), cpu.get("COUNTERS")
+            assert np.array_equal(og[[0, 2, 3]], oc[[0, 2, 3]]), (og, oc)
+            k2, w2 = int(oc[2]), int(oc[3])
+            assert oc[0] == cc[0] and 0 < k2 < kept and 0.55 * written < w2 <= 0.6 * written
+            assert np.array_equal(gpu.get("RAY_INDICES", k2), cpu.get("RAY_INDICES", k2))
+            assert np.array_equal(gpu.get("NUMSTEPS", k2 * 2), cpu.get("NUMSTEPS", k2 * 2))
+            n_all = int(oc[0])  # dropped rays leave holes: compare the coordinates of the kept rays' slots
+            ns = cpu.get("NUMSTEPS", k2 * 2).reshape(-1, 2)
+            xg, xc = gpu.get("COORDS", n_all * 7).view(np.uint32).reshape(-1, 7), cpu.get("COORDS", n_all * 7).view(np.uint32).reshape(-1, 7)
+            for steps, base in ns[:: max(1, k2 // 2000)]:
+                assert np.array_equal(xg[base:base + steps], xc[base:base + steps])
+            for c in (gpu, cpu):
+                c.generate_training_samples(R, 4096)
         # a5-a7 (nerf_network.h:97-253) on every marched sample
         for c in (gpu, cpu):
             c.forward_infer_staged(written)
@@ -637,8 +655,10 @@ def test_whole_step_against_the_default_oracle(scene, states, regime):
     fed the other side's output (test_full_size_step_against_oracle isolates the kernels by doing exactly that): occupancy state -> march ->
     two-round network evaluation -> loss -> backward; then the optimizer at the run's own Adam state. Asserted: marched sample set identical
     (counters 0, 2, 3), compaction count identical up to a handful of rays whose T < 1e-4 cut flips on a half ulp of the network output
-    (<= 2e-4 relative), the three loss sums within the north star's 1e-4 relative, gradient blocks at the stage test's tolerances, and the
-    parameters and moments after the optimizer step on every parameter stepped on both sides (masters: 99.99 % within 2e-5 of the block's scale, all within 1e-3)."""
+    (<= 2e-4 relative), the three loss sums within the north star's 1e-4 relative; the loss gradients row by row (every row within its half rounding
+    except a few hundred at most, whose share D of the norm is measured), the gradient blocks and the parameters and moments after the optimizer step on
+    every parameter stepped on both sides within bounds that grow with D (masters: 99.99 % within 2e-5 of the block's scale). The trained state differs from
+    process to process (float atomics), and with it D: profiles/r04_whole_step_state_spread.txt."""
     import json
     state = states[regime]
     cpu = _oracle_clone(scene, state)
@@ -651,9 +671,25 @@ def test_whole_step_against_the_default_oracle(scene, states, regime):
         assert cg[0] == cc[0] and cg[2] == cc[2] and cg[3] == cc[3], (cg, cc)
         assert abs(int(cg[1]) - int(cc[1])) <= 2e-4 * int(cc[1]) + 1, (cg, cc)
         rel = [abs(x - y) / abs(y) for x, y in zip(sg, sc)]
+        kept = int(cc[2])
+        ng, nc = gpu.get("NUMSTEPS", kept * 2).reshape(-1, 2), cpu.get("NUMSTEPS", kept * 2).reshape(-1, 2)
+        flips = int(np.count_nonzero(ng[:, 0] != nc[:, 0]))  # rays whose T < 1e-4 cut fell on another sample
         g, r = gpu.get("GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
         lay = cpu.param_layout()
-        out = {"regime": regime, "step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_oracle": [int(x) for x in cc],
+        # Where do the loss gradients differ by more than their half rounding? Rows paired ray by ray (a ray whose cut moved has a sample more on one side).
+        # A converged SDF has 1/s in the hundreds: one ulp of the half-precision sdf output moves a sample's alpha -- and its dL/dsdf -- by tens of per cent, so a few
+        # samples of a few rays carry all of the deviation; the weight gradients inherit it in proportion (asserted below).
+        both = np.minimum(ng[:, 0], nc[:, 0]).astype(np.int64)
+        within = np.arange(int(both.sum())) - np.repeat(np.cumsum(both) - both, both)
+        ig, ic = np.repeat(ng[:, 1].astype(np.int64), both) + within, np.repeat(nc[:, 1].astype(np.int64), both) + within
+        dg = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[ig].astype(np.float64)
+        dc = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[ic].astype(np.float64)
+        row, dev = np.abs(dc).max(axis=1), np.abs(dg - dc).max(axis=1)
+        off = dev > 5e-3 * row + 1e-7 * row.max()
+        dl = {"rows": int(both.sum()), "rows_off": int(off.sum()), "rays_of_rows_off": int(np.unique(np.repeat(np.arange(kept), both)[off]).size),
+              "dev_norm_over_norm": float(np.linalg.norm(dg - dc) / np.linalg.norm(dc)), "dev_norm_of_other_rows_over_norm": float(np.linalg.norm((dg - dc)[~off]) / np.linalg.norm(dc)),
+              "worst": [{"row": int(i), "hip_dsdf": float(dg[i, 3]), "oracle_dsdf": float(dc[i, 3]), "row_max": float(row[i])} for i in np.argsort(-dev)[:3]]}
+        out = {"regime": regime, "rays_with_another_cut": flips, "dloss_dout": dl, "step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_oracle": [int(x) for x in cc],
                "loss_sums_rel_dev": [float(x) for x in rel]}
         for name, (lo, hi) in {"sdf_mlp": (lay["sdf"], lay["rgb"]), "hash_grid": (lay["grid"], lay["variance"])}.items():
             x, y = g[lo:hi], r[lo:hi]
@@ -684,15 +720,21 @@ def test_whole_step_against_the_default_oracle(scene, states, regime):
         except OSError:
             pass
         assert max(rel) <= 1e-4, rel                                       # north star: fp32 losses within 1e-4 relative
-        assert out["sdf_mlp"]["max_dev_over_scale"] < 5e-3, out["sdf_mlp"]
-        assert out["hash_grid"]["max_dev_over_scale"] < 5e-3 and out["hash_grid"]["sparsity_mismatch"] < 2e-3 and out["hash_grid"]["cosine"] > 0.9999, out["hash_grid"]
-        assert abs(vg - vr) <= 5e-3 * abs(vr) + 1e-6, out["variance_grad"]
+        # the loss gradients: all of the deviation sits in a few hundred rows at most (14 runs, six different trained states: 12 .. 247 rows of 2.6e5, everything else within
+        # 1.3e-5 .. 7.5e-5 of the norm); their share D of the norm (1.8e-4 .. 1.3e-3) is what the weight gradients and the optimizer's output can differ by
+        D = dl["dev_norm_over_norm"]
+        assert dl["rows_off"] <= 2e-3 * dl["rows"] and dl["dev_norm_of_other_rows_over_norm"] <= 3e-4 and D <= 5e-3, dl
+        amp = 1.0 + D / 2e-4
+        assert out["sdf_mlp"]["rms_dev_over_rms"] < 5e-4 * amp and out["sdf_mlp"]["max_dev_over_scale"] < 1e-3 * amp, (out["sdf_mlp"], D)
+        assert out["hash_grid"]["rms_dev_over_rms"] < 1e-3 * amp and out["hash_grid"]["max_dev_over_scale"] < 5e-3 * amp, (out["hash_grid"], D)
+        assert out["hash_grid"]["sparsity_mismatch"] < 2e-3 and out["hash_grid"]["cosine"] > 0.9999, out["hash_grid"]
+        assert abs(vg - vr) <= (2e-3 * abs(vr) + 5e-5) * amp, (out["variance_grad"], D)  # one scalar, a near-cancelling sum over the samples (-0.054 .. +0.028 over the states seen)
         assert steps_equal > 0.9999, steps_equal                             # a parameter is stepped iff its (half-narrowed) gradient is non-zero
         # on the parameters stepped on both sides. Adam's update is lr x m / sqrt(v): for an entry whose gradient is a near-cancelling sum it keeps its size (~lr)
         # while the sum's last bits decide its direction, so the maximum is bounded by the step size and the bulk by the gradient's agreement
-        for name, tol, tol_q in (("PARAMS_FP32", 1e-3, 2e-5), ("ADAM_M", 2e-3, 5e-4), ("ADAM_V", 2e-3, 5e-4)):
+        for name, tol, tol_q in (("PARAMS_FP32", 1e-3 * amp, 2e-5), ("ADAM_M", 2e-3 * amp, 1e-3 * amp), ("ADAM_V", 2e-3 * amp, 5e-4 * amp)):
             r_ = out["after_adam_" + name]
-            assert max(r_["sdf_mlp"], r_["hash_grid"]) < tol and max(r_["sdf_mlp_q9999"], r_["hash_grid_q9999"]) < tol_q, (name, r_)
+            assert max(r_["sdf_mlp"], r_["hash_grid"]) < tol and max(r_["sdf_mlp_q9999"], r_["hash_grid_q9999"]) < tol_q, (name, r_, D)
     finally:
         gpu.close()
         cpu.close()

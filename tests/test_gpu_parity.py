@@ -414,6 +414,11 @@ def test_large_batch_march_bit_exact(bigpair):
             c.generate_training_samples(n_rays, n_rays_total, max_samples)
         cc = _assert_samples_equal(gpu, cpu)
     assert cc[0] > 50000 and cc[3] <= 50000  # the last case overflowed max_samples: rays were dropped identically
+    total = min(int(cc[0]), B16)
+    for frac in (0.3, 0.8):  # the first dropped ray in the first / in the second 4096-ray tile of k_scan_rays_chain
+        for c in bigpair:
+            c.generate_training_samples(8192, 99, int(frac * total))
+        _assert_samples_equal(gpu, cpu)
 
 
 @pytest.mark.parametrize("narrow_thread_per_ray_only", [False, True])
