@@ -196,7 +196,7 @@ struct rnb_ctx {
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
-		bool march_write_split = true; // RNB_MARCH_WRITE_SPLIT=0: k_march_write of a march generated ahead as one launch (rounds 1-3). Split: what the first network evaluation reads (idx1, the heads'
+		int march_write_split = -1; // RNB_MARCH_WRITE_SPLIT=0|1: k_march_write of a march generated ahead as one launch (rounds 1-3) / always split; default: split below 65 536 rays per step. Split: what the first network evaluation reads (idx1, the heads'
 		                               // coordinates) in a first launch, whose completion the critical stream waits for; the rest (ray constants, ray records, the tails' coordinates) in a second one
 		                               // that runs beside that evaluation and is joined in front of the loss pass
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
@@ -691,7 +691,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (wait_before_write) HIP_TRY(hipStreamWaitEvent(s, wait_before_write, 0)); // (rnb_ctx::tail_pending)
-	c->gen_split = rest_done != nullptr && a.k1 != 0 && c->knobs.march_write_split;
+	c->gen_split = rest_done != nullptr && a.k1 != 0 && (c->knobs.march_write_split < 0 ? n_rays < 65536u : c->knobs.march_write_split != 0); // (measured: -2.7 / -3.5 us per step at 12.6 k / 50 k rays, +3.2 at 94 k: the join costs a barrier packet)
 	for (uint32_t part = c->gen_split ? 1u : 0u; part <= (c->gen_split ? 2u : 0u); ++part) {
 		a.part = part;
 		hipEvent_t ev = part == 2 ? rest_done : done;
@@ -1313,7 +1313,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
-		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
