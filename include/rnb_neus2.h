@@ -29,8 +29,9 @@ extern "C" {
 #endif
 
 /* 2 (round 4): RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS became staging views (see rnb_buffer); buffer ids 25, 26 and
- * rnb_bitfield_changed were added after 1 without a bump -- a binary built against 1 must not link silently. */
-#define RNB_ABI_VERSION 2
+ * rnb_bitfield_changed were added after 1 without a bump -- a binary built against 1 must not link silently.
+ * 3 (round 4): rnb_shard_layout fills up to RNB_MAX_SHARD_PARTS = 3 blocks (2: two) -- a caller's array must have room for them. */
+#define RNB_ABI_VERSION 3
 
 typedef enum rnb_status {
 	RNB_OK = 0,
@@ -348,12 +349,14 @@ int rnb_train_step_apply_early(rnb_ctx* ctx, void* stream);
  *     rnb_train_step_apply_shard(ctx, k, stream)                     Adam + EMA on the own chunk, the rest of the block's accumulators cleared
  *     all-gather      PARAMS_FP16[own_lo, own_hi) -> [lo, hi)        (in place)
  * then rnb_train_step_apply_done on a stream that has joined the blocks' streams (it replaces rnb_train_step_apply).
- * Blocks are world_size equal chunks of a multiple of 4 parameters; the last block ends at *capacity >= n_params, the
+ * Blocks, in the order they become final (MLPs + coarse and middle levels | first half of the fine levels | second half + variance: the exchange of each runs
+ * beside the scatter of the next), are world_size equal chunks of a multiple of 4 parameters; the last block ends at *capacity >= n_params, the
  * allocated (zero-padded) length of every parameter-shaped buffer of rnb_buffer. The fp32 masters / EMA / Adam state of a
  * rank are complete only on its own chunks: all-gather them over the same layout before reading them as a whole
  * (snapshots, inference with EMA weights). No reference counterpart (the reference is single-GPU). */
+#define RNB_MAX_SHARD_PARTS 3 /* ABI 3 (ABI 2: two blocks) */
 typedef struct rnb_shard_part { uint64_t lo, hi, own_lo, own_hi; } rnb_shard_part;
-int rnb_shard_layout(rnb_ctx* ctx, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity);
+int rnb_shard_layout(rnb_ctx* ctx, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity);
 int rnb_train_step_apply_shard(rnb_ctx* ctx, uint32_t part, void* stream);
 int rnb_train_step_apply_done(rnb_ctx* ctx, void* stream);
 

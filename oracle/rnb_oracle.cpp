@@ -1449,16 +1449,18 @@ void optimizer_step(orc_ctx_s* c) {
 	c->opt_begun = false;
 }
 
-// Blocks of the sharded data-parallel optimizer (rnb_shard_layout): the split sits in front of the four finest levels, as
-// in the HIP library's overlapped schedule, so that the two-block protocol is exercised.
-void shard_layout(const orc_ctx_s* c, rnb_shard_part parts[2], uint32_t* n_parts) {
+// Blocks of the sharded data-parallel optimizer (rnb_shard_layout): the splits sit in front of the four and of the two finest levels, as
+// in the HIP library's overlapped schedule for the default network, so that the three-block protocol is exercised.
+void shard_layout(const orc_ctx_s* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts) {
 	const uint64_t W = std::max(1u, c->cfg.world_size), r = c->cfg.rank, q = 4 * W;
 	const uint32_t L = c->cfg.n_levels;
-	const uint64_t split = L > 4 ? c->off_grid + (uint64_t)c->offsets[L - 4] * 2 : 0;
-	const uint64_t m0 = split / q * q;
+	const uint64_t split = L > 4 ? c->off_grid + (uint64_t)c->offsets[L - 4] * 2 : 0, mid = L > 4 ? c->off_grid + (uint64_t)c->offsets[L - 2] * 2 : 0;
+	const uint64_t m0 = split / q * q, m1 = std::max(m0, mid / q * q);
+	const bool three = m1 > m0 && m1 < c->param_capacity;
 	uint32_t n = 0;
 	if (m0) { parts[n].lo = 0; parts[n].hi = m0; ++n; }
-	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
+	if (three) { parts[n].lo = m0; parts[n].hi = m1; ++n; }
+	parts[n].lo = three ? m1 : m0; parts[n].hi = c->param_capacity; ++n;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint64_t chunk = (parts[k].hi - parts[k].lo) / W;
 		parts[k].own_lo = parts[k].lo + r * chunk;
@@ -2053,7 +2055,7 @@ int rnb_gradient_parts(orc_ctx_s* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
 	return RNB_OK;
 }
-int rnb_shard_layout(orc_ctx_s* c, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity) {
+int rnb_shard_layout(orc_ctx_s* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity) {
 	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
 	shard_layout(c, parts, n_parts);
 	*capacity = c->param_capacity;
@@ -2061,7 +2063,7 @@ int rnb_shard_layout(orc_ctx_s* c, rnb_shard_part parts[2], uint32_t* n_parts, u
 }
 int rnb_train_step_apply_shard(orc_ctx_s* c, uint32_t part, void*) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	rnb_shard_part parts[2];
+	rnb_shard_part parts[RNB_MAX_SHARD_PARTS];
 	uint32_t n = 0;
 	shard_layout(c, parts, &n);
 	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");

@@ -6,7 +6,7 @@ the identical signatures under its own prefix.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # status codes (rnb_status)
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NO_SAMPLES = 0, -1, -2, -3, -4
@@ -169,7 +169,7 @@ PROTOTYPES = {
     "gradient_parts": (_i, [_ctx, C.POINTER(_u64 * 2 * 3), C.POINTER(_u32)]),
     "gradient_part_wait": (_i, [_ctx, _u32, _stream]),
     "train_step_apply_early": (_i, [_ctx, _stream]),
-    "shard_layout": (_i, [_ctx, C.POINTER(_u64 * 4 * 2), C.POINTER(_u32), C.POINTER(_u64)]),
+    "shard_layout": (_i, [_ctx, C.POINTER(_u64 * 4 * 3), C.POINTER(_u32), C.POINTER(_u64)]),
     "train_step_apply_shard": (_i, [_ctx, _u32, _stream]),
     "train_step_apply_done": (_i, [_ctx, _stream]),
 }

@@ -267,7 +267,7 @@ class Context:
     def shard_layout(self):
         """([(lo, hi, own_lo, own_hi), ...], capacity): blocks of the sharded data-parallel optimizer in completion order
         (rnb_shard_layout); every parameter-shaped buffer is allocated up to `capacity` elements."""
-        arr = (C.c_uint64 * 4 * 2)()
+        arr = (C.c_uint64 * 4 * 3)()  # RNB_MAX_SHARD_PARTS
         n = C.c_uint32()
         cap = C.c_uint64()
         self._check(self.f.shard_layout(self._h, C.byref(arr), C.byref(n), C.byref(cap)))

@@ -238,7 +238,7 @@ struct rnb_ctx {
 	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
 	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
-	uint64_t dp_split = 0; // first parameter of the plain-quad levels: boundary of the two data-parallel gradient blocks
+	uint64_t dp_split = 0, dp_mid = 0; // first parameter of the plain-quad levels (group A) / of their second half (A2): boundaries of the data-parallel gradient blocks
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
@@ -996,6 +996,7 @@ static void plan_scatter_groups(rnb_ctx* c) {
 		g.l_fine = l + 1;
 	}
 	c->dp_split = c->off_grid + (uint64_t)c->grid.offsets[g.l_fine] * 2;
+	c->dp_mid = c->off_grid + (uint64_t)c->grid.offsets[g.l_fine + (L - g.l_fine + 1) / 2] * 2; // (a_mid of forward_backward)
 }
 
 // End of a step's parameter update: the LDS weight images of the next step's kernels, bookkeeping.
@@ -1014,13 +1015,16 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 
 // Blocks of the sharded data-parallel optimizer, in the order their gradients become final: each block is world_size equal
 // chunks (multiples of 4 parameters), chunk r belongs to rank r; the last block ends at param_capacity.
-static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_parts) {
+static void shard_layout(const rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts) {
 	const uint64_t W = std::max(1u, c->cfg.world_size), r = c->cfg.rank, q = 4 * W;
-	uint64_t m0 = 0;
 	uint32_t n = 0;
-	m0 = c->dp_split / q * q; // static: the ownership of a parameter must not move between steps
+	// static: the ownership of a parameter must not move between steps. Boundaries rounded DOWN: the parameters between a rounded boundary and the group's first
+	// one belong to the later block and were final earlier. Blocks: MLPs + groups C, B | first half of the fine levels (A1) | second half (A2) + variance (round 4:
+	// the exchange of A1 runs beside the scatter of A2; rounds 2-3 had A as one block of 16.8 MB behind the scatter)
+	const uint64_t m0 = c->dp_split / q * q, m1 = std::max(m0, c->dp_mid / q * q);
 	if (m0) { parts[n].lo = 0; parts[n].hi = m0; ++n; }
-	parts[n].lo = m0; parts[n].hi = c->param_capacity; ++n;
+	if (m1 > m0 && m1 < c->param_capacity) { parts[n].lo = m0; parts[n].hi = m1; ++n; }
+	parts[n].lo = (m1 > m0 && m1 < c->param_capacity) ? m1 : m0; parts[n].hi = c->param_capacity; ++n;
 	for (uint32_t k = 0; k < n; ++k) {
 		const uint64_t chunk = (parts[k].hi - parts[k].lo) / W;
 		parts[k].own_lo = parts[k].lo + r * chunk;
@@ -1094,7 +1098,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 // Sharded optimizer (data parallel): block `part` of shard_layout has been reduce-scattered by the caller; step this rank's
 // chunk and clear the rest of the block's accumulators (their sums live on the other ranks).
 int optimizer_step_shard(rnb_ctx* c, uint32_t part, hipStream_t st) {
-	rnb_shard_part parts[2];
+	rnb_shard_part parts[RNB_MAX_SHARD_PARTS];
 	uint32_t n = 0;
 	shard_layout(c, parts, &n);
 	if (part >= n) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_shard: no such block");
@@ -2046,10 +2050,12 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
-	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A: everything in front of A's levels is final first (ev_sc[0])
+	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A1, A2: everything in front of A's levels is final first (ev_sc[0]), then A1 (ev_sc[1])
+		const bool mid = c->sc.split_mid > c->sc.split[0] && c->sc.split_mid < c->off_var;
 		ranges[0][0] = 0;              ranges[0][1] = c->sc.split[0];
-		ranges[1][0] = c->sc.split[0]; ranges[1][1] = c->n_params;
-		*n_parts = 2;
+		ranges[1][0] = c->sc.split[0]; ranges[1][1] = mid ? c->sc.split_mid : c->n_params;
+		if (mid) { ranges[2][0] = c->sc.split_mid; ranges[2][1] = c->n_params; }
+		*n_parts = mid ? 3 : 2;
 	} else if (c->sc.valid && c->sc.split[1] < c->sc.split[0]) { // scatter order B, A, C: B's levels are final first (ev_sc[0])
 		ranges[0][0] = c->sc.split[1]; ranges[0][1] = c->sc.split[0];
 		ranges[1][0] = 0;              ranges[1][1] = c->sc.split[1];
@@ -2066,7 +2072,7 @@ int rnb_train_step_apply_early(rnb_ctx* c, void* stream) {
 	return optimizer_step_early(c, as_stream(stream));
 }
 
-int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[2], uint32_t* n_parts, uint64_t* capacity) {
+int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity) {
 	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true;
 	c->sc.sharded = true;
@@ -2091,14 +2097,20 @@ int rnb_train_step_apply_done(rnb_ctx* c, void* stream) {
 
 int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
-	// block 0 of the overlapped schedule has its own event; everything is final at the end of the backward pass
+	// blocks 0 (and, in the data-parallel order, 1 = the first half of the fine levels) of the overlapped schedule have their own events; everything is final at the
+	// end of the backward pass
 	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
+	bool mid = false;
+	if (part == 1 && c->sc.valid && c->sc.dp) { // is block 1 the middle one of three? (the same test as rnb_gradient_parts / shard_layout)
+		if (c->sc.sharded) { rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n = 0; shard_layout(c, parts, &n); mid = n == 3; }
+		else mid = c->sc.split_mid > c->sc.split[0] && c->sc.split_mid < c->off_var;
+	}
 	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // the weight-gradient GEMMs' side stream has not been joined
-	if (!early && !c->sc.all_final_recorded) { // only data-parallel callers pay for this marker
+	if (!early && !mid && !c->sc.all_final_recorded) { // only data-parallel callers pay for this marker
 		HIP_TRY(hipEventRecord(c->ev_all, c->backward_stream));
 		c->sc.all_final_recorded = true;
 	}
-	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : c->ev_all, 0));
+	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : mid ? c->ev_sc[1] : c->ev_all, 0));
 	if (early && c->sc.dp) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // block 0 holds the MLPs' gradients (side stream)
 	return RNB_OK;
 }

@@ -150,13 +150,16 @@ class DataParallelTrainer:
         if len(parts) > 1 and dist.get_backend() == "nccl":
             if self._early is None:
                 self._early = torch.cuda.Stream()
-            lo, hi = parts[0]
-            with torch.cuda.stream(self._early):
-                ctx.gradient_part_wait(0, self._early.cuda_stream)
-                dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
-                ctx.train_step_apply_early(self._early.cuda_stream)  # Adam on that block, beside the rest of the exchange
-            for lo, hi in parts[1:]:
-                dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+            with torch.cuda.stream(self._early):  # every block but the last as soon as its levels are final, beside the scatter of the levels behind it
+                for k, (lo, hi) in enumerate(parts[:-1]):
+                    ctx.gradient_part_wait(k, self._early.cuda_stream)
+                    dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+                    if k == 0:
+                        ctx.train_step_apply_early(self._early.cuda_stream)  # Adam on that block, beside the rest of the exchange
+            lo, hi = parts[-1]
+            dist.all_reduce(self._grads[lo:hi], op=dist.ReduceOp.SUM)
+            if len(parts) > 2:
+                (self.stream or torch.cuda.current_stream()).wait_stream(self._early)  # the middle block's sums: train_step_apply steps it on that stream
         else:
             dist.all_reduce(self._grads, op=dist.ReduceOp.SUM)
 
@@ -171,8 +174,8 @@ class DataParallelTrainer:
 
     def _sharded_apply(self, ctx):
         """Per gradient block, in completion order: reduce-scatter -> Adam + EMA on the own chunk -> all-gather of the fp16
-        training weights. The first block (everything in front of the finest levels) goes through this on a side stream while
-        the finest levels are still being scattered."""
+        training weights. Every block but the last (everything in front of the finest levels; then the first half of the finest
+        levels) goes through this on a side stream while the levels behind it are still being scattered."""
         parts = self._shard_setup(ctx)
         on_device = bool(getattr(self._shard, "on_device", False))
         early = None
@@ -182,11 +185,12 @@ class DataParallelTrainer:
                 self._early = torch.cuda.Stream()
             early = self._early
             with torch.cuda.stream(early):
-                ctx.gradient_part_wait(0, early.cuda_stream)
-                self._shard.reduce_scatter("GRADS_FP32", parts[0])
-                ctx.train_step_apply_shard(0, early.cuda_stream)
-                self._shard.all_gather("PARAMS_FP16", parts[0])
-            rest = range(1, len(parts))
+                for k in range(len(parts) - 1):
+                    ctx.gradient_part_wait(k, early.cuda_stream)
+                    self._shard.reduce_scatter("GRADS_FP32", parts[k])
+                    ctx.train_step_apply_shard(k, early.cuda_stream)
+                    self._shard.all_gather("PARAMS_FP16", parts[k])
+            rest = range(len(parts) - 1, len(parts))
         else:
             rest = range(len(parts))
         handle = _raw_stream(self.stream)

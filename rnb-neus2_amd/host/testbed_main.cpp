@@ -311,16 +311,18 @@ struct Dist {
 		// gradients: block by block in completion order; the optimizer runs even when the step had no samples
 		float* g = buffer<float>(ctx, RNB_BUF_GRADS_FP32);
 		if (sharded) {
-			rnb_shard_part parts[2]; uint32_t n_parts = 0; uint64_t capacity = 0;
+			rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n_parts = 0; uint64_t capacity = 0;
 			rc = rnb_shard_layout(ctx, parts, &n_parts, &capacity);
 			if (rc != RNB_OK) return rc;
 			uint16_t* w16 = buffer<uint16_t>(ctx, RNB_BUF_PARAMS_FP16);
 			uint32_t first = 0;
-			if (n_parts > 1) { // beside the scatter of the finest levels
-				rc = shard_block(ctx, parts[0], 0, g, w16, comm_early, s_early);
-				if (rc != RNB_OK) return rc;
+			if (n_parts > 1) { // every block but the last on the early stream, each as soon as its levels are final: beside the scatter of the levels behind it
+				for (uint32_t k = 0; k + 1 < n_parts; ++k) {
+					rc = shard_block(ctx, parts[k], k, g, w16, comm_early, s_early);
+					if (rc != RNB_OK) return rc;
+				}
 				if (hipEventRecord(ev_early, s_early) != hipSuccess) throw std::runtime_error("hipEventRecord failed");
-				first = 1;
+				first = n_parts - 1;
 			}
 			for (uint32_t k = first; k < n_parts; ++k) {
 				rc = shard_block(ctx, parts[k], k, g, w16, comm, s_main);
@@ -344,7 +346,13 @@ struct Dist {
 			nccl_ok(ncclAllReduce(g + ranges[0][0], g + ranges[0][0], ranges[0][1] - ranges[0][0], ncclFloat, ncclSum, comm_early, s_early), "ncclAllReduce (early block)");
 			rc = rnb_train_step_apply_early(ctx, s_early); // Adam on that block, beside the scatter of the finest levels and their exchange
 			if (rc != RNB_OK) return rc;
-			first = 1;
+			for (uint32_t k = 1; k + 1 < n_parts; ++k) { // the first half of the finest levels, beside the scatter of the second
+				rc = rnb_gradient_part_wait(ctx, k, s_early);
+				if (rc != RNB_OK) return rc;
+				nccl_ok(ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm_early, s_early), "ncclAllReduce (middle block)");
+			}
+			if (n_parts > 2 && (hipEventRecord(ev_early, s_early) != hipSuccess || hipStreamWaitEvent(s_main, ev_early, 0) != hipSuccess)) throw std::runtime_error("early stream join failed");
+			first = n_parts - 1;
 		}
 		for (uint32_t k = first; k < n_parts; ++k) {
 			rc = rnb_gradient_part_wait(ctx, k, s_main);
@@ -363,7 +371,7 @@ struct Dist {
 	void sync_parameters(rnb_ctx* ctx) {
 #ifdef RNB_WITH_RCCL
 		if (!on || !sharded || synced) return;
-		rnb_shard_part parts[2]; uint32_t n_parts = 0; uint64_t capacity = 0;
+		rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n_parts = 0; uint64_t capacity = 0;
 		if (rnb_shard_layout(ctx, parts, &n_parts, &capacity) != RNB_OK) throw std::runtime_error(rnb_last_error());
 		if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
 		const struct { int id; ncclDataType_t type; size_t size; } bufs[] = {{RNB_BUF_PARAMS_FP32, ncclFloat, 4}, {RNB_BUF_PARAMS_EMA, ncclHalf, 2}, {RNB_BUF_ADAM_M, ncclFloat, 4},

@@ -202,7 +202,8 @@ def test_two_rank_sharded_optimizer_equals_replicated():
         assert pa[0] == pb[0] and pa[1] == pb[1]
         assert pa[2] == pa[0] and pa[3] == pb[2] and pb[3] == pb[1] and (pa[3] - pa[2]) == (pb[3] - pb[2]) and (pa[3] - pa[2]) % 4 == 0
     assert res[0]["parts"][0][0] == 0 and res[0]["parts"][-1][1] == res[0]["capacity"]
-    assert len(res[0]["parts"]) == 2 and res[0]["parts"][0][1] == res[0]["parts"][1][0]
+    p = res[0]["parts"]  # MLPs + coarse and middle levels | first half of the fine levels | second half + variance
+    assert len(p) == 3 and p[0][1] == p[1][0] and p[1][1] == p[2][0]
 
 
 @pytest.mark.timeout(600)

@@ -262,7 +262,8 @@ def test_sharded_optimizer_two_emulated_ranks(scene, trained):
             for c in group:
                 c.train_step_finish(loc[0][0] + loc[1][0], loc[0][1] + loc[1][1])
         n = rep[0].n_params
-        assert rep[0].gradient_parts() == rep[1].gradient_parts() and len(rep[0].gradient_parts()) == 2  # data-parallel scatter order: two blocks
+        assert rep[0].gradient_parts() == rep[1].gradient_parts() and len(rep[0].gradient_parts()) == 3  # data-parallel scatter order C, B | A1 | A2: three blocks
+        gp = rep[0].gradient_parts()
         g = rep[0].get("GRADS_FP32") + rep[1].get("GRADS_FP32")  # the all-reduce
         for c in rep:
             c.put("GRADS_FP32", g)
@@ -272,8 +273,10 @@ def test_sharded_optimizer_two_emulated_ranks(scene, trained):
         before = {name: sh[0].get(name).copy() for name in ("PARAMS_FP32", "ADAM_STEPS")}
         layouts = [c.shard_layout() for c in sh]
         (p0, cap0), (p1, cap1) = layouts
-        assert cap0 == cap1 >= n and cap0 % 8 == 0 and len(p0) == len(p1) == 2
-        assert p0[0][0] == 0 and p0[0][1] == p0[1][0] and p0[1][1] == cap0
+        assert cap0 == cap1 >= n and cap0 % 8 == 0 and len(p0) == len(p1) == 3
+        assert p0[0][0] == 0 and p0[0][1] == p0[1][0] and p0[1][1] == p0[2][0] and p0[2][1] == cap0
+        # a shard block ends at or (rounded to the chunking) just in front of the gradient block's end
+        assert all(0 <= gp[k][1] - p0[k][1] < 8 for k in range(2)), (gp, p0)
         for a, b in zip(p0, p1):
             assert a[:2] == b[:2] and a[2] == a[0] and a[3] == b[2] and b[3] == b[1] and (a[3] - a[2]) == (b[3] - b[2]) and (a[3] - a[2]) % 4 == 0
         own = []
