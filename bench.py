@@ -14,11 +14,16 @@ compacted samples per rank and step; --strong: the single-GPU step divided over 
 `strong_scaling` / `weak_scaling`, measured in the same job.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 # more hardware queues than HIP's default 4: the library's side streams, torch's and RCCL's must not be multiplexed onto the
@@ -81,7 +86,70 @@ def parse(argv=None):
     ap.add_argument("--fixed-cost-steps", type=int, default=400)
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the HBM counters of `roofline.traffic` in this run (child processes under rocprofv3 --pmc); the record "
+                    "then carries the committed summary's value and says so")
+    ap.add_argument("--live-pmc-steps", type=int, default=10, help="steps each of those counter passes averages over")
     return ap.parse_args(argv)
+
+
+# kernels of a bench kernel group (substring of the kernel name as rocprofv3 prints it, mangled or not)
+PMC_GROUPS = {"k_forward": ("k_forward_chained",), "k_fwd_bwd": ("k_fwd_bwd", "k_rgb_fwd_bwd"), "k_grid_scatter": ("k_grid_scatter",), "k_adam_ema": ("k_adam_ema",),
+              "k_march_count": ("k_march_count",), "k_march_write": ("k_march_write",), "k_point_query": ("k_point_query",), "k_loss_pass1": ("k_loss_pass1",),
+              "k_loss_pass2+k_rollover": ("k_loss_pass2",), "k_dw*7+k_dw_finish": ("k_dw_",)}
+
+
+def live_pmc(args, first_step, counters=("FETCH_SIZE", "WRITE_SIZE", "TCC_ATOMIC_sum"), timeout_s=240):
+    """HBM bytes per step and kernel group, measured NOW: one child process of this script per counter under `rocprofv3 --pmc <counter> --kernel-trace`
+    (separate passes, as MI355X_MICROARCH.md prescribes for the HBM counters; kernels serialised with cfg.overlap = 0 so that a group is one launch per step),
+    trained to `first_step` like this run and averaged over the --live-pmc-steps steps from there. Conversions as in tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE
+    count KiB; FETCH_SIZE is NOT doubled (the guide's x2 for gfx950 is calibrated on wide coalesced streams; gathers and atomics are uncalibrated -- stated in the record).
+    Returns (per_step dict or None, note)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    n = max(1, args.live_pmc_steps)
+    burn = max(0, first_step - 2)
+    per_step, t0 = {}, time.perf_counter()
+    for counter in counters:
+        d = tempfile.mkdtemp(prefix="rnb_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", str(n), "--warmup", "2",
+               "--burn-in", str(burn), "--profile-steps", "0", "--no-cpu-baseline", "--window-end", "0", "--late-step", "0", "--fixed-cost-steps", "0", "--no-live-pmc",
+               "--views", str(args.views), "--res", str(args.res), "--batch-log2", str(args.batch_log2)] + (["--albedo"] if args.albedo else []) + (["--focal", str(args.focal)] if args.focal else [])
+        env = dict(os.environ, RNB_OVERLAP_OFF="1", TMPDIR="/tmp")
+        try:
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)  # the exact process group started here
+                proc.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return None, "rocprofv3 --pmc %s did not finish within %d s" % (counter, timeout_s)
+            rows = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == counter:
+                            rows.append((int(r.get("Dispatch_Id", 0)), r["Kernel_Name"], float(r["Counter_Value"])))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        rows.sort()
+        starts = [r[0] for r in rows if "k_march_count" in r[1]]  # serialised: every step begins with its march (an update step: a few kernels earlier)
+        if rc != 0 or len(starts) < n:
+            return None, "rocprofv3 --pmc %s: exit code %d, %d steps seen" % (counter, rc, len(starts))
+        lo = starts[-n]
+        for g, names in PMC_GROUPS.items():
+            v = sum(x for i, k, x in rows if i >= lo and any(s in k for s in names)) / n
+            e = per_step.setdefault(g, {"fetch_bytes": 0, "write_bytes": 0, "atomic_lines": 0})
+            if counter == "FETCH_SIZE":
+                e["fetch_bytes"] = round(v * 1024)
+            elif counter == "WRITE_SIZE":
+                e["write_bytes"] = round(v * 1024)
+            else:
+                e["atomic_lines"] = round(v)
+    for e in per_step.values():
+        e["total_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+    return per_step, "this run: %d child passes under rocprofv3 --pmc (%s), kernels serialised, steps %d-%d, %.0f s" % (len(counters), ", ".join(counters), burn + 2, burn + 2 + n, time.perf_counter() - t0)
 
 
 def _free_port():
@@ -232,6 +300,7 @@ def main(argv=None, engine=None):
     # same kernels strictly one after the other.
     prof = []
     tail = last
+    prof_first_step = int(ctx.training_step)
     if args.profile_steps > 0:
         ctx.profile_enable(True)
         for _ in range(args.profile_steps):
@@ -302,6 +371,8 @@ def main(argv=None, engine=None):
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays / elapsed
+        # the HBM counters of the record's rooflines, collected now and in the regime of the per-kernel pass above (child processes; this process's contexts are idle)
+        live, live_note = (None, "--no-live-pmc") if (args.no_live_pmc or world != 1 or engine.name != "hip" or not prof) else live_pmc(args, prof_first_step)
 
         def pmc_file(name):
             p = os.path.join(ROOT, "profiles", name)
@@ -319,13 +390,18 @@ def main(argv=None, engine=None):
             # HBM bytes per launch: NOT measured in this process (a PMC pass cannot run inside it) but read from the committed summary of
             # separate rocprofv3 --pmc passes over the same command (tools/collect_pmc.sh); `traffic_source` says so in the record
             traffic, traffic_source = None, None
-            try:
-                path, fname = pmc_file(PMC_TRAFFIC)
-                with open(path) as f:
-                    traffic = json.load(f)["per_step"][kname]["total_bytes"] / max(p["launches"] / max(args.profile_steps, 1), 1.0)
-                traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run" % fname
-            except Exception:
-                pass
+            launches_per_step = max(p["launches"] / max(args.profile_steps, 1), 1.0)
+            if live is not None and kname in live:
+                traffic = live[kname]["total_bytes"] / launches_per_step
+                traffic_source = live_note + "; FETCH_SIZE + WRITE_SIZE in KiB x 1024, FETCH_SIZE not doubled (the guide's gfx950 x2 is calibrated on wide coalesced streams; gathers / atomics uncalibrated)"
+            else:
+                try:
+                    path, fname = pmc_file(PMC_TRAFFIC)
+                    with open(path) as f:
+                        traffic = json.load(f)["per_step"][kname]["total_bytes"] / launches_per_step
+                    traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run (%s)" % (fname, live_note)
+                except Exception:
+                    pass
             limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py); also from a committed file
             try:
                 path, fname = pmc_file(PMC_UNITS)
@@ -334,11 +410,14 @@ def main(argv=None, engine=None):
                 if kname == "k_grid_scatter":
                     parts = [units["kernels"][k] for k in units["kernels"] if k.startswith("k_grid_scatter")]
                     req = sum(q.get("l2_atomic_requests", 0) for q in parts)
+                    src = "per_launch: committed file profiles/%s (TCC_ATOMIC_sum pass at steps 2000-2010, builder-run; the duration is this run's, whose regime may put more lines on the path)" % fname
+                    if live is not None and live.get(kname, {}).get("atomic_lines"):
+                        req = live[kname]["atomic_lines"]  # all launches of the group in one step = one `launch` of the group in the serialised pass
+                        src = "per_launch: " + live_note
                     limiter = {"unit": "L2 atomic lines (one 64-byte line of one instruction)", "per_launch": req, "achieved_per_s": round(req / (avg_ms * 1e-3)),
                                "probe_rate_per_s": units["_atomic_probe_requests_per_s"],
                                "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3),
-                               "limiter_source": "per_launch: committed file profiles/%s (TCC_ATOMIC_sum pass at steps 2000-2010, builder-run; the duration is this run's, whose "
-                                                 "regime may put more lines on the path); probe rate: tools/probe_atomics4.hip" % fname}
+                               "limiter_source": src + "; probe rate: tools/probe_atomics4.hip"}
             except Exception:
                 pass
             if limiter is None and kname in LIMITER_NOTES:
@@ -379,6 +458,7 @@ def main(argv=None, engine=None):
             "late_regime": late,
             "fixed_cost": fixed,
             "roofline": roofline,
+            "pmc_live": {"note": live_note, "bytes_and_atomic_lines_per_step": live},
             "rooflines_next": rooflines_next,
             "kernels_ms_per_step": kernels,
             "profiles": PROFILE_FILES,

@@ -7,7 +7,15 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
 F = json.load(open(d + "/FETCH_SIZE.json"))["kernels"]
 W = json.load(open(d + "/WRITE_SIZE.json"))["kernels"]
 fb = [k for k in F if k.startswith("k_fwd_bwd")]
-steps = sum(F[k]["launches"] for k in fb)  # one k_fwd_bwd* launch per step
+steps_total = sum(F[k]["launches_total"] for k in fb)  # one k_fwd_bwd* launch per step
+
+
+def per_step(T, ks):
+    # average of the kernel's last launches x its launches per step (k_forward_chained runs twice a step; rounds 2-3 divided the sum over the last 100 launches of
+    # every kernel by 100 steps, which halved the two-launch kernels)
+    return sum(T[k]["avg"] * T[k]["launches_total"] / steps_total for k in ks if k in T) * 1024
+
+
 groups = {"k_forward": ["k_forward_chained"], "k_fwd_bwd": fb, "k_grid_scatter": ["k_grid_scatter_quad_rl", "k_grid_scatter_quad", "k_grid_scatter_lds"],
           "k_adam_ema": ["k_adam_ema"], "k_dw*7+k_dw_finish": [k for k in F if "k_dw" in k], "k_loss_pass1": ["k_loss_pass1", "k_loss_pass1_heads"],
           "k_loss_pass2+k_rollover": ["k_loss_pass2"], "k_march_count": [k for k in F if k.startswith("k_march_count")], "k_march_write": [k for k in F if k.startswith("k_march_write")],
@@ -16,8 +24,7 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
        "_units": "bytes per training step (counter value in KiB x 1024). FETCH_SIZE is NOT doubled: the x2 gfx950 correction of the guide is calibrated for wide coalesced streams only; on k_adam_ema (a 16 B/lane stream) the doubled value matches the expected 8 B + 16 B x live fraction per parameter. Gathers / atomics are uncalibrated.",
        "per_step": {}}
 for g, ks in groups.items():
-    f = sum(F.get(k, {"avg": 0, "launches": 0})["avg"] * F.get(k, {"launches": 0})["launches"] for k in ks) / steps * 1024
-    w = sum(W.get(k, {"avg": 0, "launches": 0})["avg"] * W.get(k, {"launches": 0})["launches"] for k in ks) / steps * 1024
+    f, w = per_step(F, ks), per_step(W, ks)
     out["per_step"][g] = {"fetch_bytes": round(f), "write_bytes": round(w), "total_bytes": round(f + w)}
 json.dump(out, open(out_path, "w"), indent=1)
 print({g: round(v["total_bytes"] / 1e6, 1) for g, v in out["per_step"].items()})
