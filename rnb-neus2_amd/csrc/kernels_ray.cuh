@@ -1097,7 +1097,11 @@ struct LossArgs {
 	uint32_t* unfinished;  // [n_rays] list of the rays round 1 left unsettled (count in fwd_counts[3])
 	uint32_t* idx2;        // sample slots still to evaluate (round 2)
 	uint32_t* fwd_counts;  // [0] = samples of round 1; 8-byte pair [2] = entries of idx2, [3] = entries of `unfinished`
+	// chain records (round 4): pass 1 leaves the running values right after every sample it composites -- {weight, T, weight sum, rgb[0]} (+ {rgb[1..3], -} with albedo) at
+	// CHAIN_REC_FLOATS floats per marched-sample slot -- and pass 2 reads them instead of replaying the recurrence (the same function on the same inputs: same bits)
+	float* chain_rec;      // null: pass 2 replays
 };
+constexpr uint32_t CHAIN_REC_FLOATS = 8;
 
 __device__ __forceinline__ void albedo_from_output(const LossFlags& F, const half_t* __restrict__ o, float albedo[4]) { // testbed_nerf.cu:1614-1639
 	if (F.apply_no_albedo) { albedo[0] = albedo[1] = albedo[2] = 1.f; albedo[3] = 0.f; return; }
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 // of the first such sample. Returns true if the ray terminated inside these samples.
 template <bool NO_ALBEDO, int LR>
 __device__ __forceinline__ bool composite_replay(const int cnt, const int lane, const int lane64, const float alpha, const float shading, const float (&albedo)[4],
-                                                 float& T, float (&rgb)[4], float& weight_sum, uint32_t& n) {
+                                                 float& T, float (&rgb)[4], float& weight_sum, uint32_t& n, float* __restrict__ rec = nullptr) {
 	const ChainState s = replay_chain<NO_ALBEDO, LR>(cnt, alpha, shading, albedo, 0.f, T, weight_sum, rgb, 0.f);
 	// the transmittance the loop tests before it takes sample `lane`: the lane in front's (wave_shr:1 / row_shr:1), lane 0 keeps the incoming one
 	const float T_before = LR == 64 ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x138, 0xf, 0xf, false))
@@ -1316,6 +1320,11 @@ __device__ __forceinline__ bool composite_replay(const int cnt, const int lane, 
 	if (LR != 64) stop = (stop >> (lane64 & ~(LR - 1))) & ((1ull << LR) - 1ull); // my group's lanes
 	const int taken = stop ? (int)__builtin_ctzll(stop) : cnt; // samples composited here
 	n += (uint32_t)taken;
+	if (rec && lane < taken) { // the chain records of the samples this ray keeps (rec: the chunk's first record)
+		f4* q = reinterpret_cast<f4*>(rec + (size_t)lane * CHAIN_REC_FLOATS);
+		q[0] = f4{s.w, s.T, s.ws, s.rgb[0]};
+		if (!NO_ALBEDO) q[1] = f4{s.rgb[1], s.rgb[2], s.rgb[3], 0.f};
+	}
 	const int last = max(taken - 1, 0);
 	const float T1 = group_read<LR>(s.T, last, lane64), w1 = group_read<LR>(s.ws, last, lane64), r0 = group_read<LR>(s.rgb[0], last, lane64);
 	if (taken > 0) { T = T1; weight_sum = w1; rgb[0] = r0; }
@@ -1377,8 +1386,9 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		}
 		const int cnt = act ? (int)min((uint32_t)LR, numsteps - c0) : 0;
-		const bool stopped = a.F.apply_no_albedo ? composite_replay<true, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n)
-		                                         : composite_replay<false, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n);
+		float* rec = a.chain_rec ? a.chain_rec + ((size_t)base + c0) * CHAIN_REC_FLOATS : nullptr;
+		const bool stopped = a.F.apply_no_albedo ? composite_replay<true, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec)
+		                                         : composite_replay<false, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec);
 		done = done || stopped;
 	}
 	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
@@ -1505,7 +1515,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_compact_offsets(const uint32_t
 // sequential loop are replayed from broadcasts and captured by the lane that owns each sample.
 // LR lanes per ray (64: one wavefront per ray; 16: four rays per wavefront for batches of many short rays -- the per-ray part
 // of this kernel, ~200 instructions, then runs once for four rays). Every lane of the wavefront stays active (chain.cuh).
-template <int LR>
+template <int LR, bool REC>
 __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
 	const int lane = threadIdx.x & (LR - 1), lane64 = threadIdx.x & 63;
@@ -1600,17 +1610,32 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 		const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
 		// the sequential recurrences (chain.cuh): lane q ends with its own weight and the running values right after sample q
 		const int cnt = c0 < compacted_numsteps ? (int)min((uint32_t)LR, compacted_numsteps - c0) : 0;
-		const ChainState cs = F.apply_no_albedo ? replay_chain<true, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
-		                                        : replay_chain<false, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
+		ChainState cs;
+		if (REC) { // pass 1 left the running values of every sample it kept; only the eikonal sum (not formed there) is chained here
+			cs.w = cs.T = cs.ws = 0.f; cs.rgb[0] = cs.rgb[1] = cs.rgb[2] = cs.rgb[3] = 0.f;
+			if (valid) {
+				const f4* q = reinterpret_cast<const f4*>(a.chain_rec + ((size_t)base + j) * CHAIN_REC_FLOATS);
+				const f4 r0 = q[0];
+				cs.w = r0[0]; cs.T = r0[1]; cs.ws = r0[2]; cs.rgb[0] = r0[3];
+				if (!F.apply_no_albedo) { const f4 r1 = q[1]; cs.rgb[1] = r1[0]; cs.rgb[2] = r1[1]; cs.rgb[3] = r1[2]; }
+			}
+			cs.ek = replay_ek<LR>(cnt, ekterm, ek);
+		} else
+			cs = F.apply_no_albedo ? replay_chain<true, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
+			                       : replay_chain<false, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
 		const float my_weight = cs.w, my_T = cs.T, my_w2 = cs.ws;
 		float my_rgb2[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
 		if (F.apply_no_albedo) { my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3]; } // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
 		{ // the running values after the chunk's last sample (a ray that is through keeps its own)
 			const int last = max(cnt - 1, 0);
-			const float T1 = group_read<LR>(cs.T, last, lane64), w1 = group_read<LR>(cs.ws, last, lane64), e1 = group_read<LR>(cs.ek, last, lane64);
-			if (cnt > 0) { T = T1; weight_sum2 = w1; ek = e1; }
+			const float e1 = group_read<LR>(cs.ek, last, lane64);
+			if (cnt > 0) ek = e1;
+			if (!REC) {
+				const float T1 = group_read<LR>(cs.T, last, lane64), w1 = group_read<LR>(cs.ws, last, lane64);
+				if (cnt > 0) { T = T1; weight_sum2 = w1; }
 #pragma unroll
-			for (int k = 0; k < 4; ++k) { const float rk = group_read<LR>(my_rgb2[k], last, lane64); if (cnt > 0) rgb_ray2[k] = rk; }
+				for (int k = 0; k < 4; ++k) { const float rk = group_read<LR>(my_rgb2[k], last, lane64); if (cnt > 0) rgb_ray2[k] = rk; }
+			}
 		}
 		if (valid) {
 			const float alpha = at.alpha;
@@ -1635,10 +1660,15 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 #pragma unroll
 			for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
 			const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+			if (F.apply_no_albedo) { // 0 x loss_scale x (drgb x a factor in [0, 1/4]): a zero with the sign of drgb (round 4: three exp and three divisions per sample for it before)
 #pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				const float sg = logistic(h2f(o[d]));
-				dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+				for (int d = 0; d < 3; ++d) dl[d] = f2h(copysignf(0.f, drgb[d]));
+			} else {
+#pragma unroll
+				for (int d = 0; d < 3; ++d) {
+					const float sg = logistic(h2f(o[d]));
+					dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+				}
 			}
 			const float sum_weight_suffix = weight_sum - my_w2;
 			float dot_term = 0.f;

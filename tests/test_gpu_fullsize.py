@@ -883,14 +883,18 @@ def test_overlapped_backward_equals_serial(scene, trained, albedo):
     assert not bad, bad[:10]
 
 
-def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, trained):
+@pytest.mark.parametrize("albedo", [False, True])
+def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, trained, albedo):
     """From 18 432 rays per step on the loss passes give a ray 16 lanes (four rays per wavefront, the recurrence through row_shr:1);
     forced back to one wavefront per ray (RNB_LOSS_WAVE_PER_RAY) the same 40 000-ray step yields the same bits everywhere:
-    compaction, dL/d(output), per-ray losses. Both through the two-round evaluation of a whole training step."""
+    compaction, dL/d(output), per-ray losses. Both through the two-round evaluation of a whole training step. Round 4: pass 2 reads the
+    running values of the recurrence that pass 1 left per sample (chain records) instead of replaying it; with RNB_LOSS_CHAIN_RECORDS=0 it
+    replays as in rounds 1-3 -- the same bits again, in both lane forms, --no-albedo and albedo mode."""
     _, state = trained
     out = []
-    for env in (None, {"RNB_LOSS_WAVE_PER_RAY": "1"}):
-        c = _clone(scene, state, env=env, overlap=0)
+    kw = dict(apply_no_albedo=0) if albedo else {}
+    for env in (None, {"RNB_LOSS_WAVE_PER_RAY": "1"}, {"RNB_LOSS_CHAIN_RECORDS": "0"}, {"RNB_LOSS_CHAIN_RECORDS": "0", "RNB_LOSS_WAVE_PER_RAY": "1"}):
+        c = _clone(scene, state, env=env, overlap=0, **kw)
         try:
             c.set_controller(state["step"] | 1, 40000, state["before"], 0)
             st = c.train_step()
@@ -898,11 +902,13 @@ def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, traine
             out.append((st, {name: c.get(name, count).copy() for name, count in (("NUMSTEPS", 2 * n), ("COORDS_COMPACTED", None), ("DLOSS_DOUT", None), ("LOSS", n), ("EK_LOSS", n), ("MASK_LOSS", n))}))
         finally:
             c.close()
-    (s1, a), (s2, b) = out
-    assert s1.rays_per_batch == 40000 and s1.n_rays_kept == s2.n_rays_kept and s1.measured_batch_size == s2.measured_batch_size
-    assert s1.loss == s2.loss and s1.ek_loss == s2.ek_loss and s1.mask_loss == s2.mask_loss
-    for name in a:
-        assert np.array_equal(a[name].view(np.uint8), b[name].view(np.uint8)), name
+    (s1, a) = out[0]
+    assert s1.rays_per_batch == 40000 and s1.measured_batch_size > 100000
+    for s2, b in out[1:]:
+        assert s1.n_rays_kept == s2.n_rays_kept and s1.measured_batch_size == s2.measured_batch_size
+        assert s1.loss == s2.loss and s1.ek_loss == s2.ek_loss and s1.mask_loss == s2.mask_loss
+        for name in a:
+            assert np.array_equal(a[name].view(np.uint8), b[name].view(np.uint8)), name
 
 
 def test_dpp_chain_matches_the_sequential_loop(tmp_path):
