@@ -97,20 +97,4 @@ __device__ __forceinline__ ChainState replay_chain(const int cnt_any_lane, const
 	return s;
 }
 
-// The eikonal sum alone (pass 2 with the chain records of pass 1, k_loss_pass2<LR, true>): ek_q = ek_(q-1) + ekterm_q in the same order and with the same
-// masking scheme as above, one DPP add per sample. The add reads the register the previous add wrote: two wait states in front of each (s_nop 1).
-#define RNB_CHAINE_STEP(SH, RM, BM) "s_nop 1\n\t" "v_add_f32_dpp %[ek], %[ek], %[ekt] " SH " row_mask:" RM " bank_mask:" BM "\n\t"
-#define RNB_CHAINE_GROUP(SH, RM, BM) \
-	asm volatile(RNB_CHAINE_STEP(SH, RM, BM) RNB_CHAINE_STEP(SH, RM, BM) RNB_CHAINE_STEP(SH, RM, BM) RNB_CHAINE_STEP(SH, RM, BM) : [ek] "+v"(ek) : [ekt] "v"(ekterm))
-template <int LR = 64>
-__device__ __forceinline__ float replay_ek(const int cnt_any_lane, const float ekterm, const float ek_in) {
-	static_assert(LR == 64 || LR == 16, "lanes per ray");
-	int cnt_all = cnt_any_lane;
-	if (LR == 16) { cnt_all = max(cnt_all, __shfl_xor(cnt_all, 16, 64)); cnt_all = max(cnt_all, __shfl_xor(cnt_all, 32, 64)); }
-	const int cnt = __builtin_amdgcn_readfirstlane(cnt_all);
-	float ek = ek_in + ekterm;
-	if (LR == 64) { RNB_CHAIN_GROUPS(RNB_CHAINE_GROUP) } else { RNB_CHAIN_GROUPS_ROW(RNB_CHAINE_GROUP) }
-	return ek;
-}
-
 } // namespace rnb

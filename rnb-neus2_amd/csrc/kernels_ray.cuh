@@ -1064,6 +1064,7 @@ struct RayLoss { // pass 1 -> pass 2
 	float rgb_ray[4];
 	float weight_sum_raw;
 	float T_resume; // transmittance after the samples pass 1 has consumed (two-round evaluation: phase 1 continues from it)
+	float ek_resume; // the eikonal sum over those samples (formed in pass 1 when it leaves chain records)
 	float rgbtarget[4];
 	float light[3];
 	float dir[3];
@@ -1097,9 +1098,12 @@ struct LossArgs {
 	uint32_t* unfinished;  // [n_rays] list of the rays round 1 left unsettled (count in fwd_counts[3])
 	uint32_t* idx2;        // sample slots still to evaluate (round 2)
 	uint32_t* fwd_counts;  // [0] = samples of round 1; 8-byte pair [2] = entries of idx2, [3] = entries of `unfinished`
-	// chain records (round 4): pass 1 leaves the running values right after every sample it composites -- {weight, T, weight sum, rgb[0]} (+ {rgb[1..3], -} with albedo) at
+	// chain records (round 4): pass 1 leaves the running values right after every sample it composites -- {weight, T, weight sum, rgb[0]}, {rgb[1..3], eikonal sum} at
 	// CHAIN_REC_FLOATS floats per marched-sample slot -- and pass 2 reads them instead of replaying the recurrence (the same function on the same inputs: same bits)
 	float* chain_rec;      // null: pass 2 replays
+	// pass 2 in two launches for batches of many short rays (k_loss_pass2_rays + k_loss_pass2_samples): per kept ray 16 floats, per compacted sample its ray and its marched slot
+	float* ray_grad;
+	uint32_t *ray_of, *slot_of;
 };
 constexpr uint32_t CHAIN_REC_FLOATS = 8;
 
@@ -1311,8 +1315,8 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 // of the first such sample. Returns true if the ray terminated inside these samples.
 template <bool NO_ALBEDO, int LR>
 __device__ __forceinline__ bool composite_replay(const int cnt, const int lane, const int lane64, const float alpha, const float shading, const float (&albedo)[4],
-                                                 float& T, float (&rgb)[4], float& weight_sum, uint32_t& n, float* __restrict__ rec = nullptr) {
-	const ChainState s = replay_chain<NO_ALBEDO, LR>(cnt, alpha, shading, albedo, 0.f, T, weight_sum, rgb, 0.f);
+                                                 float& T, float (&rgb)[4], float& weight_sum, uint32_t& n, float* __restrict__ rec, const float ekterm, float& ek) {
+	const ChainState s = replay_chain<NO_ALBEDO, LR>(cnt, alpha, shading, albedo, ekterm, T, weight_sum, rgb, ek);
 	// the transmittance the loop tests before it takes sample `lane`: the lane in front's (wave_shr:1 / row_shr:1), lane 0 keeps the incoming one
 	const float T_before = LR == 64 ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x138, 0xf, 0xf, false))
 	                                : __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(s.T), 0x111, 0xf, 0xf, false));
@@ -1323,11 +1327,12 @@ __device__ __forceinline__ bool composite_replay(const int cnt, const int lane, 
 	if (rec && lane < taken) { // the chain records of the samples this ray keeps (rec: the chunk's first record)
 		f4* q = reinterpret_cast<f4*>(rec + (size_t)lane * CHAIN_REC_FLOATS);
 		q[0] = f4{s.w, s.T, s.ws, s.rgb[0]};
-		if (!NO_ALBEDO) q[1] = f4{s.rgb[1], s.rgb[2], s.rgb[3], 0.f};
+		q[1] = f4{s.rgb[1], s.rgb[2], s.rgb[3], s.ek};
 	}
 	const int last = max(taken - 1, 0);
 	const float T1 = group_read<LR>(s.T, last, lane64), w1 = group_read<LR>(s.ws, last, lane64), r0 = group_read<LR>(s.rgb[0], last, lane64);
 	if (taken > 0) { T = T1; weight_sum = w1; rgb[0] = r0; }
+	if (rec) { const float e1 = group_read<LR>(s.ek, last, lane64); if (taken > 0) ek = e1; } // (uniform: every ray of the launch has records or none has)
 	if (!NO_ALBEDO) {
 #pragma unroll
 		for (int k = 1; k < 4; ++k) { const float rk = group_read<LR>(s.rgb[k], last, lane64); if (taken > 0) rgb[k] = rk; }
@@ -1364,9 +1369,10 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 	uint32_t n = 0;
 	bool done = false;
 	uint32_t c_begin = 0;
+	float ek_run = 0.f; // the eikonal sum of pass 2 (testbed_nerf.cu:1902-1904), formed here in the same order when chain records are left
 	if (a.phase == 1) { // continue where phase 0 stopped (it consumed exactly `cap` samples without terminating)
 		const RayLoss P = a.ray_loss[valid ? i : 0u];
-		T = P.T_resume; weight_sum = P.weight_sum_raw; n = P.n_comp; c_begin = a.cap;
+		T = P.T_resume; weight_sum = P.weight_sum_raw; n = P.n_comp; c_begin = a.cap; ek_run = P.ek_resume;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rgb_ray[k] = P.rgb_ray[k];
 	}
@@ -1374,7 +1380,7 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 		const bool act = c0 < numsteps && !done; // this ray still has samples to composite (LR = 64: the same for the whole wavefront)
 		if (!__any(act)) break;
 		const uint32_t j = c0 + lane;
-		float alpha = 0.f, shading = 0.f, albedo[4] = {1.f, 1.f, 1.f, 0.f};
+		float alpha = 0.f, shading = 0.f, albedo[4] = {1.f, 1.f, 1.f, 0.f}, ekterm = 0.f;
 		if (act && j < numsteps) {
 			half_t o[16];
 			load_out16(net + (size_t)j * 16, o);
@@ -1384,11 +1390,15 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 			alpha = at.alpha;
 			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+			if (a.chain_rec) {
+				const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
+				ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
+			}
 		}
 		const int cnt = act ? (int)min((uint32_t)LR, numsteps - c0) : 0;
 		float* rec = a.chain_rec ? a.chain_rec + ((size_t)base + c0) * CHAIN_REC_FLOATS : nullptr;
-		const bool stopped = a.F.apply_no_albedo ? composite_replay<true, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec)
-		                                         : composite_replay<false, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec);
+		const bool stopped = a.F.apply_no_albedo ? composite_replay<true, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec, ekterm, ek_run)
+		                                         : composite_replay<false, LR>(cnt, lane, lane64, alpha, shading, albedo, T, rgb_ray, weight_sum, n, rec, ekterm, ek_run);
 		done = done || stopped;
 	}
 	if (a.F.apply_no_albedo) { rgb_ray[1] = rgb_ray[0]; rgb_ray[2] = rgb_ray[0]; } // same addends in the same order; channel 3 only ever receives weight * 0
@@ -1408,6 +1418,7 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 		for (int k = 0; k < 4; ++k) R.rgb_ray[k] = rgb_ray[k];
 		R.weight_sum_raw = weight_sum;
 		R.T_resume = T;
+		R.ek_resume = ek_run;
 		R.dir[0] = dir[0]; R.dir[1] = dir[1]; R.dir[2] = dir[2];
 		a.ray_loss[i] = R;
 		a.ncomp[i] = n;
@@ -1511,10 +1522,131 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_compact_offsets(const uint32_t
 	if (blockIdx.x == gridDim.x - 1 && tid == 0) counters[1] = tile_base + total; // numsteps_counter_compacted
 }
 
-// Pass 2 (testbed_nerf.cu:1836-2095), one wavefront per ray: lanes own samples; the running sums of the reference's
-// sequential loop are replayed from broadcasts and captured by the lane that owns each sample.
-// LR lanes per ray (64: one wavefront per ray; 16: four rays per wavefront for batches of many short rays -- the per-ray part
-// of this kernel, ~200 instructions, then runs once for four rays). Every lane of the wavefront stays active (chain.cuh).
+// Pass 2 (testbed_nerf.cu:1836-2095).
+// What a ray contributes to every one of its samples (testbed_nerf.cu:1836-1890): the loss gradient, the mask term, and the ray's three loss values.
+struct RayGrad { float grad[4], weight_sum, gradient_weight_sum, light[3], dir[3], rgb_ray[4]; }; // 16 floats
+static_assert(sizeof(RayGrad) == 64, "RayGrad is read as four 16-byte words");
+__device__ __forceinline__ void pass2_ray_terms(const LossFlags& F, const RayLoss& R, const float gn, RayGrad& G, float& loss_row, float& mask_row) {
+	float loss = 0.f;
+	{
+		float diff[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) diff[k] = R.rgb_ray[k] - R.rgbtarget[k];
+		if (F.apply_L2) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) G.grad[k] = 2 * diff[k];
+			loss = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
+		} else {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) G.grad[k] = copysignf(1.0f, diff[k]);
+			loss = fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
+		}
+	}
+	if (F.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) G.grad[k] /= 2; }
+	loss *= R.mask_certainty;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) G.grad[k] *= R.mask_certainty;
+	float weight_sum = R.weight_sum_raw;
+	float gradient_weight_sum;
+	if (weight_sum >= 1.0 - 1e-4) { weight_sum = (float)(1.0 - 1e-4); gradient_weight_sum = 0.0f; }
+	else if (weight_sum <= 1e-4) { weight_sum = 1e-4; gradient_weight_sum = 0.0f; }
+	else {
+		const float sig = 1.0f / (1.0f + expf(-weight_sum));
+		if (F.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * F.mask_loss_weight;
+		else gradient_weight_sum = (sig - R.mask_gt) * F.mask_loss_weight;
+	}
+	G.weight_sum = weight_sum; G.gradient_weight_sum = gradient_weight_sum;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) { G.light[k] = R.light[k]; G.dir[k] = R.dir[k]; }
+#pragma unroll
+	for (int k = 0; k < 4; ++k) G.rgb_ray[k] = R.rgb_ray[k];
+	loss_row = loss / gn;
+	const float sig = 1.0f / (1.0f + expf(-weight_sum));
+	if (F.apply_bce) mask_row = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
+	else mask_row = -(R.mask_gt * logf(sig) + (1 - R.mask_gt) * logf(1 - sig));
+}
+
+// dL/d(network output) of one compacted sample (testbed_nerf.cu:1893-2075) from the ray's terms, the sample's network output `o`, its step `dt` and the
+// running values of the compositing recurrence right after it: its weight, the transmittance Tj, the weight sum w2, the colour sums rgb2.
+__device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& G, const float loss_scale, const half_t (&o)[16], const float dt,
+                                             const float my_weight, const float Tj, const float my_w2, const float (&my_rgb2)[4], half_t (&dl)[16]) {
+	float albedo[4];
+	albedo_from_output(F, o, albedo);
+	const float dir[3] = {G.dir[0], G.dir[1], G.dir[2]};
+	const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
+	float shading = at.g[0] * G.light[0] + at.g[1] * G.light[1] + at.g[2] * G.light[2];
+	if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+	const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
+	const float* grad = G.grad;
+	const float alpha = at.alpha;
+	const float weight = my_weight;
+	float suffix[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) suffix[k] = G.rgb_ray[k] - my_rgb2[k];
+	const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
+	float dloss_dn[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (G.light[d] * aG);
+	float J3[3] = {0, 0, 0};
+	if (F.apply_rgbplus) {
+		if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
+		else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
+	}
+	float drgb[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
+#pragma unroll
+	for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
+	const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+	if (F.apply_no_albedo) { // 0 x loss_scale x (drgb x a factor in [0, 1/4]): a zero with the sign of drgb (round 4: three exp and three divisions per sample for it before)
+#pragma unroll
+		for (int d = 0; d < 3; ++d) dl[d] = f2h(copysignf(0.f, drgb[d]));
+	} else {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const float sg = logistic(h2f(o[d]));
+			dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+		}
+	}
+	const float sum_weight_suffix = G.weight_sum - my_w2;
+	float dot_term = 0.f;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) dot_term += grad[k] * (Tj * albedo[k] * shading - suffix[k]);
+	const float dloss_dalpha = (float)((dot_term + (G.gradient_weight_sum * (Tj - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
+	float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
+	if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
+		const float plus_sigmoid_x = at.inv_s * at.iter_cos * dt;
+		const float plus_e = expf(plus_sigmoid_x);
+		const float e_minus = expf(-at.est_next * at.inv_s);
+		dE_dsdf = -at.inv_s * e_minus;
+		dE_dinvs = -at.est_next * e_minus;
+		const float aa = 1 + e_minus;
+		const float bb = 1 + plus_e * e_minus;
+		const float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
+		const float delta = aa * (bb * bb) * (cc * cc);
+		dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
+		dalpha_dEp = -e_minus / (delta);
+		dEp_dinvs = plus_e * at.iter_cos * dt;
+		dEp_ditc = plus_e * at.inv_s * dt;
+		dE_ditc = (float)(-at.inv_s * e_minus * dt * 0.5);
+	}
+	const float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
+	const float dloss_dvariance = dloss_dinvs * at.inv_s * 10;
+	const float d_iter_cos_true_cos = (at.true_cos >= 0) ? 0.0f : 1.0f;
+	const float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
+	const float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
+	const float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
+	dl[3] = f2h(loss_scale * dloss_dsdf);
+#pragma unroll
+	for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * at.g[d]);
+	dl[7] = f2h(loss_scale * dloss_dvariance);
+#pragma unroll
+	for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
+}
+
+// One launch, LR lanes per ray (64: one wavefront per ray; 16: four rays per wavefront): lanes own samples. REC: the running values of the recurrence come from
+// the chain records pass 1 left (LossArgs::chain_rec), the eikonal sum included; otherwise (rounds 1-3) the recurrence is replayed here (chain.cuh).
+// Every lane of the wavefront stays active.
 template <int LR, bool REC>
 __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
@@ -1541,48 +1673,15 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 	half_t* dloss = a.dloss + (size_t)compacted_base * 16;
 	const LossFlags F = a.F;
 	const float gn = (float)a.n_rays_global;
-
-	float grad[4];
-	float loss = 0.f;
-	{
-		float diff[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) diff[k] = R.rgb_ray[k] - R.rgbtarget[k];
-		if (F.apply_L2) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) grad[k] = 2 * diff[k];
-			loss = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
-		} else {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) grad[k] = copysignf(1.0f, diff[k]);
-			loss = fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
-		}
-	}
-	if (F.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) grad[k] /= 2; }
-	loss *= R.mask_certainty;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) grad[k] *= R.mask_certainty;
-	float weight_sum = R.weight_sum_raw;
-	float gradient_weight_sum;
-	if (weight_sum >= 1.0 - 1e-4) { weight_sum = (float)(1.0 - 1e-4); gradient_weight_sum = 0.0f; }
-	else if (weight_sum <= 1e-4) { weight_sum = 1e-4; gradient_weight_sum = 0.0f; }
-	else {
-		const float sig = 1.0f / (1.0f + expf(-weight_sum));
-		if (F.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * F.mask_loss_weight;
-		else gradient_weight_sum = (sig - R.mask_gt) * F.mask_loss_weight;
-	}
-	if (ray_live && lane == 0) {
-		a.loss[i] = loss / gn;
-		const float sig = 1.0f / (1.0f + expf(-weight_sum));
-		if (F.apply_bce) a.mask_loss[i] = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
-		else a.mask_loss[i] = -(R.mask_gt * logf(sig) + (1 - R.mask_gt) * logf(1 - sig));
-	}
+	RayGrad G;
+	float loss_row, mask_row;
+	pass2_ray_terms(F, R, gn, G, loss_row, mask_row);
+	if (ray_live && lane == 0) { a.loss[i] = loss_row; a.mask_loss[i] = mask_row; }
 
 	const float loss_scale = LOSS_SCALE / gn; // testbed_nerf.cu:1832
 	float rgb_ray2[4] = {0, 0, 0, 0};
 	float weight_sum2 = 0.f;
 	float T = 1.f;
-	const float dir[3] = {R.dir[0], R.dir[1], R.dir[2]};
 	float ek = 0.f;
 	for (uint32_t c0 = 0; __any(c0 < compacted_numsteps); c0 += LR) {
 		const uint32_t j = c0 + lane;
@@ -1591,119 +1690,53 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 #pragma unroll
 		for (int q = 0; q < 16; ++q) o[q] = (half_t)0.f;
 		float dt = MIN_CONE_STEPSIZE;
-		float albedo[4] = {1.f, 1.f, 1.f, 0.f};
-		AlphaTerms at;
-		at.alpha = 0.f; at.inv_s = 1.f; at.sdf_value = 0.f; at.true_cos = 0.f; at.iter_cos = 0.f; at.est_next = 0.f; at.p_div_c = 0.f; at.g[0] = at.g[1] = at.g[2] = 0.f;
-		float shading = 0.f, gradient_norm = 1.f;
 		if (valid) {
 #pragma unroll
 			for (int q = 0; q < 7; ++q) coords_out[(size_t)j * 7 + q] = coords_in[(size_t)j * 7 + q];
 			if (a.src_slot) a.src_slot[compacted_base + j] = base + j;
 			load_out16(net + (size_t)j * 16, o);
 			dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
-			albedo_from_output(F, o, albedo);
-			at = alpha_terms(o, dt, dir, 1.0f);
-			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
-			if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
-			gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
 		}
-		const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
-		// the sequential recurrences (chain.cuh): lane q ends with its own weight and the running values right after sample q
-		const int cnt = c0 < compacted_numsteps ? (int)min((uint32_t)LR, compacted_numsteps - c0) : 0;
 		ChainState cs;
-		if (REC) { // pass 1 left the running values of every sample it kept; only the eikonal sum (not formed there) is chained here
-			cs.w = cs.T = cs.ws = 0.f; cs.rgb[0] = cs.rgb[1] = cs.rgb[2] = cs.rgb[3] = 0.f;
+		if (REC) {
+			cs.w = cs.T = cs.ws = cs.ek = 0.f; cs.rgb[0] = cs.rgb[1] = cs.rgb[2] = cs.rgb[3] = 0.f;
 			if (valid) {
 				const f4* q = reinterpret_cast<const f4*>(a.chain_rec + ((size_t)base + j) * CHAIN_REC_FLOATS);
 				const f4 r0 = q[0];
 				cs.w = r0[0]; cs.T = r0[1]; cs.ws = r0[2]; cs.rgb[0] = r0[3];
 				if (!F.apply_no_albedo) { const f4 r1 = q[1]; cs.rgb[1] = r1[0]; cs.rgb[2] = r1[1]; cs.rgb[3] = r1[2]; }
 			}
-			cs.ek = replay_ek<LR>(cnt, ekterm, ek);
-		} else
-			cs = F.apply_no_albedo ? replay_chain<true, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
-			                       : replay_chain<false, LR>(cnt, at.alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
-		const float my_weight = cs.w, my_T = cs.T, my_w2 = cs.ws;
-		float my_rgb2[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
-		if (F.apply_no_albedo) { my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = rgb_ray2[3]; } // albedo = (1,1,1,0): one accumulator serves the three equal colour channels
-		{ // the running values after the chunk's last sample (a ray that is through keeps its own)
+		} else {
+			// the per-sample inputs of the recurrence, as pass 1 forms them
+			float albedo[4] = {1.f, 1.f, 1.f, 0.f};
+			float alpha = 0.f, shading = 0.f, gradient_norm = 1.f;
+			if (valid) {
+				albedo_from_output(F, o, albedo);
+				const AlphaTerms at = alpha_terms(o, dt, G.dir, 1.0f);
+				alpha = at.alpha;
+				shading = at.g[0] * G.light[0] + at.g[1] * G.light[1] + at.g[2] * G.light[2];
+				if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+				gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
+			}
+			const float ekterm = (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
+			// the sequential recurrences (chain.cuh): lane q ends with its own weight and the running values right after sample q
+			const int cnt = c0 < compacted_numsteps ? (int)min((uint32_t)LR, compacted_numsteps - c0) : 0;
+			cs = F.apply_no_albedo ? replay_chain<true, LR>(cnt, alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek)
+			                       : replay_chain<false, LR>(cnt, alpha, shading, albedo, ekterm, T, weight_sum2, rgb_ray2, ek);
+			// the running values after the chunk's last sample (a ray that is through keeps its own)
 			const int last = max(cnt - 1, 0);
-			const float e1 = group_read<LR>(cs.ek, last, lane64);
-			if (cnt > 0) ek = e1;
-			if (!REC) {
-				const float T1 = group_read<LR>(cs.T, last, lane64), w1 = group_read<LR>(cs.ws, last, lane64);
-				if (cnt > 0) { T = T1; weight_sum2 = w1; }
+			const float T1 = group_read<LR>(cs.T, last, lane64), w1 = group_read<LR>(cs.ws, last, lane64), e1 = group_read<LR>(cs.ek, last, lane64);
+			if (cnt > 0) { T = T1; weight_sum2 = w1; ek = e1; }
+			float tmp[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
+			if (F.apply_no_albedo) { tmp[1] = tmp[0]; tmp[2] = tmp[0]; tmp[3] = rgb_ray2[3]; }
 #pragma unroll
-				for (int k = 0; k < 4; ++k) { const float rk = group_read<LR>(my_rgb2[k], last, lane64); if (cnt > 0) rgb_ray2[k] = rk; }
-			}
+			for (int k = 0; k < 4; ++k) { const float rk = group_read<LR>(tmp[k], last, lane64); if (cnt > 0) rgb_ray2[k] = rk; }
 		}
+		float my_rgb2[4] = {cs.rgb[0], cs.rgb[1], cs.rgb[2], cs.rgb[3]};
+		if (F.apply_no_albedo) { my_rgb2[1] = my_rgb2[0]; my_rgb2[2] = my_rgb2[0]; my_rgb2[3] = 0.f; } // albedo = (1,1,1,0): one accumulator serves the three equal colour channels; the fourth only ever receives weight x 0
 		if (valid) {
-			const float alpha = at.alpha;
-			const float weight = my_weight;
-			const float Tj = my_T;
-			float suffix[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) suffix[k] = R.rgb_ray[k] - my_rgb2[k];
-			const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
-			float dloss_dn[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (R.light[d] * aG);
-			float J3[3] = {0, 0, 0};
-			if (F.apply_rgbplus) {
-				if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
-				else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
-			}
-			float drgb[3];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
 			half_t dl[16];
-#pragma unroll
-			for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
-			const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
-			if (F.apply_no_albedo) { // 0 x loss_scale x (drgb x a factor in [0, 1/4]): a zero with the sign of drgb (round 4: three exp and three divisions per sample for it before)
-#pragma unroll
-				for (int d = 0; d < 3; ++d) dl[d] = f2h(copysignf(0.f, drgb[d]));
-			} else {
-#pragma unroll
-				for (int d = 0; d < 3; ++d) {
-					const float sg = logistic(h2f(o[d]));
-					dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
-				}
-			}
-			const float sum_weight_suffix = weight_sum - my_w2;
-			float dot_term = 0.f;
-#pragma unroll
-			for (int k = 0; k < 4; ++k) dot_term += grad[k] * (Tj * albedo[k] * shading - suffix[k]);
-			const float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (Tj - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
-			float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
-			if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
-				const float plus_sigmoid_x = at.inv_s * at.iter_cos * dt;
-				const float plus_e = expf(plus_sigmoid_x);
-				const float e_minus = expf(-at.est_next * at.inv_s);
-				dE_dsdf = -at.inv_s * e_minus;
-				dE_dinvs = -at.est_next * e_minus;
-				const float aa = 1 + e_minus;
-				const float bb = 1 + plus_e * e_minus;
-				const float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
-				const float delta = aa * (bb * bb) * (cc * cc);
-				dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
-				dalpha_dEp = -e_minus / (delta);
-				dEp_dinvs = plus_e * at.iter_cos * dt;
-				dEp_ditc = plus_e * at.inv_s * dt;
-				dE_ditc = (float)(-at.inv_s * e_minus * dt * 0.5);
-			}
-			const float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
-			const float dloss_dvariance = dloss_dinvs * at.inv_s * 10;
-			const float d_iter_cos_true_cos = (at.true_cos >= 0) ? 0.0f : 1.0f;
-			const float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
-			const float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
-			const float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
-			dl[3] = f2h(loss_scale * dloss_dsdf);
-#pragma unroll
-			for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * at.g[d]);
-			dl[7] = f2h(loss_scale * dloss_dvariance);
-#pragma unroll
-			for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
+			pass2_sample(F, G, loss_scale, o, dt, cs.w, cs.T, cs.ws, my_rgb2, dl);
 			h8 w0, w1;
 #pragma unroll
 			for (int q = 0; q < 8; ++q) { w0[q] = dl[q]; w1[q] = dl[8 + q]; }
@@ -1712,7 +1745,85 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 			dst[1] = w1;
 		}
 	}
+	if (REC && ray_live) ek = a.chain_rec[((size_t)base + compacted_numsteps - 1) * CHAIN_REC_FLOATS + 7]; // the sum right after the ray's last kept sample, formed in pass 1
 	if (ray_live && lane == 0) a.ek_loss[i] = ek / ((float)compacted_numsteps * gn);
+}
+
+// Pass 2 in two launches for batches of many short rays (round 4; needs the chain records). With 16 lanes per ray and four rays per wavefront a wavefront
+// walks as many 16-sample chunks as its longest ray has -- half of its lanes idle at 27 kept samples per ray (step 6000) -- and the kernel is bound by the
+// instructions it issues (~700 per chunk). Here the rays only write what they contribute to their samples (RayGrad), their loss rows, and for every compacted
+// sample its ray and its marched slot; the samples are then worked on one per lane whatever ray they belong to. Same expressions on the same inputs: same bits.
+template <int LR>
+__global__ __launch_bounds__(256) void k_loss_pass2_rays(const LossArgs a) {
+	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
+	const int lane = threadIdx.x & (LR - 1);
+	if (!(i_raw < a.n_rays && i_raw < a.counters[2])) return;
+	const uint32_t i = i_raw;
+	const RayLoss R = a.ray_loss[i];
+	const uint32_t compacted_base = a.cbase[i];
+	const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
+	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) {
+		a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
+		a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+	}
+	if (compacted_numsteps == 0) { if (lane == 0) { a.loss[i] = 0.f; a.ek_loss[i] = 0.f; a.mask_loss[i] = 0.f; } return; } // (see k_loss_pass2)
+	const float gn = (float)a.n_rays_global;
+	RayGrad G;
+	float loss_row, mask_row;
+	pass2_ray_terms(a.F, R, gn, G, loss_row, mask_row);
+	if (lane == 0) {
+		a.loss[i] = loss_row; a.mask_loss[i] = mask_row;
+		a.ek_loss[i] = a.chain_rec[((size_t)base + compacted_numsteps - 1) * CHAIN_REC_FLOATS + 7] / ((float)compacted_numsteps * gn);
+		f4* g = reinterpret_cast<f4*>(a.ray_grad + (size_t)i * 16);
+		g[0] = f4{G.grad[0], G.grad[1], G.grad[2], G.grad[3]};
+		g[1] = f4{G.weight_sum, G.gradient_weight_sum, G.light[0], G.light[1]};
+		g[2] = f4{G.light[2], G.dir[0], G.dir[1], G.dir[2]};
+		g[3] = f4{G.rgb_ray[0], G.rgb_ray[1], G.rgb_ray[2], G.rgb_ray[3]};
+	}
+	for (uint32_t j = lane; j < compacted_numsteps; j += LR) {
+		a.ray_of[compacted_base + j] = i;
+		a.slot_of[compacted_base + j] = base + j;
+		if (a.src_slot) a.src_slot[compacted_base + j] = base + j;
+	}
+}
+__global__ __launch_bounds__(256) void k_loss_pass2_samples(const LossArgs a) {
+	const uint32_t n = min(a.counters[1], a.B);
+	const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+	if (q >= n) return;
+	const uint32_t slot = a.slot_of[q];
+	RayGrad G;
+	{
+		const f4* g = reinterpret_cast<const f4*>(a.ray_grad + (size_t)a.ray_of[q] * 16);
+		const f4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+		G.grad[0] = g0[0]; G.grad[1] = g0[1]; G.grad[2] = g0[2]; G.grad[3] = g0[3];
+		G.weight_sum = g1[0]; G.gradient_weight_sum = g1[1]; G.light[0] = g1[2]; G.light[1] = g1[3];
+		G.light[2] = g2[0]; G.dir[0] = g2[1]; G.dir[1] = g2[2]; G.dir[2] = g2[3];
+		G.rgb_ray[0] = g3[0]; G.rgb_ray[1] = g3[1]; G.rgb_ray[2] = g3[2]; G.rgb_ray[3] = g3[3];
+	}
+	const float* ci = a.coords + (size_t)slot * 7;
+	float* co = a.coords_compacted + (size_t)q * 7;
+	float cv[7];
+#pragma unroll
+	for (int k = 0; k < 7; ++k) cv[k] = ci[k];
+#pragma unroll
+	for (int k = 0; k < 7; ++k) co[k] = cv[k];
+	half_t o[16];
+	load_out16(a.mlp_out + (size_t)slot * 16, o);
+	const float dt = unwarp_dt(cv[3]);
+	const f4* rq = reinterpret_cast<const f4*>(a.chain_rec + (size_t)slot * CHAIN_REC_FLOATS);
+	const f4 r0 = rq[0];
+	float my_rgb2[4] = {r0[3], r0[3], r0[3], 0.f};
+	if (!a.F.apply_no_albedo) { const f4 r1 = rq[1]; my_rgb2[1] = r1[0]; my_rgb2[2] = r1[1]; my_rgb2[3] = r1[2]; }
+	half_t dl[16];
+	pass2_sample(a.F, G, LOSS_SCALE / (float)a.n_rays_global, o, dt, r0[0], r0[1], r0[2], my_rgb2, dl);
+	h8 w0, w1;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) { w0[k] = dl[k]; w1[k] = dl[8 + k]; }
+	h8* dst = reinterpret_cast<h8*>(a.dloss + (size_t)q * 16);
+	dst[0] = w0;
+	dst[1] = w1;
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)

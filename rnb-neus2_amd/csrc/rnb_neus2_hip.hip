@@ -154,6 +154,7 @@ struct rnb_ctx {
 	DevBuf<float> rays, coords, coords_compacted, loss; // loss: [3][max_rays] = colour, eikonal, mask terms per ray
 	float *ek_loss = nullptr, *mask_loss = nullptr;       // rows 1, 2 of `loss`
 	DevBuf<half_t> mlp_out, dloss_dout;
+	DevBuf<float> ray_grad; DevBuf<uint32_t> ray_of, slot_of; // pass 2 of the loss in two launches (k_loss_pass2_rays -> k_loss_pass2_samples)
 	DevBuf<float> chain_rec; // per marched-sample slot: the compositing recurrence's running values, left by pass 1 of the loss for pass 2 (LossArgs::chain_rec)
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
 	DevBuf<double> loss_partial; // per-tile loss sums of large batches
@@ -197,6 +198,7 @@ struct rnb_ctx {
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
+		bool loss_flat = true; // RNB_LOSS_FLAT=0: pass 2 of the loss as one launch with 64 / 16 lanes per ray (default: k_loss_pass2_rays, then k_loss_pass2_samples with one lane per compacted sample; needs the chain records)
 		bool loss_chain_records = true; // RNB_LOSS_CHAIN_RECORDS=0: pass 2 of the loss replays the compositing recurrence itself (rounds 1-3) instead of reading the running values pass 1 left
 		int march_write_split = -1; // RNB_MARCH_WRITE_SPLIT=0|1: k_march_write of a march generated ahead as one launch (rounds 1-3) / always split; default: split below 65 536 rays per step. Split: what the first network evaluation reads (idx1, the heads'
 		                               // coordinates) in a first launch, whose completion the critical stream waits for; the rest (ray constants, ray records, the tails' coordinates) in a second one
@@ -720,6 +722,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.coords_compacted = c->coords_compacted.p; a.dloss = c->dloss_dout.p; a.loss = c->loss.p; a.ek_loss = c->ek_loss; a.mask_loss = c->mask_loss;
 	a.src_slot = c->cin_flow ? c->src_slot.p : nullptr;
 	a.chain_rec = c->knobs.loss_chain_records ? c->chain_rec.p : nullptr;
+	a.ray_grad = c->ray_grad.p; a.ray_of = c->ray_of.p; a.slot_of = c->slot_of.p;
 	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
 	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
@@ -754,7 +757,10 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	} else
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
-	if (a.chain_rec) {
+	if (a.chain_rec && c->knobs.loss_flat) { // at every batch size (step 1000, 12 k long rays: 0.6247 -> 0.6189 ms/step; step 2000: 0.6216 -> 0.6100; step 6000: 0.6526 -> 0.6367)
+		hipLaunchKernelGGL(k_loss_pass2_rays<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_loss_pass2_samples, dim3((a.B + 255) / 256), dim3(256), 0, s, a);
+	} else if (a.chain_rec) {
 		if (rows) hipLaunchKernelGGL((k_loss_pass2<16, true>), dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 		else hipLaunchKernelGGL((k_loss_pass2<64, true>), dim3(blocks), dim3(256), 0, s, a);
 	} else {
@@ -1169,7 +1175,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_range.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
-	c->loss.free(); c->mlp_out.free(); c->chain_rec.free(); c->dloss_dout.free();
+	c->loss.free(); c->mlp_out.free(); c->chain_rec.free(); c->ray_grad.free(); c->ray_of.free(); c->slot_of.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->scan_words.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->mc_table.free(); c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
@@ -1239,7 +1245,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
-	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->chain_rec, (size_t)B * 16 * CHAIN_REC_FLOATS); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
+	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->chain_rec, (size_t)B * 16 * CHAIN_REC_FLOATS); ALLOC(c->ray_grad, (size_t)maxr * 16); ALLOC(c->ray_of, B); ALLOC(c->slot_of, B); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
@@ -1325,6 +1331,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_LOSS_FLAT")) k.loss_flat = atoi(e) != 0;
 		if (const char* e = getenv("RNB_LOSS_CHAIN_RECORDS")) k.loss_chain_records = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 	}

@@ -883,27 +883,30 @@ def test_overlapped_backward_equals_serial(scene, trained, albedo):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("albedo", [False, True])
-def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, trained, albedo):
+@pytest.mark.parametrize("albedo,n_rays", [(False, 40000), (True, 40000), (False, 12032)])
+def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, trained, albedo, n_rays):
     """From 18 432 rays per step on the loss passes give a ray 16 lanes (four rays per wavefront, the recurrence through row_shr:1);
     forced back to one wavefront per ray (RNB_LOSS_WAVE_PER_RAY) the same 40 000-ray step yields the same bits everywhere:
     compaction, dL/d(output), per-ray losses. Both through the two-round evaluation of a whole training step. Round 4: pass 2 reads the
     running values of the recurrence that pass 1 left per sample (chain records) instead of replaying it; with RNB_LOSS_CHAIN_RECORDS=0 it
-    replays as in rounds 1-3 -- the same bits again, in both lane forms, --no-albedo and albedo mode."""
+    replays as in rounds 1-3 -- the same bits again, in both lane forms, --no-albedo and albedo mode; and the large-batch form of pass 2 is two launches
+    (k_loss_pass2_rays, k_loss_pass2_samples: one lane per compacted sample), RNB_LOSS_FLAT=0 the one-launch form: the same bits once more.
+    Third parametrisation: a batch of 12 032 long rays (the small-batch forms: a wavefront per ray in pass 1 and in the one-launch pass 2)."""
     _, state = trained
     out = []
     kw = dict(apply_no_albedo=0) if albedo else {}
-    for env in (None, {"RNB_LOSS_WAVE_PER_RAY": "1"}, {"RNB_LOSS_CHAIN_RECORDS": "0"}, {"RNB_LOSS_CHAIN_RECORDS": "0", "RNB_LOSS_WAVE_PER_RAY": "1"}):
+    # default: chain records + pass 2 in two launches (rays, then one lane per compacted sample); then: one launch with 16 lanes per ray; a wavefront per ray; replay, both lane forms
+    for env in (None, {"RNB_LOSS_FLAT": "0"}, {"RNB_LOSS_WAVE_PER_RAY": "1"}, {"RNB_LOSS_CHAIN_RECORDS": "0"}, {"RNB_LOSS_CHAIN_RECORDS": "0", "RNB_LOSS_WAVE_PER_RAY": "1"}):
         c = _clone(scene, state, env=env, overlap=0, **kw)
         try:
-            c.set_controller(state["step"] | 1, 40000, state["before"], 0)
+            c.set_controller(state["step"] | 1, n_rays, state["before"], 0)
             st = c.train_step()
             n = int(st.n_rays_kept)
             out.append((st, {name: c.get(name, count).copy() for name, count in (("NUMSTEPS", 2 * n), ("COORDS_COMPACTED", None), ("DLOSS_DOUT", None), ("LOSS", n), ("EK_LOSS", n), ("MASK_LOSS", n))}))
         finally:
             c.close()
     (s1, a) = out[0]
-    assert s1.rays_per_batch == 40000 and s1.measured_batch_size > 100000
+    assert s1.rays_per_batch == n_rays and s1.measured_batch_size > 100000
     for s2, b in out[1:]:
         assert s1.n_rays_kept == s2.n_rays_kept and s1.measured_batch_size == s2.measured_batch_size
         assert s1.loss == s2.loss and s1.ek_loss == s2.ek_loss and s1.mask_loss == s2.mask_loss
