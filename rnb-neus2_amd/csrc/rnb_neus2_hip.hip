@@ -599,15 +599,18 @@ static LossFlags loss_flags(const rnb_ctx* c) {
 	return F;
 }
 
-// Head length of the two-round network evaluation for a batch of n_rays rays. Measured in round 2 (ms/step by head length at 19 k /
-// 26 k / 50 k / 85 k / 95 k rays per step, i.e. 13.8 / 9.9 / 5.2 / 3.1 / 2.8 compacted samples per ray): the best head is ~4.5 x the
-// compacted samples per ray -- 48: 0.712 / 0.764 / 0.796 / 0.822 / 0.842; 32: 0.732 / 0.759 / 0.765 / 0.803 / 0.827; 24: 0.789 / 0.784 /
-// 0.754 / 0.788 / 0.816; 16: 0.840 / 0.849 / 0.769 / 0.782 / 0.796 -- and the controller holds the compacted batch at B, so that is
-// 4.5 B / n_rays, kept within [12, 48]. The results do not depend on it (tests/test_gpu_fullsize.py).
+// Head length of the two-round network evaluation for a batch of n_rays rays. The results do not depend on it (tests/test_gpu_fullsize.py); the step time
+// does, sharply (tools/sweep_k1.sh, profiles/r04_sweep_k1.txt, ms/step of 200-step slices with a fixed head of 12 / 16 / 24 / 32 / 40 / 48 / 64):
+//   step 1000, 13 k rays: .755 .753 .728 .656 .621 .615 .620     step 2000, 48 k: .626 .608 .602 .617 .628 .644 .658
+//   step 1400, 22 k rays: .715 .692 .627 .598 .597 .602 .628     step 3000, 85 k: .627 .619 .638 .650 .664 .669 .678
+//   step 1700, 33 k rays: .666 .624 .596 .589 .603 .618 .646     step 6000, 95 k: .637 .636 .657 .671 .680 .685 .692
+// The optimum follows 8 + 3 B / n_rays (the controller holds the compacted batch at B, so B / n_rays is the kept samples per ray), in multiples of 8 within
+// [16, 48]. (Round 2's rule, 4.5 B / n_rays within [12, 48], was fitted to that round's kernels: 48 instead of 40 at 22 k rays, 14 instead of 16 at 85 k.)
 static uint32_t k1_for(const rnb_ctx* c, uint32_t n_rays) {
 	if (c->fwd_k1 == 0 || c->fwd_k1_fixed) return c->fwd_k1;
-	const uint32_t k = (uint32_t)(4.5f * (float)c->cfg.target_batch_size / (float)std::max(1u, n_rays));
-	return std::min(c->fwd_k1, std::max(12u, k)); // floor 12 (round 3: 0.680 vs 0.687 ms/step at 95 k rays per step; 8: 0.689)
+	const float k = 8.f + 3.f * (float)c->cfg.target_batch_size / (float)std::max(1u, n_rays);
+	const uint32_t k8 = (uint32_t)std::min(48.f, std::max(16.f, k) + 4.f) / 8u * 8u;
+	return std::min(c->fwd_k1, std::max(16u, k8));
 }
 
 // Is t -> fl(t + C) the addition of ONE constant inside each binade of [0.25, 8)? It is unless C sits exactly half way between two
