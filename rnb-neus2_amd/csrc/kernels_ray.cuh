@@ -1104,6 +1104,12 @@ struct LossArgs {
 	// pass 2 in two launches for batches of many short rays (k_loss_pass2_rays + k_loss_pass2_samples): per kept ray 16 floats, per compacted sample its ray and its marched slot
 	float* ray_grad;
 	uint32_t *ray_of, *slot_of;
+	// ... which also pad the compacted batch (fill_rollover*, common_device.h:514-535) and -- in the training step -- reduce and publish the step's loss sums
+	// (what k_rollover / k_reduce_losses_rollover do behind the one-launch forms): a kernel boundary on the critical stream costs 6-9 us here
+	double* wg_partial;    // [workgroups of k_loss_pass2_rays][3]: sums of the three loss rows over the workgroup's 16 rays
+	double* red_out;       // null: no reduction (stage API); else the device block of reduce_losses_body
+	double* red_host_out;  // its pinned twin
+	uint32_t red_host_seq;
 };
 constexpr uint32_t CHAIN_REC_FLOATS = 8;
 
@@ -1755,42 +1761,90 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 // sample its ray and its marched slot; the samples are then worked on one per lane whatever ray they belong to. Same expressions on the same inputs: same bits.
 template <int LR>
 __global__ __launch_bounds__(256) void k_loss_pass2_rays(const LossArgs a) {
+	__shared__ double rows[256 / LR][3];
 	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
 	const int lane = threadIdx.x & (LR - 1);
-	if (!(i_raw < a.n_rays && i_raw < a.counters[2])) return;
-	const uint32_t i = i_raw;
-	const RayLoss R = a.ray_loss[i];
-	const uint32_t compacted_base = a.cbase[i];
-	const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
-	const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
-	__builtin_amdgcn_wave_barrier();
-	if (lane == 0) {
-		a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
-		a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+	const bool ray_ok = i_raw < a.n_rays && i_raw < a.counters[2];
+	const uint32_t i = ray_ok ? i_raw : 0u;
+	float loss_row = 0.f, mask_row = 0.f, ek_row = 0.f;
+	if (ray_ok) {
+		const RayLoss R = a.ray_loss[i];
+		const uint32_t compacted_base = a.cbase[i];
+		const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
+		const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) {
+			a.numsteps[(size_t)i * 2 + 0] = compacted_numsteps;
+			a.numsteps[(size_t)i * 2 + 1] = compacted_base;
+		}
+		if (compacted_numsteps != 0) {
+			const float gn = (float)a.n_rays_global;
+			RayGrad G;
+			pass2_ray_terms(a.F, R, gn, G, loss_row, mask_row);
+			ek_row = a.chain_rec[((size_t)base + compacted_numsteps - 1) * CHAIN_REC_FLOATS + 7] / ((float)compacted_numsteps * gn);
+			if (lane == 0) {
+				f4* g = reinterpret_cast<f4*>(a.ray_grad + (size_t)i * 16);
+				g[0] = f4{G.grad[0], G.grad[1], G.grad[2], G.grad[3]};
+				g[1] = f4{G.weight_sum, G.gradient_weight_sum, G.light[0], G.light[1]};
+				g[2] = f4{G.light[2], G.dir[0], G.dir[1], G.dir[2]};
+				g[3] = f4{G.rgb_ray[0], G.rgb_ray[1], G.rgb_ray[2], G.rgb_ray[3]};
+			}
+			for (uint32_t j = lane; j < compacted_numsteps; j += LR) {
+				a.ray_of[compacted_base + j] = i;
+				a.slot_of[compacted_base + j] = base + j;
+				if (a.src_slot) a.src_slot[compacted_base + j] = base + j;
+			}
+		}
+		if (lane == 0) { a.loss[i] = loss_row; a.ek_loss[i] = ek_row; a.mask_loss[i] = mask_row; } // zeros for a kept ray without compacted samples (see k_loss_pass2)
 	}
-	if (compacted_numsteps == 0) { if (lane == 0) { a.loss[i] = 0.f; a.ek_loss[i] = 0.f; a.mask_loss[i] = 0.f; } return; } // (see k_loss_pass2)
-	const float gn = (float)a.n_rays_global;
-	RayGrad G;
-	float loss_row, mask_row;
-	pass2_ray_terms(a.F, R, gn, G, loss_row, mask_row);
-	if (lane == 0) {
-		a.loss[i] = loss_row; a.mask_loss[i] = mask_row;
-		a.ek_loss[i] = a.chain_rec[((size_t)base + compacted_numsteps - 1) * CHAIN_REC_FLOATS + 7] / ((float)compacted_numsteps * gn);
-		f4* g = reinterpret_cast<f4*>(a.ray_grad + (size_t)i * 16);
-		g[0] = f4{G.grad[0], G.grad[1], G.grad[2], G.grad[3]};
-		g[1] = f4{G.weight_sum, G.gradient_weight_sum, G.light[0], G.light[1]};
-		g[2] = f4{G.light[2], G.dir[0], G.dir[1], G.dir[2]};
-		g[3] = f4{G.rgb_ray[0], G.rgb_ray[1], G.rgb_ray[2], G.rgb_ray[3]};
-	}
-	for (uint32_t j = lane; j < compacted_numsteps; j += LR) {
-		a.ray_of[compacted_base + j] = i;
-		a.slot_of[compacted_base + j] = base + j;
-		if (a.src_slot) a.src_slot[compacted_base + j] = base + j;
+	// the workgroup's share of the step's loss sums (fp64 sums of the fp32 rows in ray order: deterministic), for the reduction inside k_loss_pass2_samples
+	if (lane == 0) { rows[threadIdx.x / LR][0] = loss_row; rows[threadIdx.x / LR][1] = ek_row; rows[threadIdx.x / LR][2] = mask_row; }
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		double sum = 0;
+#pragma unroll
+		for (int r = 0; r < 256 / LR; ++r) sum += rows[r][threadIdx.x];
+		a.wg_partial[(size_t)blockIdx.x * 3 + threadIdx.x] = sum;
 	}
 }
+// the step's 48-byte readback from the three sums (the tail of reduce_losses_body)
+__device__ __forceinline__ void publish_losses(const double s0, const double s1, const double s2, const uint32_t* __restrict__ counters, const uint32_t* __restrict__ fwd_counts,
+                                               double* __restrict__ out, double* __restrict__ host_out, const uint32_t host_seq) {
+	const uint32_t t = threadIdx.x;
+	if (t == 0) { out[0] = s0; out[1] = s1; out[2] = s2; out[12] = s0; out[13] = s1; out[14] = s2; }
+	if (t < 4) { reinterpret_cast<uint32_t*>(out + 3)[t] = counters[t]; out[8 + t] = (double)counters[t]; }
+	if (t < 2) reinterpret_cast<uint32_t*>(out + 5)[t] = fwd_counts ? fwd_counts[t * 2] : 0u;
+	if (host_out) {
+		if (t == 0) { host_out[0] = s0; host_out[1] = s1; host_out[2] = s2; }
+		if (t < 4) reinterpret_cast<uint32_t*>(host_out + 3)[t] = counters[t];
+		if (t < 2) reinterpret_cast<uint32_t*>(host_out + 5)[t] = fwd_counts ? fwd_counts[t * 2] : 0u;
+		if (host_seq) { // (see reduce_losses_body)
+			__syncthreads();
+			if (t == 0) __hip_atomic_store(reinterpret_cast<uint32_t*>(host_out + 6), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+// Workgroup 0: the step's loss sums from the partial sums of k_loss_pass2_rays (fixed order) and their publication; the others: one lane per compacted sample,
+// which also writes the sample's wrapped copies behind the compacted batch when that is shorter than B (fill_rollover_and_rescale<half> + fill_rollover<float>).
 __global__ __launch_bounds__(256) void k_loss_pass2_samples(const LossArgs a) {
-	const uint32_t n = min(a.counters[1], a.B);
-	const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+	if (blockIdx.x == 0) {
+		if (!a.red_out) return;
+		__shared__ double sh[4][3];
+		const uint32_t n_part = (min(a.counters[2], a.n_rays) + 15u) / 16u; // workgroups of k_loss_pass2_rays<16> that hold kept rays
+		double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
+		for (uint32_t p = threadIdx.x; p < n_part; p += 256) { s0 += a.wg_partial[(size_t)p * 3 + 0]; s1 += a.wg_partial[(size_t)p * 3 + 1]; s2 += a.wg_partial[(size_t)p * 3 + 2]; }
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+		if ((threadIdx.x & 63u) == 0) { sh[threadIdx.x >> 6][0] = s0; sh[threadIdx.x >> 6][1] = s1; sh[threadIdx.x >> 6][2] = s2; }
+		__syncthreads();
+		s0 = ((sh[0][0] + sh[1][0]) + sh[2][0]) + sh[3][0]; s1 = ((sh[0][1] + sh[1][1]) + sh[2][1]) + sh[3][1]; s2 = ((sh[0][2] + sh[1][2]) + sh[2][2]) + sh[3][2];
+		publish_losses(s0, s1, s2, a.counters, a.fwd_counts, a.red_out, a.red_host_out, a.red_host_seq); // loss, eikonal, mask: the order of reduce_losses_body's rows
+		return;
+	}
+	const uint32_t n_in = a.counters[1];
+	const uint32_t n = min(n_in, a.B);
+	const uint32_t q = (blockIdx.x - 1) * 256 + threadIdx.x;
 	if (q >= n) return;
 	const uint32_t slot = a.slot_of[q];
 	RayGrad G;
@@ -1821,9 +1875,25 @@ __global__ __launch_bounds__(256) void k_loss_pass2_samples(const LossArgs a) {
 	h8 w0, w1;
 #pragma unroll
 	for (int k = 0; k < 8; ++k) { w0[k] = dl[k]; w1[k] = dl[8 + k]; }
+	// the wrapped copies below must start from the BITS stored here: without the barrier the compiler forms some of these halfs twice, once as multiply + convert and once
+	// as v_fma_mixlo_f16 with a +0 addend, which turns a -0 product into +0 (seen in the ISA; the one-launch forms read the stored row back, k_rollover)
+	asm volatile("" : "+v"(w0), "+v"(w1));
 	h8* dst = reinterpret_cast<h8*>(a.dloss + (size_t)q * 16);
 	dst[0] = w0;
 	dst[1] = w1;
+	// the batch wraps: sample q again at q + n_in, q + 2 n_in ... < B, its loss gradient rescaled (common_device.h:514-535; same expressions as rollover_body)
+	for (uint32_t q2 = q + n_in; q2 < a.B; q2 += n_in) {
+		float* co2 = a.coords_compacted + (size_t)q2 * 7;
+#pragma unroll
+		for (int k = 0; k < 7; ++k) co2[k] = cv[k];
+		h8 v0, v1;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) { v0[k] = f2h(h2f(w0[k]) * n_in / a.B); v1[k] = f2h(h2f(w1[k]) * n_in / a.B); }
+		h8* d2 = reinterpret_cast<h8*>(a.dloss + (size_t)q2 * 16);
+		d2[0] = v0;
+		d2[1] = v1;
+		if (a.src_slot) a.src_slot[q2] = slot;
+	}
 }
 
 // fill_rollover_and_rescale<half> + fill_rollover<float> (common_device.h:514-535; testbed_nerf.cu:4044-4049)

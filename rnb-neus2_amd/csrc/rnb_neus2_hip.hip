@@ -154,6 +154,8 @@ struct rnb_ctx {
 	DevBuf<float> rays, coords, coords_compacted, loss; // loss: [3][max_rays] = colour, eikonal, mask terms per ray
 	float *ek_loss = nullptr, *mask_loss = nullptr;       // rows 1, 2 of `loss`
 	DevBuf<half_t> mlp_out, dloss_dout;
+	DevBuf<double> wg_partial; // loss sums per workgroup of k_loss_pass2_rays
+	bool loss_reduced = false; // the running step's loss sums were reduced and published by k_loss_pass2_samples (launch_reduce_losses has nothing left to do)
 	DevBuf<float> ray_grad; DevBuf<uint32_t> ray_of, slot_of; // pass 2 of the loss in two launches (k_loss_pass2_rays -> k_loss_pass2_samples)
 	DevBuf<float> chain_rec; // per marched-sample slot: the compositing recurrence's running values, left by pass 1 of the loss for pass 2 (LossArgs::chain_rec)
 	DevBuf<float> ray_setup, ray_dunnorm, ray_t;
@@ -659,7 +661,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	return a;
 }
 
-int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr, hipEvent_t wait_before_write = nullptr, hipEvent_t rest_done = nullptr) {
+int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples, hipEvent_t done = nullptr, hipEvent_t wait_before_write = nullptr, hipEvent_t rest_done = nullptr, hipEvent_t wait_before_scans = nullptr) {
 	if (!c->coarse_valid) { const int rc0 = rebuild_coarse(c, s); if (rc0 != RNB_OK) return rc0; } // a caller may have written the bitfield (rnb_buffer)
 	MarchArgs a = march_args(c, n_rays, n_rays_total, max_samples);
 	c->gen_k1 = a.k1;
@@ -683,6 +685,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
 	}
 	c->prof.mark(s, P_MARCH_COUNT);
+	if (wait_before_scans) HIP_TRY(hipStreamWaitEvent(s, wait_before_scans, 0)); // (launch_premarch: the previous step's second loss pass may still be reading what the scans and k_march_write overwrite)
 	const uint32_t n_scan_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
 	if (c->knobs.scan_chain && n_scan_tiles <= 64) { // one launch, one workgroup per 4096-ray tile (k_scan_rays_chain)
 		ScanChainArgs q;
@@ -712,7 +715,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 }
 
 // defer_rollover: the training step pads the batch in the same launch as its loss reduction (launch_reduce_losses)
-int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t two_round_n_max = 0, bool defer_rollover = false) {
+int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_total, uint32_t two_round_n_max = 0, bool defer_rollover = false, bool reduce_too = false) {
 	LossArgs a;
 	a.n_rays = n_rays; a.n_rays_global = n_rays * c->cfg.world_size; a.ray_offset = c->cfg.rank * n_rays; a.n_rays_total = n_rays_total;
 	a.n_images = c->n_views; a.B = c->cfg.target_batch_size;
@@ -726,6 +729,8 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.src_slot = c->cin_flow ? c->src_slot.p : nullptr;
 	a.chain_rec = c->knobs.loss_chain_records ? c->chain_rec.p : nullptr;
 	a.ray_grad = c->ray_grad.p; a.ray_of = c->ray_of.p; a.slot_of = c->slot_of.p;
+	a.wg_partial = c->wg_partial.p; a.red_out = nullptr; a.red_host_out = nullptr; a.red_host_seq = 0;
+	c->loss_reduced = false;
 	if (!c->pre.loss_cleared) HIP_TRY(hipMemsetAsync(c->loss.p, 0, c->loss.bytes(), s)); // all three rows in one fill (the pre-generated step had it done beside the previous backward pass)
 	c->pre.loss_cleared = false;
 	const uint32_t blocks = (n_rays + 3) / 4; // one wavefront per ray
@@ -762,7 +767,18 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	c->prof.mark(s, P_SCAN_COMPACT);
 	if (a.chain_rec && c->knobs.loss_flat) { // at every batch size (step 1000, 12 k long rays: 0.6247 -> 0.6189 ms/step; step 2000: 0.6216 -> 0.6100; step 6000: 0.6526 -> 0.6367)
 		hipLaunchKernelGGL(k_loss_pass2_rays<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
-		hipLaunchKernelGGL(k_loss_pass2_samples, dim3((a.B + 255) / 256), dim3(256), 0, s, a);
+		hipEvent_t ev = nullptr;
+		if (reduce_too) { // the training step: the loss sums and their readback in the same launch (launch_reduce_losses for the one-launch forms)
+			const bool poll = c->poll_loss();
+			if (poll) { if (++c->rb_seq == 0) ++c->rb_seq; c->loss_polled = false; }
+			a.red_out = c->loss_sums.p; a.red_host_out = reinterpret_cast<double*>(c->host_rb_dev); a.red_host_seq = poll ? c->rb_seq : 0u;
+			ev = poll ? nullptr : c->ev_loss;
+			c->loss_reduced = true;
+		}
+		LAUNCH_EV(k_loss_pass2_samples, dim3(1 + (a.B + 255) / 256), dim3(256), 0, s, ev, a); // workgroup 0: the reduction; the samples also write their wrapped copies (no k_rollover)
+		c->prof.mark(s, P_LOSS_PASS2);
+		HIP_TRY(hipGetLastError());
+		return RNB_OK;
 	} else if (a.chain_rec) {
 		if (rows) hipLaunchKernelGGL((k_loss_pass2<16, true>), dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 		else hipLaunchKernelGGL((k_loss_pass2<64, true>), dim3(blocks), dim3(256), 0, s, a);
@@ -1178,7 +1194,7 @@ int rnb_destroy(rnb_ctx* c) {
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_range.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
 	c->ray_indices.free(); c->numsteps.free(); c->counters.free(); c->rays.free(); c->coords.free(); c->coords_compacted.free();
-	c->loss.free(); c->mlp_out.free(); c->chain_rec.free(); c->ray_grad.free(); c->ray_of.free(); c->slot_of.free(); c->dloss_dout.free();
+	c->loss.free(); c->mlp_out.free(); c->chain_rec.free(); c->ray_grad.free(); c->ray_of.free(); c->slot_of.free(); c->wg_partial.free(); c->dloss_dout.free();
 	c->wimg_fwd.free(); c->wimg_fbs.free(); c->wimg_train.free(); c->wimg_rgb.free(); c->cin_eval.free(); c->dcin.free(); c->rgb_out_scratch.free(); c->src_slot.free(); c->ray_const.free(); c->ray_base1.free(); c->scan_words.free(); c->idx1.free(); c->idx2.free(); c->fwd_counts.free(); c->unfinished.free();
 	c->ray_setup.free(); c->ray_t.free(); c->ray_dunnorm.free(); c->ray_steps.free(); c->ray_base.free(); c->ray_slot.free(); c->ncomp.free(); c->cbase.free(); c->scan_tiles.free(); c->loss_partial.free(); c->ray_loss.free();
 	c->mc_table.free(); c->fm.free(); c->g12.free(); c->srec.free(); c->var_partial.free(); c->dw_partial.free();
@@ -1248,7 +1264,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
-	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->chain_rec, (size_t)B * 16 * CHAIN_REC_FLOATS); ALLOC(c->ray_grad, (size_t)maxr * 16); ALLOC(c->ray_of, B); ALLOC(c->slot_of, B); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
+	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->chain_rec, (size_t)B * 16 * CHAIN_REC_FLOATS); ALLOC(c->ray_grad, (size_t)maxr * 16); ALLOC(c->ray_of, B); ALLOC(c->slot_of, B); ALLOC(c->wg_partial, ((size_t)maxr + 15) / 16 * 3); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
 	ALLOC(c->loss, (size_t)maxr * 3); c->ek_loss = c->loss.p + maxr; c->mask_loss = c->loss.p + (size_t)maxr * 2;
 	ALLOC(c->ray_setup, (size_t)maxr * 8); ALLOC(c->ray_t, (size_t)maxr * RNB_MAX_STEPS); ALLOC(c->ray_dunnorm, (size_t)maxr * 3); ALLOC(c->ray_steps, maxr); ALLOC(c->ray_base, maxr); ALLOC(c->ray_slot, maxr);
 	ALLOC(c->scan_tiles, 256 + 64); ALLOC(c->loss_partial, 64 * 3);
@@ -1829,7 +1845,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 	if (rc != RNB_OK) return rc;
 	c->prof.mark(s, P_FORWARD);
 	if (join_rest) HIP_TRY(hipStreamWaitEvent(s, c->ev_march_rest, 0));
-	rc = compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true);
+	rc = compute_loss(c, s, n_rays, n_rays_total, two_round ? max_inference : 0, true, true);
 	if (rc != RNB_OK) return rc;
 	return pregenerate_grid_samples(c, s); // after an update: the next one's samples, behind everything this step's front needed from the host
 }
@@ -1858,6 +1874,7 @@ static int wait_loss_readback(rnb_ctx* c, hipStream_t s) {
 }
 
 static int launch_reduce_losses(rnb_ctx* c, hipStream_t s) {
+	if (c->loss_reduced) return RNB_OK; // k_loss_pass2_samples did it (compute_loss)
 	c->prof.mark(s, P_NONE);
 	// the 48-byte readback goes straight into the pinned host block (no copy kernel, no marker packet); ev_loss is the kernel's completion
 	const bool tiled = c->cur_n_rays >= c->knobs.march_narrow_from;
@@ -1896,7 +1913,10 @@ static int launch_premarch(rnb_ctx* c) {
 	// exclude each other on a SIMD; a march that has started beside the first keeps the second at half occupancy (253 instead of 113 us, the step 0.79 instead of
 	// 0.76 ms). Behind them it runs beside the scatter, as it effectively does with --no-albedo, where k_fwd_bwd_sdf claims the registers first.
 	if (c->knobs.march_late || c->rgb_split()) HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_fb, 0));
-	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march, c->tail_pending ? c->ev_tail : nullptr, c->ev_march_rest);
+	int rc = generate_training_samples(c, c->s_march, n_rays, n_rays_total, max_inference, c->ev_march, c->tail_pending ? c->ev_tail : nullptr, c->ev_march_rest,
+	                                   // the loss sums were published from INSIDE k_loss_pass2_samples (workgroup 0), whose other workgroups may still be reading the step's sample buffers when the host
+	                                   // gets here: k_march_count touches none of them, everything behind it waits for k_fwd_bwd*'s completion (same stream as the loss pass, behind it)
+	                                   c->loss_reduced ? c->ev_fb : nullptr);
 	if (rc != RNB_OK) return rc;
 	c->tail_pending = false; // the next step reaches ev_tail through ev_march
 	c->pre.loss_cleared = true;
