@@ -18,7 +18,7 @@ def per_step(T, ks):
 
 groups = {"k_forward": ["k_forward_chained"], "k_fwd_bwd": fb, "k_grid_scatter": ["k_grid_scatter_quad_rl", "k_grid_scatter_quad", "k_grid_scatter_lds"],
           "k_adam_ema": ["k_adam_ema"], "k_dw*7+k_dw_finish": [k for k in F if "k_dw" in k], "k_loss_pass1": ["k_loss_pass1", "k_loss_pass1_heads"],
-          "k_loss_pass2+k_rollover": ["k_loss_pass2"], "k_march_count": [k for k in F if k.startswith("k_march_count")], "k_march_write": [k for k in F if k.startswith("k_march_write")],
+          "k_loss_pass2+k_rollover": [k for k in F if k.startswith("k_loss_pass2")], "k_march_count": [k for k in F if k.startswith("k_march_count")], "k_march_write": [k for k in F if k.startswith("k_march_write")],
           "k_scan_rays": [k for k in F if k.startswith("k_scan_rays")], "k_scan_compact": [k for k in F if k.startswith("k_scan_compact")]}
 out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernels serialised, cfg.overlap=0), bench.py --steps 10 after 2000 burn-in steps; tools/collect_pmc.sh + tools/pmc_traffic.py",
        "_units": "bytes per training step (counter value in KiB x 1024). FETCH_SIZE is NOT doubled: the x2 gfx950 correction of the guide is calibrated for wide coalesced streams only; on k_adam_ema (a 16 B/lane stream) the doubled value matches the expected 8 B + 16 B x live fraction per parameter. Gathers / atomics are uncalibrated.",

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rnb::", "")))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2].startswith("k_loss_pass2")]
+marks = [i for i, r in enumerate(rows) if r[2].startswith("k_loss_pass2") and not r[2].startswith("k_loss_pass2_samples")]  # one per step: k_loss_pass2_rays (two-launch form) or k_loss_pass2<..>
 lo = marks[-n_steps - 1]
 hi = marks[-1]
 acc = {}

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rnb::", ""), r.get("Queue_Id", "?")))
 rows.sort()
 # one cycle = from one k_scan_compact (once per step) to the next
-starts = [i for i, r in enumerate(rows) if r[2].startswith("k_loss_pass2")]
+starts = [i for i, r in enumerate(rows) if r[2].startswith("k_loss_pass2") and not r[2].startswith("k_loss_pass2_samples")]  # one per step: k_loss_pass2_rays (two-launch form) or k_loss_pass2<..>
 i0, i1 = starts[-back - 1], starts[-back]
 t0 = rows[i0][0]
 print("step length %.1f us" % ((rows[i1][0] - t0) / 1e3))
