@@ -1106,6 +1106,11 @@ struct LossArgs {
 	uint32_t *ray_of, *slot_of;
 	// ... which also pad the compacted batch (fill_rollover*, common_device.h:514-535) and -- in the training step -- reduce and publish the step's loss sums
 	// (what k_rollover / k_reduce_losses_rollover do behind the one-launch forms): a kernel boundary on the critical stream costs 6-9 us here
+	// ... and form the compaction offsets themselves (k_scan_compact* of the one-launch forms): scan_words != null
+	unsigned long long* scan_words; // [64]: ticket << 32 | kept samples of a 4096-ray tile, published by the tile's first workgroup
+	uint32_t scan_ticket;
+	uint32_t* scan_error;  // mapped host word: a wait gave up
+	uint32_t* scan_total;  // &counters[1]
 	double* wg_partial;    // [workgroups of k_loss_pass2_rays][3]: sums of the three loss rows over the workgroup's 16 rays
 	double* red_out;       // null: no reduction (stage API); else the device block of reduce_losses_body
 	double* red_host_out;  // its pinned twin
@@ -1761,15 +1766,63 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 // sample its ray and its marched slot; the samples are then worked on one per lane whatever ray they belong to. Same expressions on the same inputs: same bits.
 template <int LR>
 __global__ __launch_bounds__(256) void k_loss_pass2_rays(const LossArgs a) {
-	__shared__ double rows[256 / LR][3];
-	const uint32_t i_raw = blockIdx.x * (256 / LR) + threadIdx.x / LR;
+	constexpr uint32_t RPW = 256 / LR, WG_PER_TILE = SCAN_TILE / RPW;
+	__shared__ double rows[RPW][3];
+	__shared__ uint32_t wsum[16], n_of[RPW], sh_base;
+	const uint32_t i_raw = blockIdx.x * RPW + threadIdx.x / LR;
 	const int lane = threadIdx.x & (LR - 1);
-	const bool ray_ok = i_raw < a.n_rays && i_raw < a.counters[2];
+	const uint32_t kept = min(a.counters[2], a.n_rays);
+	const bool ray_ok = i_raw < kept;
 	const uint32_t i = ray_ok ? i_raw : 0u;
+	uint32_t scanned_base = 0;
+	if (a.scan_words) {
+		// The compaction offsets (exclusive prefix of ncomp over the kept rays; counters[1] = total), formed here instead of by a launch of their own on the critical stream:
+		// the first workgroup of every 4096-ray tile publishes the tile's sum at once (ticketed word, as k_scan_compact_chain); a workgroup adds the sums of the tiles in front
+		// of its own (polled), the counts in front of it inside its tile (<= 4080 loads from L2, 16 per thread) and those of its own rays in front of each ray.
+		const uint32_t tid = threadIdx.x, lane64 = tid & 63u, wave = tid >> 6;
+		const uint32_t tile = blockIdx.x / WG_PER_TILE, tile_start = tile * SCAN_TILE, i0 = blockIdx.x * RPW;
+		uint32_t total;
+		if (blockIdx.x % WG_PER_TILE == 0) {
+			uint32_t mine = 0;
+#pragma unroll
+			for (uint32_t e = 0; e < SCAN_TILE / 256; ++e) { const uint32_t k = tile_start + e * 256 + tid; mine += k < kept ? a.ncomp[k] : 0u; }
+			(void)block_exclusive_scan<4>(mine, lane64, wave, wsum, total);
+			if (tid == 0) atomicExch(a.scan_words + tile, ((unsigned long long)a.scan_ticket << 32) | total);
+		}
+		uint32_t mine = 0;
+		const uint32_t stop = min(i0, kept);
+#pragma unroll
+		for (uint32_t e = 0; e < SCAN_TILE / 256; ++e) { const uint32_t k = tile_start + e * 256 + tid; mine += k < stop ? a.ncomp[k] : 0u; }
+		(void)block_exclusive_scan<4>(mine, lane64, wave, wsum, total);
+		uint32_t in_front = total;
+		if (tid < 64) { // tiles in front: one lane each (<= 63)
+			uint32_t v = 0;
+			if (tid < tile) {
+				unsigned long long w;
+				uint32_t spins = 0;
+				do { w = atomicAdd(a.scan_words + tid, 0ull); if ((uint32_t)(w >> 32) == a.scan_ticket) break; __builtin_amdgcn_s_sleep(2); } while (++spins < 20000000u); // (bounded, see chain_prefix)
+				if ((uint32_t)(w >> 32) != a.scan_ticket) { w = 0; if (a.scan_error) atomicExch(a.scan_error, 1u); }
+				v = (uint32_t)w;
+			}
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+			if (tid == 0) sh_base = v + in_front;
+		}
+		if (lane == 0) n_of[threadIdx.x / LR] = ray_ok ? a.ncomp[i] : 0u;
+		__syncthreads();
+		scanned_base = sh_base;
+		for (uint32_t r = 0; r < threadIdx.x / LR; ++r) scanned_base += n_of[r];
+		if (ray_ok && lane == 0) a.cbase[i] = scanned_base;
+		if (threadIdx.x == 0 && (kept == 0 ? blockIdx.x == 0 : (kept - 1) / RPW == blockIdx.x)) { // the workgroup of the last kept ray: numsteps_counter_compacted
+			uint32_t t = sh_base;
+			for (uint32_t r = 0; r < RPW; ++r) t += n_of[r];
+			*a.scan_total = t;
+		}
+	}
 	float loss_row = 0.f, mask_row = 0.f, ek_row = 0.f;
 	if (ray_ok) {
 		const RayLoss R = a.ray_loss[i];
-		const uint32_t compacted_base = a.cbase[i];
+		const uint32_t compacted_base = a.scan_words ? scanned_base : a.cbase[i];
 		const uint32_t compacted_numsteps = min(a.B - min(a.B, compacted_base), R.n_comp); // testbed_nerf.cu:1723
 		const uint32_t base = a.numsteps[(size_t)i * 2 + 1];
 		__builtin_amdgcn_wave_barrier();

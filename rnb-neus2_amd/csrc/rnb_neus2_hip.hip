@@ -200,6 +200,8 @@ struct rnb_ctx {
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
+		bool loss_scan_fused_always = false; // RNB_LOSS_SCAN_FUSED=2 (tests): at every batch size
+		bool loss_scan_fused = true; // RNB_LOSS_SCAN_FUSED=0: the compaction offsets by k_scan_compact* in front of the two pass-2 launches (default: formed inside k_loss_pass2_rays)
 		bool loss_flat = true; // RNB_LOSS_FLAT=0: pass 2 of the loss as one launch with 64 / 16 lanes per ray (default: k_loss_pass2_rays, then k_loss_pass2_samples with one lane per compacted sample; needs the chain records)
 		bool loss_chain_records = true; // RNB_LOSS_CHAIN_RECORDS=0: pass 2 of the loss replays the compositing recurrence itself (rounds 1-3) instead of reading the running values pass 1 left
 		int march_write_split = -1; // RNB_MARCH_WRITE_SPLIT=0|1: k_march_write of a march generated ahead as one launch (rounds 1-3) / always split; default: split below 65 536 rays per step. Split: what the first network evaluation reads (idx1, the heads'
@@ -729,6 +731,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	a.src_slot = c->cin_flow ? c->src_slot.p : nullptr;
 	a.chain_rec = c->knobs.loss_chain_records ? c->chain_rec.p : nullptr;
 	a.ray_grad = c->ray_grad.p; a.ray_of = c->ray_of.p; a.slot_of = c->slot_of.p;
+	a.scan_words = nullptr; a.scan_ticket = 0; a.scan_error = nullptr; a.scan_total = nullptr;
 	a.wg_partial = c->wg_partial.p; a.red_out = nullptr; a.red_host_out = nullptr; a.red_host_seq = 0;
 	c->loss_reduced = false;
 	// all three rows in one fill -- for the stage API only (rows beyond the kept rays read as zeros, as in the reference); the training step reads the kept rays' rows, which
@@ -757,7 +760,11 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	if (a.phase) hipLaunchKernelGGL(k_loss_pass1, dim3(std::min(blocks, 1024u)), dim3(256), 0, s, a);
 	else launch_heads();
 	c->prof.mark(s, P_LOSS_PASS1);
-	if (n_rays >= c->knobs.march_narrow_from && c->knobs.scan_chain && (n_rays + SCAN_TILE - 1) / SCAN_TILE <= 64) {
+	const bool flat = a.chain_rec && c->knobs.loss_flat;
+	// the offsets formed inside k_loss_pass2_rays: step 1000 (13 k rays, 4 tiles) 0.6065 -> 0.6015 ms/step; step 6000 (95 k rays, 24 tiles: 5.9 k workgroups polling) 0.6274 -> 0.6270: up to 8 tiles
+	if (flat && c->knobs.loss_scan_fused && (n_rays + SCAN_TILE - 1) / SCAN_TILE <= (c->knobs.loss_scan_fused_always ? 64u : 8u)) {
+		a.scan_words = c->scan_words.p + 64 * 4; a.scan_ticket = ++c->scan_ticket; a.scan_error = c->host_coarse_dev + 6; a.scan_total = c->counters.p + 1;
+	} else if (n_rays >= c->knobs.march_narrow_from && c->knobs.scan_chain && (n_rays + SCAN_TILE - 1) / SCAN_TILE <= 64) {
 		hipLaunchKernelGGL(k_scan_compact_chain, dim3((n_rays + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_WG), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p,
 		                   c->scan_words.p + 64 * 4, ++c->scan_ticket, c->host_coarse_dev + 6);
 	} else if (n_rays >= c->knobs.march_narrow_from) {
@@ -767,7 +774,7 @@ int compute_loss(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32_t n_rays_tot
 	} else
 		hipLaunchKernelGGL(k_scan_compact, dim3(1), dim3(1024), 0, s, n_rays, c->ncomp.p, c->cbase.p, c->counters.p);
 	c->prof.mark(s, P_SCAN_COMPACT);
-	if (a.chain_rec && c->knobs.loss_flat) { // at every batch size (step 1000, 12 k long rays: 0.6247 -> 0.6189 ms/step; step 2000: 0.6216 -> 0.6100; step 6000: 0.6526 -> 0.6367)
+	if (flat) { // at every batch size (step 1000, 12 k long rays: 0.6247 -> 0.6189 ms/step; step 2000: 0.6216 -> 0.6100; step 6000: 0.6526 -> 0.6367)
 		hipLaunchKernelGGL(k_loss_pass2_rays<16>, dim3((n_rays + 15) / 16), dim3(256), 0, s, a);
 		hipEvent_t ev = nullptr;
 		if (reduce_too) { // the training step: the loss sums and their readback in the same launch (launch_reduce_losses for the one-launch forms)
@@ -1352,6 +1359,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_LOSS_SCAN_FUSED")) { k.loss_scan_fused = atoi(e) != 0; k.loss_scan_fused_always = atoi(e) == 2; }
 		if (const char* e = getenv("RNB_LOSS_FLAT")) k.loss_flat = atoi(e) != 0;
 		if (const char* e = getenv("RNB_LOSS_CHAIN_RECORDS")) k.loss_chain_records = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;

@@ -896,7 +896,8 @@ def test_loss_passes_with_16_lanes_per_ray_equal_wavefront_per_ray(scene, traine
     out = []
     kw = dict(apply_no_albedo=0) if albedo else {}
     # default: chain records + pass 2 in two launches (rays, then one lane per compacted sample); then: one launch with 16 lanes per ray; a wavefront per ray; replay, both lane forms
-    for env in (None, {"RNB_LOSS_FLAT": "0"}, {"RNB_LOSS_WAVE_PER_RAY": "1"}, {"RNB_LOSS_CHAIN_RECORDS": "0"}, {"RNB_LOSS_CHAIN_RECORDS": "0", "RNB_LOSS_WAVE_PER_RAY": "1"}):
+    # (the compaction offsets: inside k_loss_pass2_rays up to 8 tiles of rays by default; =2: at every size, =0: by k_scan_compact*)
+    for env in (None, {"RNB_LOSS_SCAN_FUSED": "0"}, {"RNB_LOSS_SCAN_FUSED": "2"}, {"RNB_LOSS_FLAT": "0"}, {"RNB_LOSS_WAVE_PER_RAY": "1"}, {"RNB_LOSS_CHAIN_RECORDS": "0"}, {"RNB_LOSS_CHAIN_RECORDS": "0", "RNB_LOSS_WAVE_PER_RAY": "1"}):
         c = _clone(scene, state, env=env, overlap=0, **kw)
         try:
             c.set_controller(state["step"] | 1, n_rays, state["before"], 0)
