@@ -242,6 +242,11 @@ class DataParallelTrainer:
         finish (ray controller; queues the NEXT step's march on the side stream) -> gradient all-reduce -> apply (Adam).
         The next step's march therefore runs beside this step's backward pass, gradient all-reduce and optimizer."""
         ctx = self.ctx
+        if not self._collectives and not os.environ.get("RNB_DP_SPLIT_CALLS"):
+            # one rank, nothing to exchange: the library's own step (rnb_train_step = begin, apply, local, finish in one call). The next step's march is then queued
+            # by the C code the moment the loss readback arrives; through the four Python calls below it started ~25 us later (measured, late regime: its chain is what
+            # the next network evaluation waits for there)
+            return ctx.train_step(self.stream, allow_no_samples=allow_no_samples)
         ctx.train_step_begin(self.stream)
         counters, sums = ctx.train_step_local(self.stream)
         if self._collectives:
