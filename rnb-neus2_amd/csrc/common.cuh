@@ -172,11 +172,24 @@ __device__ __forceinline__ void encode_level_core(const uint32_t* __restrict__ g
 	// (fewer accesses, +18 % time), unconditional second gathers (+10 %), a single wave-level branch around the four
 	// second gathers (+5 % on the one-wave-per-SIMD kernels). (Entry `size` is readable: the parameter block continues
 	// past every level.)
+	// The eight entries (grid_entry's values), formed per LEVEL rather than per corner (round 4): whether the level is dense or hashed and whether its table is a power
+	// of two is wave-uniform, and (y + 1) * c = y * c + c in uint32 arithmetic, so a level costs two integer multiplies instead of up to 32 (v_mul_lo_u32 issues at a
+	// quarter of the rate: they were a fifth of k_forward_chained's issue cycles, 426 of 7 678 instructions at four times the cost).
+	uint32_t stride = res;
+	bool dense = false;
+	if (stride <= hashmap_size) { stride *= res; if (stride <= hashmap_size) { const uint32_t s2 = stride; stride *= res; dense = !(hashmap_size < stride); stride = s2; } }
+	const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+	uint32_t ty[2], tz[2];
+	if (dense) { ty[0] = pg[1] * res; ty[1] = ty[0] + res; tz[0] = pg[2] * stride; tz[1] = tz[0] + stride; }       // index = x + y res + z res^2
+	else { ty[0] = pg[1] * 2654435761u; ty[1] = ty[0] + 2654435761u; tz[0] = pg[2] * 805459861u; tz[1] = tz[0] + 805459861u; } // index = x ^ y P1 ^ z P2
 	uint32_t v[8];
 #pragma unroll
 	for (uint32_t yz = 0; yz < 4; ++yz) {
-		const uint32_t e0 = grid_entry(hashmap_size, res, pg[0], pg[1] + (yz & 1u), pg[2] + (yz >> 1));
-		const uint32_t e1 = grid_entry(hashmap_size, res, pg[0] + 1u, pg[1] + (yz & 1u), pg[2] + (yz >> 1));
+		uint32_t e0, e1;
+		if (dense) { e0 = pg[0] + ty[yz & 1u] + tz[yz >> 1]; e1 = e0 + 1u; }
+		else { const uint32_t h = ty[yz & 1u] ^ tz[yz >> 1]; e0 = pg[0] ^ h; e1 = (pg[0] + 1u) ^ h; }
+		if (pow2) { e0 &= hashmap_size - 1u; e1 &= hashmap_size - 1u; }
+		else { e0 = e0 >= hashmap_size ? e0 - hashmap_size : e0; e1 = e1 >= hashmap_size ? e1 - hashmap_size : e1; }
 		const U2 p = *reinterpret_cast<const U2*>(g + e0);
 		uint32_t v1 = p.y;
 		if (e1 != e0 + 1u) v1 = g[e1];
