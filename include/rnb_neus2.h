@@ -288,7 +288,9 @@ int rnb_train_step(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
 /* Everything up to and including the backward pass; leaves gradients in GRADS_FP32. */
 int rnb_train_step_begin(rnb_ctx* ctx, void* stream);
 /* Optimizer step, ++training_step, Counters::update_after_training (testbed_nerf.cu:3532-3558). Syncs.
- * == apply; local; finish(local values). Data-parallel hosts call the three pieces and sum the local counters /
+ * == apply; local; finish(local values) -- in the overlapped schedule (cfg.overlap) queued as local; finish; apply: the next step's march goes out the moment
+ * the loss readback arrives, the optimizer's launches behind it (same results; the optimizer runs even when the step produced no samples, whose error code is
+ * then returned). Data-parallel hosts call the three pieces and sum the local counters /
  * loss sums over the ranks before finish, so every rank draws the same rays_per_batch for the next step. */
 int rnb_train_step_end(rnb_ctx* ctx, void* stream, rnb_step_stats* stats);
 int rnb_train_step_apply(rnb_ctx* ctx, void* stream);
