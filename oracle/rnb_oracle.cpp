@@ -33,7 +33,7 @@
 // Export the rnb_neus2.h signatures under the orc_ prefix.
 #include "orc_prefix.h"
 #include "../include/rnb_neus2.h"
-#include "../rnb-neus2_amd/host/mesh.hpp" // the host marching-cubes loop (shared with the testbed CLI)
+#include "orc_mesh.h" // the checker's own marching cubes (no source shared with the product's mesh code)
 
 #include <algorithm>
 #include <chrono>
@@ -1801,18 +1801,18 @@ int rnb_sdf_lattice(orc_ctx_s* c, void*, const uint32_t res[3], float lattice_mi
 	return RNB_OK;
 }
 
-// marching_cubes_gpu (src/marching_cubes.cu:794-822): host twin of rnb_marching_cubes over the same loop as the testbed's host mesh code.
+// marching_cubes_gpu (src/marching_cubes.cu:794-822): the checker's twin of rnb_marching_cubes (orc_mesh.h).
 int rnb_marching_cubes(orc_ctx_s* c, void*, const float* density, const uint32_t res[3], const float aabb_min[3], const float aabb_max[3], float thresh,
                        float** verts, uint32_t** indices, uint32_t* n_verts, uint32_t* n_indices) {
 	if (!c || !density || !res || !aabb_min || !aabb_max || !verts || !indices || !n_verts || !n_indices) return fail(RNB_ERR_INVALID, "null argument");
-	mesh::Mesh m;
-	try { m = mesh::marching_cubes(density, (int)res[0], (int)res[1], (int)res[2], aabb_min, aabb_max, thresh, false); }
-	catch (const std::exception& e) { return fail(RNB_ERR_INVALID, e.what()); }
-	*n_verts = (uint32_t)m.verts.size(); *n_indices = (uint32_t)m.indices.size();
-	*verts = m.verts.empty() ? nullptr : (float*)std::malloc(m.verts.size() * 12);
-	*indices = m.indices.empty() ? nullptr : (uint32_t*)std::malloc(m.indices.size() * 4);
-	if (*verts) std::memcpy(*verts, m.verts.data(), m.verts.size() * 12);
-	if (*indices) std::memcpy(*indices, m.indices.data(), m.indices.size() * 4);
+	std::vector<float> v;
+	std::vector<uint32_t> idx;
+	if (!orc_mesh::marching_cubes(density, res, aabb_min, aabb_max, thresh, v, idx)) return fail(RNB_ERR_INVALID, "marching cubes: missing edge vertex");
+	*n_verts = (uint32_t)(v.size() / 3); *n_indices = (uint32_t)idx.size();
+	*verts = v.empty() ? nullptr : (float*)std::malloc(v.size() * 4);
+	*indices = idx.empty() ? nullptr : (uint32_t*)std::malloc(idx.size() * 4);
+	if (*verts) std::memcpy(*verts, v.data(), v.size() * 4);
+	if (*indices) std::memcpy(*indices, idx.data(), idx.size() * 4);
 	return RNB_OK;
 }
 
