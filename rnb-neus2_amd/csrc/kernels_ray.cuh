@@ -1319,6 +1319,25 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 }
 
 
+// The per-ray constants of the loss as a launch of their own, one thread per KEPT ray (round 4). Inside k_march_write the first RAYS threads of a 1024-thread
+// workgroup work them out (~2000 dependent instructions, pixel fetches) while its other wavefronts have long finished: the workgroup holds its slots for that
+// chain, and the kernel took 50-80 us beside the optimizer for 15-30 us of writing. Needs RAY_INDICES (k_march_write).
+__global__ __launch_bounds__(64) void k_ray_constants(const MarchArgs a, float* __restrict__ ray_const) {
+	const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+	if (s >= min(a.counters[2], a.n_rays)) return;
+	RayConstIn in;
+	in.rng = a.rng; in.ray_offset = a.ray_offset; in.n_rays_global = a.n_rays_global; in.n_rays_total = a.n_rays_total; in.n_images = a.n_images;
+	in.views = a.views; in.F = a.F; in.light_dirs = a.light_dirs;
+	struct { float rgbtarget[4], light[3], mask_certainty, mask_gt; } rc;
+	ray_constants_core(in, a.ray_indices[s], rc);
+	float* q = ray_const + (size_t)s * RAY_CONST_FLOATS;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) q[k] = rc.rgbtarget[k];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) q[4 + k] = rc.light[k];
+	q[7] = rc.mask_certainty; q[8] = rc.mask_gt;
+}
+
 // The sequential part of the compositing loop (testbed_nerf.cu:1608-1697) for up to 64 samples whose per-sample terms sit
 // one per lane: the recurrence runs through chain.cuh (every lane ends with the running values right after its sample, in
 // the reference's operation order, so the rounding -- and with it the early stop -- is identical); the loop's exit test

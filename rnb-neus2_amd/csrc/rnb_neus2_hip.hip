@@ -204,6 +204,8 @@ struct rnb_ctx {
 		bool loss_scan_fused = true; // RNB_LOSS_SCAN_FUSED=0: the compaction offsets by k_scan_compact* in front of the two pass-2 launches (default: formed inside k_loss_pass2_rays)
 		bool loss_flat = true; // RNB_LOSS_FLAT=0: pass 2 of the loss as one launch with 64 / 16 lanes per ray (default: k_loss_pass2_rays, then k_loss_pass2_samples with one lane per compacted sample; needs the chain records)
 		bool loss_chain_records = true; // RNB_LOSS_CHAIN_RECORDS=0: pass 2 of the loss replays the compositing recurrence itself (rounds 1-3) instead of reading the running values pass 1 left
+		int ray_const_dense = 2; // RNB_RAY_CONST_DENSE=0: the loss's per-ray constants inside k_march_write (rounds 2-4); 1: k_ray_constants (one thread per kept ray) behind a k_march_write that is never split;
+		                         // 2 (default): behind k_march_write split as before. ms/step at steps 1000 / 2000 / 6000: 0: 0.6019 / 0.5884 / 0.6292, 1: 0.6088 / 0.5954 / 0.6269, 2: 0.5999 / 0.5877 / (= 1)
 		int march_write_split = -1; // RNB_MARCH_WRITE_SPLIT=0|1: k_march_write of a march generated ahead as one launch (rounds 1-3) / always split; default: split below 65 536 rays per step. Split: what the first network evaluation reads (idx1, the heads'
 		                               // coordinates) in a first launch, whose completion the critical stream waits for; the rest (ray constants, ray records, the tails' coordinates) in a second one
 		                               // that runs beside that evaluation and is joined in front of the loss pass
@@ -703,13 +705,18 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL(k_scan_rays, dim3(1), dim3(1024), 0, s, n_rays, max_samples, c->ray_steps.p, c->ray_base.p, c->ray_slot.p, c->counters.p, a.k1, c->ray_base1.p, c->fwd_counts.p);
 	c->prof.mark(s, P_SCAN_RAYS);
 	if (wait_before_write) HIP_TRY(hipStreamWaitEvent(s, wait_before_write, 0)); // (rnb_ctx::tail_pending)
-	c->gen_split = rest_done != nullptr && a.k1 != 0 && (c->knobs.march_write_split < 0 ? n_rays < 65536u : c->knobs.march_write_split != 0); // (measured: -2.7 / -3.5 us per step at 12.6 k / 50 k rays, +3.2 at 94 k: the join costs a barrier packet)
+	const bool dense_const = c->knobs.ray_const_dense != 0;
+	float* const ray_const = a.ray_const;
+	if (dense_const) a.ray_const = nullptr; // k_ray_constants below
+	c->gen_split = rest_done != nullptr && a.k1 != 0 && (c->knobs.ray_const_dense == 1 ? false : (c->knobs.march_write_split < 0 ? n_rays < 65536u : c->knobs.march_write_split != 0)); // (measured: -2.7 / -3.5 us per step at 12.6 k / 50 k rays, +3.2 at 94 k: the join costs a barrier packet)
 	for (uint32_t part = c->gen_split ? 1u : 0u; part <= (c->gen_split ? 2u : 0u); ++part) {
 		a.part = part;
 		hipEvent_t ev = part == 2 ? rest_done : done;
+		if (dense_const && part != 1) ev = nullptr; // the constants' launch carries the event
 		if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
 		else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
 	}
+	if (dense_const) LAUNCH_EV(k_ray_constants, dim3((n_rays + 63) / 64), dim3(64), 0, s, c->gen_split ? rest_done : done, a, ray_const); // one thread per kept ray
 	c->prof.mark(s, P_MARCH_WRITE);
 	c->prof.units[P_MARCH_COUNT] += n_rays;
 	HIP_TRY(hipGetLastError());
@@ -1362,6 +1369,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_LOSS_SCAN_FUSED")) { k.loss_scan_fused = atoi(e) != 0; k.loss_scan_fused_always = atoi(e) == 2; }
 		if (const char* e = getenv("RNB_LOSS_FLAT")) k.loss_flat = atoi(e) != 0;
 		if (const char* e = getenv("RNB_LOSS_CHAIN_RECORDS")) k.loss_chain_records = atoi(e) != 0;
+		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 	}
 	plan_scatter_groups(c);
