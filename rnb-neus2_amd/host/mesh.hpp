@@ -1,9 +1,9 @@
-// mesh.hpp — iso-surface extraction and OBJ output for `--save-mesh` (src/marching_cubes.cu:276-430, 794-982;
-// src/testbed_nerf.cu:4218-4350). Vertices sit on lattice edges exactly where the reference's gen_vertices puts them
-// (linear interpolation of the SDF lattice, one shared vertex per crossing edge). Cells are triangulated with the table the
-// reference uses (mc_table.hpp: the public Bourke / PyMCubes table, src/marching_cubes.cu:401-659), so on identical lattices the
-// triangle set is the reference's; vertices and triangles are numbered in lattice order (the reference numbers them with atomic
-// counters, i.e. in no particular order). Normals and face order follow save_mesh (src/marching_cubes.cu:354-356, 930-975).
+// mesh.hpp — host side of `--save-mesh` (src/marching_cubes.cu:794-982; src/testbed_nerf.cu:4218-4350): the case table in the form the device
+// kernels take it (mc_table.hpp: the public Bourke / PyMCubes table the reference uses, src/marching_cubes.cu:401-659), area-weighted normals and
+// the OBJ writer. The extraction itself runs on the device (rnb_marching_cubes, csrc/kernels_mesh.cuh): vertices on lattice edges where the
+// reference's gen_vertices puts them, vertices and triangles numbered in lattice order (the reference numbers them with atomic counters, i.e. in
+// no particular order). Until round 4 this file also held a host loop of the extraction; its only caller was the CPU checker, which has its own
+// statement now (oracle/orc_mesh.h). Normals and face order follow save_mesh (src/marching_cubes.cu:354-356, 930-975).
 #pragma once
 #include <array>
 #include <cmath>
@@ -40,7 +40,6 @@ struct Mesh {
 	std::vector<uint32_t> indices;
 };
 
-// density[x + y*rx + z*rx*ry]; lattice point (x,y,z) sits at aabb_min + (x,y,z) * (aabb_max - aabb_min) / res
 // area-weighted vertex normals exactly as accumulate_1ring forms them (marching_cubes.cu:354-356): n = (pb - pa) x (pa - pc), i.e. the
 // NEGATIVE of the counter-clockwise normal of (a, b, c). With the table's winding and "corner bit = sdf > 0" that is the direction of
 // decreasing SDF (into the object); the reference writes these to the OBJ as they are, and so does save_obj.
@@ -53,54 +52,6 @@ inline void compute_normals(Mesh& m) {
 		const Vec3 n = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
 		for (uint32_t q : {ia, ib, ic}) { m.normals[q].x += n.x; m.normals[q].y += n.y; m.normals[q].z += n.z; }
 	}
-}
-
-inline Mesh marching_cubes(const float* density, int rx, int ry, int rz, const float aabb_min[3], const float aabb_max[3], float thresh, bool with_normals = true) {
-	static const Tables T;
-	Mesh m;
-	const size_t res2 = (size_t)rx * ry, res3 = res2 * rz;
-	std::vector<int32_t> vidx(res3 * 3, -1);
-	const float sc[3] = {(aabb_max[0] - aabb_min[0]) / rx, (aabb_max[1] - aabb_min[1]) / ry, (aabb_max[2] - aabb_min[2]) / rz};
-	auto inside = [&](size_t i) { return density[i] > thresh; };
-	for (int z = 0; z < rz; ++z) for (int y = 0; y < ry; ++y) for (int x = 0; x < rx; ++x) { // gen_vertices (marching_cubes.cu:276-327)
-		const size_t idx = (size_t)x + (size_t)y * rx + (size_t)z * res2;
-		const float f0 = density[idx];
-		const bool in0 = f0 > thresh;
-		const int lim[3] = {rx - 1, ry - 1, rz - 1};
-		const int p[3] = {x, y, z};
-		const size_t step[3] = {1, (size_t)rx, res2};
-		for (int a = 0; a < 3; ++a) {
-			if (p[a] >= lim[a]) continue;
-			const float f1 = density[idx + step[a]];
-			if (in0 != (f1 > thresh)) {
-				const float dt = (thresh - f0) / (f1 - f0);
-				float q[3] = {(float)x, (float)y, (float)z};
-				q[a] += dt;
-				vidx[idx + res3 * a] = (int32_t)m.verts.size();
-				m.verts.push_back({q[0] * sc[0] + aabb_min[0], q[1] * sc[1] + aabb_min[1], q[2] * sc[2] + aabb_min[2]});
-			}
-		}
-	}
-	for (int z = 0; z + 1 < rz; ++z) for (int y = 0; y + 1 < ry; ++y) for (int x = 0; x + 1 < rx; ++x) { // gen_faces
-		const size_t idx = (size_t)x + (size_t)y * rx + (size_t)z * res2;
-		int mask = 0;
-		for (int c = 0; c < 8; ++c) if (inside(idx + CORNER[c][0] + (size_t)CORNER[c][1] * rx + (size_t)CORNER[c][2] * res2)) mask |= 1 << c;
-		if (mask == 0 || mask == 255) continue;
-		const int8_t* t = T.tri[mask].data();
-		for (int k = 0; t[k] >= 0; ++k) {
-			const int e = t[k];
-			const int a = EDGE[e][0], b = EDGE[e][1];
-			int axis = 0;
-			for (int d = 0; d < 3; ++d) if (CORNER[a][d] != CORNER[b][d]) axis = d;
-			const int lo = (CORNER[a][0] + CORNER[a][1] + CORNER[a][2] <= CORNER[b][0] + CORNER[b][1] + CORNER[b][2]) ? a : b;
-			const size_t cidx = idx + CORNER[lo][0] + (size_t)CORNER[lo][1] * rx + (size_t)CORNER[lo][2] * res2;
-			const int32_t v = vidx[cidx + res3 * axis];
-			if (v < 0) throw std::runtime_error("marching cubes: missing edge vertex");
-			m.indices.push_back((uint32_t)v);
-		}
-	}
-	if (with_normals) compute_normals(m);
-	return m;
 }
 
 // OBJ with per-vertex colours and normals (save_mesh, marching_cubes.cu:922-981): v = n2w_s * ((p - offset) / scale) + n2w_t.

@@ -3,8 +3,8 @@ import numpy as np
 
 
 def host_marching_cubes(density, thresh=0.0, aabb_min=(0, 0, 0), aabb_max=(1, 1, 1)):
-    """The host loop of rnb-neus2_amd/host/mesh.hpp through the oracle library's entry point (the oracle's rnb_marching_cubes IS
-    that loop): the reference ordering every device implementation must reproduce."""
+    """The checker's own marching cubes (oracle/orc_mesh.h, vertices and triangles numbered by prefix sums in lattice order) through the oracle
+    library's entry point: the ordering every device implementation must reproduce bit for bit."""
     from tests import oracle_lib
     cpu = oracle_lib.context(target_batch_size=128, max_rays_per_batch=128, initial_rays_per_batch=128, n_levels=2, log2_hashmap_size=12)
     try:
