@@ -238,7 +238,9 @@ int rnb_update_density_grid(rnb_ctx* ctx, void* stream);
 /* Data parallel: the occupancy update sharded over the ranks. The update evaluates the network on a SET of 2^20 sample points and splats the densities
  * with atomicMax into DENSITY_GRID_TMP (testbed_nerf.cu:616-635); with world_size > 1
  *     rnb_update_density_grid_begin   K1 (all samples: every rank draws the same ones) + K2-K3 on samples [rank n / W, (rank + 1) n / W) of the evaluation order
- *     element-wise MAX of DENSITY_GRID_TMP over the ranks (float[128^3 (max_cascade + 1)], all values >= 0: the same as a max of the words as int32 / uint32)
+ *     element-wise MAX of DENSITY_GRID_TMP over the ranks (float[128^3 (max_cascade + 1)]) taken on the words as UINT32, the order of the single-rank atomicMax
+ *                                     (testbed_nerf.cu:634; values are >= 0 or NaN, and a NaN with its sign bit set must win as it does on one rank). The pointer
+ *                                     behind RNB_BUF_DENSITY_GRID_TMP changes from update to update (two targets swap roles): fetch it after every _begin
  *     rnb_update_density_grid_end     K4-K5: EMA, mean, bitfield, pools
  * leaves every rank with the grid a single rank computes, bit for bit, for 1 / W of the network evaluations. rnb_update_density_grid = begin; [the exchange]; end,
  * where the exchange is the callback of rnb_set_grid_exchange (stream-ordered work on `stream`, e.g. one ncclAllReduce(ncclMax); returns 0 on success) -- which is

@@ -1820,7 +1820,11 @@ __global__ __launch_bounds__(256) void k_loss_pass2_rays(const LossArgs a) {
 				unsigned long long w;
 				uint32_t spins = 0;
 				do { w = atomicAdd(a.scan_words + tid, 0ull); if ((uint32_t)(w >> 32) == a.scan_ticket) break; __builtin_amdgcn_s_sleep(2); } while (++spins < 20000000u); // (bounded, see chain_prefix)
-				if ((uint32_t)(w >> 32) != a.scan_ticket) { w = 0; if (a.scan_error) atomicExch(a.scan_error, 1u); }
+				if ((uint32_t)(w >> 32) != a.scan_ticket) { // gave up: report, and poison the step -- k_loss_pass2_samples sees the word and compacts nothing (zero counter), as the chain scans do
+					w = 0;
+					if (a.scan_error) atomicExch(a.scan_error, 1u);
+					atomicExch(a.scan_words + 64, ((unsigned long long)a.scan_ticket << 32) | 1ull);
+				}
 				v = (uint32_t)w;
 			}
 #pragma unroll
@@ -1899,7 +1903,10 @@ __device__ __forceinline__ void publish_losses(const double s0, const double s1,
 // Workgroup 0: the step's loss sums from the partial sums of k_loss_pass2_rays (fixed order) and their publication; the others: one lane per compacted sample,
 // which also writes the sample's wrapped copies behind the compacted batch when that is shorter than B (fill_rollover_and_rescale<half> + fill_rollover<float>).
 __global__ __launch_bounds__(256) void k_loss_pass2_samples(const LossArgs a) {
+	// a wait of the compaction scan inside k_loss_pass2_rays gave up (word 64 of its block carries this launch's ticket): the offsets are wrong, nothing is compacted
+	const bool poisoned = a.scan_words && (uint32_t)(a.scan_words[64] >> 32) == a.scan_ticket;
 	if (blockIdx.x == 0) {
+		if (poisoned) { if (threadIdx.x == 0) *a.scan_total = 0u; __syncthreads(); }
 		if (!a.red_out) return;
 		__shared__ double sh[4][3];
 		const uint32_t n_part = (min(a.counters[2], a.n_rays) + 15u) / 16u; // workgroups of k_loss_pass2_rays<16> that hold kept rays
@@ -1914,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2_samples(const LossArgs a) {
 		publish_losses(s0, s1, s2, a.counters, a.fwd_counts, a.red_out, a.red_host_out, a.red_host_seq); // loss, eikonal, mask: the order of reduce_losses_body's rows
 		return;
 	}
-	const uint32_t n_in = a.counters[1];
+	const uint32_t n_in = poisoned ? 0u : a.counters[1];
 	const uint32_t n = min(n_in, a.B);
 	const uint32_t q = (blockIdx.x - 1) * 256 + threadIdx.x;
 	if (q >= n) return;

@@ -248,6 +248,7 @@ struct rnb_ctx {
 	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
 	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
+	hipStream_t step_stream = nullptr;     // the stream of the running step (rnb_train_step_begin): what wait_loss_readback synchronises before it declares a readback lost
 	uint64_t dp_split = 0, dp_mid = 0; // first parameter of the plain-quad levels (group A) / of their second half (A2): boundaries of the data-parallel gradient blocks
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
@@ -284,7 +285,7 @@ static bool prep_due(uint32_t step) { // testbed.cu:2805
 static void join_tail_host(rnb_ctx* c) { if (c->tail_pending) { (void)hipEventSynchronize(c->ev_tail); c->tail_pending = false; } }
 
 // The one-launch scans (kernels_ray.cuh, chain_prefix) report a wait that gave up through two mapped host words; read after a synchronisation.
-// The launch itself has poisoned its result (zero counters), so nothing was trained on it.
+// The launch itself has poisoned its result (zero counters -- the fused scan of k_loss_pass2_rays through k_loss_pass2_samples), so nothing was trained on it.
 static int check_scan_errors(rnb_ctx* c) {
 	const bool rays = c->host_coarse[5] != 0, compact = c->host_coarse[6] != 0;
 	if (!rays && !compact) return RNB_OK;
@@ -419,7 +420,7 @@ int update_bitfield(rnb_ctx* c, hipStream_t s, bool wait = true, bool have_parti
 
 int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, half_t* out, const uint32_t* splat_idx, float* grid_tmp, int want_density, bool inference, const uint32_t* range = nullptr) {
 	if (n == 0) return RNB_OK;
-	if (!inference) join_tail_host(c);
+	join_tail_host(c); // (inference launches too: the same side-stream launch writes the MLPs' and the variance's EMA weights)
 	PointArgs a;
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
@@ -463,6 +464,9 @@ static int pregenerate_grid_samples(rnb_ctx* c, hipStream_t s_main) {
 		if (c->gs_range.alloc(2) != hipSuccess || c->gs_sorted_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_sorted_idx.alloc(n) != hipSuccess || c->gs_hist.alloc((size_t)(1u << 20) + 2048) != hipSuccess ||
 		    c->gs_stage_pos.alloc(c->grid_sample_pos.n) != hipSuccess || c->gs_stage_idx.alloc(c->grid_sample_idx.n) != hipSuccess ||
 		    c->gs_eval_pos.alloc((size_t)n * 3) != hipSuccess || c->gs_eval_idx.alloc(n) != hipSuccess) {
+			// a sharded update divides the samples by the order they are evaluated in: one rank that falls back to the reference's order alone would leave
+			// cells uncovered without any error, so a data-parallel job fails here instead (RNB_GRID_PRESORT must likewise be the same on every rank)
+			if (c->cfg.world_size > 1 && c->grid_exchange) return fail(RNB_ERR_NOMEM, "hipMalloc failed for the cell-ordered occupancy samples (data parallel: every rank must evaluate the same order)");
 			c->knobs.grid_presort = false; // not essential: the update then keeps the reference's order
 			return RNB_OK;
 		}
@@ -585,7 +589,7 @@ static int ensure_rgb_buffers(rnb_ctx* c) {
 
 int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_t* n_ptr, uint32_t n_max, half_t* out, bool inference, const uint32_t* idx = nullptr, half_t* cin_out = nullptr) {
 	if (n_max == 0) return RNB_OK;
-	if (!inference) join_tail_host(c);
+	join_tail_host(c); // (inference launches too: the same side-stream launch writes the MLPs' and the variance's EMA weights)
 	FwdArgs a;
 	a.coords = coords; a.n_ptr = n_ptr; a.n_max = n_max; a.out = out; a.sdf_bias = c->cfg.sdf_bias; a.idx = idx; a.cin_out = cin_out;
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
@@ -1382,6 +1386,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	const unsigned dev_flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
 	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_march_rest, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
+	std::memset(c->host_rb, 0, sizeof(*c->host_rb)); // (a recycled pinned block may hold a previous context's sequence word: wait_loss_readback would take it for this context's first step)
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_coarse), 64, hipHostMallocMapped));
 	std::memset(c->host_coarse, 0, 64); // [0] block count of the LDS occupancy, [5] / [6] k_scan_rays_chain / k_scan_compact_chain gave up a wait
@@ -1492,7 +1497,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		if (rc != RNB_OK) return rc;
 		if (!read_only) c->opt_rec_current = false;
 	}
-	if (id == RNB_BUF_PARAMS_FP16) join_tail_host(c);
+	if (id == RNB_BUF_PARAMS_FP16 || id == RNB_BUF_PARAMS_EMA) join_tail_host(c); // both are written by the side stream's optimizer launch (ev_tail)
 	if (!read_only) { // a possible write before the caller's next call: drop the cached forms now (a kept pointer written later: rnb_params_changed / rnb_bitfield_changed)
 		if (id == RNB_BUF_PARAMS_FP16) c->wimg_valid = false;
 		else if (id == RNB_BUF_DENSITY_BITFIELD) { discard_premarch(c); c->coarse_valid = false; c->gs_pre.valid = false; c->bitfield_foreign = true; }
@@ -1922,7 +1927,7 @@ static int launch_premarch(rnb_ctx* c) {
 	// the generic kernel of the albedo mode -- a sample set that the same launch on an idle GPU does not produce. Without packed
 	// fp32 (rnb-neus2_amd/build.py) and with that index read through one cross-lane shuffle instead: 0 of 2000 launches beside
 	// k_fwd_bwd (0 of 1300 for the one-thread-per-ray kernel of the large batches). DESIGN.md section 6.
-	if (c->poll_loss()) { const int rc0 = wait_loss_readback(c, nullptr); if (rc0 != RNB_OK) return rc0; } // the host has SEEN the loss pass end: nothing to wait for on the device
+	if (c->poll_loss()) { const int rc0 = wait_loss_readback(c, c->step_stream); if (rc0 != RNB_OK) return rc0; } // the host has SEEN the loss pass end: nothing to wait for on the device
 	else HIP_TRY(hipStreamWaitEvent(c->s_march, c->ev_loss, 0));
 	// No fill in front of the march: every step counter is written with a plain store by the scans (k_scan_rays*, k_scan_compact*), and the
 	// loss rows are written for every kept ray by k_loss_pass2 (zeros for a ray without compacted samples) -- k_reduce_losses reads nothing
@@ -1948,6 +1953,7 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	hipStream_t s = as_stream(stream);
 	c->cur_step = c->training_step;
+	c->step_stream = s;
 	int rc = step_front(c, s);
 	if (rc != RNB_OK) { c->cin_flow = false; return rc; }
 	// the step's counters and loss sums are final here: hand them to the host now, so that the ray controller (and the next

@@ -129,15 +129,22 @@ class DataParallelTrainer:
         self.grid_sharded = grid_exchange is not None
 
     def _torch_grid_exchange(self, ptr, n, stream_handle):
-        """Element-wise max of DENSITY_GRID_TMP over the ranks, in place on the device (densities are >= 0: float order = int32 order)."""
+        """Element-wise max of DENSITY_GRID_TMP over the ranks, in place on the device, in the order of the single-rank splat: atomicMax on the
+        words as UINT32 (testbed_nerf.cu:634). torch has no unsigned all-reduce, so the sign bit is flipped around a signed max (uint order
+        = int order of word ^ 0x80000000): a NaN density with its sign bit set wins here exactly as it does on one rank."""
         import torch
         import torch.distributed as dist
         t = torch.as_tensor(_DeviceArray(ptr, n, "<i4"), device="cuda")
+
+        def run():
+            t.bitwise_xor_(-0x80000000)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t.bitwise_xor_(-0x80000000)
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                run()
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            run()
 
     def _torch_reduce_grads(self, ctx):
         """Sum of the fp32 gradient accumulators over the ranks. The block of levels whose scatter finishes first is exchanged

@@ -283,7 +283,7 @@ struct Dist {
 	static int grid_exchange(void* user, void* grid_tmp, uint64_t n_elements, void* stream) {
 #ifdef RNB_WITH_RCCL
 		Dist* d = static_cast<Dist*>(user);
-		return ncclAllReduce(grid_tmp, grid_tmp, n_elements, ncclInt32, ncclMax, d->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1; // densities are >= 0: float order = int order
+		return ncclAllReduce(grid_tmp, grid_tmp, n_elements, ncclUint32, ncclMax, d->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1; // the order of the single-rank splat: atomicMax on the words as uint32 (a sign-bit NaN wins on both)
 #else
 		(void)user; (void)grid_tmp; (void)n_elements; (void)stream;
 		return -1;

@@ -126,12 +126,12 @@ def _worker_sharded_body(rank, world, port, q):
     parts, capacity = sh.shard_layout()
     n_exchanges = [0]
 
-    def grid_max(ptr, n, stream):  # rnb_set_grid_exchange over gloo: element-wise max of the checker's host buffer (densities >= 0: int32 order = float order)
+    def grid_max(ptr, n, stream):  # rnb_set_grid_exchange over gloo: element-wise max of the checker's host buffer (uint32 order, as the single-rank atomicMax)
         import ctypes as C
         v = np.frombuffer((C.c_char * (n * 4)).from_address(ptr), dtype=np.int32)
-        t = torch.from_numpy(v.copy())
+        t = torch.from_numpy(v ^ np.int32(-0x80000000))  # uint32 order of the single-rank atomicMax as a signed max
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        v[:] = t.numpy()
+        v[:] = t.numpy() ^ np.int32(-0x80000000)
         n_exchanges[0] += 1
 
     tr_rep = dp.DataParallelTrainer(rep, all_reduce_grads=reduce_grads)  # replicated optimizer AND replicated occupancy updates
