@@ -86,6 +86,10 @@ def parse(argv=None):
     ap.add_argument("--fixed-cost-steps", type=int, default=400)
     ap.add_argument("--albedo", action="store_true", help="secondary workload: stage 2 of the two-stage pipeline (colour MLP + reflectance loss live) instead of "
                     "the normals-only path the metric is quoted on")
+    ap.add_argument("--accumulate", choices=["fp32", "half"], default="fp32", help="rnb_config::accumulate of every leg: fp32 (the default product mode, the one `value` is quoted for) or half "
+                    "(the reference's arithmetic as coded: half k-step accumulators, packed half atomics into a half gradient vector)")
+    ap.add_argument("--parity-mode-steps", type=int, default=400, help="single-GPU fp32 runs: a second context in the OTHER accumulate mode (half), trained to the same step and timed over the driver's K steps "
+                    "and over this many more (`parity_mode` in the record); 0 = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect the HBM counters of `roofline.traffic` in this run (child processes under rocprofv3 --pmc); the record "
                     "then carries the committed summary's value and says so")
     ap.add_argument("--live-pmc-steps", type=int, default=10, help="steps each of those counter passes averages over")
@@ -114,6 +118,7 @@ def live_pmc(args, first_step, counters=("FETCH_SIZE", "WRITE_SIZE", "TCC_ATOMIC
         d = tempfile.mkdtemp(prefix="rnb_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", str(n), "--warmup", "2",
                "--burn-in", str(burn), "--profile-steps", "0", "--no-cpu-baseline", "--window-end", "0", "--late-step", "0", "--fixed-cost-steps", "0", "--no-live-pmc",
+               "--parity-mode-steps", "0", "--accumulate", args.accumulate,
                "--views", str(args.views), "--res", str(args.res), "--batch-log2", str(args.batch_log2)] + (["--albedo"] if args.albedo else []) + (["--focal", str(args.focal)] if args.focal else [])
         env = dict(os.environ, RNB_OVERLAP_OFF="1", TMPDIR="/tmp")
         try:
@@ -237,6 +242,7 @@ def main(argv=None, engine=None):
     scene = synthetic.make_scene(args.views, args.res) if args.focal is None else synthetic.make_scene(args.views, args.res, args.focal)
     scene_s = time.time() - t0
     flags = dict(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0)  # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
+    accumulate = 1 if args.accumulate == "half" else 0
 
     def state_of(ctx, st):
         return dict(params=ctx.get("PARAMS_FP32").copy(), grid=ctx.get("DENSITY_GRID").copy(), step=ctx.training_step, rays=ctx.rays_per_batch,
@@ -247,7 +253,7 @@ def main(argv=None, engine=None):
             sizes = dp.strong_scaling_sizes(world, B, min(1 << 18, B), min(1 << 12, B))
         else:
             sizes = dict(target_batch_size=B, max_rays_per_batch=min(1 << 18, B), initial_rays_per_batch=min(1 << 12, B)) if B != (1 << 18) else {}
-        ctx = engine.context(world_size=world, rank=rank, **flags, **sizes)
+        ctx = engine.context(world_size=world, rank=rank, accumulate=accumulate, **flags, **sizes)
         ctx.init_params()
         ctx.set_dataset(*scene)
         return ctx, engine.trainer(ctx)
@@ -338,7 +344,7 @@ def main(argv=None, engine=None):
     fixed = None
     if world == 1 and rank == 0 and args.fixed_cost_world > 1 and args.fixed_cost_steps > 0 and not args.strong and B % (128 * args.fixed_cost_world) == 0:
         Wf = args.fixed_cost_world
-        fctx = engine.context(world_size=1, rank=0, **flags, **dp.strong_scaling_sizes(Wf, B, min(1 << 18, B), min(1 << 12, B)))
+        fctx = engine.context(world_size=1, rank=0, accumulate=accumulate, **flags, **dp.strong_scaling_sizes(Wf, B, min(1 << 18, B), min(1 << 12, B)))
         fctx.init_params()
         fctx.set_dataset(*scene)
         ftr = engine.trainer(fctx)
@@ -366,6 +372,34 @@ def main(argv=None, engine=None):
                  "ms_per_step_with_both_divided_estimate": round(f_step - (1.0 - 1.0 / Wf) * (f_adam + f_pq), 4),
                  "strong_scaling_bound": {"measured": round(1e3 * elapsed / args.steps / f_step, 2), "with_both_divided_estimate": round(1e3 * elapsed / args.steps / max(f_sharded, 1e-6), 2),
                                           "note": "speed-up <= single-GPU ms_per_step / this, before any exchange; weak scaling (bench.py --gpus N: N x 2^18 samples per step) is the mode the >= 6x at 8 GPUs is claimed for (DESIGN.md section 7)"}}
+
+    # ---- one GPU: the same workload in the other accumulate mode (half: the reference's arithmetic as coded) ----
+    parity = None
+    if world == 1 and rank == 0 and args.parity_mode_steps > 0 and not args.strong and accumulate == 0 and engine.name == "hip":
+        sizes = dict(target_batch_size=B, max_rays_per_batch=min(1 << 18, B), initial_rays_per_batch=min(1 << 12, B)) if B != (1 << 18) else {}
+        pctx = engine.context(world_size=1, rank=0, accumulate=1, **flags, **sizes)
+        pctx.init_params()
+        pctx.set_dataset(*scene)
+        ptr = engine.trainer(pctx)
+        for _ in range(args.burn_in + args.warmup):
+            ptr.step()
+        p_el, p_rays, _, _, _, p_last = timed_run(ptr, args.steps)          # the driver's K steps
+        q_el, q_rays, _, _, q_ms, q_last = timed_run(ptr, args.parity_mode_steps)
+        pctx.profile_enable(True)
+        n_prof = 64
+        for _ in range(n_prof):
+            ptr.step()
+        barrier()
+        pprof = {p["kernel"]: round(p["total_ms"] / n_prof, 4) for p in pctx.profile() if p["launches"]}
+        pctx.profile_enable(False)
+        pctx.close()
+        parity = {"what": "rnb_config::accumulate = RNB_ACCUM_HALF on the same workload, same steps: every MLP dot product rounds its accumulator to half after each 16-wide k-step "
+                          "(fully_fused_mlp.cu:59-68), the hash-grid gradients go through global_atomic_pk_add_f16 into a half gradient vector (grid.h:410-430, trainer.h:78-84) that the "
+                          "optimizer reads at 2 bytes per parameter; loss parity against the reference-as-coded model: tests/test_gpu_fullsize.py::test_hip_against_the_reference_as_coded_emulation[half]",
+                  "accumulate": "half", "first_step": int(p_last.training_step) - args.steps, "steps": args.steps, "ms_per_step": round(1e3 * p_el / args.steps, 4), "rays_per_s": round(p_rays / p_el, 1),
+                  "next_steps": {"steps": args.parity_mode_steps, "ms_per_step": round(1e3 * q_el / args.parity_mode_steps, 4), "p50_ms_per_step": round(float(np.median(q_ms)), 4),
+                                 "rays_per_s": round(q_rays / q_el, 1), "loss": round(float(q_last.loss), 6)},
+                  "kernels_ms_per_step_serialised": pprof}
 
     result = None
     if rank == 0:
@@ -443,7 +477,7 @@ def main(argv=None, engine=None):
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f16 storage / f32 accumulate",
+            "dtype": "f16 storage / f16 accumulate (k-step model)" if accumulate else "f16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "config 4: synthetic %d-view %dx%d normals+mask sphere, %s --mask-weight 1.0, %s compacted samples/step/GPU"
                                    % (args.views, args.res, args.res, "albedo + reflectance loss (NOT the metric's workload)" if args.albedo else "--no-albedo",
@@ -457,6 +491,7 @@ def main(argv=None, engine=None):
             "window_1000_2000": window,
             "late_regime": late,
             "fixed_cost": fixed,
+            "parity_mode": parity,
             "roofline": roofline,
             "pmc_live": {"note": live_note, "bytes_and_atomic_lines_per_step": live},
             "rooflines_next": rooflines_next,
@@ -473,7 +508,7 @@ def main(argv=None, engine=None):
     # shorter one from the late regime's state stands next to `late_regime`.
     def cpu_leg(state, n_steps):
         from tests import oracle_lib
-        cpu = oracle_lib.context(**flags)
+        cpu = oracle_lib.context(accumulate=accumulate, **flags)
         try:
             cpu.set_dataset(*scene)
             cpu.set_params(state["params"])

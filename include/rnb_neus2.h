@@ -30,8 +30,9 @@ extern "C" {
 
 /* 2 (round 4): RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS became staging views (see rnb_buffer); buffer ids 25, 26 and
  * rnb_bitfield_changed were added after 1 without a bump -- a binary built against 1 must not link silently.
- * 3 (round 4): rnb_shard_layout fills up to RNB_MAX_SHARD_PARTS = 3 blocks (2: two) -- a caller's array must have room for them. */
-#define RNB_ABI_VERSION 3
+ * 3 (round 4): rnb_shard_layout fills up to RNB_MAX_SHARD_PARTS = 3 blocks (2: two) -- a caller's array must have room for them.
+ * 4 (round 5): rnb_config::accumulate (taken from `reserved`; 0 keeps the behaviour of ABI 3) and RNB_BUF_GRADS_FP16. */
+#define RNB_ABI_VERSION 4
 
 typedef enum rnb_status {
 	RNB_OK = 0,
@@ -103,8 +104,14 @@ typedef struct rnb_config {
 	uint32_t rank;                    /* 0 */
 	uint32_t only_sdf_training;       /* 0; Adam skips the colour MLP (adam.h:121-165), set by --fractional-training (testbed.cu:1886-1895) */
 	uint32_t overlap;                 /* 1; run independent stages of consecutive steps on side streams (same results); 0 = strictly serial */
-	uint32_t reserved[6];
+	uint32_t accumulate;              /* rnb_accumulate: the width of the accumulators. RNB_ACCUM_FP32 (0, default): every dot product and gradient sum in fp32, narrowed to
+	                                     half where the reference stores half. RNB_ACCUM_HALF (1): the reference's arithmetic as coded -- the MLPs' dot products round their
+	                                     accumulator to half after every 16-wide k-step (WMMA half fragments, fully_fused_mlp.cu:59-68, 198), the hash-grid gradients are summed
+	                                     by atomicAdd(__half2) into a half gradient vector (grid.h:410-430, trainer.h:78-84: RNB_BUF_GRADS_FP16 replaces RNB_BUF_GRADS_FP32).
+	                                     Fixed at rnb_create. */
+	uint32_t reserved[5];
 } rnb_config;
+typedef enum rnb_accumulate { RNB_ACCUM_FP32 = 0, RNB_ACCUM_HALF = 1 } rnb_accumulate;
 
 /* One training view — TrainingImageMetadata + TrainingXForm (nerf_loader.h:33-49). */
 typedef struct rnb_view {
@@ -133,7 +140,7 @@ typedef enum rnb_buffer_id {
 	RNB_BUF_PARAMS_FP32 = 0,   /* float[n_params]  master weights (trainer.h:78-84) */
 	RNB_BUF_PARAMS_FP16 = 1,   /* half[n_params]   training weights */
 	RNB_BUF_PARAMS_EMA = 2,    /* half[n_params]   EMA = inference weights (ema.h:63-78) */
-	RNB_BUF_GRADS_FP32 = 3,    /* float[n_params]  gradient accumulators (x loss_scale 128) */
+	RNB_BUF_GRADS_FP32 = 3,    /* float[n_params]  gradient accumulators (x loss_scale 128); accumulate = RNB_ACCUM_HALF: not there (RNB_ERR_INVALID), see RNB_BUF_GRADS_FP16 */
 	RNB_BUF_ADAM_M = 4,        /* float[n_params] */
 	RNB_BUF_ADAM_V = 5,        /* float[n_params] */
 	RNB_BUF_ADAM_STEPS = 6,    /* uint32[n_params] */
@@ -158,6 +165,8 @@ typedef enum rnb_buffer_id {
 	                              (rnb_train_step_local has returned); data-parallel callers all-reduce it in place */
 	RNB_BUF_GRID_SAMPLE_POS_EVAL = 25, /* float[n*3] / uint32[n]: the same samples in the order the last update evaluated them (cell order, prepared an */
 	RNB_BUF_GRID_SAMPLE_IDX_EVAL = 26, /* update interval ahead); 0 bytes when it evaluated them in the reference's order (GRID_SAMPLE_POS / _IDX). HIP library only */
+	RNB_BUF_GRADS_FP16 = 27,   /* half[n_params]: the gradient vector of accumulate = RNB_ACCUM_HALF (x loss_scale 128); RNB_ERR_INVALID in the fp32 mode. The data-parallel
+	                              entry points (rnb_gradient_parts, rnb_shard_layout ...) then describe ranges of THIS buffer and the caller sums halfs */
 	RNB_BUF_COUNT
 } rnb_buffer_id;
 /* OR-ed into the buffer id: the caller only reads through the pointer (see rnb_buffer). */

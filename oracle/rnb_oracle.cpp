@@ -21,9 +21,10 @@
  *   D4 the per-ray light index is PCG32 draw #7 of the ray's stream, mod 3
  *      (reference: curand_init(clock64(), ...) — irreproducible, testbed_nerf.cu:1557-1561).
  *   D5 density-grid mean is summed in fp64 (reference: fp32 tree reduce_sum).
- * D1 and D2 can be switched to an EMULATION of the reference's half accumulation (ORC_EMULATE_FP16_ACCUM=1,
- * ORC_EMULATE_HALF_ATOMICS=1 in the environment of orc_create) so that their size can be measured
- * (tools/oracle_deviation_report.py). The HIP path is never compared with those modes.
+ * rnb_config::accumulate = RNB_ACCUM_HALF switches D1 and D2 to a MODEL of the reference's half accumulation (dot_h, emulated_dw,
+ * half atomics in sample order) -- what the HIP library's mode of the same name is compared with; ORC_EMULATE_FP16_ACCUM=1 /
+ * ORC_EMULATE_HALF_ATOMICS=1 in the environment of orc_create switch the two parts on one by one so that their sizes can be measured
+ * (tools/oracle_deviation_report.py).
  *
  * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may load
  * this library.
@@ -155,6 +156,9 @@ struct orc_ctx_s {
 	// Emulation of the reference's half accumulation (off by default: deviations D1 / D2 are what the HIP path implements)
 	bool emul_fp16_acc = false;     // D1 off: MLP dot products and weight-gradient GEMMs accumulate in half (WMMA / CUTLASS half accumulators)
 	bool emul_half_atomics = false; // D2 off: hash-grid gradients accumulate in half, one rounding per atomicAdd(__half2), in sample order
+	uint32_t atomic_order_seed = 0; // ORC_ATOMIC_ORDER_SEED != 0: ... in a seeded random order of the samples instead -- any order is a legal outcome of the reference's atomics,
+	                                // and the distance between two orders is the floor below which no implementation of half atomics can be compared (tests/test_gpu_fullsize.py)
+	std::vector<half_t> grads16;    // RNB_BUF_GRADS_FP16: the gradient vector narrowed to half (a snapshot made by rnb_buffer)
 };
 
 namespace {
@@ -1325,7 +1329,15 @@ static void emulated_accumulate(orc_ctx_s* c, const std::vector<SampleOps>& ops)
 		float* gg = g + c->off_grid + (uint64_t)c->offsets[level] * 2;
 		const size_t n = (size_t)(c->offsets[level + 1] - c->offsets[level]) * 2;
 		std::vector<half_t> gh(c->emul_half_atomics ? n : 0, 0);
-		for (uint32_t s = 0; s < B; ++s) {
+		std::vector<uint32_t> order;
+		if (c->emul_half_atomics && c->atomic_order_seed) {
+			order.resize(B);
+			for (uint32_t s = 0; s < B; ++s) order[s] = s;
+			std::mt19937 gen(c->atomic_order_seed * 7919u + (uint32_t)level);
+			std::shuffle(order.begin(), order.end(), gen);
+		}
+		for (uint32_t si = 0; si < B; ++si) {
+			const uint32_t s = order.empty() ? si : order[si];
 			const SampleOps& o = ops[s];
 			const float g1[2] = {h2f(o.dsin[3 + level * 2]), h2f(o.dsin[3 + level * 2 + 1])};
 			const float g2[2] = {h2f(o.dsdf_din[3 + level * 2]), h2f(o.dsdf_din[3 + level * 2 + 1])};
@@ -1561,8 +1573,11 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 	c->training_step = 0;
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
-	c->emul_fp16_acc = getenv("ORC_EMULATE_FP16_ACCUM") != nullptr && atoi(getenv("ORC_EMULATE_FP16_ACCUM")) != 0;
-	c->emul_half_atomics = getenv("ORC_EMULATE_HALF_ATOMICS") != nullptr && atoi(getenv("ORC_EMULATE_HALF_ATOMICS")) != 0;
+	if (cfg->accumulate > RNB_ACCUM_HALF) { delete c; return fail(RNB_ERR_INVALID, "accumulate must be RNB_ACCUM_FP32 or RNB_ACCUM_HALF"); }
+	// rnb_config::accumulate = RNB_ACCUM_HALF: the model of the reference as coded, both parts; the two environment variables switch the parts on one by one (tools/oracle_deviation_report.py)
+	c->emul_fp16_acc = cfg->accumulate == RNB_ACCUM_HALF || (getenv("ORC_EMULATE_FP16_ACCUM") != nullptr && atoi(getenv("ORC_EMULATE_FP16_ACCUM")) != 0);
+	c->emul_half_atomics = cfg->accumulate == RNB_ACCUM_HALF || (getenv("ORC_EMULATE_HALF_ATOMICS") != nullptr && atoi(getenv("ORC_EMULATE_HALF_ATOMICS")) != 0);
+	c->atomic_order_seed = getenv("ORC_ATOMIC_ORDER_SEED") ? (uint32_t)atoi(getenv("ORC_ATOMIC_ORDER_SEED")) : 0u;
 	*out = c;
 	return RNB_OK;
 }
@@ -1574,7 +1589,7 @@ int rnb_update_config(orc_ctx_s* c, const rnb_config* cfg) {
 	rnb_config& dst = c->cfg;
 	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
 	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
-	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank)
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate)
 		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
 	dst = *cfg;
 	build_light_dirs(c);
@@ -1680,6 +1695,11 @@ int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_PARAMS_FP16: BUF_P(c->params_fp16);
 		case RNB_BUF_PARAMS_EMA: BUF_P(c->params_ema);
 		case RNB_BUF_GRADS_FP32: BUF_P(c->grads);
+		case RNB_BUF_GRADS_FP16: // (the checker keeps its gradients as floats in either mode; with accumulate = RNB_ACCUM_HALF every value is a half already)
+			if (c->cfg.accumulate != RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_FP32: the gradient accumulators are RNB_BUF_GRADS_FP32");
+			c->grads16.resize(c->grads.size());
+			for (size_t i = 0; i < c->grads.size(); ++i) c->grads16[i] = f2h(c->grads[i]);
+			BUF_P(c->grads16);
 		case RNB_BUF_ADAM_M: BUF_P(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF_P(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF_P(c->adam_steps);

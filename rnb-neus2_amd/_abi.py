@@ -6,7 +6,7 @@ the identical signatures under its own prefix.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # status codes (rnb_status)
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NO_SAMPLES = 0, -1, -2, -3, -4
@@ -58,7 +58,8 @@ class Config(C.Structure):
         ("rank", C.c_uint32),
         ("only_sdf_training", C.c_uint32),
         ("overlap", C.c_uint32),
-        ("reserved", C.c_uint32 * 6),
+        ("accumulate", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -97,14 +98,15 @@ BUF = dict(
     PARAMS_FP32=0, PARAMS_FP16=1, PARAMS_EMA=2, GRADS_FP32=3, ADAM_M=4, ADAM_V=5, ADAM_STEPS=6,
     DENSITY_GRID=7, DENSITY_BITFIELD=8, DENSITY_MEAN=9, RAY_INDICES=10, RAYS=11, NUMSTEPS=12,
     COORDS=13, MLP_OUT=14, DLOSS_DOUT=15, COORDS_COMPACTED=16, LOSS=17, EK_LOSS=18, MASK_LOSS=19,
-    COUNTERS=20, DENSITY_GRID_TMP=21, GRID_SAMPLE_POS=22, GRID_SAMPLE_IDX=23, STEP_VECTOR=24, GRID_SAMPLE_POS_EVAL=25, GRID_SAMPLE_IDX_EVAL=26,
+    COUNTERS=20, DENSITY_GRID_TMP=21, GRID_SAMPLE_POS=22, GRID_SAMPLE_IDX=23, STEP_VECTOR=24, GRID_SAMPLE_POS_EVAL=25, GRID_SAMPLE_IDX_EVAL=26, GRADS_FP16=27,
 )
 BUF_DTYPE = dict(
     PARAMS_FP32="f4", PARAMS_FP16="f2", PARAMS_EMA="f2", GRADS_FP32="f4", ADAM_M="f4", ADAM_V="f4", ADAM_STEPS="u4",
     DENSITY_GRID="f4", DENSITY_BITFIELD="u1", DENSITY_MEAN="f4", RAY_INDICES="u4", RAYS="f4", NUMSTEPS="u4",
     COORDS="f4", MLP_OUT="f2", DLOSS_DOUT="f2", COORDS_COMPACTED="f4", LOSS="f4", EK_LOSS="f4", MASK_LOSS="f4",
-    COUNTERS="u4", DENSITY_GRID_TMP="f4", GRID_SAMPLE_POS="f4", GRID_SAMPLE_IDX="u4", STEP_VECTOR="f8", GRID_SAMPLE_POS_EVAL="f4", GRID_SAMPLE_IDX_EVAL="u4",
+    COUNTERS="u4", DENSITY_GRID_TMP="f4", GRID_SAMPLE_POS="f4", GRID_SAMPLE_IDX="u4", STEP_VECTOR="f8", GRID_SAMPLE_POS_EVAL="f4", GRID_SAMPLE_IDX_EVAL="u4", GRADS_FP16="f2",
 )
+ACCUM_FP32, ACCUM_HALF = 0, 1  # rnb_accumulate
 BUF_READONLY = 0x100  # RNB_BUF_READONLY
 GRID_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)  # rnb_grid_exchange_fn(user, grid_tmp, n_elements, stream)
 PRIM = dict(PCG32=0, MORTON=1, SRGB=2, RAY_BOX=3, MARCH=4)  # rnb_primitive

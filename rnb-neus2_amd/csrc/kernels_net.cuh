@@ -142,12 +142,12 @@ __device__ __forceinline__ void point_query_chained_body(const GridMeta& G, cons
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer<4, 1, EMU>(wts + W_S0, S32, X, S32, acc, lane);
+			mfma_layer<4, 1, EMU ? EMU_NATURAL : EMU_OFF>(wts + W_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
 		f4 acc_so[1][4];
 		zero_acc<1>(acc_so);
-		mfma_layer_regs<1, 2, EMU>(wts + W_S1, S64, bz, acc_so, lane);
+		mfma_layer_regs<1, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_S1, S64, bz, acc_so, lane);
 		if (hq == 0) { // D layout: row 0 (the sdf) of sample 16 nt + r16
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt) Z[16 * nt + r16] = f2h(acc_so[0][nt][0]);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G,
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	point_query_chained_body<false>(G, net, a, wimg, smem_raw, lm);
 }
-// test-only instance with the reference's half accumulators emulated (mlp.cuh, mfma_emul16)
+// rnb_config::accumulate = RNB_ACCUM_HALF: the reference's half accumulators (mlp.cuh, mfma_emul16)
 __global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
@@ -215,12 +215,12 @@ __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const Ne
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer<4, 1, EMU>(wts + W_S0, S32, X, S32, acc, lane);
+			mfma_layer<4, 1, EMU ? EMU_NATURAL : EMU_OFF>(wts + W_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
 		f4 acc_so[1][4];
 		zero_acc<1>(acc_so);
-		mfma_layer_regs<1, 2, EMU>(wts + W_S1, S64, bz, acc_so, lane); // sdf_out = W1 z1
+		mfma_layer_regs<1, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_S1, S64, bz, acc_so, lane); // sdf_out = W1 z1
 		{
 			// the backward transfer tests the stored half activation (common_device.h:182 ff.)
 #pragma unroll
@@ -236,7 +236,7 @@ __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const Ne
 		{
 			f4 acc[2][4];
 			zero_acc<2>(acc);
-			mfma_layer_regs<2, 2, EMU>(wts + W_S0T, S64, bz, acc, lane); // d sdf / d in = W0^T dz1
+			mfma_layer_regs<2, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_S0T, S64, bz, acc, lane); // d sdf / d in = W0^T dz1
 			store_acc<2, false>(acc, X, S32, 0, lane);
 		}
 		wave_lds_sync();
@@ -296,19 +296,19 @@ __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const Ne
 			}
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 1, EMU>(wts + W_C0, S32, bin, acc, lane);
+			mfma_layer_regs<4, 1, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_C0, S32, bin, acc, lane);
 			chain_pack<true>(acc, bh);
 		}
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 2, EMU>(wts + W_C1, S64, bh, acc, lane);
+			mfma_layer_regs<4, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_C1, S64, bh, acc, lane);
 			chain_pack<true>(acc, bh);
 		}
 		{
 			f4 acc[1][4];
 			zero_acc<1>(acc);
-			mfma_layer_regs<1, 2, EMU>(wts + W_C2, S64, bh, acc, lane);
+			mfma_layer_regs<1, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + W_C2, S64, bh, acc, lane);
 			store_acc<1, false>(acc, X, S32, 0, lane); // X rows were last read before the previous sync
 		}
 		wave_lds_sync();
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	forward_chained_body<false>(G, net, a, smem_raw, lm);
 }
-// test-only instance with the reference's half accumulators emulated (mlp.cuh, mfma_emul16)
-__global__ __launch_bounds__(WG, 1) void k_forward_chained_emul(const GridMeta G, const NetW net, const FwdArgs a) {
+// rnb_config::accumulate = RNB_ACCUM_HALF: the reference's half accumulators (mlp.cuh, mfma_emul16)
+__global__ __launch_bounds__(WG, 2) void k_forward_chained_emul(const GridMeta G, const NetW net, const FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	forward_chained_body<true>(G, net, a, smem_raw, lm);
@@ -734,7 +734,10 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 // dL/d(grad sdf) gains the colour MLP's rows 19..21 -- both known before the encode, so everything else is the kernel above with
 //   dz = (W1^T dso) (.) relu'(z1)  as a K = 16 MFMA (both orientations) instead of one product per element, and
 //   dW1 += dso z1^T                as a 16 x 64 MFMA (dso^T by an identity MFMA) instead of row 0 on the VALU.
-template <bool FULL>
+// EMU (rnb_config::accumulate = RNB_ACCUM_HALF): every dot product over features rounds its accumulator to half after each of the reference's 16-wide k-steps (mlp.cuh);
+// products with K = 16 (W1^T dso, the identity transposes) are one k-step and need nothing. The weight gradients (K = samples) keep their fp32 accumulators: their
+// summation order is this kernel's tiling, not the reference's split-K slices (deviation D1').
+template <bool FULL, bool EMU = false>
 __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& net, const TrainArgs& a, char* smem_raw, LevelMeta* lm) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	constexpr int W_END = FULL ? SWF_END : SW_END;
@@ -880,6 +883,8 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
 				const h8 wbn = *reinterpret_cast<const h8*>(wts + SW_S0 + (16 * nt + r16) * S32 + 8 * hq);
+				h8 wbn_lo = wbn, wbn_hi = wbn;
+				if (EMU) split_ksteps<EMU_FBS>(wbn, hq, wbn_lo, wbn_hi);
 				const half_t w1h = wts[SW_W1N + 16 * nt + r16];
 				const float w1f = h2f(w1h);
 				h8 wb1t;
@@ -890,8 +895,8 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
 						const int mt = 2 * ks + h;
-						const f4 z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
-						const f4 fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
+						const f4 z = EMU ? mfma_emul16_split(ain[mt], wbn_lo, wbn_hi, zero4) : __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
+						const f4 fr = EMU ? mfma_emul16_split(add[mt], wbn_lo, wbn_hi, zero4) : __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
 						f4 dzt = zero4;
 						if (FULL) dzt = __builtin_amdgcn_mfma_f32_16x16x32_f16(fso[mt], wb1t, zero4, 0, 0, 0); // (W1^T dso)^T: lane = hidden unit, registers = samples
 #pragma unroll
@@ -924,7 +929,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer<4, 1>(wts + SW_S0, S32, X, S32, acc, lane);
+			mfma_layer<4, 1, EMU ? EMU_FBS : EMU_OFF>(wts + SW_S0, S32, X, S32, acc, lane);
 			chain_pack<true>(acc, bz);
 		}
 		half_t d3[4];
@@ -965,7 +970,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		{ // d sdf / d in = W0^T dz1 -> rows of X
 			f4 acc[2][4];
 			zero_acc<2>(acc);
-			mfma_layer_regs<2, 2>(wts + SW_S0T, S64, bz, acc, lane);
+			mfma_layer_regs<2, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + SW_S0T, S64, bz, acc, lane);
 			store_acc<2, false>(acc, X, S32, 0, lane);
 		}
 		wave_lds_sync();
@@ -975,7 +980,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		{ // dL/d in = W0^T dz -> rows of X; its feature columns are the first-order dL/dfeat of the grid
 			f4 acc[2][4];
 			zero_acc<2>(acc);
-			mfma_layer_regs<2, 2>(wts + SW_S0T, S64, bdz, acc, lane);
+			mfma_layer_regs<2, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + SW_S0T, S64, bdz, acc, lane);
 			store_acc<2, false>(acc, X, S32, 0, lane);
 		}
 		wave_lds_sync();
@@ -1037,6 +1042,17 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full(const GridMeta G, co
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fwd_bwd_sdf_body<true>(G, net, a, smem_raw, lm);
+}
+// rnb_config::accumulate = RNB_ACCUM_HALF
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_h(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<false, true>(G, net, a, smem_raw, lm);
+}
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full_h(const GridMeta G, const NetW net, const TrainArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<true, true>(G, net, a, smem_raw, lm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1116,8 +1132,8 @@ __device__ __forceinline__ void transpose_frags(const h8 (&in)[4][KS], h8 (&out)
 	}
 }
 
-__global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const RgbArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+template <bool EMU>
+__device__ __forceinline__ void rgb_fwd_bwd_body(const NetW& net, const RgbArgs& a, char* smem_raw) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	if (a.wimg) copy_weight_image(wts, a.wimg, RW_END, threadIdx.x, WG);
 	else load_weights_rgb(wts, net, threadIdx.x, WG);
@@ -1161,13 +1177,13 @@ __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const Rgb
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 1>(wts + RW_C0, S32, cf, acc, lane);
+			mfma_layer_regs<4, 1, EMU ? EMU_NATURAL : EMU_OFF>(wts + RW_C0, S32, cf, acc, lane); // (the input rows are in the reference's column order)
 			chain_pack<true>(acc, bh1);
 		}
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 2>(wts + RW_C1, S64, bh1, acc, lane);
+			mfma_layer_regs<4, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + RW_C1, S64, bh1, acc, lane);
 			chain_pack<true>(acc, bh2);
 		}
 		// ---- dW2 += dr h2^T (the transposes of h2 and dr)
@@ -1210,7 +1226,7 @@ __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const Rgb
 		{
 			f4 acc[4][4];
 			zero_acc<4>(acc);
-			mfma_layer_regs<4, 2>(wts + RW_C1T, S64, bh2, acc, lane);
+			mfma_layer_regs<4, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + RW_C1T, S64, bh2, acc, lane);
 			h8 d[4][2];
 			chain_pack<false>(acc, d);
 #pragma unroll
@@ -1224,7 +1240,7 @@ __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const Rgb
 		{
 			f4 acc[2][4];
 			zero_acc<2>(acc);
-			mfma_layer_regs<2, 2>(wts + RW_C0T, S64, bh1, acc, lane);
+			mfma_layer_regs<2, 2, EMU ? EMU_CHAINED : EMU_OFF>(wts + RW_C0T, S64, bh1, acc, lane);
 #pragma unroll
 			for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1286,6 +1302,14 @@ __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const Rgb
 		float* dst = a.dw_c2 + (size_t)blockIdx.x * N;
 		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];
 	}
+}
+__global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const RgbArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	rgb_fwd_bwd_body<false>(net, a, smem_raw);
+}
+__global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd_h(const NetW net, const RgbArgs a) { // rnb_config::accumulate = RNB_ACCUM_HALF
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	rgb_fwd_bwd_body<true>(net, a, smem_raw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1367,6 +1391,7 @@ struct DwFinishArgs {
 	const float* var_partial;
 	uint32_t n_var_partials;
 	float* grads;            // GRADS_FP32
+	half_t* grads16;         // rnb_config::accumulate = RNB_ACCUM_HALF: GRADS_FP16 instead (the values below are half-rounded already: exact)
 	uint32_t off_sdf, off_rgb, off_var;
 	uint32_t skip_rgb;       // colour-MLP gradients are exactly zero (see TrainArgs::skip_rgb): their accumulators are clear already and no workgroup is launched for them
 };
@@ -1405,7 +1430,10 @@ __global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
 			if ((int)threadIdx.x < off) shv[threadIdx.x] += shv[threadIdx.x + off];
 			__syncthreads();
 		}
-		if (threadIdx.x == 0) { a.grads[a.off_var + 0] = shv[0]; a.grads[a.off_var + 1] = 0.f; a.grads[a.off_var + 2] = 0.f; a.grads[a.off_var + 3] = 0.f; }
+		if (threadIdx.x == 0) {
+			if (a.grads16) { a.grads16[a.off_var + 0] = f2h(shv[0]); a.grads16[a.off_var + 1] = (half_t)0.f; a.grads16[a.off_var + 2] = (half_t)0.f; a.grads16[a.off_var + 3] = (half_t)0.f; } // nerf_network.h:338-339: the fp32 sum narrowed to half
+			else { a.grads[a.off_var + 0] = shv[0]; a.grads[a.off_var + 1] = 0.f; a.grads[a.off_var + 2] = 0.f; a.grads[a.off_var + 3] = 0.f; }
+		}
 		return;
 	}
 	// all parameters of a workgroup lie in the same matrix and, for the colour MLP's first matrix, in the same row (matrix sizes and 48 are multiples of 16)
@@ -1413,12 +1441,12 @@ __global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
 	if (i < 64 * 32) { // sdf W0
 		g = rh(dw_sum(a.partial[4], 64 * 32, i, a.n_partials, slice, sh, e));
 		g = rh(dw_sum(a.partial[5], 64 * 32, i, a.n_partials, slice, sh, e) + g);
-		if (slice == 0) a.grads[a.off_sdf + i] = g;
+		if (slice == 0) { if (a.grads16) a.grads16[a.off_sdf + i] = f2h(g); else a.grads[a.off_sdf + i] = g; }
 	} else if (i < RNB_N_SDF_MLP_PARAMS) { // sdf W1
 		const uint32_t j = i - 64 * 32;
 		g = rh(dw_sum(a.partial[3], 16 * 64, j, a.n_partials, slice, sh, e));
 		g = rh(dw_sum(a.partial[6], 16 * 64, j, a.n_partials, slice, sh, e) + g);
-		if (slice == 0) a.grads[a.off_sdf + i] = g;
+		if (slice == 0) { if (a.grads16) a.grads16[a.off_sdf + i] = f2h(g); else a.grads[a.off_sdf + i] = g; }
 	} else {
 		const uint32_t j = i - RNB_N_SDF_MLP_PARAMS;
 		if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
@@ -1431,7 +1459,7 @@ __global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
 		} else {
 			g = rh(dw_sum(a.partial[0], 16 * 64, j - 64 * 48 - 64 * 64, a.n_partials, slice, sh, e));
 		}
-		if (slice == 0) a.grads[a.off_rgb + j] = g;
+		if (slice == 0) { if (a.grads16) a.grads16[a.off_rgb + j] = f2h(g); else a.grads[a.off_rgb + j] = g; }
 	}
 }
 
@@ -1454,7 +1482,14 @@ struct ScatterArgs {
 	const float* srec;   // [B][8]      TrainScratch::srec
 	uint32_t B;
 	float* grid_grad;    // GRADS_FP32 + off_grid
+	uint32_t* grid_grad16; // rnb_config::accumulate = RNB_ACCUM_HALF: GRADS_FP16 + off_grid, one half2 per table entry (the reference's gradient vector, trainer.h:78-84)
 };
+
+// atomicAdd(__half2) of grid.h:416 / 476-494: one packed L2 atomic carries both features of a table entry (global_atomic_pk_add_f16, no return value)
+__device__ __forceinline__ void atomic_add_h2(uint32_t* __restrict__ entry, const float v0, const float v1) {
+	const h2 v = {f2h(v0), f2h(v1)};
+	(void)__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)(entry), v);
+}
 
 struct ScatterSample { float x, y, z, dn[3]; };
 __device__ __forceinline__ ScatterSample load_srec(const float* __restrict__ srec, const uint32_t s) {
@@ -1485,6 +1520,27 @@ __device__ __forceinline__ float corner_addend(const float g1, const float g2, c
 	return add;
 }
 
+// The same four addends one by one (the reference issues each as an atomic of its own: one from kernel_grid_backward, grid.h:410-430, three from the
+// second-order kernel, grid.h:655-681).
+__device__ __forceinline__ void corner_addends(const float g1, const float g2, const float scale, const float (&dn)[3], const float (&pos)[3], const uint32_t (&c)[3], float (&out)[4]) {
+	float w[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) w[d] = c[d] ? pos[d] : 1 - pos[d];
+	float weight = 1;
+	weight *= w[0]; weight *= w[1]; weight *= w[2];
+	out[0] = rh(g1 * weight);
+#pragma unroll
+	for (uint32_t gd = 0; gd < 3; ++gd) {
+		float w2 = scale * dn[gd] * 1.0f;
+#pragma unroll
+		for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+			const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+			w2 *= w[d];
+		}
+		out[1 + gd] = rh(g2 * (c[gd] ? w2 : -w2));
+	}
+}
+
 // Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
 // global atomics pile up on a handful of lines. Each workgroup accumulates its slice of the batch into a private copy of
 // the levels' gradient tables in LDS, then flushes the non-zero entries once. ds_add_f32 retires at ~3 cycles per LANE per CU
@@ -1495,7 +1551,8 @@ __device__ __forceinline__ float corner_addend(const float g1, const float g2, c
 struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_wg; }; // levels [0, n_levels)
 
 // LDS layout: level l's table at float offset 2 * G.offsets[l]. The per-sample loads of a walk are issued four samples ahead.
-__global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) {
+template <bool HALF>
+__device__ __forceinline__ void grid_scatter_lds_body(const GridMeta& G, const ScatterLdsArgs& p) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	float* tab = reinterpret_cast<float*>(smem_raw);
 	const ScatterArgs& a = p.a;
@@ -1562,12 +1619,21 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, cons
 		}
 	}
 	__syncthreads();
+	if (HALF) { // the workgroup's private sums leave as packed half atomics, one per table entry
+		for (uint32_t e = threadIdx.x; e < n_tab / 2; e += blockDim.x) {
+			const float v0 = tab[2 * e], v1 = tab[2 * e + 1];
+			if (v0 != 0.f || v1 != 0.f) atomic_add_h2(a.grid_grad16 + e, v0, v1);
+		}
+		return;
+	}
 	float* gg = a.grid_grad;
 	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) {
 		const float v = tab[q];
 		if (v != 0.f) atomicAdd(gg + q, v);
 	}
 }
+__global__ __launch_bounds__(512) void k_grid_scatter_lds(const GridMeta G, const ScatterLdsArgs p) { grid_scatter_lds_body<false>(G, p); }
+__global__ __launch_bounds__(512) void k_grid_scatter_lds_h(const GridMeta G, const ScatterLdsArgs p) { grid_scatter_lds_body<true>(G, p); }
 
 // One L2 atomic per corner. Four adjacent lanes own one (sample, level): lane&3 = (dx << 1) | feature. The x-neighbour of a
 // cell is the next table entry on dense levels and for even x on hashed ones (hash prime 1), so the four lanes' atomics mostly
@@ -1610,6 +1676,53 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 	}
 }
 
+// rnb_config::accumulate = RNB_ACCUM_HALF: the gradient table is the reference's half2 per entry and one packed atomic carries both features, so the four lanes of a
+// (sample, level) are (dx, dy) and each issues the 2 dz corners: half the atomic instructions, the same cache lines (an x-pair's 8 bytes travel together).
+// PER_ADDEND (RNB_SCATTER_PLAIN=1, tests): the four addends of a corner as four atomics, the reference's own sequence of half additions -- on the coarse levels, where
+// thousands of addends meet one entry, the sequential half sum rounds small addends away, and only this form reproduces that.
+template <bool PER_ADDEND>
+__device__ __forceinline__ void grid_scatter_quad_h_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const uint32_t n_vblocks) {
+	const uint32_t level = blockIdx.y + level0;
+	if (level > G.valid_level) return;
+	uint32_t* gg = a.grid_grad16 + G.offsets[level];
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+#pragma unroll 1
+	for (uint32_t vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+		const uint32_t t = vb * blockDim.x + threadIdx.x;
+		const uint32_t s = t >> 2;
+		if (s >= a.B) continue;
+		const uint32_t dx = (t >> 1) & 1u, dy = t & 1u;
+		const ScatterSample sm = load_srec(a.srec, s);
+		float pos[3];
+		uint32_t pg[3];
+		pos_fract(sm.x, scale, &pos[0], &pg[0]);
+		pos_fract(sm.y, scale, &pos[1], &pg[1]);
+		pos_fract(sm.z, scale, &pos[2], &pg[2]);
+		const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
+		const h2 g1 = unpack_h2(q12.x), g2 = unpack_h2(q12.y);
+#pragma unroll
+		for (uint32_t dz = 0; dz < 2; ++dz) {
+			const uint32_t c[3] = {dx, dy, dz};
+			uint32_t* entry = gg + grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]);
+			if (PER_ADDEND) {
+				float t0[4], t1[4];
+				corner_addends(h2f(g1[0]), h2f(g2[0]), scale, sm.dn, pos, c, t0);
+				corner_addends(h2f(g1[1]), h2f(g2[1]), scale, sm.dn, pos, c, t1);
+#pragma unroll
+				for (int q = 0; q < 4; ++q) if (t0[q] != 0.f || t1[q] != 0.f) atomic_add_h2(entry, t0[q], t1[q]);
+				continue;
+			}
+			const float add0 = corner_addend(h2f(g1[0]), h2f(g2[0]), scale, sm.dn, pos, c);
+			const float add1 = corner_addend(h2f(g1[1]), h2f(g2[1]), scale, sm.dn, pos, c);
+			if (add0 != 0.f || add1 != 0.f) atomic_add_h2(entry, add0, add1);
+		}
+	}
+}
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) { grid_scatter_quad_h_body<false>(G, a, level0, n_vblocks); }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_h_per_addend(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) { grid_scatter_quad_h_body<true>(G, a, level0, n_vblocks); }
+
 // Middle levels (cell a few march steps wide): the quad layout above, but each quad walks K consecutive samples of the
 // ray-ordered batch and keeps the four (dy, dz) corner sums of its (dx, feature) in registers while the cell does not
 // change. Same-address lanes of one atomic instruction are serialised by the memory system (one request each), so merging
@@ -1618,7 +1731,9 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, con
 // (exactly as many as its run length needs); k_log2 holds log2(K) of level0 + i in bits [4i, 4i+4).
 struct ScatterRlPlan { uint32_t n; uint32_t wg_start[17]; uint64_t k_log2; };
 
-__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) {
+// HALF (rnb_config::accumulate = RNB_ACCUM_HALF): lanes (dx, dy), registers (dz, feature), packed half atomics (see k_grid_scatter_quad_h); a run is still summed in fp32.
+template <bool HALF>
+__device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
 #pragma unroll 1
 	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) { // virtual workgroups (see k_grid_scatter_quad)
 		uint32_t li = 0;
@@ -1630,14 +1745,25 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 		const uint32_t t = (vb - plan.wg_start[li]) * blockDim.x + threadIdx.x;
 		const uint32_t s0 = (t >> 2) * K;
 		if (s0 >= a.B) continue;
-		const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+		const uint32_t dx = (t >> 1) & 1u, f = t & 1u; // HALF: f is dy
 		float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+		uint32_t* gg16 = a.grid_grad16 + G.offsets[level];
 		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
 		const float scale = G.scale[level];
 		const uint32_t res = G.resolution[level];
-		float acc[4] = {0.f, 0.f, 0.f, 0.f};
+		float acc[4] = {0.f, 0.f, 0.f, 0.f}; // fp32: the four (dy, dz) corners of (dx, feature); HALF: [2 dz + feature] of the corner (dx, dy)
 		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
 		auto flush = [&]() {
+			if (HALF) {
+#pragma unroll
+				for (uint32_t dz = 0; dz < 2; ++dz) {
+					if (acc[2 * dz] != 0.f || acc[2 * dz + 1] != 0.f) {
+						atomic_add_h2(gg16 + grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + f, cur[2] + dz), acc[2 * dz], acc[2 * dz + 1]);
+						acc[2 * dz] = 0.f; acc[2 * dz + 1] = 0.f;
+					}
+				}
+				return;
+			}
 #pragma unroll
 			for (uint32_t yz = 0; yz < 4; ++yz) {
 				if (acc[yz] != 0.f) {
@@ -1669,6 +1795,16 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 					if (cur[0] != 0xffffffffu) flush();
 					cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
 				}
+				if (HALF) {
+					const h2 g1 = unpack_h2(q12[j].x), g2 = unpack_h2(q12[j].y);
+#pragma unroll
+					for (uint32_t dz = 0; dz < 2; ++dz) {
+						const uint32_t c[3] = {dx, f, dz};
+						acc[2 * dz] += corner_addend(h2f(g1[0]), h2f(g2[0]), scale, sm[j].dn, pos, c);
+						acc[2 * dz + 1] += corner_addend(h2f(g1[1]), h2f(g2[1]), scale, sm[j].dn, pos, c);
+					}
+					continue;
+				}
 				const float g1 = h2f(unpack_h2(q12[j].x)[f]);
 				const float g2 = h2f(unpack_h2(q12[j].y)[f]);
 #pragma unroll
@@ -1681,6 +1817,8 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, 
 		flush();
 	}
 }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false>(G, a, level0, plan); }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<true>(G, a, level0, plan); }
 
 // ---------------------------------------------------------------------------------------------
 // K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.
@@ -1691,6 +1829,7 @@ struct AdamArgs {
 	float* rec;                // optimizer records, one 64-byte record per 4-parameter group: {fp32 weight x4 | m x4 | v x4 | step count x4} (see k_adam_ema)
 	half_t* w16; half_t* ema;
 	float* grads;
+	half_t* grads16;           // rnb_config::accumulate = RNB_ACCUM_HALF: the gradient vector is half (trainer.h:78-84) -- 2 bytes read and 2 cleared per parameter instead of 4 + 4
 	float base_lr, beta1, beta2, epsilon, l2_reg;
 	float ema_decay, ema_debias_old, ema_debias_new;
 	uint64_t begin, end;       // parameter range of this launch (multiples of 4)
@@ -1722,8 +1861,15 @@ __global__ __launch_bounds__(256) void k_adam_ema(const AdamArgs a) {
 	const uint64_t q_end = a.end / 4;
 	for (uint64_t q = a.begin / 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_end; q += (uint64_t)gridDim.x * blockDim.x) {
 		const uint64_t i0 = q * 4;
-		f4 graw = reinterpret_cast<const f4*>(a.grads)[q];
-		if (graw[0] != 0.f || graw[1] != 0.f || graw[2] != 0.f || graw[3] != 0.f) reinterpret_cast<f4*>(a.grads)[q] = f4{0.f, 0.f, 0.f, 0.f}; // leave the accumulators clear
+		f4 graw;
+		if (a.grads16) {
+			const h4 g16 = reinterpret_cast<const h4*>(a.grads16)[q];
+			graw = f4{h2f(g16[0]), h2f(g16[1]), h2f(g16[2]), h2f(g16[3])};
+			if (graw[0] != 0.f || graw[1] != 0.f || graw[2] != 0.f || graw[3] != 0.f) reinterpret_cast<h4*>(a.grads16)[q] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+		} else {
+			graw = reinterpret_cast<const f4*>(a.grads)[q];
+			if (graw[0] != 0.f || graw[1] != 0.f || graw[2] != 0.f || graw[3] != 0.f) reinterpret_cast<f4*>(a.grads)[q] = f4{0.f, 0.f, 0.f, 0.f}; // leave the accumulators clear
+		}
 		h4 w16 = reinterpret_cast<const h4*>(a.w16)[q];
 		const h4 ema = reinterpret_cast<const h4*>(a.ema)[q];
 		const bool is_matrix = i0 < a.n_matrix;

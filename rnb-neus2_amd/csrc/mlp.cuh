@@ -9,7 +9,7 @@
 //               one sample -> one ds_write_b64 into the next layer's sample-major tile.
 // Row strides of 40 (K=32) and 72 (K=64) halfs make every ds_read_b128 of a fragment conflict-free
 // (16 rows x {80,144} B land on 16 distinct 16-byte slots of the 64-bank LDS).
-// fp32 accumulation in the MFMA (the reference's WMMA accumulates in fp16, fully_fused_mlp.cu:68).
+// fp32 accumulation in the MFMA by default (the reference's WMMA accumulates in fp16, fully_fused_mlp.cu:68: the EMU_* forms below).
 #pragma once
 #include "common.cuh"
 
@@ -52,33 +52,52 @@ __device__ inline void load_weights(half_t* __restrict__ w, const NetW& net, int
 	}
 }
 
-// EMU (test-only, RNB_EMULATE_FP16_ACCUM=1): the reference's tensor-core path accumulates in HALF -- wmma 16x16x16 fragments of __half
-// (fully_fused_mlp.cu:59-68, 198) -- where these kernels accumulate in fp32 (deviation D1). The emulation follows the model of the
-// CPU checker (oracle/rnb_oracle.cpp dot_h, ORC_EMULATE_FP16_ACCUM): products exact, the 16 products of one logical k-step summed in fp32, the running
-// accumulator rounded to half after every k-step. One 32-wide MFMA covers TWO logical k-steps: it is issued twice with the other step's operand lanes
-// zeroed and the accumulator rounded in between. Which lanes / elements belong to which step depends on the operand's K order:
-//   NATURAL (tile read from LDS, k = 8 hq + j): step 0 = lanes hq < 2;      chained fragments (k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3)): step 0 = j < 4.
+// Half accumulation (the product mode rnb_config::accumulate = RNB_ACCUM_HALF): the reference's tensor-core path accumulates in HALF -- wmma 16x16x16
+// fragments of __half (fully_fused_mlp.cu:59-68, 198) -- where the default mode accumulates in fp32 (deviation D1). The matrix cores of
+// gfx950 have no half accumulator, so the model of the CPU checker (oracle/rnb_oracle.cpp dot_h) is followed instead: products exact, the 16 products of one
+// LOGICAL k-step (the reference's k index 16 q .. 16 q + 15) summed in fp32, the running accumulator rounded to half after every k-step. One 32-wide MFMA
+// covers TWO logical k-steps: it is issued twice, each time with the other step's operand elements zeroed, and the accumulator is rounded in between.
+// Which elements of a lane's 8-element operand belong to the first of the two steps depends on the operand's K order (k = 8 hq + j is the physical slot):
+//   EMU_NATURAL  tile read from LDS in the reference's column order                                  first step = lanes hq < 2
+//   EMU_CHAINED  chained fragments, k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3) (below)     first step = elements j < 4
+//   EMU_FBS      k_fwd_bwd_sdf's 32-wide input tiles, 28 hash features | x y z | pad (fbs_logical)  first step = reference columns 0..15 = slots 0..12, 28..30
+constexpr int EMU_OFF = 0, EMU_NATURAL = 1, EMU_CHAINED = 2, EMU_FBS = 3;
 __device__ __forceinline__ f4 round_acc_half(f4 a) {
 #pragma unroll
 	for (int r = 0; r < 4; ++r) a[r] = h2f(f2h(a[r]));
 	return a;
 }
-template <bool NATURAL>
-__device__ __forceinline__ f4 mfma_emul16(const h8 a, const h8 b, f4 acc, const int hq) {
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+// The two halves of operand b by logical k-step (an operand is masked once and may then serve several MFMAs).
+template <int ORD>
+__device__ __forceinline__ void split_ksteps(const h8 b, const int hq, h8& lo, h8& hi) {
 	const h8 zero = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-	h8 lo = zero, hi = zero;
-	if (NATURAL) { if (hq < 2) lo = b; else hi = b; }
-	else {
+	lo = zero; hi = zero;
+	if (ORD == EMU_NATURAL) { if (hq < 2) lo = b; else hi = b; }
+	else if (ORD == EMU_CHAINED) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) { lo[j] = b[j]; hi[4 + j] = b[4 + j]; }
+	} else { // EMU_FBS: slots 8 hq + j with fbs_logical(slot) < 16: hq 0: all; hq 1: j <= 4; hq 2: none; hq 3: j = 4, 5, 6
+		const u4 m = hq == 0 ? u4{~0u, ~0u, ~0u, ~0u} : hq == 1 ? u4{~0u, ~0u, 0xffffu, 0u} : hq == 2 ? u4{0u, 0u, 0u, 0u} : u4{0u, 0u, ~0u, 0xffffu};
+		const u4 raw = __builtin_bit_cast(u4, b);
+		lo = __builtin_bit_cast(h8, raw & m);
+		hi = __builtin_bit_cast(h8, raw & ~m);
 	}
+}
+__device__ __forceinline__ f4 mfma_emul16_split(const h8 a, const h8 lo, const h8 hi, f4 acc) {
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, lo, acc, 0, 0, 0));
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, hi, acc, 0, 0, 0));
 	return acc;
 }
+template <int ORD>
+__device__ __forceinline__ f4 mfma_emul16(const h8 a, const h8 b, f4 acc, const int hq) {
+	h8 lo, hi;
+	split_ksteps<ORD>(b, hq, lo, hi);
+	return mfma_emul16_split(a, lo, hi, acc);
+}
 
 // acc[mt][nt] += W[16mt.., :] * X[16nt.., :]^T over K = 32*K_STEPS.
-template <int M_TILES, int K_STEPS, bool EMU = false>
+template <int M_TILES, int K_STEPS, int EMU = EMU_OFF>
 __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const int w_stride, const half_t* __restrict__ X, const int x_stride, f4 (&acc)[M_TILES][4], const int lane) {
 	const int r16 = lane & 15, hq = lane >> 4;
 	h8 b[4][K_STEPS];
@@ -92,7 +111,7 @@ __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const i
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<true>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<EMU>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
 		}
 	}
 }
@@ -183,7 +202,7 @@ __device__ inline void load_weights_chained(half_t* __restrict__ w, const NetW& 
 }
 
 // acc[mt][nt] += W[16mt.., :] * B over K = 32*K_STEPS, B fragments in registers.
-template <int M_TILES, int K_STEPS, bool EMU = false>
+template <int M_TILES, int K_STEPS, int EMU = EMU_OFF>
 __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, const int w_stride, const h8 (&b)[4][K_STEPS], f4 (&acc)[M_TILES][4], const int lane) {
 	const int r16 = lane & 15, hq = lane >> 4;
 #pragma unroll
@@ -192,7 +211,7 @@ __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, co
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<false>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<EMU>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
 		}
 	}
 }

@@ -113,6 +113,10 @@ struct rnb_ctx {
 
 	DevBuf<float> params_fp32, grads, adam_m, adam_v;
 	DevBuf<half_t> params_fp16, params_ema;
+	DevBuf<half_t> grads16; // cfg.accumulate = RNB_ACCUM_HALF: the half gradient vector (RNB_BUF_GRADS_FP16) instead of the fp32 accumulators `grads`
+	bool half_acc() const { return cfg.accumulate == RNB_ACCUM_HALF; }
+	size_t grad_elem() const { return half_acc() ? sizeof(half_t) : sizeof(float); }
+	char* grad_ptr(uint64_t i) const { return half_acc() ? reinterpret_cast<char*>(grads16.p + i) : reinterpret_cast<char*>(grads.p + i); }
 	DevBuf<uint32_t> adam_steps;
 	// Optimizer state as k_adam_ema keeps it: one 64-byte record {fp32 weight, m, v, step count} per 4-parameter group (kernels_net.cuh). params_fp32 /
 	// adam_m / adam_v / adam_steps above are the staging views rnb_buffer hands out: unpacked from the records when a caller asks for one
@@ -194,8 +198,6 @@ struct rnb_ctx {
 		bool scan_chain = true; // RNB_SCAN_CHAIN=0: the ray scans as in rounds 1-3 (one 1024-thread workgroup for small batches, three tiled launches for large ones)
 		uint32_t march_wave_per_ray_below = 4096; // RNB_MARCH_WAVE_PER_RAY_BELOW=n: one wavefront per ray for batches of at most n rays (single-cascade scenes). At an eighth of the batch
 		                                          // (1.8 k rays per step): 0.2985 -> 0.2890 ms/step with 4096 (2560: 0.2887); bit-exact at every size (the full-size tests were run with n = 100 000)
-		bool emulate_fp16_accum = false; // RNB_EMULATE_FP16_ACCUM=1 (tests only, never benchmarked): the network evaluations (k_forward_chained, k_point_query_chained) round their
-		                                  // accumulators to half after every 16-wide k-step, as the reference's WMMA path does (fully_fused_mlp.cu:59-68) and ORC_EMULATE_FP16_ACCUM models
 		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
@@ -209,6 +211,9 @@ struct rnb_ctx {
 		int march_write_split = -1; // RNB_MARCH_WRITE_SPLIT=0|1: k_march_write of a march generated ahead as one launch (rounds 1-3) / always split; default: split below 65 536 rays per step. Split: what the first network evaluation reads (idx1, the heads'
 		                               // coordinates) in a first launch, whose completion the critical stream waits for; the rest (ray constants, ray records, the tails' coordinates) in a second one
 		                               // that runs beside that evaluation and is joined in front of the loss pass
+		bool scatter_plain = false; // RNB_SCATTER_PLAIN=1 (A/B, tests): no LDS-privatised and no run-length scatter -- every corner of every level is its own L2 atomic, as in the reference; with
+		                            // accumulate = RNB_ACCUM_HALF every one of a corner's four addends is (k_grid_scatter_quad_h_per_addend), which reproduces the reference's sequential half sums
+		                            // on the coarse levels too
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -366,7 +371,7 @@ int reset_optimizer_state(rnb_ctx* c) {
 	HIP_TRY(hipMemset(c->adam_m.p, 0, c->adam_m.bytes()));
 	HIP_TRY(hipMemset(c->adam_v.p, 0, c->adam_v.bytes()));
 	HIP_TRY(hipMemset(c->adam_steps.p, 0, c->adam_steps.bytes()));
-	HIP_TRY(hipMemset(c->grads.p, 0, c->grads.bytes()));
+	HIP_TRY(hipMemset(c->grad_ptr(0), 0, c->param_capacity * c->grad_elem()));
 	c->grads_clean = true;
 	c->optimizer_step_count = 0;
 	c->opt_plain_current = true; c->opt_rec_current = false; // the views are the truth until the next optimizer launch packs them
@@ -425,7 +430,7 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
-	if (c->knobs.emulate_fp16_accum) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	if (c->half_acc()) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -595,7 +600,7 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
-	if (c->knobs.emulate_fp16_accum) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	if (c->half_acc()) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -818,7 +823,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const uint32_t L = c->cfg.n_levels;
 	const uint32_t e_c = sg.e_c, l_fine = sg.l_fine;
 	join_tail_host(c);
-	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grads.p, 0, c->grads.bytes(), s));
+	const bool half = c->half_acc();
+	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grad_ptr(0), 0, c->n_params * c->grad_elem(), s));
 	c->grads_clean = false;
 	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
 	TrainArgs a;
@@ -857,11 +863,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		r.cin = c->cin_eval.p; r.src_slot = flow ? c->src_slot.p : nullptr; r.dout = c->dloss_dout.p; r.dcin = c->dcin.p; r.B = B;
 		r.wimg = c->wimg_valid ? c->wimg_rgb.p : nullptr;
 		r.dw_c0 = p_rgb0; r.dw_c1 = p_rgb1; r.dw_c2 = p_rgb2;
-		hipLaunchKernelGGL(k_rgb_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
+		if (half) hipLaunchKernelGGL(k_rgb_fwd_bwd_h, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
+		else hipLaunchKernelGGL(k_rgb_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
 		a.dcin = c->dcin.p;
 		// (one workgroup per CU -- no register spills, the two-per-CU instance keeps ~80 values in scratch -- lost: 0.88 vs 0.80 ms/step, half the wavefronts to hide the gathers)
-		LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
-	} else if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+		if (half) LAUNCH_EV(k_fwd_bwd_sdf_full_h, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+		else LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+	} else if (sdf_only && half) LAUNCH_EV(k_fwd_bwd_sdf_h, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+	else if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
 	c->prof.units[P_FWD_BWD] += B;
@@ -890,7 +899,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
 		f.n_partials = (uint32_t)slab;
 		f.var_partial = c->var_partial.p; f.n_var_partials = fb_grid * WAVES_PER_WG;
-		f.grads = c->grads.p; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
+		f.grads = c->grads.p; f.grads16 = half ? c->grads16.p : nullptr; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + (a.skip_rgb ? 0 : RNB_N_RGB_MLP_PARAMS)) / DWF_PARAMS + 1; // + the variance workgroup
 		LAUNCH_EV(k_dw_finish, dim3(n_fin_blocks), dim3(DWF_WG), 0, sd, done, f);
 	};
@@ -904,11 +913,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	// long pole beside the scatter and gets the wave slots a capped scatter leaves
 	const uint32_t scatter_cap = c->knobs.scatter_wg_per_cu >= 0 ? (uint32_t)c->knobs.scatter_wg_per_cu : ((sdf_only && !split) ? 0u : 2u);
 	ScatterArgs sa;
-	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = c->grads.p + c->off_grid;
+	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = half ? nullptr : c->grads.p + c->off_grid;
+	sa.grid_grad16 = half ? reinterpret_cast<uint32_t*>(c->grads16.p + c->off_grid) : nullptr; // (off_grid is even: half2 entries are 4-byte aligned)
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
 		const uint32_t n_vb = (B * 4 + 255) / 256, cap = scatter_cap ? std::max(1u, (uint32_t)c->n_cus * scatter_cap / std::max(1u, l1 - l0)) : n_vb;
-		if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
+		if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EV(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
+		else if (l1 > l0 && half) LAUNCH_EV(k_grid_scatter_quad_h, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
+		else if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
@@ -919,7 +931,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + sg.Ks[e_c + q] - 1) / sg.Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
 		const uint32_t cap_rl = scatter_cap ? (uint32_t)c->n_cus * scatter_cap : wg;
-		LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+		if (half) LAUNCH_EV(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+		else LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
 		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -927,7 +940,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		const uint32_t wg_cap = 128; // workgroups of the LDS scatter (measured optimum: half the CUs, each zeroing / flushing its private table once)
 		const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 		la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
-		LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
+		if (half) LAUNCH_EV(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
+		else LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
 	};
 
 	if (!side_streams) {
@@ -1001,7 +1015,7 @@ static int optimizer_begin(rnb_ctx* c) {
 	AdamArgs& a = c->opt.args;
 	a.n = c->n_params; a.n_matrix = RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
 	a.rec = c->opt_rec.p; a.w16 = c->params_fp16.p; a.ema = c->params_ema.p;
-	a.grads = c->grads.p;
+	a.grads = c->grads.p; a.grads16 = c->half_acc() ? c->grads16.p : nullptr;
 	a.base_lr = cfg.learning_rate * c->lr_factor; a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.epsilon = cfg.epsilon; a.l2_reg = cfg.l2_reg;
 	a.ema_decay = cfg.ema_decay;
 	a.skip_lo = cfg.only_sdf_training ? (uint64_t)c->off_rgb : 0; a.skip_hi = cfg.only_sdf_training ? (uint64_t)c->off_grid : 0;
@@ -1041,6 +1055,11 @@ static void plan_scatter_groups(rnb_ctx* c) {
 			const float run = 590.f / (float)c->grid.resolution[l]; // compacted samples of a ray that share a cell of this level
 			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
 		}
+	}
+	if (c->knobs.scatter_plain) { // RNB_SCATTER_PLAIN=1: every level through the plain kernel, one atomic per corner and sample -- the reference's own scatter structure (grid.h:366-495)
+		for (l = 0; l < L; ++l) g.Ks[l] = 1;
+		c->dp_split = c->off_grid; c->dp_mid = c->off_grid + (uint64_t)c->grid.offsets[(L + 1) / 2] * 2;
+		return;
 	}
 	for (l = 0; l < L; ++l) if (l == g.e_c && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) g.e_c = l + 1; // the coarsest levels whose fp32 gradient tables fit in LDS together
 	g.l_fine = g.e_c;
@@ -1158,8 +1177,8 @@ int optimizer_step_shard(rnb_ctx* c, uint32_t part, hipStream_t st) {
 	const rnb_shard_part& p = parts[part];
 	{ const int rc = optimizer_begin(c); if (rc != RNB_OK) return rc; }
 	if (!c->sc.dw_joined) HIP_TRY(hipStreamWaitEvent(st, c->ev_dw, 0)); // any block may hold MLP parameters
-	if (p.own_lo > p.lo) HIP_TRY(hipMemsetAsync(c->grads.p + p.lo, 0, (p.own_lo - p.lo) * sizeof(float), st));
-	if (p.hi > p.own_hi) HIP_TRY(hipMemsetAsync(c->grads.p + p.own_hi, 0, (p.hi - p.own_hi) * sizeof(float), st));
+	if (p.own_lo > p.lo) HIP_TRY(hipMemsetAsync(c->grad_ptr(p.lo), 0, (p.own_lo - p.lo) * c->grad_elem(), st));
+	if (p.hi > p.own_hi) HIP_TRY(hipMemsetAsync(c->grad_ptr(p.own_hi), 0, (p.hi - p.own_hi) * c->grad_elem(), st));
 	adam_launch(c, st, std::min<uint64_t>(p.own_lo, c->n_params), std::min<uint64_t>(p.own_hi, c->n_params));
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1171,7 +1190,7 @@ static int update_config_common(rnb_config& dst, const rnb_config* cfg) {
 	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
 	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
 	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
-	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank)
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate)
 		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
 	dst = *cfg;
 	return RNB_OK;
@@ -1209,7 +1228,7 @@ int rnb_default_config(rnb_config* cfg) {
 
 int rnb_destroy(rnb_ctx* c) {
 	if (!c) return RNB_OK;
-	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
+	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->grads16.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_grid_tmp_alt.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_range.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
@@ -1237,6 +1256,8 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (cfg->target_batch_size == 0 || cfg->target_batch_size % 128 != 0) return fail(RNB_ERR_INVALID, "target_batch_size must be a positive multiple of 128");
 	if (cfg->max_rays_per_batch == 0 || cfg->max_rays_per_batch > (1u << 18)) return fail(RNB_ERR_INVALID, "max_rays_per_batch must be in [1, 2^18]");
 	if (cfg->world_size == 0 || cfg->rank >= cfg->world_size) return fail(RNB_ERR_INVALID, "bad rank/world_size");
+	if (cfg->accumulate > RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate must be RNB_ACCUM_FP32 or RNB_ACCUM_HALF");
+	if (cfg->accumulate == RNB_ACCUM_HALF && getenv("RNB_FWD_BWD_GENERIC")) return fail(RNB_ERR_INVALID, "RNB_FWD_BWD_GENERIC (the generic training kernel of rounds 1-3) has no half-accumulate form");
 	int dev = 0;
 	HIP_TRY(hipGetDevice(&dev));
 	hipDeviceProp_t prop;
@@ -1278,7 +1299,8 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	} while (0)
 	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
 	ALLOC(c->opt_rec, c->param_capacity * 4);
-	ALLOC_P(c->params_fp32); ALLOC_P(c->grads); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
+	if (cfg->accumulate == RNB_ACCUM_HALF) ALLOC_P(c->grads16); else ALLOC_P(c->grads);
+	ALLOC_P(c->params_fp32); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_grid_tmp_alt, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
 	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
@@ -1336,6 +1358,10 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_h), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	{
 		const int march_lds_max = (int)((2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS) * sizeof(uint32_t));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
@@ -1366,7 +1392,6 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_FUSED_UPDATE")) k.fused_update = atoi(e) != 0;
 		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
-		if (const char* e = getenv("RNB_EMULATE_FP16_ACCUM")) k.emulate_fp16_accum = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
@@ -1375,6 +1400,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_LOSS_CHAIN_RECORDS")) k.loss_chain_records = atoi(e) != 0;
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
+		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
@@ -1507,7 +1533,8 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_PARAMS_FP32: BUF(c->params_fp32);
 		case RNB_BUF_PARAMS_FP16: BUF(c->params_fp16);
 		case RNB_BUF_PARAMS_EMA: BUF(c->params_ema);
-		case RNB_BUF_GRADS_FP32: BUF(c->grads);
+		case RNB_BUF_GRADS_FP32: if (c->half_acc()) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_HALF: the gradient vector is RNB_BUF_GRADS_FP16"); BUF(c->grads);
+		case RNB_BUF_GRADS_FP16: if (!c->half_acc()) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_FP32: the gradient accumulators are RNB_BUF_GRADS_FP32"); BUF(c->grads16);
 		case RNB_BUF_ADAM_M: BUF(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF(c->adam_steps);

@@ -33,7 +33,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert not missing, missing
     # callable without a GPU: version + defaults (no compute)
     fns = api.load_library()
-    assert fns.abi_version() == 3
+    assert fns.abi_version() == 4
     cfg = api.default_config()
     assert (cfg.n_levels, cfg.log2_hashmap_size, cfg.target_batch_size, cfg.seed) == (14, 19, 1 << 18, 1337)
     assert abs(cfg.per_level_scale - 1.45242) < 1e-4  # exp(ln(2048/16)/13), testbed.cu:2320-2323
@@ -75,8 +75,8 @@ def test_config_struct_layout_matches_the_header():
 #include <stddef.h>
 #include "rnb_neus2.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(rnb_config), offsetof(rnb_config, target_batch_size), offsetof(rnb_config, learning_rate),
-         offsetof(rnb_config, world_size), sizeof(rnb_view), sizeof(rnb_step_stats), offsetof(rnb_step_stats, loss));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rnb_config), offsetof(rnb_config, target_batch_size), offsetof(rnb_config, learning_rate),
+         offsetof(rnb_config, world_size), sizeof(rnb_view), sizeof(rnb_step_stats), offsetof(rnb_step_stats, loss), offsetof(rnb_config, accumulate));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -86,7 +86,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     want = [C.sizeof(_abi.Config), _abi.Config.target_batch_size.offset, _abi.Config.learning_rate.offset, _abi.Config.world_size.offset,
-            C.sizeof(_abi.View), C.sizeof(_abi.StepStats), _abi.StepStats.loss.offset]
+            C.sizeof(_abi.View), C.sizeof(_abi.StepStats), _abi.StepStats.loss.offset, _abi.Config.accumulate.offset]
     assert got == want
 
 

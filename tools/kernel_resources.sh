@@ -1,0 +1,25 @@
+#!/bin/bash
+# Registers, scratch and LDS of every kernel of the shipped library (the code object's metadata notes), and the packed-fp32 guard:
+#   tools/kernel_resources.sh [pattern]        lines "kernel vgpr sgpr scratch lds" (pattern: grep on the kernel name)
+#   tools/kernel_resources.sh --check-no-pk-f32  exit 1 if the gfx950 code contains a v_pk_{mul,add,fma}_f32 instruction (rnb-neus2_amd/build.py)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SO=$ROOT/rnb-neus2_amd/librnb_neus2_hip.so
+LLVM=/opt/rocm/lib/llvm/bin
+TMP=$(mktemp -d)
+trap 'rm -rf "$TMP"' EXIT
+$LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=<($LLVM/llvm-objcopy --dump-section .hip_fatbin=/dev/stdout "$SO") --output="$TMP/dev.co" --unbundle 2>/dev/null || {
+  $LLVM/llvm-objcopy --dump-section .hip_fatbin="$TMP/fat.bin" "$SO"
+  $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input="$TMP/fat.bin" --output="$TMP/dev.co" --unbundle
+}
+if [ "$1" = "--check-no-pk-f32" ]; then
+  n=$($LLVM/llvm-objdump -d --mcpu=gfx950 "$TMP/dev.co" | grep -c -E 'v_pk_(mul|add|fma)_f32' || true)
+  echo "v_pk_*_f32 instructions in librnb_neus2_hip.so: $n"
+  [ "$n" = "0" ]
+  exit $?
+fi
+$LLVM/llvm-readelf --notes "$TMP/dev.co" | awk -v pat="${1:-.}" '
+  /\.name:/ {name=$2}
+  /\.vgpr_count:/ {v=$2} /\.sgpr_count:/ {s=$2} /\.private_segment_fixed_size:/ {p=$2} /\.group_segment_fixed_size:/ {g=$2} /\.agpr_count:/ {a=$2}
+  /\.vgpr_spill_count:/ {sp=$2}
+  /\.wavefront_size:/ { if (name ~ pat) printf "%-70s vgpr %3s agpr %3s sgpr %3s scratch %5s spill %4s lds %6s\n", name, v, a, s, p, sp, g }'
