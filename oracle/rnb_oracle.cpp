@@ -158,7 +158,7 @@ struct orc_ctx_s {
 	bool emul_half_atomics = false; // D2 off: hash-grid gradients accumulate in half, one rounding per atomicAdd(__half2), in sample order
 	uint32_t atomic_order_seed = 0; // ORC_ATOMIC_ORDER_SEED != 0: ... in a seeded random order of the samples instead -- any order is a legal outcome of the reference's atomics,
 	                                // and the distance between two orders is the floor below which no implementation of half atomics can be compared (tests/test_gpu_fullsize.py)
-	std::vector<half_t> grads16;    // RNB_BUF_GRADS_FP16: the gradient vector narrowed to half (a snapshot made by rnb_buffer)
+	std::vector<half_t> grads16;    // accumulate = RNB_ACCUM_HALF: the half gradient vector (RNB_BUF_GRADS_FP16), filled from `grads` at the end of the backward pass
 };
 
 namespace {
@@ -1399,6 +1399,9 @@ void forward_backward(orc_ctx_s* c) {
 	// the optimizer narrows every gradient to half once (deviation D2), after the data-parallel all-reduce.
 	c->grads[c->off_var] = (float)var;
 	for (int q = 1; q < RNB_N_VARIANCE_PARAMS; ++q) c->grads[c->off_var + q] = 0.f;
+	// accumulate = RNB_ACCUM_HALF: the gradient vector IS half (trainer.h:78-84) -- what RNB_BUF_GRADS_FP16 hands out, what data-parallel callers exchange and what the
+	// optimizer reads (the weight and grid sums above are half values already; the variance's fp32 sum is narrowed here, nerf_network.h:338-339)
+	if (c->cfg.accumulate == RNB_ACCUM_HALF) for (uint64_t i = 0; i < c->n_params; ++i) c->grads16[i] = f2h(c->grads[i]);
 }
 
 // ExponentialDecayOptimizer::step (exponential_decay.h:61-72): once per optimizer step.
@@ -1424,7 +1427,7 @@ void optimizer_range(orc_ctx_s* c, const uint64_t lo, const uint64_t hi) {
 #pragma omp parallel for schedule(static)
 	for (int64_t ii = (int64_t)lo; ii < (int64_t)hi; ++ii) {
 		const uint64_t i = (uint64_t)ii;
-		float gradient = h2f(f2h(c->grads[i])) / LOSS_SCALE;
+		float gradient = (c->cfg.accumulate == RNB_ACCUM_HALF ? h2f(c->grads16[i]) : h2f(f2h(c->grads[i]))) / LOSS_SCALE;
 		const bool is_matrix = i < n_matrix;
 		if (!is_matrix && gradient == 0) continue;
 		if (cfg.only_sdf_training && i >= c->off_rgb && i < c->off_grid) continue; // found_reflectance && only_sdf_training (adam.h:121-165)
@@ -1547,6 +1550,7 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 	c->params_fp16.assign(c->param_capacity, 0);
 	c->params_ema.assign(c->param_capacity, 0);
 	c->grads.assign(c->param_capacity, 0.f);
+	c->grads16.assign(c->cfg.accumulate == RNB_ACCUM_HALF ? c->param_capacity : 0, (half_t)0);
 	c->adam_m.assign(c->param_capacity, 0.f);
 	c->adam_v.assign(c->param_capacity, 0.f);
 	c->adam_steps.assign(c->param_capacity, 0);
@@ -1694,12 +1698,8 @@ int rnb_buffer(orc_ctx_s* c, int id, void** ptr, uint64_t* n_bytes) {
 		case RNB_BUF_PARAMS_FP32: BUF_P(c->params_fp32);
 		case RNB_BUF_PARAMS_FP16: BUF_P(c->params_fp16);
 		case RNB_BUF_PARAMS_EMA: BUF_P(c->params_ema);
-		case RNB_BUF_GRADS_FP32: BUF_P(c->grads);
-		case RNB_BUF_GRADS_FP16: // (the checker keeps its gradients as floats in either mode; with accumulate = RNB_ACCUM_HALF every value is a half already)
-			if (c->cfg.accumulate != RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_FP32: the gradient accumulators are RNB_BUF_GRADS_FP32");
-			c->grads16.resize(c->grads.size());
-			for (size_t i = 0; i < c->grads.size(); ++i) c->grads16[i] = f2h(c->grads[i]);
-			BUF_P(c->grads16);
+		case RNB_BUF_GRADS_FP32: if (c->cfg.accumulate == RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_HALF: the gradient vector is RNB_BUF_GRADS_FP16"); BUF_P(c->grads);
+		case RNB_BUF_GRADS_FP16: if (c->cfg.accumulate != RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate = RNB_ACCUM_FP32: the gradient accumulators are RNB_BUF_GRADS_FP32"); BUF_P(c->grads16);
 		case RNB_BUF_ADAM_M: BUF_P(c->adam_m);
 		case RNB_BUF_ADAM_V: BUF_P(c->adam_v);
 		case RNB_BUF_ADAM_STEPS: BUF_P(c->adam_steps);
@@ -2091,6 +2091,7 @@ int rnb_train_step_apply_shard(orc_ctx_s* c, uint32_t part, void*) {
 	const rnb_shard_part& p = parts[part];
 	std::fill(c->grads.begin() + p.lo, c->grads.begin() + p.own_lo, 0.f);
 	std::fill(c->grads.begin() + p.own_hi, c->grads.begin() + p.hi, 0.f);
+	if (c->cfg.accumulate == RNB_ACCUM_HALF) { std::fill(c->grads16.begin() + p.lo, c->grads16.begin() + p.own_lo, (half_t)0); std::fill(c->grads16.begin() + p.own_hi, c->grads16.begin() + p.hi, (half_t)0); }
 	optimizer_range(c, std::min<uint64_t>(p.own_lo, c->n_params), std::min<uint64_t>(p.own_hi, c->n_params));
 	return RNB_OK;
 }
@@ -2102,6 +2103,7 @@ int rnb_train_step_apply_done(orc_ctx_s* c, void*) {
 	return RNB_OK;
 }
 int rnb_train_step_apply_early(orc_ctx_s* c, void*) { return c ? RNB_OK : fail(RNB_ERR_INVALID, "null ctx"); } // one block: nothing to do early
-int rnb_gradient_part_wait(orc_ctx_s* c, uint32_t part, void*) { return (c && part == 0) ? RNB_OK : fail(RNB_ERR_INVALID, "bad part"); }
+// (every gradient is final when rnb_train_step_begin returns: nothing to wait for, whichever block of rnb_gradient_parts / rnb_shard_layout is meant)
+int rnb_gradient_part_wait(orc_ctx_s* c, uint32_t part, void*) { return (c && part < RNB_MAX_SHARD_PARTS) ? RNB_OK : fail(RNB_ERR_INVALID, "bad part"); }
 
 } // extern "C"

@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
 ROOT = os.path.dirname(PKG_DIR)
 TESTBED_SRC = os.path.join(PKG_DIR, "host", "testbed_main.cpp")
 TESTBED_OUT = os.path.join(ROOT, "build", "testbed")
-TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "dataset.hpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp", "mc_table.hpp")] + [
+TESTBED_DEPS = [os.path.join(PKG_DIR, "host", f) for f in ("testbed_main.cpp", "dataset.hpp", "json_min.hpp", "png16.hpp", "msgpack_min.hpp", "mesh.hpp", "mc_table.hpp", "dist_transport.hpp")] + [
     os.path.join(ROOT, "include", "rnb_neus2.h")]
 
 
@@ -72,7 +72,7 @@ def build_testbed(force=False, verbose=False):
     with_rccl = not os.environ.get("RNB_NO_RCCL") and rccl_libdir is not None and os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h"))
     hip_libdir = next((os.path.join(rocm, d) for d in ("lib", "lib64") if os.path.exists(os.path.join(rocm, d, "libamdhip64.so"))), os.path.join(rocm, "lib"))
     # the HIP headers / runtime are linked whether or not RCCL is there (the file may call HIP outside its RNB_WITH_RCCL blocks)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-D__HIP_PLATFORM_AMD__", "-DRNB_WITH_HIP", "-I" + os.path.join(rocm, "include"), TESTBED_SRC, "-o", TESTBED_OUT,
            "-L" + PKG_DIR, "-lrnb_neus2_hip", "-lz", "-L" + hip_libdir, "-lamdhip64", "-Wl,-rpath,$ORIGIN/../rnb-neus2_amd", "-Wl,-rpath," + hip_libdir]
     if with_rccl:
         cmd += ["-DRNB_WITH_RCCL", "-L" + rccl_libdir, "-lrccl", "-Wl,-rpath," + rccl_libdir]

@@ -40,16 +40,23 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def grads_name(ctx):
+    """The gradient vector the ranks exchange: the fp32 accumulators, or -- rnb_config::accumulate = RNB_ACCUM_HALF -- the half vector (summed in half over the ranks)."""
+    return "GRADS_FP16" if ctx.cfg.accumulate else "GRADS_FP32"
+
+
 def grads_tensor(ctx):
-    """torch view (no copy) of the context's fp32 gradient accumulators, for dist.all_reduce."""
+    """torch view (no copy) of the context's gradient vector, for dist.all_reduce."""
     import torch
-    ptr, nbytes = ctx.buffer("GRADS_FP32")
-    return torch.as_tensor(_DeviceArray(ptr, nbytes // 4, "<f4"), device="cuda")
+    name = grads_name(ctx)
+    ptr, nbytes = ctx.buffer(name)
+    size = 2 if name == "GRADS_FP16" else 4
+    return torch.as_tensor(_DeviceArray(ptr, nbytes // size, _PARAM_BUFFERS[name]), device="cuda")
 
 
 # parameter-shaped buffers and the element type their exchange uses (uint32 counters travel as int32)
 _STAGING_VIEWS = ("PARAMS_FP32", "ADAM_M", "ADAM_V", "ADAM_STEPS")  # include/rnb_neus2.h, rnb_buffer
-_PARAM_BUFFERS = {"GRADS_FP32": "<f4", "PARAMS_FP16": "<f2", "PARAMS_FP32": "<f4", "PARAMS_EMA": "<f2", "ADAM_M": "<f4", "ADAM_V": "<f4", "ADAM_STEPS": "<i4"}
+_PARAM_BUFFERS = {"GRADS_FP32": "<f4", "GRADS_FP16": "<f2", "PARAMS_FP16": "<f2", "PARAMS_FP32": "<f4", "PARAMS_EMA": "<f2", "ADAM_M": "<f4", "ADAM_V": "<f4", "ADAM_STEPS": "<i4"}
 
 
 class TorchShardCollectives:
@@ -194,7 +201,7 @@ class DataParallelTrainer:
             with torch.cuda.stream(early):
                 for k in range(len(parts) - 1):
                     ctx.gradient_part_wait(k, early.cuda_stream)
-                    self._shard.reduce_scatter("GRADS_FP32", parts[k])
+                    self._shard.reduce_scatter(grads_name(ctx), parts[k])
                     ctx.train_step_apply_shard(k, early.cuda_stream)
                     self._shard.all_gather("PARAMS_FP16", parts[k])
             rest = range(len(parts) - 1, len(parts))
@@ -204,7 +211,7 @@ class DataParallelTrainer:
         for k in rest:
             if on_device:
                 ctx.gradient_part_wait(k, handle)
-            self._shard.reduce_scatter("GRADS_FP32", parts[k])
+            self._shard.reduce_scatter(grads_name(ctx), parts[k])
             ctx.train_step_apply_shard(k, handle)
             self._shard.all_gather("PARAMS_FP16", parts[k])
         if early is not None:

@@ -13,8 +13,12 @@
 #include "msgpack_min.hpp"
 #include "png16.hpp"
 
-#ifdef RNB_WITH_RCCL // the HIP build: several processes, one per GPU, exchange counters and gradients over RCCL (no reference counterpart)
+#include "dist_transport.hpp"
+
+#ifdef RNB_WITH_HIP // the build over librnb_neus2_hip.so (the CPU-checker build of this file, tests/, has no device)
 #include <hip/hip_runtime_api.h>
+#endif
+#ifdef RNB_WITH_RCCL // several processes, one per GPU, exchange counters and gradients over RCCL (no reference counterpart)
 #include <rccl/rccl.h>
 #endif
 
@@ -30,6 +34,7 @@
 #include <cstring>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -76,6 +81,7 @@ const std::vector<FlagSpec> FLAGS = {
 	{{"v", "version"}, false, "VERSION", "Display the version of neural graphics primitives."},
 	{{"mask-weight"}, true, "MASK_WEIGHT", "Mask weight."},
 	{{"fractional-training"}, true, "FRACTIONAL_TRAINING", "Step for fractional training"},
+	{{"accumulate"}, true, "ACCUMULATE", "fp32 (default) or half: width of the accumulators (half = the reference's arithmetic as coded). Not a flag of the reference."},
 };
 
 struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -185,42 +191,26 @@ static jsonmin::Value mpk_to_json(const mpk::Value& m) {
 // library's device block, then the gradient blocks are exchanged in the order they become final through the SHARDED optimizer
 // (the C++ form of dp.DataParallelTrainer._sharded_apply): reduce-scatter of a block -> Adam + EMA on this rank's 1/W of it ->
 // all-gather of the fp16 training weights; block 0 (everything in front of the finest levels) on its own stream and its own
-// communicator beside the scatter of the finest levels. RNB_DP_SHARDED=0: all-reduce + replicated optimizer instead.
-// RCCL orders the operations of ONE communicator, whatever streams they are given; the three exchanges that are meant to run
-// beside each other (step vector, early block, the rest) therefore use three communicators, each with its own non-blocking stream.
+// channel beside the scatter of the finest levels. RNB_DP_SHARDED=0: all-reduce + replicated optimizer instead.
+// The collectives go through a function table (dist_transport.hpp). Product: RCCL -- it orders the operations of ONE communicator, whatever
+// streams they are given, so the three exchanges that are meant to run beside each other (step vector, early block, the rest) are three
+// channels = three communicators, each with its own non-blocking stream. RNB_DP_TRANSPORT=staged + RNB_DP_STAGE_DIR (tests only) stages the
+// same call sequence through host files, which is how the multi-rank path runs on two ranks sharing one GPU and in the CPU-checker build.
 // Rank 0 alone writes meshes, snapshots and progress lines (after sync_parameters(): with the sharded optimizer a rank's fp32
 // masters, EMA weights and Adam state are current on its own chunks only).
-struct Dist {
-	int world = 1, rank = 0, local_rank = 0;
-	bool on = false, weak = false, sharded = true;
 #ifdef RNB_WITH_RCCL
-	ncclComm_t comm = nullptr, comm_early = nullptr, comm_vec = nullptr;
-	hipStream_t s_main = nullptr, s_early = nullptr, s_vec = nullptr;
-	hipEvent_t ev_early = nullptr;
-	double* host7 = nullptr;
-	bool synced = true; // no sharded update since the last sync_parameters()
-#endif
-	static int env_int(const char* a, const char* b, int def) {
-		const char* v = std::getenv(a);
-		if (!v) v = std::getenv(b);
-		return v ? std::atoi(v) : def;
-	}
-	void init() {
-		world = env_int("RNB_WORLD_SIZE", "WORLD_SIZE", 1);
-		rank = env_int("RNB_RANK", "RANK", 0);
-		local_rank = env_int("RNB_LOCAL_RANK", "LOCAL_RANK", rank);
-		weak = std::getenv("RNB_WEAK_SCALING") != nullptr;
-		if (const char* e = std::getenv("RNB_DP_SHARDED")) sharded = std::atoi(e) != 0;
-		on = world > 1 || std::getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr; // the variable exercises the collective path on one rank
-		if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad RNB_WORLD_SIZE / RNB_RANK");
-		if (!on) return;
-#ifdef RNB_WITH_RCCL
-		if (hipSetDevice(local_rank) != hipSuccess) throw std::runtime_error("hipSetDevice(" + std::to_string(local_rank) + ") failed");
+class RcclTransport : public dist::Transport {
+	ncclComm_t comm_[3] = {nullptr, nullptr, nullptr};
+	int world_;
+	static void ok(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
+	static ncclDataType_t type(dist::DType t) { return t == dist::F16 ? ncclHalf : t == dist::F64 ? ncclDouble : t == dist::U32 ? ncclUint32 : t == dist::I32 ? ncclInt32 : ncclFloat; }
+
+public:
+	RcclTransport(int world, int rank, const char* idf) : world_(world) {
 		ncclUniqueId ids[3];
-		const char* idf = std::getenv("RNB_RCCL_ID_FILE");
 		if (world > 1 && !idf) throw std::runtime_error("RNB_RCCL_ID_FILE is not set (use tools/launch_testbed.sh)");
 		if (rank == 0) {
-			for (auto& id : ids) if (ncclGetUniqueId(&id) != ncclSuccess) throw std::runtime_error("ncclGetUniqueId failed");
+			for (auto& id : ids) ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
 			if (idf) {
 				const std::string tmp = std::string(idf) + ".tmp";
 				std::FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -236,16 +226,93 @@ struct Dist {
 			}
 			if (!got) throw std::runtime_error(std::string("no ncclUniqueIds in ") + idf);
 		}
-		ncclComm_t* comms[3] = {&comm, &comm_early, &comm_vec};
-		for (int k = 0; k < 3; ++k) if (ncclCommInitRank(comms[k], world, ids[k], rank) != ncclSuccess) throw std::runtime_error("ncclCommInitRank failed");
-		int n_ranks = 0;
-		if (ncclCommCount(comm, &n_ranks) != ncclSuccess || n_ranks != world) throw std::runtime_error("RCCL communicator does not span the job");
-		if (rank == 0) std::cout << "rccl_ranks: " << n_ranks << (sharded ? " (sharded optimizer)" : " (all-reduce, replicated optimizer)") << std::endl;
-		if (hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_early, hipStreamNonBlocking) != hipSuccess ||
-		    hipStreamCreateWithFlags(&s_vec, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess ||
-		    hipHostMalloc((void**)&host7, 7 * sizeof(double), 0) != hipSuccess) throw std::runtime_error("stream / pinned buffer creation failed");
+		for (int k = 0; k < 3; ++k) ok(ncclCommInitRank(&comm_[k], world, ids[k], rank), "ncclCommInitRank");
+		int n = 0;
+		if (ncclCommCount(comm_[0], &n) != ncclSuccess || n != world) throw std::runtime_error("RCCL communicator does not span the job");
+	}
+	const char* name() const override { return "rccl"; }
+	int n_ranks() const override { return world_; }
+	void all_reduce(void* buf, size_t n, dist::DType t, dist::Op op, int chan, void* stream) override {
+		ok(ncclAllReduce(buf, buf, n, type(t), op == dist::SUM ? ncclSum : ncclMax, comm_[chan], (hipStream_t)stream), "ncclAllReduce");
+	}
+	void reduce_scatter(void* block, void* own, size_t chunk, dist::DType t, int chan, void* stream) override {
+		ok(ncclReduceScatter(block, own, chunk, type(t), ncclSum, comm_[chan], (hipStream_t)stream), "ncclReduceScatter");
+	}
+	void all_gather(const void* own, void* block, size_t chunk, dist::DType t, int chan, void* stream) override {
+		ok(ncclAllGather(own, block, chunk, type(t), comm_[chan], (hipStream_t)stream), "ncclAllGather");
+	}
+	void shutdown() override {
+		if (comm_[0]) (void)hipDeviceSynchronize();
+		for (auto& c : comm_) if (c) { ncclCommDestroy(c); c = nullptr; }
+	}
+};
+#endif
+
+static std::string g_abort_file; // staged test transport: the file a failing rank leaves so that the others stop waiting for it
+
+struct Dist {
+	int world = 1, rank = 0, local_rank = 0;
+	bool on = false, weak = false, sharded = true;
+	std::unique_ptr<dist::Transport> tr;
+	dist::StagedTransport* staged = nullptr; // (tr, when it is the test transport: a failing rank tells the others)
+	enum { CH_MAIN = 0, CH_EARLY = 1, CH_VEC = 2 };
+	// streams of the three channels; null in the CPU-checker build (no device: every call is synchronous there)
+	void *s_main = nullptr, *s_early = nullptr, *s_vec = nullptr;
+#ifdef RNB_WITH_HIP
+	hipEvent_t ev_early = nullptr;
+#endif
+	double host7[7] = {0, 0, 0, 0, 0, 0, 0};
+	bool synced = true; // no sharded update since the last sync_parameters()
+	static int env_int(const char* a, const char* b, int def) {
+		const char* v = std::getenv(a);
+		if (!v) v = std::getenv(b);
+		return v ? std::atoi(v) : def;
+	}
+	// how the staged transport and the step-vector readback reach a library buffer
+#ifdef RNB_WITH_HIP
+	static void mem_to_host(void* dst, const void* src, size_t bytes, void* stream) {
+		if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || (bytes && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess)) throw std::runtime_error("staged transport: device -> host copy failed");
+	}
+	static void mem_from_host(void* dst, const void* src, size_t bytes, void*) {
+		if (bytes && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("staged transport: host -> device copy failed");
+	}
 #else
-		throw std::runtime_error("this build of testbed has no RCCL support (RNB_WORLD_SIZE > 1)");
+	static void mem_to_host(void* dst, const void* src, size_t bytes, void*) { if (bytes) std::memcpy(dst, src, bytes); }
+	static void mem_from_host(void* dst, const void* src, size_t bytes, void*) { if (bytes) std::memcpy(dst, src, bytes); }
+#endif
+	void init() {
+		world = env_int("RNB_WORLD_SIZE", "WORLD_SIZE", 1);
+		rank = env_int("RNB_RANK", "RANK", 0);
+		local_rank = env_int("RNB_LOCAL_RANK", "LOCAL_RANK", rank);
+		weak = std::getenv("RNB_WEAK_SCALING") != nullptr;
+		if (const char* e = std::getenv("RNB_DP_SHARDED")) sharded = std::atoi(e) != 0;
+		on = world > 1 || std::getenv("RNB_DP_FORCE_COLLECTIVES") != nullptr; // the variable exercises the collective path on one rank
+		if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("bad RNB_WORLD_SIZE / RNB_RANK");
+		if (!on) return;
+		const char* which = std::getenv("RNB_DP_TRANSPORT");
+		const bool want_staged = which && std::string(which) == "staged";
+		if (which && !want_staged && std::string(which) != "rccl") throw std::runtime_error("RNB_DP_TRANSPORT must be rccl or staged");
+#ifdef RNB_WITH_HIP
+		if (hipSetDevice(local_rank) != hipSuccess) throw std::runtime_error("hipSetDevice(" + std::to_string(local_rank) + ") failed");
+#endif
+		if (want_staged) {
+			const char* dir = std::getenv("RNB_DP_STAGE_DIR");
+			staged = new dist::StagedTransport(dir ? dir : "", world, rank, dist::MemOps{&Dist::mem_to_host, &Dist::mem_from_host});
+			tr.reset(staged);
+			g_abort_file = std::string(dir) + "/abort";
+		} else {
+#ifdef RNB_WITH_RCCL
+			tr.reset(new RcclTransport(world, rank, std::getenv("RNB_RCCL_ID_FILE")));
+#else
+			throw std::runtime_error("this build of testbed has no RCCL support (RNB_WORLD_SIZE > 1)");
+#endif
+		}
+		if (rank == 0) std::cout << (want_staged ? "staged_ranks: " : "rccl_ranks: ") << tr->n_ranks() << (sharded ? " (sharded optimizer)" : " (all-reduce, replicated optimizer)") << std::endl;
+#ifdef RNB_WITH_HIP
+		hipStream_t a, b, c;
+		if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess ||
+		    hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("stream creation failed");
+		s_main = a; s_early = b; s_vec = c;
 #endif
 	}
 	// sizes of ONE rank (dp.strong_scaling_sizes of the Python side)
@@ -257,78 +324,85 @@ struct Dist {
 		cfg.max_rays_per_batch = std::max(128u, cfg.max_rays_per_batch / (uint32_t)world);
 		cfg.initial_rays_per_batch = std::max(1u, cfg.initial_rays_per_batch / (uint32_t)world);
 	}
-#ifdef RNB_WITH_RCCL
-	static void nccl_ok(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
-	template <typename T>
-	static T* buffer(rnb_ctx* ctx, int id) {
+	static char* buffer(rnb_ctx* ctx, int id) {
 		void* p; uint64_t nb;
 		if (rnb_buffer(ctx, id, &p, &nb) != RNB_OK) throw std::runtime_error(rnb_last_error());
-		return (T*)p;
+		return (char*)p;
 	}
-	// one block of the sharded optimizer on `st` / `cm`: reduce-scatter in place (the own chunk receives the sum), Adam + EMA on the own
+	// the gradient vector of the context's accumulate mode: fp32 accumulators, or the half vector the ranks then sum in half
+	bool half_grads = false;
+	int grads_id() const { return half_grads ? RNB_BUF_GRADS_FP16 : RNB_BUF_GRADS_FP32; }
+	dist::DType grads_type() const { return half_grads ? dist::F16 : dist::F32; }
+	size_t grads_elem() const { return half_grads ? 2 : 4; }
+	// the early stream's work (blocks exchanged beside the scatter) joins the main stream
+	void join_early() {
+#ifdef RNB_WITH_HIP
+		if (hipEventRecord(ev_early, (hipStream_t)s_early) != hipSuccess || hipStreamWaitEvent((hipStream_t)s_main, ev_early, 0) != hipSuccess) throw std::runtime_error("early stream join failed");
+#endif
+	}
+	// one block of the sharded optimizer on channel `chan` / stream `st`: reduce-scatter in place (the own chunk receives the sum), Adam + EMA on the own
 	// chunk, all-gather of the fp16 training weights in place
-	int shard_block(rnb_ctx* ctx, const rnb_shard_part& p, uint32_t k, float* g, uint16_t* w16, ncclComm_t cm, hipStream_t st) {
+	int shard_block(rnb_ctx* ctx, const rnb_shard_part& p, uint32_t k, char* g, char* w16, int chan, void* st) {
 		const uint64_t chunk = p.own_hi - p.own_lo;
 		int rc = rnb_gradient_part_wait(ctx, k, st);
 		if (rc != RNB_OK) return rc;
-		nccl_ok(ncclReduceScatter(g + p.lo, g + p.own_lo, chunk, ncclFloat, ncclSum, cm, st), "ncclReduceScatter");
+		tr->reduce_scatter(g + p.lo * grads_elem(), g + p.own_lo * grads_elem(), chunk, grads_type(), chan, st);
 		rc = rnb_train_step_apply_shard(ctx, k, st);
 		if (rc != RNB_OK) return rc;
-		nccl_ok(ncclAllGather(w16 + p.own_lo, w16 + p.lo, chunk, ncclHalf, cm, st), "ncclAllGather");
+		tr->all_gather(w16 + p.own_lo * 2, w16 + p.lo * 2, chunk, dist::F16, chan, st);
 		return RNB_OK;
 	}
-#endif
 	// Occupancy updates sharded over the ranks (rnb_set_grid_exchange): the element-wise max of the splat targets, one all-reduce of 8 MB every 16 steps
 	// instead of every rank evaluating all 2^20 samples. RNB_DP_SHARD_GRID=0 keeps the updates replicated.
 	static int grid_exchange(void* user, void* grid_tmp, uint64_t n_elements, void* stream) {
-#ifdef RNB_WITH_RCCL
 		Dist* d = static_cast<Dist*>(user);
-		return ncclAllReduce(grid_tmp, grid_tmp, n_elements, ncclUint32, ncclMax, d->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1; // the order of the single-rank splat: atomicMax on the words as uint32 (a sign-bit NaN wins on both)
-#else
-		(void)user; (void)grid_tmp; (void)n_elements; (void)stream;
-		return -1;
-#endif
+		try { d->tr->all_reduce(grid_tmp, n_elements, dist::U32, dist::MAX, CH_MAIN, stream); } // the order of the single-rank splat: atomicMax on the words as uint32 (a sign-bit NaN wins on both)
+		catch (const std::exception& e) { std::cerr << "grid exchange: " << e.what() << std::endl; return -1; }
+		return 0;
 	}
-	void attach(rnb_ctx* ctx) {
+	void attach(rnb_ctx* ctx, const rnb_config& cfg) {
+		half_grads = cfg.accumulate == RNB_ACCUM_HALF;
 		const char* e = std::getenv("RNB_DP_SHARD_GRID");
 		if (on && !(e && std::atoi(e) == 0) && rnb_set_grid_exchange(ctx, &Dist::grid_exchange, this) != RNB_OK) throw std::runtime_error(rnb_last_error());
 	}
 	int train_step(rnb_ctx* ctx, rnb_step_stats* st) {
 		if (!on) return rnb_train_step(ctx, nullptr, st);
-#ifdef RNB_WITH_RCCL
+		try { return train_step_collective(ctx, st); }
+		catch (...) { if (staged) staged->abort_job(); throw; }
+	}
+	int train_step_collective(rnb_ctx* ctx, rnb_step_stats* st) {
 		int rc = rnb_train_step_begin(ctx, s_main);
 		if (rc != RNB_OK) return rc;
 		uint64_t cnt[4]; double sums[3];
 		rc = rnb_train_step_local(ctx, s_main, cnt, sums); // the host waits for the loss pass only
 		if (rc != RNB_OK) return rc;
-		double* vec = buffer<double>(ctx, RNB_BUF_STEP_VECTOR);
-		nccl_ok(ncclAllReduce(vec, vec, 7, ncclDouble, ncclSum, comm_vec, s_vec), "ncclAllReduce (step vector)");
-		if (hipMemcpyAsync(host7, vec, 7 * sizeof(double), hipMemcpyDeviceToHost, s_vec) != hipSuccess || hipStreamSynchronize(s_vec) != hipSuccess) throw std::runtime_error("step vector readback failed");
+		char* vec = buffer(ctx, RNB_BUF_STEP_VECTOR);
+		tr->all_reduce(vec, 7, dist::F64, dist::SUM, CH_VEC, s_vec);
+		mem_to_host(host7, vec, 7 * sizeof(double), s_vec);
 		for (int k = 0; k < 4; ++k) cnt[k] = (uint64_t)std::llround(host7[k]);
 		for (int k = 0; k < 3; ++k) sums[k] = host7[4 + k];
 		const int rc_finish = rnb_train_step_finish(ctx, cnt, sums, st); // ray controller; queues the next step's march
 		if (rc_finish != RNB_OK && rc_finish != RNB_ERR_NO_SAMPLES) return rc_finish;
 		// gradients: block by block in completion order; the optimizer runs even when the step had no samples
-		float* g = buffer<float>(ctx, RNB_BUF_GRADS_FP32);
+		char* g = buffer(ctx, grads_id());
 		if (sharded) {
 			rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n_parts = 0; uint64_t capacity = 0;
 			rc = rnb_shard_layout(ctx, parts, &n_parts, &capacity);
 			if (rc != RNB_OK) return rc;
-			uint16_t* w16 = buffer<uint16_t>(ctx, RNB_BUF_PARAMS_FP16);
+			char* w16 = buffer(ctx, RNB_BUF_PARAMS_FP16);
 			uint32_t first = 0;
 			if (n_parts > 1) { // every block but the last on the early stream, each as soon as its levels are final: beside the scatter of the levels behind it
 				for (uint32_t k = 0; k + 1 < n_parts; ++k) {
-					rc = shard_block(ctx, parts[k], k, g, w16, comm_early, s_early);
+					rc = shard_block(ctx, parts[k], k, g, w16, CH_EARLY, s_early);
 					if (rc != RNB_OK) return rc;
 				}
-				if (hipEventRecord(ev_early, s_early) != hipSuccess) throw std::runtime_error("hipEventRecord failed");
 				first = n_parts - 1;
 			}
 			for (uint32_t k = first; k < n_parts; ++k) {
-				rc = shard_block(ctx, parts[k], k, g, w16, comm, s_main);
+				rc = shard_block(ctx, parts[k], k, g, w16, CH_MAIN, s_main);
 				if (rc != RNB_OK) return rc;
 			}
-			if (first && hipStreamWaitEvent(s_main, ev_early, 0) != hipSuccess) throw std::runtime_error("hipStreamWaitEvent failed");
+			if (first) join_early();
 			rc = rnb_params_changed(ctx); // the training weights were written through a pointer: the kernels' weight images are stale
 			if (rc != RNB_OK) return rc;
 			rc = rnb_train_step_apply_done(ctx, s_main);
@@ -339,60 +413,55 @@ struct Dist {
 		uint64_t ranges[3][2]; uint32_t n_parts = 0;
 		rc = rnb_gradient_parts(ctx, ranges, &n_parts);
 		if (rc != RNB_OK) return rc;
+		const size_t ge = grads_elem();
 		uint32_t first = 0;
 		if (n_parts > 1) {
 			rc = rnb_gradient_part_wait(ctx, 0, s_early);
 			if (rc != RNB_OK) return rc;
-			nccl_ok(ncclAllReduce(g + ranges[0][0], g + ranges[0][0], ranges[0][1] - ranges[0][0], ncclFloat, ncclSum, comm_early, s_early), "ncclAllReduce (early block)");
+			tr->all_reduce(g + ranges[0][0] * ge, ranges[0][1] - ranges[0][0], grads_type(), dist::SUM, CH_EARLY, s_early);
 			rc = rnb_train_step_apply_early(ctx, s_early); // Adam on that block, beside the scatter of the finest levels and their exchange
 			if (rc != RNB_OK) return rc;
 			for (uint32_t k = 1; k + 1 < n_parts; ++k) { // the first half of the finest levels, beside the scatter of the second
 				rc = rnb_gradient_part_wait(ctx, k, s_early);
 				if (rc != RNB_OK) return rc;
-				nccl_ok(ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm_early, s_early), "ncclAllReduce (middle block)");
+				tr->all_reduce(g + ranges[k][0] * ge, ranges[k][1] - ranges[k][0], grads_type(), dist::SUM, CH_EARLY, s_early);
 			}
-			if (n_parts > 2 && (hipEventRecord(ev_early, s_early) != hipSuccess || hipStreamWaitEvent(s_main, ev_early, 0) != hipSuccess)) throw std::runtime_error("early stream join failed");
+			if (n_parts > 2) join_early();
 			first = n_parts - 1;
 		}
 		for (uint32_t k = first; k < n_parts; ++k) {
 			rc = rnb_gradient_part_wait(ctx, k, s_main);
 			if (rc != RNB_OK) return rc;
-			nccl_ok(ncclAllReduce(g + ranges[k][0], g + ranges[k][0], ranges[k][1] - ranges[k][0], ncclFloat, ncclSum, comm, s_main), "ncclAllReduce");
+			tr->all_reduce(g + ranges[k][0] * ge, ranges[k][1] - ranges[k][0], grads_type(), dist::SUM, CH_MAIN, s_main);
 		}
 		rc = rnb_train_step_apply(ctx, s_main);
 		if (rc != RNB_OK) return rc;
 		return rc_finish;
-#else
-		return RNB_ERR_INVALID;
-#endif
 	}
 	// Sharded optimizer: all-gather the per-rank chunks of the fp32 masters, EMA weights and Adam state so that every rank holds them
 	// whole (dp.DataParallelTrainer.sync_parameters). A collective: every rank calls it, before rank 0 writes a mesh or a snapshot.
 	void sync_parameters(rnb_ctx* ctx) {
-#ifdef RNB_WITH_RCCL
 		if (!on || !sharded || synced) return;
-		rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n_parts = 0; uint64_t capacity = 0;
-		if (rnb_shard_layout(ctx, parts, &n_parts, &capacity) != RNB_OK) throw std::runtime_error(rnb_last_error());
-		if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
-		const struct { int id; ncclDataType_t type; size_t size; } bufs[] = {{RNB_BUF_PARAMS_FP32, ncclFloat, 4}, {RNB_BUF_PARAMS_EMA, ncclHalf, 2}, {RNB_BUF_ADAM_M, ncclFloat, 4},
-		                                                                  {RNB_BUF_ADAM_V, ncclFloat, 4}, {RNB_BUF_ADAM_STEPS, ncclInt32, 4}};
-		for (const auto& b : bufs) {
-			char* base = buffer<char>(ctx, b.id);
-			for (uint32_t k = 0; k < n_parts; ++k)
-				nccl_ok(ncclAllGather(base + parts[k].own_lo * b.size, base + parts[k].lo * b.size, parts[k].own_hi - parts[k].own_lo, b.type, comm, s_main), "ncclAllGather (sync_parameters)");
-		}
-		if (hipStreamSynchronize(s_main) != hipSuccess) throw std::runtime_error("sync_parameters failed");
-		synced = true;
-#else
-		(void)ctx;
+		try {
+			rnb_shard_part parts[RNB_MAX_SHARD_PARTS]; uint32_t n_parts = 0; uint64_t capacity = 0;
+			if (rnb_shard_layout(ctx, parts, &n_parts, &capacity) != RNB_OK) throw std::runtime_error(rnb_last_error());
+#ifdef RNB_WITH_HIP
+			if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
 #endif
-	}
-	void shutdown() {
-#ifdef RNB_WITH_RCCL
-		if (comm) (void)hipDeviceSynchronize();
-		for (ncclComm_t* c : {&comm, &comm_early, &comm_vec}) if (*c) { ncclCommDestroy(*c); *c = nullptr; }
+			const struct { int id; dist::DType type; size_t size; } bufs[] = {{RNB_BUF_PARAMS_FP32, dist::F32, 4}, {RNB_BUF_PARAMS_EMA, dist::F16, 2}, {RNB_BUF_ADAM_M, dist::F32, 4},
+			                                                              {RNB_BUF_ADAM_V, dist::F32, 4}, {RNB_BUF_ADAM_STEPS, dist::I32, 4}};
+			for (const auto& b : bufs) {
+				char* base = buffer(ctx, b.id);
+				for (uint32_t k = 0; k < n_parts; ++k) tr->all_gather(base + parts[k].own_lo * b.size, base + parts[k].lo * b.size, parts[k].own_hi - parts[k].own_lo, b.type, CH_MAIN, s_main);
+			}
+#ifdef RNB_WITH_HIP
+			if (hipStreamSynchronize((hipStream_t)s_main) != hipSuccess) throw std::runtime_error("sync_parameters failed");
 #endif
+			synced = true;
+		} catch (...) { if (staged) staged->abort_job(); throw; }
 	}
+	void abort_job() { if (staged) staged->abort_job(); }
+	void shutdown() { if (tr) tr->shutdown(); }
 };
 
 struct Testbed {
@@ -413,7 +482,36 @@ struct Testbed {
 
 	~Testbed() { if (ctx) rnb_destroy(ctx); }
 
+	// What of a network config this build cannot honour is refused by name instead of being ignored. The architecture of the path is the reference's base.json
+	// (nerf_network.h:40-83): density MLP 32 -> 64 -> 16, colour MLP 48 -> 64 -> 64 -> 16, two features per level.
+	static void check_supported(const jsonmin::Value& c) {
+		auto need = [](const jsonmin::Value& blk, const char* block, const char* key, double want) {
+			if (!blk.contains(key) || blk[key].is_null()) return;
+			const double v = blk[key].as_number();
+			if (v != want) throw std::runtime_error(std::string("network config: ") + block + "." + key + " = " + std::to_string(v) + " is not supported by this build (fixed at " + std::to_string(want) + ")");
+		};
+		auto need_str = [](const jsonmin::Value& blk, const char* block, const char* key, const char* want) {
+			if (!blk.contains(key) || blk[key].is_null()) return;
+			if (blk[key].as_string() != want) throw std::runtime_error(std::string("network config: ") + block + "." + key + " = \"" + blk[key].as_string() + "\" is not supported by this build (fixed at \"" + want + "\")");
+		};
+		const auto& enc = c["encoding"];
+		need(enc, "encoding", "n_features_per_level", 2);
+		const uint32_t L = enc.value("n_levels", 16u);
+		// NerfNetwork pads the density network's input [x y z | 2 L features] to a multiple of 16 and picks the geometric initialisation by that width
+		// (load_sdf_mlp_weight, nerf_network.h:585-604): 32 -> utils/mlp_weights_hidden_layer_num_1_hidden_size_32.txt, 48 -> utils/mlp_weights.txt
+		if (3 + 2 * L > 32) throw std::runtime_error("network config: encoding.n_levels = " + std::to_string(L) + " gives a density-network input of width " + std::to_string((3 + 2 * L + 15) / 16 * 16) +
+		                                             " (the reference's utils/mlp_weights.txt case, nerf_network.h:595-600); this build supports width 32 only (n_levels <= 14)");
+		for (const char* blk : {"network", "rgb_network"}) {
+			need(c[blk], blk, "n_neurons", 64);
+			need(c[blk], blk, "n_hidden_layers", std::string(blk) == "network" ? 1 : 2);
+			need_str(c[blk], blk, "activation", "ReLU");
+			need_str(c[blk], blk, "output_activation", "None");
+		}
+		need_str(c["optimizer"], "optimizer", "otype", "Ema");
+	}
+
 	void apply_network_config(const jsonmin::Value& c) { // Testbed::reset_network, src/testbed.cu:2245-2335
+		check_supported(c);
 		const auto& enc = c["encoding"];
 		cfg.n_levels = enc.value("n_levels", 16u);
 		cfg.log2_hashmap_size = enc.value("log2_hashmap_size", 15u);
@@ -452,7 +550,7 @@ struct Testbed {
 		if (ctx) { rnb_destroy(ctx); ctx = nullptr; }
 		dist.apply_sizes(cfg);
 		RNB_CHECK(rnb_create(&cfg, &ctx));
-		dist.attach(ctx);
+		dist.attach(ctx, cfg);
 		// geometric initialisation of the SDF MLP (nerf_network.h:585-623): <exe_dir>/../utils/...
 		const std::string wpath = parent_path(exe_dir()) + "/utils/mlp_weights_hidden_layer_num_1_hidden_size_32.txt";
 		std::FILE* fp = std::fopen(wpath.c_str(), "r");
@@ -711,7 +809,13 @@ int main(int argc, char** argv) {
 	try {
 		Testbed tb;
 		rnb_default_config(&tb.cfg);
+		if (args.has("accumulate")) { // (not a flag of the reference: its arithmetic is the `half` mode, include/rnb_neus2.h rnb_config::accumulate)
+			const std::string m = args.get("accumulate");
+			if (m != "fp32" && m != "half") { std::cerr << "--accumulate takes fp32 or half" << std::endl; print_help(std::cerr, argv[0]); return -1; }
+			tb.cfg.accumulate = m == "half" ? RNB_ACCUM_HALF : RNB_ACCUM_FP32;
+		}
 		tb.dist.init();
+		struct AbortGuard { bool done = false; ~AbortGuard() { if (!done && !g_abort_file.empty()) if (std::FILE* f = std::fopen(g_abort_file.c_str(), "wb")) std::fclose(f); } } abort_guard; // any exit but the regular one
 		const bool lead = tb.dist.rank == 0; // meshes, snapshots and progress lines come from rank 0 only
 		try {
 			if (args.has("maxiter")) tb.max_iter = args.get_u32("maxiter");
@@ -827,8 +931,10 @@ int main(int argc, char** argv) {
 			tb.save_snapshot(snapshot_filename, step, rays_per_batch, measured, measured_before);
 		}
 		tb.dist.shutdown();
+		abort_guard.done = true;
 	} catch (const std::exception& e) {
 		std::cerr << "Uncaught exception: " << e.what() << std::endl;
+		if (!g_abort_file.empty()) if (std::FILE* f = std::fopen(g_abort_file.c_str(), "wb")) std::fclose(f);
 		return 1;
 	}
 	return 0;

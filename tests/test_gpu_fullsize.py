@@ -780,7 +780,7 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
         assert cg[0] == cc[0] and cg[2] == cc[2] and cg[3] == cc[3], (cg, cc)      # the march does not depend on the network
         assert abs(int(cg[1]) - int(cc[1])) <= (2e-4 if half else 1e-3) * int(cc[1]) + 1, (cg, cc)     # compaction: T < 1e-4 cuts flip on a few rays (fp32 mode, measured: 3 ... 87 of 265 k samples)
         rel = [abs(x - y) / abs(y) for x, y in zip(sg, sc)]
-        g, r = gpu.get("GRADS_FP16" if half else "GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
+        g, r = gpu.get("GRADS_FP16" if half else "GRADS_FP32").astype(np.float64), cpu.get("GRADS_FP16").astype(np.float64)
         lay = cpu.param_layout()
         blocks = {"sdf_mlp": (lay["sdf"], lay["rgb"]), "hash_grid": (lay["grid"], lay["variance"])}
         out = {"hip_mode": hip_mode, "step": int(state["step"] | 1), "rays": int(state["rays"]), "counters_hip": [int(x) for x in cg], "counters_emulated": [int(x) for x in cc],
@@ -801,7 +801,7 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
                 try:
                     c2.set_controller(state["step"] | 1, state["rays"], state["before"], 0)
                     c2.train_step_begin()
-                    return c2.get("GRADS_FP32").astype(np.float64)
+                    return c2.get("GRADS_FP16" if over.get("accumulate") else "GRADS_FP32").astype(np.float64)
                 finally:
                     c2.close()
             # the floor: the model against itself with the atomics in another order (same addends: only the hash grid differs)

@@ -101,9 +101,7 @@ def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo)
     for c in pair:
         c.forward_backward()
     g16 = gpu.get("GRADS_FP16")
-    g, r = g16.astype(np.float64), cpu.get("GRADS_FP32").astype(np.float64)
-    lay0 = cpu.param_layout()
-    assert np.array_equal(cpu.get("GRADS_FP16").astype(np.float64)[:lay0["variance"]], r[:lay0["variance"]])  # the model's gradient vector IS half (its variance sum is narrowed by the optimizer)
+    g, r = g16.astype(np.float64), cpu.get("GRADS_FP16").astype(np.float64)
     lay = cpu.param_layout()
     for lo, hi, name in ((lay["sdf"], lay["rgb"], "sdf mlp"), (lay["rgb"], lay["grid"], "rgb mlp")):
         if no_albedo and name == "rgb mlp":
@@ -124,7 +122,7 @@ def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo)
     assert np.quantile(rel, 0.999) < 1e-2 and np.abs(gg - rg).max() / scale < 4e-3, (np.quantile(rel, 0.999), np.abs(gg - rg).max() / scale)
     cos = float(gg @ rg / (np.linalg.norm(gg) * np.linalg.norm(rg)))
     assert cos > 0.999995, cos
-    assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 1.1e-3 * abs(r[lay["variance"]]) + 1e-7  # one rounding of the fp32 sum on the device, of the fp64 sum in the model
+    assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2.1e-3 * abs(r[lay["variance"]]) + 1e-7  # the fp32 sum on the device, the fp64 sum in the model, each narrowed to half once
 
 
 def test_half_mode_optimizer_reads_and_clears_the_half_gradient_vector(hpair):
@@ -140,7 +138,7 @@ def test_half_mode_optimizer_reads_and_clears_the_half_gradient_vector(hpair):
         gpu.put(name, v)
     for _ in range(2):
         gpu.put("GRADS_FP16", grads)
-        cpu.put("GRADS_FP32", grads.astype(np.float32))
+        cpu.put("GRADS_FP16", grads)
         for c in pair:
             c.optimizer_step()
     for name, tol in (("PARAMS_FP32", 2e-6), ("ADAM_M", 1e-6), ("ADAM_V", 1e-6)):

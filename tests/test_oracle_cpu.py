@@ -297,3 +297,65 @@ def test_training_moves_the_sdf_towards_the_sphere():
     assert after < 0.9 * before, (before, after)
     assert c.training_step == 60 and st.rays_per_batch % 128 == 0
     c.close()
+
+
+def _staged_backward(env=None, **over):
+    """A small context with signal on every path, samples staged and the loss gradients in place: (context, the gradient vector after forward_backward)."""
+    from rnb_neus2_amd import synthetic
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        c = oracle_lib.context(**dict(SMALL, **over))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    c.init_params()
+    c.set_dataset(*synthetic.make_scene(3, 48, 84.0))
+    _randomize(c, seed=5)
+    c.set_training_step(700)
+    c.update_density_grid()
+    c.generate_training_samples(256, 0, SMALL["target_batch_size"] * 16)
+    n = int(c.get("COUNTERS")[3])
+    c.put("MLP_OUT", c.forward_infer(c.get("COORDS", n * 7).reshape(-1, 7)).ravel())
+    c.compute_loss(256, 0)
+    c.forward_backward()
+    return c
+
+
+def test_half_accumulate_mode_is_the_model_of_the_reference_as_coded():
+    """rnb_config::accumulate = RNB_ACCUM_HALF on the checker == its two emulation switches (dot_h's 16-wide k-steps rounded to half, emulated_dw's split-K slices,
+    half atomics in sample order); the gradient vector is then half (RNB_BUF_GRADS_FP16) and RNB_BUF_GRADS_FP32 is refused, as in the HIP library; another order of
+    the same half atomics (ORC_ATOMIC_ORDER_SEED) moves hash-grid entries only, by a few half roundings."""
+    from rnb_neus2_amd import api
+    a = _staged_backward(accumulate=1)
+    b = _staged_backward(env={"ORC_EMULATE_FP16_ACCUM": "1", "ORC_EMULATE_HALF_ATOMICS": "1"})
+    d = _staged_backward()
+    o = _staged_backward(env={"ORC_ATOMIC_ORDER_SEED": "3"}, accumulate=1)
+    try:
+        with pytest.raises(api.RnbError):
+            a.get("GRADS_FP32")
+        with pytest.raises(api.RnbError):
+            d.get("GRADS_FP16")
+        ga, gb, gd, go = a.get("GRADS_FP16"), b.get("GRADS_FP32"), d.get("GRADS_FP32"), o.get("GRADS_FP16")
+        assert ga.dtype == np.float16 and np.array_equal(ga.astype(np.float32), gb.astype(np.float16).astype(np.float32))
+        lay = a.param_layout()
+        assert np.array_equal(ga[:lay["variance"]].astype(np.float32), gb[:lay["variance"]])  # sums of the half mode are half values already
+        # the default mode (fp32 accumulators) is close to, and not equal to, the model
+        x, y = ga.astype(np.float64), gd.astype(np.float64)
+        assert not np.array_equal(x, y) and x @ y / (np.linalg.norm(x) * np.linalg.norm(y)) > 0.999
+        lo, hi = lay["grid"], lay["variance"]
+        assert np.array_equal(ga[:lo].view(np.uint16), go[:lo].view(np.uint16))
+        diff = ga[lo:hi].astype(np.float64) - go[lo:hi].astype(np.float64)
+        assert np.any(diff != 0) and np.abs(diff).max() <= 4e-3 * np.abs(ga[lo:hi].astype(np.float64)).max()
+        # the optimizer reads the half vector
+        a.optimizer_step()
+        b.optimizer_step()
+        assert np.array_equal(a.get("PARAMS_FP32"), b.get("PARAMS_FP32"))
+    finally:
+        for c in (a, b, d, o):
+            c.close()

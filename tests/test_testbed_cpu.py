@@ -373,3 +373,73 @@ def test_resume_from_a_reference_style_snapshot(install, trained, tmp_path):
     with open(scene / "output" / "snapshot_5.msgpack", "rb") as f:
         after = msgpack.unpackb(f.read(), raw=False)["snapshot"]
     assert after["training_step"] == 5 and after["params_binary"] != snap["params_binary"]
+
+
+# ---------------------------------------------------------------- the reference's own network config through --config
+def reference_style_config():
+    """A config of the shape (every key, every value) of the reference's configs/nerf/base.json, rebuilt from tests/golden/reference_config_keys.json."""
+    with open(os.path.join(ROOT, "tests", "golden", "reference_config_keys.json")) as f:
+        leaves = json.load(f)["leaves"]
+    root = {}
+    for path, value in leaves:
+        node = root
+        for k, nxt in zip(path[:-1], path[1:]):
+            if isinstance(node, list):
+                while len(node) <= k:
+                    node.append(None)
+                if node[k] is None:
+                    node[k] = [] if isinstance(nxt, int) else {}
+                node = node[k]
+            else:
+                node = node.setdefault(k, [] if isinstance(nxt, int) else {})
+        if isinstance(node, list):
+            while len(node) <= path[-1]:
+                node.append(None)
+        node[path[-1]] = value
+    return root
+
+
+def test_the_references_own_config_file_parses_and_is_kept_whole(install, tmp_path):
+    """`--config <the reference's base.json>`: keys this path never reads (loss, globalmove, dir_encoding's Composite, predict_global_movement, anneal_end,
+    optimize_*_params ...) must parse cleanly, give the rnb_config the shipped configs/nerf/base.json gives, and travel whole in the snapshot (m_network_config,
+    src/testbed.cu:3282-3313). Training with it runs on the GPU (tests/test_gpu_parity.py: the full network is minutes per step on the CPU checker)."""
+    cfg = reference_style_config()
+    assert set(cfg) == {"loss", "optimizer", "encoding", "network", "dir_encoding", "rgb_network", "hyperparams", "globalmove"}
+    assert cfg["dir_encoding"]["nested"][0]["otype"] == "SphericalHarmonics" and cfg["hyperparams"]["anneal_end"] == 0
+    path = tmp_path / "reference_base.json"
+    path.write_text(json.dumps(cfg, indent=4))
+    views, normals, albedos = synthetic.make_scene(2, 16, 28.0)
+    snaps = {}
+    for name, args in (("reference", ["--config", str(path)]), ("shipped", [])):
+        scene = tmp_path / name
+        synthetic.write_scene(str(scene), views, normals, albedos)
+        r = run(install, "--scene", str(scene) + "/", "--maxiter", 0, "--no-gui", "--no-train", "--mask-weight", 1.0, "--no-albedo", "--save-snapshot", *args)
+        assert r.returncode == 0, r.stderr[-2000:]
+        with open(scene / "output" / "snapshot_0.msgpack", "rb") as f:
+            snaps[name] = msgpack.unpackb(f.read(), raw=False)
+    a, b = snaps["reference"], snaps["shipped"]
+    assert a["snapshot"]["n_params"] == b["snapshot"]["n_params"] and a["snapshot"]["params_binary"] == b["snapshot"]["params_binary"]
+    for blk in ("encoding", "network", "rgb_network", "hyperparams"):
+        for k, v in b[blk].items():
+            assert a[blk][k] == v, (blk, k)
+    assert a["optimizer"]["nested"]["nested"]["learning_rate"] == b["optimizer"]["nested"]["nested"]["learning_rate"] == float(np.float32(0.001))  # (overlaid with the value in effect, a float)
+    # the keys this build does not read are still there for a reader of the snapshot
+    assert a["loss"]["otype"] == "Huber" and a["globalmove"]["optimizer"]["nested"]["decay_interval"] == 25
+    assert a["dir_encoding"]["otype"] == "Composite" and a["hyperparams"]["predict_global_movement"] is True
+    assert a["optimizer"]["nested"]["nested"]["optimize_params_components"] == {"rgb_network": True, "density_network": True}
+
+
+def test_unsupported_network_configs_are_refused_by_name(install, tmp_path):
+    """A width-48 density network (n_levels 15..22: the reference then loads utils/mlp_weights.txt, nerf_network.h:595-600), other layer sizes or feature counts:
+    refused with the key's name, exit code 1 -- not silently trained with the fixed architecture."""
+    views, normals, albedos = synthetic.make_scene(2, 16, 28.0)
+    synthetic.write_scene(str(tmp_path / "s"), views, normals, albedos)
+    for patch, needle in (({"encoding": {"n_levels": 16}}, "width 48"), ({"network": {"n_neurons": 128}}, "network.n_neurons"), ({"rgb_network": {"n_hidden_layers": 3}}, "rgb_network.n_hidden_layers"),
+                          ({"encoding": {"n_features_per_level": 4}}, "encoding.n_features_per_level"), ({"network": {"activation": "Sine"}}, "network.activation")):
+        cfg = reference_style_config()
+        for blk, kv in patch.items():
+            cfg[blk].update(kv)
+        p = tmp_path / "bad.json"
+        p.write_text(json.dumps(cfg))
+        r = run(install, "--scene", str(tmp_path / "s") + "/", "--maxiter", 1, "--no-gui", "--config", str(p))
+        assert r.returncode == 1 and needle in r.stderr, (patch, r.returncode, r.stderr[-500:])
