@@ -35,11 +35,22 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_TRAFFIC, PMC_UNITS = "r04_pmc_traffic.json", "r04_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
-PMC_FALLBACK = {"r04_pmc_traffic.json": "r03_pmc_traffic.json", "r04_pmc_units.json": "r03_pmc_units.json"}
+PMC_TRAFFIC, PMC_UNITS = "r05_pmc_traffic.json", "r05_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
+PMC_FALLBACK = {"r05_pmc_traffic.json": "r04_pmc_traffic.json", "r05_pmc_units.json": "r04_pmc_units.json"}
 # committed rocprofv3 summaries of this same command from which every `frac` of the record can be recomputed (profiles/README.md)
-PROFILE_FILES = {"kernel_trace_serial": "profiles/r04_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r04_steady_overlapped_step1000.json",
-                 "pmc_traffic": "profiles/" + PMC_TRAFFIC, "pmc_units": "profiles/" + PMC_UNITS}
+PROFILE_FILES = {"kernel_trace_serial": "profiles/r05_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r05_steady_overlapped_step1000.json",
+                 "pmc_traffic": "profiles/" + PMC_TRAFFIC, "pmc_units": "profiles/" + PMC_UNITS, "counter_calibration": "profiles/r05_counter_calibration.json"}
+# What FETCH_SIZE means on gfx950, calibrated on this path's own access patterns (tools/probe_counters.hip -> profiles/r05_counter_calibration.json): the counter is the L2's
+# memory-side read REQUESTS x 64 B. A scattered 8-byte gather is one 64-byte request (p_gather8_far: 64.0 B counted per gather = the bytes moved: x1); a coalesced stream is
+# 128-byte requests counted as 64 (16 B and 8 B per lane, and 64-byte records read as 4 x 16 B: 0.500 / 0.500 / 0.503 of the true bytes: x2). WRITE_SIZE is exact for
+# coalesced stores (1.000 / 1.000 / 1.007); an atomic without return is ONE write request counted as 32 B and no fetch (it executes memory-side).
+# Per kernel group: the factor of the pattern that makes up (nearly) all of its reads.
+FETCH_CORRECTION = {"k_adam_ema": 2.0, "k_grid_scatter": 2.0, "k_grid_scatter_lds": 2.0, "k_grid_scatter_quad_rl": 2.0, "k_grid_scatter_quad": 2.0, "k_dw*7+k_dw_finish": 2.0,
+                    "k_loss_pass1": 2.0, "k_loss_pass2+k_rollover": 2.0, "k_march_write": 2.0, "k_scan_rays": 2.0, "k_scan_compact": 2.0,
+                    "k_forward": 1.0, "k_fwd_bwd": 1.0, "k_point_query": 1.0, "k_march_count": 1.0}
+FETCH_CORRECTION_NOTE = ("FETCH_SIZE (KiB x 1024) x %s + WRITE_SIZE (KiB x 1024); calibration profiles/r05_counter_calibration.json (tools/probe_counters.hip): scattered 8-byte gathers are "
+                         "64-byte requests counted at 64 B (x1: k_forward, k_fwd_bwd, k_point_query -- their coalesced share, coordinates and indices, is < 7 %% of the bytes), coalesced streams are "
+                         "128-byte requests counted at 64 B (x2: k_adam_ema, the scatter's operand reads, the loss passes), stores are exact, an atomic is one write request counted as 32 B")
 # Algorithmic bytes per unit (restated in DESIGN.md §measurement)
 ALGO_BYTES = {
     "k_forward": 508.0,            # 448 B gathers + 28 B coords + 32 B out, per un-compacted sample
@@ -98,6 +109,7 @@ def parse(argv=None):
 
 # kernels of a bench kernel group (substring of the kernel name as rocprofv3 prints it, mangled or not)
 PMC_GROUPS = {"k_forward": ("k_forward_chained",), "k_fwd_bwd": ("k_fwd_bwd", "k_rgb_fwd_bwd"), "k_grid_scatter": ("k_grid_scatter",), "k_adam_ema": ("k_adam_ema",),
+              "k_grid_scatter_lds": ("k_grid_scatter_lds",), "k_grid_scatter_quad_rl": ("k_grid_scatter_quad_rl",), "k_grid_scatter_quad": ("k_grid_scatter_quad_h", "k_grid_scatter_quadENS", "k_grid_scatter_quad("),
               "k_march_count": ("k_march_count",), "k_march_write": ("k_march_write",), "k_point_query": ("k_point_query",), "k_loss_pass1": ("k_loss_pass1",),
               "k_loss_pass2+k_rollover": ("k_loss_pass2",), "k_dw*7+k_dw_finish": ("k_dw_",)}
 
@@ -106,7 +118,7 @@ def live_pmc(args, first_step, counters=("FETCH_SIZE", "WRITE_SIZE", "TCC_ATOMIC
     """HBM bytes per step and kernel group, measured NOW: one child process of this script per counter under `rocprofv3 --pmc <counter> --kernel-trace`
     (separate passes, as MI355X_MICROARCH.md prescribes for the HBM counters; kernels serialised with cfg.overlap = 0 so that a group is one launch per step),
     trained to `first_step` like this run and averaged over the --live-pmc-steps steps from there. Conversions as in tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE
-    count KiB; FETCH_SIZE is NOT doubled (the guide's x2 for gfx950 is calibrated on wide coalesced streams; gathers and atomics are uncalibrated -- stated in the record).
+    count KiB; FETCH_SIZE is corrected per kernel group by the factor its access pattern calibrates to (FETCH_CORRECTION above, profiles/r05_counter_calibration.json).
     Returns (per_step dict or None, note)."""
     exe = shutil.which("rocprofv3")
     if exe is None:
@@ -152,8 +164,10 @@ def live_pmc(args, first_step, counters=("FETCH_SIZE", "WRITE_SIZE", "TCC_ATOMIC
                 e["write_bytes"] = round(v * 1024)
             else:
                 e["atomic_lines"] = round(v)
-    for e in per_step.values():
-        e["total_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+    for g, e in per_step.items():
+        e["fetch_correction"] = FETCH_CORRECTION.get(g, 1.0)
+        e["total_bytes_as_counted"] = e["fetch_bytes"] + e["write_bytes"]
+        e["total_bytes"] = round(e["fetch_bytes"] * e["fetch_correction"]) + e["write_bytes"]
     return per_step, "this run: %d child passes under rocprofv3 --pmc (%s), kernels serialised, steps %d-%d, %.0f s" % (len(counters), ", ".join(counters), burn + 2, burn + 2 + n, time.perf_counter() - t0)
 
 
@@ -427,13 +441,15 @@ def main(argv=None, engine=None):
             launches_per_step = max(p["launches"] / max(args.profile_steps, 1), 1.0)
             if live is not None and kname in live:
                 traffic = live[kname]["total_bytes"] / launches_per_step
-                traffic_source = live_note + "; FETCH_SIZE + WRITE_SIZE in KiB x 1024, FETCH_SIZE not doubled (the guide's gfx950 x2 is calibrated on wide coalesced streams; gathers / atomics uncalibrated)"
+                traffic_source = live_note + "; " + FETCH_CORRECTION_NOTE % ("%g" % FETCH_CORRECTION.get(kname, 1.0))
             else:
                 try:
                     path, fname = pmc_file(PMC_TRAFFIC)
                     with open(path) as f:
-                        traffic = json.load(f)["per_step"][kname]["total_bytes"] / launches_per_step
-                    traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run (%s)" % (fname, live_note)
+                        e = json.load(f)["per_step"][kname]
+                    traffic = (e["fetch_bytes"] * FETCH_CORRECTION.get(kname, 1.0) + e["write_bytes"]) / launches_per_step
+                    traffic_source = "committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, steps 2000-2010, builder-run), not this run (%s); %s" % (
+                        fname, live_note, FETCH_CORRECTION_NOTE % ("%g" % FETCH_CORRECTION.get(kname, 1.0)))
                 except Exception:
                     pass
             limiter = None  # the unit that actually bounds the kernel when it is not HBM bytes (tools/pmc_report.py); also from a committed file
@@ -452,6 +468,18 @@ def main(argv=None, engine=None):
                                "probe_rate_per_s": units["_atomic_probe_requests_per_s"],
                                "frac": round(req / (avg_ms * 1e-3) / units["_atomic_probe_requests_per_s"], 3),
                                "limiter_source": src + "; probe rate: tools/probe_atomics4.hip"}
+                    # the same per KERNEL of the group (round 5): each kernel's own lines over its own serialised duration
+                    per_kernel = {}
+                    by_name = {q["kernel"]: q for q in prof}
+                    for kk in ("k_grid_scatter_lds", "k_grid_scatter_quad_rl", "k_grid_scatter_quad"):
+                        q = by_name.get(kk)
+                        lines = live.get(kk, {}).get("atomic_lines") if live is not None else None
+                        if lines is None:
+                            lines = units["kernels"].get(kk, {}).get("l2_atomic_requests")
+                        if q and q["launches"] and lines:
+                            ms_k = q["total_ms"] / q["launches"]
+                            per_kernel[kk] = {"avg_launch_ms": round(ms_k, 4), "atomic_lines_per_launch": lines, "frac": round(lines / (ms_k * 1e-3) / units["_atomic_probe_requests_per_s"], 3)}
+                    limiter["per_kernel"] = per_kernel
             except Exception:
                 pass
             if limiter is None and kname in LIMITER_NOTES:
@@ -462,7 +490,7 @@ def main(argv=None, engine=None):
                     "recompute_from": "frac = algorithmic_bytes_per_unit x units_per_launch / avg_launch_ms / peak; avg_launch_ms: this run's HIP events (serialised pass), cross-check: "
                                       "the kernel's per-step duration in %s" % PROFILE_FILES["kernel_trace_serial"]}
 
-        ranked = sorted(prof, key=lambda p: -p["total_ms"])
+        ranked = sorted((p for p in prof if p["kernel"] not in ("k_grid_scatter_lds", "k_grid_scatter_quad_rl", "k_grid_scatter_quad")), key=lambda p: -p["total_ms"])  # (the group's three kernels are in its entry)
         roofline = roofline_of(ranked[0]) if ranked else None
         rooflines_next = [r for r in (roofline_of(p) for p in ranked[1:4]) if r is not None]
         kernels = {p["kernel"]: {"ms_per_step": round(p["total_ms"] / max(args.profile_steps, 1), 4), "launches": p["launches"]} for p in prof if p["launches"]}

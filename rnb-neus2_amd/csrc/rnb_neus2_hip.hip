@@ -70,9 +70,11 @@ uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid
 
 // Per-kernel-group timing with HIP events on the caller's stream (bench.py's roofline leg).
 enum ProfId { P_NONE = -1, P_GRID_SAMPLES = 0, P_POINT_QUERY, P_EMA_BITFIELD, P_MARCH_COUNT, P_SCAN_RAYS, P_MARCH_WRITE, P_FORWARD, P_LOSS_PASS1,
-              P_SCAN_COMPACT, P_LOSS_PASS2, P_FWD_BWD, P_DW, P_SCATTER, P_ADAM, P_REDUCE, P_COUNT };
+              P_SCAN_COMPACT, P_LOSS_PASS2, P_FWD_BWD, P_DW, P_SCATTER, P_ADAM, P_REDUCE, P_SCATTER_LDS, P_SCATTER_RL, P_SCATTER_QUAD, P_COUNT };
 static const char* const PROF_NAMES[P_COUNT] = {"k_grid_samples", "k_point_query", "k_ema_grid+bitfield", "k_march_count", "k_scan_rays", "k_march_write", "k_forward",
-                                                "k_loss_pass1", "k_scan_compact", "k_loss_pass2+k_rollover", "k_fwd_bwd", "k_dw*7+k_dw_finish", "k_grid_scatter", "k_adam_ema", "k_reduce_losses"};
+                                                "k_loss_pass1", "k_scan_compact", "k_loss_pass2+k_rollover", "k_fwd_bwd", "k_dw*7+k_dw_finish", "k_grid_scatter", "k_adam_ema", "k_reduce_losses",
+                                                // the three kernels of the group "k_grid_scatter" one by one (the group's entry is their sum, kept for records of earlier rounds)
+                                                "k_grid_scatter_lds", "k_grid_scatter_quad_rl", "k_grid_scatter_quad"};
 struct Profiler {
 	bool on = false;
 	std::vector<hipEvent_t> ev;
@@ -92,7 +94,10 @@ struct Profiler {
 		for (size_t i = 1; i < n; ++i) {
 			if (ids[i] < 0) continue;
 			float ms = 0.f;
-			if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) { total_ms[ids[i]] += ms; ++launches[ids[i]]; }
+			if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) {
+				total_ms[ids[i]] += ms; ++launches[ids[i]];
+				if (ids[i] == P_SCATTER_LDS || ids[i] == P_SCATTER_RL || ids[i] == P_SCATTER_QUAD) { total_ms[P_SCATTER] += ms; if (ids[i] == P_SCATTER_QUAD) ++launches[P_SCATTER]; } // the group's entry
+			}
 		}
 		n = 0;
 	}
@@ -947,7 +952,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	if (!side_streams) {
 		launch_dw(s, nullptr);
 		c->prof.mark(s, P_DW);
-		launch_c(s, nullptr); launch_b(s, nullptr); launch_a(s, nullptr, l_fine, L);
+		launch_c(s, nullptr); c->prof.mark(s, P_SCATTER_LDS);
+		launch_b(s, nullptr); c->prof.mark(s, P_SCATTER_RL);
+		launch_a(s, nullptr, l_fine, L); c->prof.mark(s, P_SCATTER_QUAD);
+		c->prof.units[P_SCATTER_LDS] += B; c->prof.units[P_SCATTER_RL] += B; c->prof.units[P_SCATTER_QUAD] += B;
 	} else {
 		// The caller's stream carries the scatter (B, A in two halves, then C), the side stream the GEMMs. After B and each half of A an
 		// event lets the optimizer step that group's levels while the rest is still being scattered (optimizer_step); what is left
@@ -985,8 +993,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		c->sc.split[1] = c->off_grid + (uint64_t)c->grid.offsets[e_c] * 2;    // B = [split1, split0), C = [off_grid, split1)
 	}
 	c->prof.units[P_DW] += B;
-	c->prof.mark(s, P_SCATTER);
-	c->prof.units[P_SCATTER] += B;
+	c->prof.units[P_SCATTER] += B; // (its time: the three kernels' marks above, summed by Profiler::collect -- the profiler runs the serial branch)
 	c->backward_stream = s; // rnb_gradient_part_wait records "every gradient is final" there if a caller asks
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
