@@ -1817,8 +1817,114 @@ __device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, con
 		flush();
 	}
 }
-__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false>(G, a, level0, plan); }
-__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<true>(G, a, level0, plan); }
+// Round 5: the same walk with its operands STAGED IN LDS. In the form above a quad loads its K samples in chunks of four, and every chunk's first wait is
+// `s_waitcnt vmcnt(n)`: on gfx9 that counter retires in order across loads AND atomics, so the loads of chunk c + 1 wait for the acknowledgement of the atomics
+// flushed in chunk c -- which execute memory-side (tools/probe_counters.hip: one write request each, no L2 fetch) and take microseconds to come back under load.
+// The walk was a chain of K / 4 such round trips (the kernel sat at 0.75 of the atomic-line rate where the plain kernel reaches 0.97). Here the workgroup first
+// copies the records of its 64 K samples into LDS with coalesced loads (each record once instead of once per lane of its quad: a quarter of the load traffic),
+// and the walk then reads LDS only (lgkmcnt) and issues its atomics without ever waiting for one. Sample j of quad q sits at slot j * 64 + q, so the 16 quads of a
+// wavefront read consecutive 32-byte records at every step of the walk (no bank conflicts; the four lanes of a quad read the same address: a broadcast).
+constexpr uint32_t RL_MAX_K = 16;
+constexpr size_t LDS_SCATTER_RL = (size_t)RL_MAX_K * 64 * 32; // 16 B {x y z dn0} + 8 B {dn1 dn2} + 8 B g12 per sample
+template <bool HALF>
+__device__ __forceinline__ void grid_scatter_quad_rl_staged_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	f4* sA = reinterpret_cast<f4*>(smem_raw);                                  // [K * 64] x y z dn0
+	float2* sB = reinterpret_cast<float2*>(smem_raw + (size_t)RL_MAX_K * 64 * 16); // [K * 64] dn1 dn2
+	uint2* sG = reinterpret_cast<uint2*>(smem_raw + (size_t)RL_MAX_K * 64 * 24);   // [K * 64] g12 of this level
+#pragma unroll 1
+	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) { // virtual workgroups (see k_grid_scatter_quad)
+		uint32_t li = 0;
+#pragma unroll 1
+		for (uint32_t q = 1; q < plan.n; ++q) if (vb >= plan.wg_start[q]) li = q;
+		const uint32_t level = level0 + li;
+		const uint32_t k_log2 = (uint32_t)(plan.k_log2 >> (4 * li)) & 15u, K = 1u << k_log2;
+		if (level > G.valid_level) continue; // (workgroup-uniform)
+		const uint32_t wg_first = (vb - plan.wg_start[li]) * 64u * K; // first sample of this workgroup's 64 quads
+		const uint32_t wg_n = min(64u * K, a.B - min(a.B, wg_first));
+		const uint2* g12l = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+		if (vb != blockIdx.x) __syncthreads(); // the previous virtual workgroup's walk has read the stage
+		for (uint32_t i = threadIdx.x; i < wg_n; i += blockDim.x) {
+			const uint32_t s = wg_first + i;
+			const f4 r0 = reinterpret_cast<const f4*>(a.srec)[(size_t)s * 2 + 0];
+			const float2 r1 = *reinterpret_cast<const float2*>(a.srec + (size_t)s * 8 + 4);
+			const uint2 g = g12l[s];
+			const uint32_t slot = (i & (K - 1u)) * 64u + (i >> k_log2);
+			sA[slot] = r0; sB[slot] = r1; sG[slot] = g;
+		}
+		__syncthreads();
+		const uint32_t quad = threadIdx.x >> 2;
+		const uint32_t n_mine = min(K, wg_n - min(wg_n, quad * K)); // samples of this quad (0 beyond the batch)
+		const uint32_t dx = (threadIdx.x >> 1) & 1u, f = threadIdx.x & 1u; // HALF: f is dy
+		float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
+		uint32_t* gg16 = a.grid_grad16 + G.offsets[level];
+		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+		const float scale = G.scale[level];
+		const uint32_t res = G.resolution[level];
+		float acc[4] = {0.f, 0.f, 0.f, 0.f}; // fp32: the four (dy, dz) corners of (dx, feature); HALF: [2 dz + feature] of the corner (dx, dy)
+		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+		auto flush = [&]() {
+			if (HALF) {
+#pragma unroll
+				for (uint32_t dz = 0; dz < 2; ++dz) {
+					if (acc[2 * dz] != 0.f || acc[2 * dz + 1] != 0.f) {
+						atomic_add_h2(gg16 + grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + f, cur[2] + dz), acc[2 * dz], acc[2 * dz + 1]);
+						acc[2 * dz] = 0.f; acc[2 * dz + 1] = 0.f;
+					}
+				}
+				return;
+			}
+#pragma unroll
+			for (uint32_t yz = 0; yz < 4; ++yz) {
+				if (acc[yz] != 0.f) {
+					const uint32_t e = grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1));
+					atomicAdd(gg + (size_t)e * 2 + f, acc[yz]);
+					acc[yz] = 0.f;
+				}
+			}
+		};
+#pragma unroll 1
+		for (uint32_t j = 0; j < n_mine; ++j) {
+			const uint32_t slot = j * 64u + quad;
+			const f4 r0 = sA[slot];
+			const float2 r1 = sB[slot];
+			const uint2 q12 = sG[slot];
+			const float dn[3] = {r0[3], r1.x, r1.y};
+			float pos[3];
+			uint32_t pg[3];
+			pos_fract(r0[0], scale, &pos[0], &pg[0]);
+			pos_fract(r0[1], scale, &pos[1], &pg[1]);
+			pos_fract(r0[2], scale, &pos[2], &pg[2]);
+			if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+				if (cur[0] != 0xffffffffu) flush();
+				cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+			}
+			if (HALF) {
+				const h2 g1 = unpack_h2(q12.x), g2 = unpack_h2(q12.y);
+#pragma unroll
+				for (uint32_t dz = 0; dz < 2; ++dz) {
+					const uint32_t c[3] = {dx, f, dz};
+					acc[2 * dz] += corner_addend(h2f(g1[0]), h2f(g2[0]), scale, dn, pos, c);
+					acc[2 * dz + 1] += corner_addend(h2f(g1[1]), h2f(g2[1]), scale, dn, pos, c);
+				}
+				continue;
+			}
+			const float g1 = h2f(unpack_h2(q12.x)[f]);
+			const float g2 = h2f(unpack_h2(q12.y)[f]);
+#pragma unroll
+			for (uint32_t yz = 0; yz < 4; ++yz) {
+				const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+				acc[yz] += corner_addend(g1, g2, scale, dn, pos, c);
+			}
+		}
+		if (n_mine) flush();
+	}
+}
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_staged_body<false>(G, a, level0, plan); }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_staged_body<true>(G, a, level0, plan); }
+// RNB_SCATTER_RL_STAGED=0 (A/B): the walk with its operands loaded from global memory four samples ahead (rounds 2-4)
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false>(G, a, level0, plan); }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<true>(G, a, level0, plan); }
 
 // ---------------------------------------------------------------------------------------------
 // K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.

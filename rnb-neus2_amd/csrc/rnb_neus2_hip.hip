@@ -219,6 +219,11 @@ struct rnb_ctx {
 		bool scatter_plain = false; // RNB_SCATTER_PLAIN=1 (A/B, tests): no LDS-privatised and no run-length scatter -- every corner of every level is its own L2 atomic, as in the reference; with
 		                            // accumulate = RNB_ACCUM_HALF every one of a corner's four addends is (k_grid_scatter_quad_h_per_addend), which reproduces the reference's sequential half sums
 		                            // on the coarse levels too
+		int scatter_rl_staged = -1; // RNB_SCATTER_RL_STAGED=0|1: the run-length scatter loads its operands from global memory inside the walk (rounds 2-4) / stages them in LDS (round 5). Alone the two take
+		                            // the same time (112 / 101 / 112 us staged vs 112 / 97 / 111 direct at steps 1000 / 2000 / 6000: the walk is NOT a chain of load -> atomic-acknowledge round trips,
+		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
+		                            // few long rays: 0.6078 -> 0.5971 ms/step at step 1000, 0.5900 -> 0.5929 at 2000, 0.6334 -> 0.6360 at 6000 (profiles/r05_ab_scatter_rl_staged.txt).
+		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -936,8 +941,12 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + sg.Ks[e_c + q] - 1) / sg.Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
 		const uint32_t cap_rl = scatter_cap ? (uint32_t)c->n_cus * scatter_cap : wg;
-		if (half) LAUNCH_EV(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
-		else LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+		const bool staged = c->knobs.scatter_rl_staged >= 0 ? c->knobs.scatter_rl_staged != 0 : (c->cur_n_rays != 0 && c->cur_n_rays < c->knobs.march_narrow_from);
+		if (!staged) {
+			if (half) LAUNCH_EV(k_grid_scatter_quad_rl_direct_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+			else LAUNCH_EV(k_grid_scatter_quad_rl_direct, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
+		} else if (half) LAUNCH_EV(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, c->meta(), sa, e_c, plan);
+		else LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
 		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -1408,6 +1417,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));

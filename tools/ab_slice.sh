@@ -6,7 +6,7 @@ burn=${BURN:-980}; steps=${STEPS:-200}
 mkdir -p gpurun_out/$tag; rm -f gpurun_out/$tag/ab_slice_raw.txt
 for r in $(seq 1 $rounds); do
   for env in "$@"; do
-    out=$(env $env python bench.py --burn-in $burn --steps $steps --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 $BENCH_ARGS 2>/dev/null | grep "^{")
+    out=$(env $env python bench.py --burn-in $burn --steps $steps --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 --no-live-pmc $BENCH_ARGS 2>/dev/null | grep "^{")
     python - "$env" "$out" <<'PY' >> gpurun_out/$tag/ab_slice_raw.txt
 import json, sys
 d = json.loads(sys.argv[2])

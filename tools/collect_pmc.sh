@@ -9,7 +9,7 @@ COUNTERS=${@:-FETCH_SIZE WRITE_SIZE}
 mkdir -p $OUT
 for C in $COUNTERS; do
   rm -rf /tmp/pmc_$C
-  RNB_OVERLAP_OFF=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python bench.py --steps 10 --warmup 2 --burn-in 2000 --profile-steps 0 --no-cpu-baseline --window-end 0 --late-step 0 --fixed-cost-steps 0 --no-live-pmc > /tmp/pmc_$C.log 2>&1
+  RNB_OVERLAP_OFF=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -- python bench.py --steps 10 --warmup 2 --burn-in 2000 --profile-steps 0 --no-cpu-baseline --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 --no-live-pmc > /tmp/pmc_$C.log 2>&1
   python tools/pmc_summary.py /tmp/pmc_$C $C > $OUT/$C.json
   head -12 $OUT/$C.json
 done

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for mode in serial overlapped; do
   rm -rf /tmp/kt_$mode
   if [ $mode = serial ]; then export RNB_OVERLAP_OFF=1; else unset RNB_OVERLAP_OFF; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in $burn --steps $steps --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 > /tmp/kt_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in $burn --steps $steps --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 --no-live-pmc > /tmp/kt_$mode.log 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | head -1); cp $f gpurun_out/$tag/kernel_stats_$mode.csv
   python tools/steady_stats.py /tmp/kt_$mode $steps > gpurun_out/$tag/steady_$mode.json
   grep "^{" /tmp/kt_$mode.log | head -c 400; echo
