@@ -1,18 +1,18 @@
 #!/bin/bash
 # GPU box: everything profiles/ holds for a round -> gpurun_out/<round>p/ (copy what is to be judged into profiles/ afterwards)
 #   bash tools/refresh_profiles.sh r02
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/${R}p
 mkdir -p $O $O/pmc
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python bench.py 2>$O/bench_default.err | grep "^{" > $O/bench_default.json                        # the defaults: steps 1000-2000 timed, + late regime
 python bench.py --steps 20 2>/dev/null | grep "^{" > $O/bench_steps20.json                        # the driver's command line
-python bench.py --albedo --no-cpu-baseline --late-step 0 2>/dev/null | grep "^{" > $O/bench_albedo.json
+python bench.py --albedo --no-cpu-baseline --late-step 0 --parity-mode-steps 0 2>/dev/null | grep "^{" > $O/bench_albedo.json
 for regime in 980 1980; do
 for mode in serial overlapped; do
   rm -rf /tmp/kt_$mode
   if [ $mode = serial ]; then export RNB_OVERLAP_OFF=1; else unset RNB_OVERLAP_OFF; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in $regime --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 > /tmp/kt_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in $regime --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 > /tmp/kt_$mode.log 2>&1
   f=$(find /tmp/kt_$mode -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_${mode}_step$((regime+20)).csv
   python tools/steady_stats.py /tmp/kt_$mode 100 > $O/steady_${mode}_step$((regime+20)).json
 done; done
@@ -32,12 +32,12 @@ PY
 for mode in serial overlapped; do
   rm -rf /tmp/kt_$mode
   if [ $mode = serial ]; then export RNB_OVERLAP_OFF=1; else unset RNB_OVERLAP_OFF; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in 5980 --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 > /tmp/kt_$mode.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$mode -- python bench.py --burn-in 5980 --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 > /tmp/kt_$mode.log 2>&1
   python tools/steady_stats.py /tmp/kt_$mode 100 > $O/steady_${mode}_step6000.json
 done
 unset RNB_OVERLAP_OFF
 python tools/timeline.py /tmp/kt_overlapped 5 > $O/timeline_overlapped_step6000.txt
-rm -rf /tmp/kt_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_tl -- python bench.py --burn-in 980 --steps 60 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 > /tmp/kt_tl.log 2>&1
+rm -rf /tmp/kt_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_tl -- python bench.py --burn-in 980 --steps 60 --warmup 20 --no-cpu-baseline --profile-steps 0 --window-end 0 --late-step 0 --fixed-cost-steps 0 --parity-mode-steps 0 > /tmp/kt_tl.log 2>&1
 python tools/timeline.py /tmp/kt_tl 5 > $O/timeline_overlapped_step1000.txt
 tools/collect_pmc_group.sh $O/sq a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES > /dev/null 2>&1
 tools/collect_pmc_group.sh $O/sq b SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM > /dev/null 2>&1
