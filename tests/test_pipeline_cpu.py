@@ -657,3 +657,55 @@ def test_full_pipeline_end_to_end_cpu(small_install, tmp_path):
     assert any("Loaded snapshot succeed" in l for l in log.lines)
     m = meshproc.load_obj(mesh_path)
     assert len(m.faces) > 100 and m.signed_volume > 0
+
+
+def test_sfm_json_loader_against_the_references_outputs(tmp_path):
+    """tests/golden/sfm_loader_vectors.json: the REFERENCE's `parse_sfm_json` and `SfmJsonDataLoader.load` (rnb_neus2/dataloaders/sfm_json_loader.py) run on four seeded
+    SfMData documents (pixel / millimetre focal lengths, the 36 mm default, a view without a pose, absolute and relative image paths, landmarks, an albedo document and a
+    mask folder) -- every camera field, matrix element and resolved path equal (the matrices are float32 casts of float64 products: bit for bit)."""
+    with open(os.path.join(ROOT, "tests", "golden", "sfm_loader_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 4
+    for ci, case in enumerate(cases):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cams, landmarks = dataloaders.parse_sfm_json(case["document"], case["sfm_dir"])
+        want = case["parse"]["cameras"]
+        assert len(cams) == len(want), ci
+        for c, w in zip(cams, want):
+            assert set(c) == set(w), (ci, set(c) ^ set(w))
+            for k, v in w.items():
+                if isinstance(v, list):
+                    np.testing.assert_array_equal(np.asarray(c[k], dtype=np.float64), np.asarray(v, dtype=np.float64), err_msg="%d %s" % (ci, k))
+                else:
+                    assert c[k] == v, (ci, k, c[k], v)
+        if case["parse"]["landmarks"] is None:
+            assert landmarks is None
+        else:
+            np.testing.assert_array_equal(np.asarray(landmarks, dtype=np.float64), np.asarray(case["parse"]["landmarks"]))
+        d = tmp_path / ("case%d" % ci)
+        os.makedirs(d / "masks")
+        with open(d / "normals.sfm", "w") as f:
+            json.dump(case["document"], f)
+        with open(d / "albedos.sfm", "w") as f:
+            json.dump(case["load"]["albedo_document"], f)
+        for name in case["load"]["mask_files"]:
+            open(d / "masks" / name, "wb").close()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = dataloaders.SfmJsonDataLoader(str(d / "normals.sfm"), albedo_sfm_path=str(d / "albedos.sfm"), mask_folder_path=str(d / "masks")).load()
+        L = case["load"]
+        assert out["image_width"] == L["image_width"] and out["image_height"] == L["image_height"] and out["scale_mat"] is None and L["scale_mat"] is None
+        assert len(out["views"]) == len(L["views"])
+        for v, w in zip(out["views"], L["views"]):
+            assert str(v["c2w"].dtype) == w["c2w_dtype"] == "float32"
+            np.testing.assert_array_equal(v["c2w"].astype(np.float64), np.asarray(w["c2w"]))
+            np.testing.assert_array_equal(np.asarray(v["K"], dtype=np.float64), np.asarray(w["K"]))
+            for k in ("normal_path", "albedo_path", "mask_path"):
+                assert v[k] == (None if w[k] is None else w[k].replace("<DIR>", str(d))), (ci, k, v[k], w[k])
+            assert v["pose_id"] == w["pose_id"]
+        if L["landmarks"] is None:
+            assert out["landmarks"] is None
+        else:
+            np.testing.assert_array_equal(np.asarray(out["landmarks"], dtype=np.float64), np.asarray(L["landmarks"]))
