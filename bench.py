@@ -474,8 +474,9 @@ def main(argv=None, engine=None):
                     for kk in ("k_grid_scatter_lds", "k_grid_scatter_quad_rl", "k_grid_scatter_quad"):
                         q = by_name.get(kk)
                         lines = live.get(kk, {}).get("atomic_lines") if live is not None else None
-                        if lines is None:
-                            lines = units["kernels"].get(kk, {}).get("l2_atomic_requests")
+                        if lines is None:  # (the committed summary names the kernel as launched: k_grid_scatter_quad_rl_direct, ..._h)
+                            hits = [v for k, v in units["kernels"].items() if k.startswith(kk) and (kk != "k_grid_scatter_quad" or not k.startswith("k_grid_scatter_quad_rl"))]
+                            lines = sum(v.get("l2_atomic_requests", 0) for v in hits) or None
                         if q and q["launches"] and lines:
                             ms_k = q["total_ms"] / q["launches"]
                             per_kernel[kk] = {"avg_launch_ms": round(ms_k, 4), "atomic_lines_per_launch": lines, "frac": round(lines / (ms_k * 1e-3) / units["_atomic_probe_requests_per_s"], 3)}
