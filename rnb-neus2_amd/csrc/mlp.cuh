@@ -62,10 +62,11 @@ __device__ inline void load_weights(half_t* __restrict__ w, const NetW& net, int
 //   EMU_CHAINED  chained fragments, k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3) (below)     first step = elements j < 4
 //   EMU_FBS      k_fwd_bwd_sdf's 32-wide input tiles, 28 hash features | x y z | pad (fbs_logical)  first step = reference columns 0..15 = slots 0..12, 28..30
 constexpr int EMU_OFF = 0, EMU_NATURAL = 1, EMU_CHAINED = 2, EMU_FBS = 3;
-__device__ __forceinline__ f4 round_acc_half(f4 a) {
-#pragma unroll
-	for (int r = 0; r < 4; ++r) a[r] = h2f(f2h(a[r]));
-	return a;
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f4 round_acc_half(f4 a) { // pairs: v_cvt_pk_f16_f32 (gfx950) + two unpacking converts = 3 instructions per 2 elements instead of 4
+	const h2 lo = __builtin_convertvector((f2v{a[0], a[1]}), h2), hi = __builtin_convertvector((f2v{a[2], a[3]}), h2);
+	const f2v l = __builtin_convertvector(lo, f2v), h = __builtin_convertvector(hi, f2v);
+	return f4{l[0], l[1], h[0], h[1]};
 }
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 // The two halves of operand b by logical k-step (an operand is masked once and may then serve several MFMAs).
