@@ -709,3 +709,28 @@ def test_sfm_json_loader_against_the_references_outputs(tmp_path):
             assert out["landmarks"] is None
         else:
             np.testing.assert_array_equal(np.asarray(out["landmarks"], dtype=np.float64), np.asarray(L["landmarks"]))
+
+
+def test_albedo_scaling_camera_loader_against_the_references_outputs(tmp_path):
+    """tests/golden/albedo_camera_vectors.json: the REFERENCE's `load_cameras` (rnb_neus2/albedo_scaling.py:128-211) on six seeded transform.json documents -- frames matched
+    to the albedo files by stem and returned in THEIR order, `intrinsic_matrix` vs per-frame vs global vs default focal lengths and principal points (with the reference's `or`
+    fall-backs), `n2w` back to world space -- K, R and centres equal bit for bit, same dtypes, same exceptions."""
+    from rnb_neus2_amd import albedo_scaling
+    with open(os.path.join(ROOT, "tests", "golden", "albedo_camera_vectors.json")) as f:
+        fix = json.load(f)
+    assert len(fix["cases"]) == 6
+    for ci, case in enumerate(fix["cases"]):
+        p = tmp_path / ("transform%d.json" % ci)
+        p.write_text(json.dumps(case["document"]))
+        K, R, C = albedo_scaling.load_cameras(str(p), case["albedo_images"])
+        assert [str(K.dtype), str(R.dtype), str(C.dtype)] == case["dtypes"], ci
+        np.testing.assert_array_equal(K.astype(np.float64), np.asarray(case["K"]), err_msg="K %d" % ci)
+        np.testing.assert_array_equal(R.astype(np.float64), np.asarray(case["R_c2w"]), err_msg="R %d" % ci)
+        np.testing.assert_array_equal(C.astype(np.float64), np.asarray(case["centers"]), err_msg="C %d" % ci)
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(fix["cases"][0]["document"]))
+    assert fix["missing_frame_raises"] == "RuntimeError" and fix["unknown_suffix_raises"] == "ValueError"
+    with pytest.raises(RuntimeError):
+        albedo_scaling.load_cameras(str(p), ["/x/00099.png"])
+    with pytest.raises(ValueError):
+        albedo_scaling.load_cameras("/x/cameras.bin", ["a.png"])
