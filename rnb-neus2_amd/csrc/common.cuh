@@ -245,12 +245,21 @@ __device__ __forceinline__ void encode_level(const GridMeta& G, const uint32_t* 
 
 // Per-level constants staged in LDS: 42 kernel-argument SGPRs that every unrolled level keeps alive would otherwise be
 // spilled to VGPR lanes (v_readlane / v_writelane traffic in the hot loop). One broadcast ds_read_b128 + 4 readfirstlane.
-struct __attribute__((aligned(16))) LevelMeta { uint32_t offset, size, res; float scale; };
+// (round 5) + what level_issue needs to form the table indices without a branch: the y / z multipliers of the index (dense: res, res^2; hashed: the two primes) and
+// whether the level is dense / its table a power of two -- grid_entry's wave-uniform decisions, taken once per workgroup instead of once per level and sample.
+struct __attribute__((aligned(16))) LevelMeta { uint32_t offset, size, res; float scale; uint32_t my, mz, dense, pow2; };
 
 __device__ __forceinline__ void fill_level_meta(LevelMeta* __restrict__ lm, const GridMeta& G, const int tid) {
 	if (tid < RNB_MAX_LEVELS) {
 		LevelMeta m;
 		m.offset = G.offsets[tid]; m.size = G.offsets[tid + 1] - G.offsets[tid]; m.res = G.resolution[tid]; m.scale = G.scale[tid];
+		uint32_t stride = m.res, s2 = m.res;
+		bool dense = false;
+		if (stride <= m.size) { stride *= m.res; if (stride <= m.size) { s2 = stride; stride *= m.res; dense = !(m.size < stride); } } // (the stride loop of grid.h:137-141, as encode_level_core walks it)
+		m.dense = dense ? 1u : 0u;
+		m.pow2 = (m.size & (m.size - 1u)) == 0u ? 1u : 0u;
+		m.my = dense ? m.res : 2654435761u;
+		m.mz = dense ? s2 : 805459861u;
 		lm[tid] = m;
 	}
 }
@@ -263,6 +272,88 @@ __device__ __forceinline__ void encode_level_lm(const LevelMeta* __restrict__ lm
 	const uint32_t off = __builtin_amdgcn_readfirstlane(raw.x), size = __builtin_amdgcn_readfirstlane(raw.y), res = __builtin_amdgcn_readfirstlane(raw.z);
 	const float scale = __uint_as_float(__builtin_amdgcn_readfirstlane(raw.w));
 	encode_level_core<GRAD>(grid + off, size, res, scale, x, y, z, f0, f1, dy0, dy1);
+}
+
+// ---- the same level in two halves, for encodes that keep the gathers of several levels in flight (round 5) ----
+// encode_level_core issues a level's eight 4-byte gathers and consumes them at once, behind wave-uniform BRANCHES (dense / hashed, power-of-two table, the second
+// gather of an x-pair): every level is a scheduling region of its own and ends in s_waitcnt vmcnt(0), so a wavefront walks its 14 levels as 14 dependent round trips
+// with eight loads in flight -- at two wavefronts per SIMD the network evaluations were bound by exactly that chain (profiles/r05_*: 41 % of the cycles waiting).
+// level_issue computes the eight table indices WITHOUT branches (the uniform conditions become selects) and issues the eight loads; level_consume recomputes the
+// interpolation weights (a few VALU instructions) and reduces the eight values: the same expressions on the same operands as encode_level_core, hence the same bits.
+// A caller issues DEPTH levels ahead of the one it consumes (vmcnt counts in order: consuming level l waits until at most 8 (DEPTH - 1) loads are outstanding).
+__device__ __forceinline__ void level_issue(const LevelMeta* __restrict__ lm, const uint32_t* __restrict__ grid, const uint32_t level, const float x, const float y, const float z, uint32_t (&v)[8]) {
+	const uint4 raw = reinterpret_cast<const uint4*>(lm + level)[0], raw2 = reinterpret_cast<const uint4*>(lm + level)[1];
+	const uint32_t off = __builtin_amdgcn_readfirstlane(raw.x), hashmap_size = __builtin_amdgcn_readfirstlane(raw.y);
+	const float scale = __uint_as_float(__builtin_amdgcn_readfirstlane(raw.w));
+	const uint32_t my = __builtin_amdgcn_readfirstlane(raw2.x), mz = __builtin_amdgcn_readfirstlane(raw2.y);
+	const bool dense = __builtin_amdgcn_readfirstlane(raw2.z) != 0u, pow2 = __builtin_amdgcn_readfirstlane(raw2.w) != 0u;
+	const uint32_t* __restrict__ g = grid + off;
+	float pos[3];
+	uint32_t pg[3];
+	pos_fract(x, scale, &pos[0], &pg[0]);
+	pos_fract(y, scale, &pos[1], &pg[1]);
+	pos_fract(z, scale, &pos[2], &pg[2]);
+	// grid_entry's value per corner (see encode_level_core): dense: index = x + y res + z res^2, else the hash; wrapped into the table. Selects, no branches.
+	const uint32_t ty0 = pg[1] * my, ty1 = ty0 + my, tz0 = pg[2] * mz, tz1 = tz0 + mz;
+#pragma unroll
+	for (uint32_t yz = 0; yz < 4; ++yz) {
+		const uint32_t ty = (yz & 1u) ? ty1 : ty0, tz = (yz >> 1) ? tz1 : tz0;
+		const uint32_t d0 = pg[0] + ty + tz, h = ty ^ tz;
+		uint32_t e0 = dense ? d0 : (pg[0] ^ h), e1 = dense ? d0 + 1u : ((pg[0] + 1u) ^ h);
+		const uint32_t w0 = e0 >= hashmap_size ? e0 - hashmap_size : e0, w1 = e1 >= hashmap_size ? e1 - hashmap_size : e1;
+		e0 = pow2 ? (e0 & (hashmap_size - 1u)) : w0;
+		e1 = pow2 ? (e1 & (hashmap_size - 1u)) : w1;
+		v[yz * 2 + 0] = g[e0];
+		v[yz * 2 + 1] = g[e1];
+	}
+}
+template <bool GRAD>
+__device__ __forceinline__ void level_consume(const LevelMeta* __restrict__ lm, const uint32_t level, const float x, const float y, const float z, const uint32_t (&v)[8],
+                                              half_t& f0, half_t& f1, float dy0[3], float dy1[3]) {
+	const float scale = __uint_as_float(__builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(lm + level)[3]));
+	float pos[3];
+	uint32_t pg[3];
+	pos_fract(x, scale, &pos[0], &pg[0]);
+	pos_fract(y, scale, &pos[1], &pg[1]);
+	pos_fract(z, scale, &pos[2], &pg[2]);
+	half_t r0 = (half_t)0.f, r1 = (half_t)0.f;
+#pragma unroll
+	for (uint32_t idx = 0; idx < 8; ++idx) {
+		float weight = 1;
+#pragma unroll
+		for (uint32_t d = 0; d < 3; ++d) {
+			if ((idx & (1u << d)) == 0) weight *= 1 - pos[d];
+			else weight *= pos[d];
+		}
+		const h2 val = unpack_h2(v[idx]);
+		r0 = r0 + f2h(weight * h2f(val[0]));
+		r1 = r1 + f2h(weight * h2f(val[1]));
+	}
+	f0 = r0;
+	f1 = r1;
+	if (GRAD) {
+#pragma unroll
+		for (uint32_t gd = 0; gd < 3; ++gd) {
+			float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+			for (uint32_t idx = 0; idx < 4; ++idx) {
+				float weight = scale;
+				uint32_t corner = 0;
+#pragma unroll
+				for (uint32_t ngd = 0; ngd < 2; ++ngd) {
+					const uint32_t d = ngd >= gd ? (ngd + 1) : ngd;
+					if ((idx & (1u << ngd)) == 0) weight *= 1 - pos[d];
+					else { weight *= pos[d]; corner |= (1u << d); }
+				}
+				const h2 vl = unpack_h2(v[corner]);
+				const h2 vr = unpack_h2(v[corner | (1u << gd)]);
+				a0 += weight * (h2f(vr[0]) - h2f(vl[0])) * 1.0f;
+				a1 += weight * (h2f(vr[1]) - h2f(vl[1])) * 1.0f;
+			}
+			dy0[gd] = a0;
+			dy1[gd] = a1;
+		}
+	}
 }
 
 // ---- occupancy helpers (src/testbed_nerf.cu:439-475, 569-583, 153-155, 301-323, 429-437) ----

@@ -224,6 +224,9 @@ struct rnb_ctx {
 		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
 		                            // few long rays: 0.6078 -> 0.5971 ms/step at step 1000, 0.5900 -> 0.5929 at 2000, 0.6334 -> 0.6360 at 6000 (profiles/r05_ab_scatter_rl_staged.txt).
 		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
+		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
+		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
+		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels (244 VGPRs) and the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -441,6 +444,9 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
 	if (c->half_acc()) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_point_query_chained_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_point_query_chained_pipe<7>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_point_query_chained_pipe<2>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else hipLaunchKernelGGL(k_point_query_chained, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -611,6 +617,9 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
 	if (c->half_acc()) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_forward_chained_pipe<2>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_forward_chained_pipe<4>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_forward_chained_pipe<7>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	HIP_TRY(hipGetLastError());
 	return RNB_OK;
@@ -1370,6 +1379,9 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_emul), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
@@ -1417,6 +1429,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
 		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
 	}
 	plan_scatter_groups(c);
