@@ -16,7 +16,7 @@ def per_step(T, ks):
     return sum(T[k]["avg"] * T[k]["launches_total"] / steps_total for k in ks if k in T) * 1024
 
 
-groups = {"k_forward": ["k_forward_chained"], "k_fwd_bwd": fb, "k_grid_scatter": [k for k in F if k.startswith("k_grid_scatter")],
+groups = {"k_forward": [k for k in F if k.startswith("k_forward_chained")], "k_fwd_bwd": fb, "k_grid_scatter": [k for k in F if k.startswith("k_grid_scatter")],
           "k_grid_scatter_lds": [k for k in F if k.startswith("k_grid_scatter_lds")], "k_grid_scatter_quad_rl": [k for k in F if k.startswith("k_grid_scatter_quad_rl")],
           "k_grid_scatter_quad": [k for k in F if k.startswith("k_grid_scatter_quad") and not k.startswith("k_grid_scatter_quad_rl")],
           "k_adam_ema": ["k_adam_ema"], "k_dw*7+k_dw_finish": [k for k in F if "k_dw" in k], "k_loss_pass1": ["k_loss_pass1", "k_loss_pass1_heads"],
