@@ -18,7 +18,7 @@ from tests.conftest import SMALL_CFG
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAUNCH = os.path.join(ROOT, "tools", "launch_testbed.sh")
-N_STEPS = 20
+N_STEPS = 10
 
 # six levels: the checker's shard layout then has three blocks (splits in front of the four and of the two finest levels, oracle/rnb_oracle.cpp shard_layout)
 CFG6 = json.loads(json.dumps(SMALL_CFG))
@@ -64,7 +64,7 @@ def _snapshot(scene):
 def jobs(job_install, scene_src, tmp_path_factory):
     tmp = tmp_path_factory.mktemp("jobs")
     out = {}
-    for name, env in (("sharded", {}), ("allreduce", {"RNB_DP_SHARDED": "0"}), ("replicated_grid", {"RNB_DP_SHARD_GRID": "0"})):
+    for name, env in (("sharded", {}), ("allreduce", {"RNB_DP_SHARDED": "0", "RNB_DP_SHARD_GRID": "0"})):  # (the second job also keeps its occupancy updates replicated)
         r, scene = _job(job_install, scene_src[0], tmp, name, 2, env)
         assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-2000:])
         out[name] = dict(stdout=r.stdout, snap=_snapshot(scene), scene=scene)
@@ -82,9 +82,9 @@ def test_two_rank_job_runs_the_sharded_protocol(jobs):
 
 def test_sharded_equals_allreduce_equals_replicated_grid_bit_for_bit(jobs):
     """sync_parameters() has gathered the other rank's chunks of the EMA weights (non-zero offsets in all three blocks): the sharded job's snapshot is the
-    all-reduce job's, and the sharded occupancy update (max exchange) leaves the replicated update's grid."""
+    all-reduce job's, and the sharded occupancy update (max exchange) leaves the replicated update's grid (the all-reduce job runs its updates replicated)."""
     ref = jobs["allreduce"]["snap"]["snapshot"]
-    for name in ("sharded", "replicated_grid"):
+    for name in ("sharded",):
         snap = jobs[name]["snap"]["snapshot"]
         assert snap["params_binary"] == ref["params_binary"], name
         assert snap["density_grid_binary"] == ref["density_grid_binary"], name
