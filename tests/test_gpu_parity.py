@@ -1092,3 +1092,27 @@ def test_testbed_trains_with_the_references_own_config_file(tmp_path):
     assert a[0]["globalmove"]["optimizer"]["nested"]["nested"]["learning_rate"] == 0.005 and a[0]["loss"]["otype"] == "Huber"
     for x, y in zip(a[1], b[1]):
         assert abs(x - y) <= 0.15 * max(x, y), (a[1], b[1])
+
+
+@pytest.mark.parametrize("n_levels", [1, 3, 6])
+def test_network_evaluation_with_fewer_levels_than_the_gathers_in_flight(n_levels):
+    """The evaluation kernels keep the gathers of four levels in flight (common.cuh: level_issue / level_consume); a network with fewer levels than that -- or with levels that
+    are not live yet (training step < 660) -- gathers the last live level's entries for the missing ones and drops them. Forward pass and point query vs the oracle, 1 / 3 / 6
+    levels, at a step where only some of them are live and at one where all are."""
+    gpu, cpu = _pair(n_levels=n_levels, log2_hashmap_size=14, per_level_scale=1.6, apply_no_albedo=0)
+    try:
+        _randomize(gpu, cpu, seed=n_levels)
+        rng = np.random.default_rng(n_levels)
+        coords = rng.random((2000, 7), dtype=np.float32)
+        for step in (50, 700):
+            for c in (gpu, cpu):
+                c.set_training_step(step)
+            assert gpu.valid_level == cpu.valid_level
+            a, b = gpu.forward_infer(coords), cpu.forward_infer(coords)
+            _half_close(a[:, 3], b[:, 3], name="sdf channel")
+            _half_close(a[:, 4:7], b[:, 4:7], rel=4e-3, abs_=2e-3, name="gradient channels")
+            s = gpu.sdf(coords[:, :3], inference=False)
+            assert np.array_equal(s.view(np.uint16), a[:, 3].view(np.uint16))  # the point query is the forward pass's sdf channel
+    finally:
+        gpu.close()
+        cpu.close()
