@@ -473,6 +473,7 @@ struct Testbed {
 	float loss_scalar = 0.f;
 	bool train = true;
 	bool fractional_training = false;
+	bool accumulate_from_flag = false; // --accumulate was given: it overrides the mode a snapshot records
 	uint32_t fractional = 0;
 	uint32_t save_each = 0;
 	uint32_t res_mesh = 512;
@@ -664,6 +665,7 @@ struct Testbed {
 		mpk::Value& hp = obj("hyperparams");
 		hp.set("batch_size", mpk::Value::uint((uint64_t)cfg.target_batch_size * ((dist.world > 1 && !dist.weak) ? dist.world : 1))); // the job's batch, not this rank's share
 		hp.set("mask_loss_weight", mpk::Value::real(cfg.mask_loss_weight)); hp.set("ek_loss_weight", mpk::Value::real(cfg.ek_loss_weight));
+		hp.set("accumulate", mpk::Value::str(cfg.accumulate == RNB_ACCUM_HALF ? "half" : "fp32")); // (this build's key: a resumed run continues in the mode the snapshot was trained in)
 		mpk::Value& net = obj("network");
 		if (!net.find("otype")) net.set("otype", mpk::Value::str("FullyFusedMLP"));
 		net.set("sdf_bias", mpk::Value::real(cfg.sdf_bias));
@@ -700,6 +702,7 @@ struct Testbed {
 			const float mask_w = cfg.mask_loss_weight;
 			apply_network_config(network_config);
 			if (!network_config["hyperparams"].contains("mask_loss_weight")) cfg.mask_loss_weight = mask_w;
+			if (!accumulate_from_flag && network_config["hyperparams"].contains("accumulate")) cfg.accumulate = network_config["hyperparams"]["accumulate"].as_string() == "half" ? RNB_ACCUM_HALF : RNB_ACCUM_FP32;
 		}
 		if (const mpk::Value* v = snap.at("nerf").find("aabb_scale")) cfg.aabb_scale = (uint32_t)v->number();
 		create_context();
@@ -813,6 +816,7 @@ int main(int argc, char** argv) {
 			const std::string m = args.get("accumulate");
 			if (m != "fp32" && m != "half") { std::cerr << "--accumulate takes fp32 or half" << std::endl; print_help(std::cerr, argv[0]); return -1; }
 			tb.cfg.accumulate = m == "half" ? RNB_ACCUM_HALF : RNB_ACCUM_FP32;
+			tb.accumulate_from_flag = true;
 		}
 		tb.dist.init();
 		struct AbortGuard { bool done = false; ~AbortGuard() { if (!done && !g_abort_file.empty()) if (std::FILE* f = std::fopen(g_abort_file.c_str(), "wb")) std::fclose(f); } } abort_guard; // any exit but the regular one

@@ -443,3 +443,40 @@ def test_unsupported_network_configs_are_refused_by_name(install, tmp_path):
         p.write_text(json.dumps(cfg))
         r = run(install, "--scene", str(tmp_path / "s") + "/", "--maxiter", 1, "--no-gui", "--config", str(p))
         assert r.returncode == 1 and needle in r.stderr, (patch, r.returncode, r.stderr[-500:])
+
+
+def test_snapshot_records_the_accumulate_mode_and_a_resume_continues_in_it(install, tmp_path):
+    """`--accumulate half` (this build's flag; include/rnb_neus2.h rnb_config::accumulate): the snapshot's hyperparams carry the mode, a resumed run without the flag continues
+    in it (equal to an uninterrupted half-mode run on the checker), and the flag overrides the record."""
+    views, normals, albedos = synthetic.make_scene(3, 32, 56.0)
+    scene = tmp_path / "s"
+    synthetic.write_scene(str(scene), views, normals, albedos)
+    common = ["--scene", str(scene) + "/", "--no-gui", "--mask-weight", 1.0, "--no-albedo", "--save-snapshot"]
+    r = run(install, *common, "--maxiter", 3, "--config", "small.json", "--accumulate", "half")
+    assert r.returncode == 0, r.stderr[-1500:]
+    snap3 = msgpack.unpackb((scene / "output" / "snapshot_3.msgpack").read_bytes(), raw=False)
+    assert snap3["hyperparams"]["accumulate"] == "half"
+    r = run(install, *common, "--maxiter", 5, "--snapshot", scene / "output" / "snapshot_3.msgpack")
+    assert r.returncode == 0, r.stderr[-1500:]
+    snap5 = msgpack.unpackb((scene / "output" / "snapshot_5.msgpack").read_bytes(), raw=False)
+    assert snap5["hyperparams"]["accumulate"] == "half"
+    # the same two steps on the checker in the half mode, from the snapshot's state
+    ctx = oracle_lib.context(accumulate=1, **SMALL_KW)
+    try:
+        ctx.init_params()
+        ctx.set_dataset(views, normals, albedos)
+        s3 = snap3["snapshot"]
+        ctx.set_params(np.frombuffer(s3["params_binary"], np.float16).astype(np.float32))
+        ctx.put("DENSITY_GRID", np.frombuffer(s3["density_grid_binary"], np.float16).astype(np.float32))
+        ctx.update_density_bitfield()
+        ctx.set_controller(3, s3["nerf"]["rgb"]["rays_per_batch"], s3["nerf"]["rgb"]["measured_batch_size_before_compaction"], 0)
+        for _ in range(2):
+            ctx.train_step()
+        np.testing.assert_array_equal(np.frombuffer(snap5["snapshot"]["params_binary"], np.uint16), ctx.get("PARAMS_EMA").view(np.uint16))
+    finally:
+        ctx.close()
+    r = run(install, *common, "--maxiter", 4, "--snapshot", scene / "output" / "snapshot_3.msgpack", "--accumulate", "fp32")
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert msgpack.unpackb((scene / "output" / "snapshot_4.msgpack").read_bytes(), raw=False)["hyperparams"]["accumulate"] == "fp32"
+    r = run(install, *common, "--maxiter", 1, "--config", "small.json", "--accumulate", "double")
+    assert r.returncode == 255 and "--accumulate takes fp32 or half" in r.stderr
