@@ -1599,10 +1599,13 @@ __device__ __forceinline__ void corner_addends(const float g1, const float g2, c
 // Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
 // global atomics pile up on a handful of lines. Each workgroup accumulates its slice of the batch into a private copy of
 // the levels' gradient tables in LDS, then flushes the non-zero entries once. ds_add_f32 retires at ~3 cycles per LANE per CU
-// (tools/probe_lds_atomics.hip; integer LDS atomics are 15x faster), so the LDS atomics are what this kernel pays for: it
-// uses the quad walk of k_grid_scatter_quad_rl below -- four lanes = (dx, feature) own K = 16 consecutive samples of the
-// ray-ordered batch and keep the four (dy, dz) corner sums in registers while the cell (37 / 27 march steps wide on levels
-// 0 / 1) does not change -- which issues a third of the LDS atomics of the earlier thread-per-4-samples form (43 -> see DESIGN.md).
+// (tools/probe_lds_atomics.hip; integer LDS atomics are 15x, ds_add_f64 6.6x faster), so it uses the quad walk of
+// k_grid_scatter_quad_rl below -- four lanes = (dx, feature) own K = 16 consecutive samples of the ray-ordered batch and keep the
+// four (dy, dz) corner sums in registers while the cell (37 / 27 march steps wide on levels 0 / 1) does not change -- which issues a
+// third of the LDS atomics of the earlier thread-per-4-samples form (43 -> 32 us). Round 5 rebuilt it on double accumulators (one lane
+// per 4 samples, all 8 corners, one feature per workgroup): 33 -> 30 us alone (walk 13.6, flush of the private tables into the same
+// ~5 k global addresses 9.2, launch + zeroing 6.6) and no change of the step, whose tail is three chains of equal length (this kernel +
+// the last optimizer chunk, the optimizer chunk of group B, the next march's k_march_write); not kept (profiles/r05_ab_scatter_lds_f64.txt).
 struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_wg; }; // levels [0, n_levels)
 
 // LDS layout: level l's table at float offset 2 * G.offsets[l]. The per-sample loads of a walk are issued four samples ahead.

@@ -21,6 +21,12 @@ __global__ __launch_bounds__(1024) void k(float* out, uint32_t per_thread, uint3
 		else if (MODE == 3) t32[e] = it;            // plain store
 		else if (MODE == 4) { float* p = reinterpret_cast<float*>(raw) + e; *p = *p + 1.0f; } // non-atomic read-modify-write
 		else if (MODE == 5) atomicAdd(reinterpret_cast<double*>(raw) + (e & 16383u), 1.0);
+		else if (MODE == 6) { typedef _Float16 h2v __attribute__((ext_vector_type(2))); const h2v one = {(_Float16)1.0f, (_Float16)1.0f};
+			(void)__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2v*)(t32 + e), one); }      // ds_pk_add_f16
+		else if (MODE == 7) unsafeAtomicAdd(reinterpret_cast<float*>(raw) + e, 1.0f);
+		else if (MODE == 8) atomicAdd(reinterpret_cast<double*>(raw) + ((e & 16383u) & ~63u) + (threadIdx.x & 63u), 1.0); // f64, one lane per bank pair: no conflicts
+		else if (MODE == 9) atomicAdd(reinterpret_cast<double*>(raw) + (e & 15u), 1.0); // f64, 16 hot entries (the coarse levels' few hundred cells)
+		else if (MODE == 10) atomicAdd(reinterpret_cast<float*>(raw) + (e & 15u), 1.0f); // f32, 16 hot entries
 	}
 	__syncthreads();
 	if (t32[threadIdx.x] == 0x7fffffffu) out[0] = 1.f;
@@ -41,6 +47,11 @@ int main() {
 	run<1>("ds atomic add u32", sink);
 	run<2>("ds atomic add u64", sink);
 	run<5>("ds atomic add f64", sink);
+	run<6>("ds pk add f16", sink);
+	run<7>("ds unsafe atomic add f32", sink);
+	run<8>("ds atomic add f64 no conflicts", sink);
+	run<9>("ds atomic add f64 16 hot", sink);
+	run<10>("ds atomic add f32 16 hot", sink);
 	run<3>("ds store b32", sink);
 	run<4>("ds load + add + store", sink);
 	return 0;
