@@ -734,3 +734,47 @@ def test_albedo_scaling_camera_loader_against_the_references_outputs(tmp_path):
         albedo_scaling.load_cameras(str(p), ["/x/00099.png"])
     with pytest.raises(ValueError):
         albedo_scaling.load_cameras("/x/cameras.bin", ["a.png"])
+
+
+def test_prepare_scaling_mode_cascade_against_the_references_outputs():
+    """tests/golden/prepare_scaling_vectors.json: the REFERENCE's `_compute_scaling` (rnb_neus2/prepare.py:44-113) on thirteen seeded loader dicts without mask files -- "none",
+    landmarks, camera centres, "auto" falling through the silhouette branch to landmarks / to the cameras (no or empty landmarks), and every mode that finds no data (or is
+    unknown) raising RuntimeError with the reference's message: centre, factor and matrix equal to float32 rounding, same dtypes, the same info lines in the same order."""
+    from rnb_neus2_amd import prepare
+
+    class Log:
+        def __init__(self):
+            self.lines = []
+
+        def info(self, msg):
+            self.lines.append(str(msg))
+
+        warning = info
+
+    with open(os.path.join(ROOT, "tests", "golden", "prepare_scaling_vectors.json")) as f:
+        fix = json.load(f)
+    assert len(fix["cases"]) == 13 and sum(c["raises"] is not None for c in fix["cases"]) == 6
+    for ci, case in enumerate(fix["cases"]):
+        data = {"views": [{"c2w": np.asarray(m, np.float32), "K": np.array([[900.0, 0, 320.0], [0, 905.0, 240.0], [0, 0, 1]], np.float32), "mask_path": "",
+                           "normal_path": "", "albedo_path": ""} for m in case["views_c2w"]]}
+        if case["landmarks"] is not None:
+            data["landmarks"] = np.asarray(case["landmarks"], np.float32).reshape(-1, 3)
+        log = Log()
+        if case["raises"] is not None:
+            assert case["raises"] == "RuntimeError"
+            with pytest.raises(RuntimeError) as ei:
+                prepare._compute_scaling(data, case["mode"], case["sphere_scale"], case["margin_px"], log)
+            assert str(ei.value) == case["message"], ci
+            assert log.lines == case["log"], ci
+            continue
+        center, factor, matrix = prepare._compute_scaling(data, case["mode"], case["sphere_scale"], case["margin_px"], log)
+        assert [str(np.asarray(center).dtype), str(np.asarray(matrix).dtype)] == case["dtypes"], (ci, case["mode"])
+        np.testing.assert_allclose(np.asarray(center, np.float64), np.asarray(case["center"]), rtol=2e-6, atol=1e-6, err_msg="center %d" % ci)
+        assert abs(float(factor) - case["factor"]) <= 2e-6 * abs(case["factor"]), (ci, factor, case["factor"])
+        np.testing.assert_allclose(np.asarray(matrix, np.float64), np.asarray(case["matrix"]), rtol=2e-6, atol=1e-6, err_msg="matrix %d" % ci)
+        assert len(log.lines) == len(case["log"]), (ci, log.lines, case["log"])
+        for mine, ref in zip(log.lines, case["log"]):
+            if ref.startswith(("Scene center:", "Scale factor:")):  # numbers: compared above; the line's shape here
+                assert mine.split(":")[0] == ref.split(":")[0], (ci, mine, ref)
+            else:
+                assert mine == ref, (ci, mine, ref)
