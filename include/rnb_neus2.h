@@ -338,8 +338,19 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *   RNB_PRIM_MARCH   in  cone_angle, max_cascade, pos 3, dir 3, t   out calc_dt(t), mip_from_pos, mip_from_dt(dt), cascaded_grid_idx_at(pos, mip),
  *                    density_grid_occupied_at (bitfield byte i = pcg32{5} draw i >> 24), distance_to_next_voxel, advance_to_next_voxel at res = 128 >> mip
  *                                                                                                        (src/testbed_nerf.cu:153-155, 301-323, 439-465, 569-583)
+ * Floating-point primitives (tests/golden/float_fixtures.json, the reference's fragments compiled without FMA contraction, as this library is):
+ *   RNB_PRIM_ACTIVATION in bits(v)     out relu(v), logistic(v), logistic'(v) = l (1 - l)   (activation_function / network_to_rgb[_derivative], testbed_nerf.cu:326-357;
+ *                                                                                             tcnn common_device.h:52-54) -- the NeuS alpha's two CDFs, the albedo and its gradient
+ *   RNB_PRIM_WARP    in  box lo hi, pos 3, dir 3, dt   out warp_position 3, warp_direction 3, unwarp_direction(warped) 3, warp_dt, unwarp_dt(warped)
+ *                                                                                                        (NerfCoordinate's fields, testbed_nerf.cu:390-437)
+ *   RNB_PRIM_LOSS    in  is_L2, target 4, prediction 4   out loss, gradient 4                              (loss_and_gradient, testbed_nerf.cu:280-299, 1389-1394)
+ *   RNB_PRIM_PIXEL   in  base_idx, n_rays, n_rays_total, n_images, w, h, snap, advance lo hi     out image_idx, x, y of nerf_random_image_pos_training with
+ *                                                                       pcg32{1337} advanced by `advance` (testbed_nerf.cu:1171-1214; no error-map CDFs)
+ *   RNB_PRIM_GRID    in  hashmap_size, resolution, pos_grid 3, bits(x), bits(scale)   out grid_index<3,2>(Hash, feature 0, ..) / 2, and pos_fract(x, scale): pos, pos_grid
+ *                                                                                                        (tcnn encodings/grid.h:113-148, common_device.h:427-434)
  * Host pointers; syncs. */
-typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4 } rnb_primitive;
+typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

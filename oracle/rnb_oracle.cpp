@@ -621,6 +621,8 @@ static inline float advance_to_next_voxel(float t, float cone_angle, const Vec3&
 	do { t += calc_dt(t, cone_angle); } while (t < t_target);
 	return t;
 }
+static inline Vec3 warp_direction(const Vec3& d) { return {(d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f}; }   // testbed_nerf.cu:413-415
+static inline Vec3 unwarp_direction(const Vec3& d) { return {d.x * 2.0f - 1.0f, d.y * 2.0f - 1.0f, d.z * 2.0f - 1.0f}; }       // testbed_nerf.cu:417-419
 static inline Vec3 warp_position(const orc_ctx_s* c, const Vec3& p) { // bounding_box.cuh:86-88
 	float diag = c->aabb_max - c->aabb_min;
 	return {(p.x - c->aabb_min) / diag, (p.y - c->aabb_min) / diag, (p.z - c->aabb_min) / diag};
@@ -926,7 +928,7 @@ void generate_training_samples(orc_ctx_s* c, uint32_t n_rays, uint32_t n_rays_to
 		ro[0] = r.o.x; ro[1] = r.o.y; ro[2] = r.o.z; ro[3] = r.d_unnorm.x; ro[4] = r.d_unnorm.y; ro[5] = r.d_unnorm.z;
 		c->numsteps[(size_t)s * 2 + 0] = steps[i];
 		c->numsteps[(size_t)s * 2 + 1] = bases[i];
-		const Vec3 wd = {(r.dir.x + 1.0f) * 0.5f, (r.dir.y + 1.0f) * 0.5f, (r.dir.z + 1.0f) * 0.5f}; // warp_direction
+		const Vec3 wd = warp_direction(r.dir);
 		float* co = &c->coords[(size_t)bases[i] * 7];
 		march(c, r, steps[i], [&](uint32_t j, const Vec3& pos, float dt) {
 			Vec3 wp = warp_position(c, pos);
@@ -941,6 +943,18 @@ void generate_training_samples(orc_ctx_s* c, uint32_t n_rays, uint32_t n_rays_to
 // ======================================================================
 
 static inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); } // common_device.h:52-54
+static inline float relu(float v) { return v > 0.0f ? v : 0.0f; }            // activation_function(.., ReLU), testbed_nerf.cu:326-335
+// The ray loss (testbed_nerf.cu:280-299, 1389-1394): L2 = sum of squares of d = prediction - target, gradient 2 d; L1 = sum of |d|, gradient copysign(1, d).
+static inline float loss_and_gradient(bool l2, const float target[4], const float prediction[4], float grad[4]) {
+	float diff[4];
+	for (int k = 0; k < 4; ++k) diff[k] = prediction[k] - target[k];
+	if (l2) {
+		for (int k = 0; k < 4; ++k) grad[k] = 2 * diff[k];
+		return diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
+	}
+	for (int k = 0; k < 4; ++k) grad[k] = copysignf(1.0f, diff[k]);
+	return fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
+}
 
 void build_light_dirs(orc_ctx_s* c) { // testbed_nerf.cu:1537-1554
 	auto radians = [](float deg) { return deg * M_PI / 180.0f; };
@@ -990,7 +1004,6 @@ static inline AlphaTerms alpha_terms(const half_t* o, float dt, const Vec3& dir,
 	a.sdf_value = h2f(o[3]);
 	a.g[0] = h2f(o[4]); a.g[1] = h2f(o[5]); a.g[2] = h2f(o[6]);
 	a.true_cos = (dir.x * a.g[0] + dir.y * a.g[1] + dir.z * a.g[2]);
-	auto relu = [](float v) { return v > 0.0f ? v : 0.0f; };
 	a.iter_cos = (float)-(relu((float)(-a.true_cos * 0.5 + 0.5)) * (1.0 - cos_anneal_ratio) + relu(-a.true_cos) * cos_anneal_ratio);
 	a.est_next = (float)(a.sdf_value + a.iter_cos * dt * 0.5);
 	float est_prev = (float)(a.sdf_value - a.iter_cos * dt * 0.5);
@@ -1087,7 +1100,7 @@ void loss_pass1(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_rays
 		float dt = unwarp_dt(coords_in[(size_t)n * 7 + 3]);
 		if (n == 0) { // BENT_DIR (testbed_nerf.cu:1645-1650)
 			Vec3 dv = v3(h2f(o[8]), h2f(o[9]), h2f(o[10]));
-			dir = normalized(v3(dv.x * 2.0f - 1.0f, dv.y * 2.0f - 1.0f, dv.z * 2.0f - 1.0f));
+			dir = normalized(unwarp_direction(dv));
 		}
 		AlphaTerms a = alpha_terms(o, dt, dir, 1.0f);
 		const float weight = a.alpha * T;
@@ -1116,14 +1129,8 @@ void loss_pass2(orc_ctx_s* c, uint32_t i, uint32_t n_rays, const RayLoss& R, uin
 	if (compacted_numsteps == 0) return; // testbed_nerf.cu:1726-1728: returns before any loss output is written
 
 	// loss (testbed_nerf.cu:1737-1802)
-	float grad[4]; float loss = 0.f;
-	for (int k = 0; k < 4; ++k) {
-		float diff = R.rgb_ray[k] - R.rgbtarget[k];
-		if (c->cfg.apply_L2) { grad[k] = 2 * diff; }
-		else { grad[k] = copysignf(1.0f, diff); }
-	}
-	if (c->cfg.apply_L2) { float d0 = R.rgb_ray[0] - R.rgbtarget[0], d1 = R.rgb_ray[1] - R.rgbtarget[1], d2 = R.rgb_ray[2] - R.rgbtarget[2], d3 = R.rgb_ray[3] - R.rgbtarget[3]; loss = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
-	else { loss = fabsf(R.rgb_ray[0] - R.rgbtarget[0]) + fabsf(R.rgb_ray[1] - R.rgbtarget[1]) + fabsf(R.rgb_ray[2] - R.rgbtarget[2]) + fabsf(R.rgb_ray[3] - R.rgbtarget[3]); }
+	float grad[4];
+	float loss = loss_and_gradient(c->cfg.apply_L2 != 0, R.rgbtarget, R.rgb_ray, grad);
 	if (c->cfg.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) grad[k] /= 2; }
 	loss *= R.mask_certainty;
 	for (int k = 0; k < 4; ++k) grad[k] *= R.mask_certainty;
@@ -2000,8 +2007,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_MARCH) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[5] = {6, 3, 1, 8, 9}, OUT_W[5] = {4, 4, 2, 3, 7};
+	if (kind < 0 || kind > RNB_PRIM_GRID) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[10] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7}, OUT_W[10] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2032,6 +2039,30 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			float t0, t1;
 			ray_intersect(&box, p, d, &t0, &t1);
 			o[0] = u(t0); o[1] = u(t1); o[2] = aabb_contains(&box, p) ? 1u : 0u;
+		} else if (kind == RNB_PRIM_ACTIVATION) {
+			const float l = logistic(f(a[0]));
+			o[0] = u(relu(f(a[0]))); o[1] = u(l); o[2] = u(l * (1 - l));
+		} else if (kind == RNB_PRIM_WARP) {
+			box.aabb_min = f(a[0]); box.aabb_max = f(a[1]);
+			const Vec3 wp = warp_position(&box, {f(a[2]), f(a[3]), f(a[4])}), wd = warp_direction({f(a[5]), f(a[6]), f(a[7])}), ud = unwarp_direction(wd);
+			const float wt = warp_dt(f(a[8]));
+			o[0] = u(wp.x); o[1] = u(wp.y); o[2] = u(wp.z); o[3] = u(wd.x); o[4] = u(wd.y); o[5] = u(wd.z); o[6] = u(ud.x); o[7] = u(ud.y); o[8] = u(ud.z); o[9] = u(wt); o[10] = u(unwarp_dt(wt));
+		} else if (kind == RNB_PRIM_LOSS) {
+			const float t[4] = {f(a[1]), f(a[2]), f(a[3]), f(a[4])}, p[4] = {f(a[5]), f(a[6]), f(a[7]), f(a[8])};
+			float g[4];
+			o[0] = u(loss_and_gradient(a[0] != 0, t, p, g));
+			o[1] = u(g[0]); o[2] = u(g[1]); o[3] = u(g[2]); o[4] = u(g[3]);
+		} else if (kind == RNB_PRIM_PIXEL) {
+			Pcg32 r{1337};
+			r.advance((int64_t)((uint64_t)a[7] | (uint64_t)a[8] << 32));
+			float xy[2];
+			random_image_pos(r, a[4], a[5], a[6] != 0, xy);
+			o[0] = image_idx(a[0], a[1], a[2], a[3]); o[1] = u(xy[0]); o[2] = u(xy[1]);
+		} else if (kind == RNB_PRIM_GRID) {
+			float pos; uint32_t cell;
+			pos_fract(f(a[5]), &pos, &cell, f(a[6]));
+			const uint32_t pg[3] = {a[2], a[3], a[4]};
+			o[0] = grid_entry(a[0], a[1], pg); o[1] = u(pos); o[2] = cell;
 		} else {
 			const float cone = f(a[0]);
 			const uint32_t max_cascade = a[1];

@@ -418,5 +418,22 @@ __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle
 }
 
 __device__ __forceinline__ float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float relu(float v) { return v > 0.0f ? v : 0.0f; } // activation_function(.., ReLU), testbed_nerf.cu:326-335
+__device__ __forceinline__ Vec3 warp_direction(const Vec3& d) { return {(d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f}; }     // testbed_nerf.cu:413-415
+__device__ __forceinline__ Vec3 unwarp_direction(const Vec3& d) { return {d.x * 2.0f - 1.0f, d.y * 2.0f - 1.0f, d.z * 2.0f - 1.0f}; }         // testbed_nerf.cu:417-419
+// The ray loss of testbed_nerf.cu:280-299, 1389-1394 on the composited rgb+ 4-vector: L2 = sum of squares, gradient 2 d; L1 = sum of |d|, gradient copysign(1, d). d = prediction - target.
+__device__ __forceinline__ float loss_and_gradient(const bool l2, const float (&target)[4], const float (&prediction)[4], float (&grad)[4]) {
+	float diff[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) diff[k] = prediction[k] - target[k];
+	if (l2) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) grad[k] = 2 * diff[k];
+		return diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
+	}
+#pragma unroll
+	for (int k = 0; k < 4; ++k) grad[k] = copysignf(1.0f, diff[k]);
+	return fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
+}
 
 } // namespace rnb

@@ -1139,8 +1139,8 @@ __device__ __forceinline__ AlphaTerms alpha_terms(const half_t* __restrict__ o, 
 	a.g[0] = h2f(o[4]); a.g[1] = h2f(o[5]); a.g[2] = h2f(o[6]);
 	a.true_cos = (dir[0] * a.g[0] + dir[1] * a.g[1] + dir[2] * a.g[2]);
 	const float r1 = (float)(-a.true_cos * 0.5 + 0.5);
-	const float relu1 = r1 > 0.0f ? r1 : 0.0f;
-	const float relu2 = -a.true_cos > 0.0f ? -a.true_cos : 0.0f;
+	const float relu1 = relu(r1);
+	const float relu2 = relu(-a.true_cos);
 	a.iter_cos = (float)-(relu1 * (1.0 - cos_anneal_ratio) + relu2 * cos_anneal_ratio);
 	a.est_next = (float)(a.sdf_value + a.iter_cos * dt * 0.5);
 	const float est_prev = (float)(a.sdf_value - a.iter_cos * dt * 0.5);
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs 
 	// part 1: samples [0, k1) of the ray; part 2: [k1, steps) (every lane keeps the samples it has in the one-launch form)
 	const uint32_t j_lo = a.part == 2 ? min(steps, a.k1) : 0u, j_hi = a.part == 1 ? min(steps, a.k1) : steps;
 	if (j_lo >= j_hi) return;
-	const Vec3 wd = {(dir.x + 1.0f) * 0.5f, (dir.y + 1.0f) * 0.5f, (dir.z + 1.0f) * 0.5f}; // warp_direction, testbed_nerf.cu:413-415
+	const Vec3 wd = warp_direction(dir);
 	const float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
 	float* co = a.coords + (size_t)base * 7;
 	for (uint32_t j = j_lo / LR * LR + lane; j < j_hi; j += LR) {
@@ -1389,7 +1389,7 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 	{ // BENT_DIR (testbed_nerf.cu:1645-1650): the direction the network echoed for the ray's first sample
 		half_t o0[16];
 		load_out16(net, o0);
-		const Vec3 dv = normalized(v3(h2f(o0[8]) * 2.0f - 1.0f, h2f(o0[9]) * 2.0f - 1.0f, h2f(o0[10]) * 2.0f - 1.0f));
+		const Vec3 dv = normalized(unwarp_direction(v3(h2f(o0[8]), h2f(o0[9]), h2f(o0[10]))));
 		dir[0] = dv.x; dir[1] = dv.y; dir[2] = dv.z;
 	}
 	float T = 1.f;
@@ -1557,21 +1557,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_compact_offsets(const uint32_t
 struct RayGrad { float grad[4], weight_sum, gradient_weight_sum, light[3], dir[3], rgb_ray[4]; }; // 16 floats
 static_assert(sizeof(RayGrad) == 64, "RayGrad is read as four 16-byte words");
 __device__ __forceinline__ void pass2_ray_terms(const LossFlags& F, const RayLoss& R, const float gn, RayGrad& G, float& loss_row, float& mask_row) {
-	float loss = 0.f;
-	{
-		float diff[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) diff[k] = R.rgb_ray[k] - R.rgbtarget[k];
-		if (F.apply_L2) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) G.grad[k] = 2 * diff[k];
-			loss = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2] + diff[3] * diff[3];
-		} else {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) G.grad[k] = copysignf(1.0f, diff[k]);
-			loss = fabsf(diff[0]) + fabsf(diff[1]) + fabsf(diff[2]) + fabsf(diff[3]);
-		}
-	}
+	float loss = loss_and_gradient(F.apply_L2 != 0, R.rgbtarget, R.rgb_ray, G.grad);
 	if (F.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) G.grad[k] /= 2; }
 	loss *= R.mask_certainty;
 #pragma unroll
@@ -2066,7 +2052,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[5] = {6, 3, 1, 8, 9}, PRIM_OUT_WORDS[5] = {4, 4, 2, 3, 7};
+constexpr uint32_t PRIM_IN_WORDS[10] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7}, PRIM_OUT_WORDS[10] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2099,6 +2085,29 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		float t0, t1;
 		ray_intersect(A, p, d, &t0, &t1);
 		o[0] = u(t0); o[1] = u(t1); o[2] = aabb_contains(A, p) ? 1u : 0u;
+	} else if (kind == RNB_PRIM_ACTIVATION) {
+		const float l = logistic(f(a[0]));
+		o[0] = u(relu(f(a[0]))); o[1] = u(l); o[2] = u(l * (1 - l));
+	} else if (kind == RNB_PRIM_WARP) {
+		SceneAabb A; A.mn = f(a[0]); A.mx = f(a[1]); A.cone_angle = 0.f; A.max_cascade = 0;
+		const Vec3 wp = warp_position(A, {f(a[2]), f(a[3]), f(a[4])}), wd = warp_direction({f(a[5]), f(a[6]), f(a[7])}), ud = unwarp_direction(wd);
+		const float wt = warp_dt(f(a[8]));
+		o[0] = u(wp.x); o[1] = u(wp.y); o[2] = u(wp.z); o[3] = u(wd.x); o[4] = u(wd.y); o[5] = u(wd.z); o[6] = u(ud.x); o[7] = u(ud.y); o[8] = u(ud.z); o[9] = u(wt); o[10] = u(unwarp_dt(wt));
+	} else if (kind == RNB_PRIM_LOSS) {
+		const float t[4] = {f(a[1]), f(a[2]), f(a[3]), f(a[4])}, p[4] = {f(a[5]), f(a[6]), f(a[7]), f(a[8])};
+		float g[4];
+		o[0] = u(loss_and_gradient(a[0] != 0, t, p, g));
+		o[1] = u(g[0]); o[2] = u(g[1]); o[3] = u(g[2]); o[4] = u(g[3]);
+	} else if (kind == RNB_PRIM_PIXEL) {
+		Pcg32 r{1337};
+		r.advance((int64_t)((uint64_t)a[7] | (uint64_t)a[8] << 32));
+		float xy[2];
+		random_image_pos(r, a[4], a[5], a[6] != 0, xy);
+		o[0] = image_idx(a[0], a[1], a[2], a[3]); o[1] = u(xy[0]); o[2] = u(xy[1]);
+	} else if (kind == RNB_PRIM_GRID) {
+		float pos; uint32_t cell;
+		pos_fract(f(a[5]), f(a[6]), &pos, &cell);
+		o[0] = grid_entry(a[0], a[1], a[2], a[3], a[4]); o[1] = u(pos); o[2] = cell;
 	} else {
 		const float cone = f(a[0]);
 		const uint32_t max_cascade = a[1];

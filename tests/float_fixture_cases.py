@@ -1,0 +1,73 @@
+"""tests/golden/float_fixtures.json (outputs of the reference's host-compilable FLOATING-POINT fragments, tests/golden/make_float_fixtures.py) as items for
+rnb_eval_primitives / orc_eval_primitives: `check(ctx, exact_exp)` evaluates every fixture through ctx.eval_primitives and compares.
+exact_exp: the logistic goes through expf(), which the CPU checker shares with the fragment (same libm: bit for bit) and the GPU does not (device expf: compared
+within 4 ulp of the value, its derivative l (1 - l) within 8 ulp of l). Everything else -- products, sums, quotients, floors, copysigns, integer index
+arithmetic -- is IEEE arithmetic without contraction on both sides: bit for bit everywhere."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "float_fixtures.json")))
+
+
+def _ulp_distance(got, want):
+    """Distance in units of the last place between float32 bit patterns (sign-magnitude order)."""
+    def key(b):
+        b = b.astype(np.int64)
+        return np.where(b & 0x80000000, 0x80000000 - b, b)
+    return np.abs(key(got) - key(want))
+
+
+def check(ctx, exact_exp):
+    fx = load()
+    n = {}
+    # ---- activations: relu, logistic (the NeuS alpha's CDFs; the albedo), its derivative
+    a = np.array(fx["activation_val_relu_logistic_rgb_rgbderivative"], dtype=np.uint32).reshape(-1, 5)
+    assert np.array_equal(a[:, 2], a[:, 3])  # activation_function(Logistic) and network_to_rgb(Logistic) are the same tcnn::logistic
+    out = ctx.eval_primitives("ACTIVATION", a[:, :1])
+    assert np.array_equal(out[:, 0], a[:, 1]), "relu"
+    if exact_exp:
+        assert np.array_equal(out[:, 1], a[:, 2]), "logistic"
+        assert np.array_equal(out[:, 2], a[:, 4]), "logistic derivative"
+    else:
+        worst = int(np.max(_ulp_distance(out[:, 1], a[:, 2])))
+        assert worst <= 4, ("logistic", worst)  # device expf (<= 1 ulp) + the sum + the quotient against libm's: <= 4 ulp of the value
+        l = a[:, 2].view(np.float32).astype(np.float64)
+        d_got, d_want = out[:, 2].view(np.float32).astype(np.float64), a[:, 4].view(np.float32).astype(np.float64)
+        # l (1 - l): a 4-ulp change of l moves the product by <= 4 ulp of l (the factor 1 - l is exact or moves by as much in absolute terms)
+        assert np.all(np.abs(d_got - d_want) <= 8 * float(np.spacing(np.float32(1.0))) * np.maximum(l, 1e-30) + 1e-45), "logistic derivative"
+    n["activation"] = len(a)
+    # ---- NerfCoordinate warps
+    w = np.array(fx["warp_lo_hi_p3_d3_dt_warpedp3_unwarpedp3_warpedd3_unwarpedd3_warpeddt_unwarpeddt"], dtype=np.uint32).reshape(-1, 23)
+    out = ctx.eval_primitives("WARP", w[:, :9])
+    assert np.array_equal(out[:, 0:3], w[:, 9:12]), "warp_position"
+    assert np.array_equal(out[:, 3:6], w[:, 15:18]), "warp_direction"
+    assert np.array_equal(out[:, 6:9], w[:, 18:21]), "unwarp_direction"
+    assert np.array_equal(out[:, 9], w[:, 21]), "warp_dt"
+    assert np.array_equal(out[:, 10], w[:, 22]), "unwarp_dt"
+    # (the fixture's own round trip: unwarp_position(warp_position(p)) comes back to p within the box's rounding)
+    assert np.max(np.abs(w[:, 12:15].view(np.float32) - w[:, 2:5].view(np.float32))) < 1e-6
+    n["warp"] = len(w)
+    # ---- the ray loss
+    lo = np.array(fx["loss_isL2_target4_prediction4_loss_gradient4"], dtype=np.uint32).reshape(-1, 14)
+    out = ctx.eval_primitives("LOSS", lo[:, :9])
+    assert np.array_equal(out, lo[:, 9:14]), "loss / gradient"
+    n["loss"] = len(lo)
+    # ---- which image, which pixel
+    px = np.array(fx["pixel_base_nrays_total_nimg_w_h_snap_advlo_advhi_img_x_y"], dtype=np.uint32).reshape(-1, 12)
+    out = ctx.eval_primitives("PIXEL", px[:, :9])
+    assert np.array_equal(out, px[:, 9:12]), "image index / pixel position"
+    n["pixel"] = len(px)
+    # ---- hash-grid index and fraction
+    g = np.array(fx["grid_size_res_pg3_index0_index1_x_scale_pos_cell"], dtype=np.uint32).reshape(-1, 11)
+    assert np.array_equal(g[:, 6], g[:, 5] + 1) and np.all(g[:, 5] % 2 == 0)  # features interleaved: entry * 2 + feature
+    out = ctx.eval_primitives("GRID", g[:, [0, 1, 2, 3, 4, 7, 8]])
+    assert np.array_equal(out[:, 0], g[:, 5] // 2), "grid_index"
+    assert np.array_equal(out[:, 1], g[:, 9]) and np.array_equal(out[:, 2], g[:, 10]), "pos_fract"
+    n["grid"] = len(g)
+    return n

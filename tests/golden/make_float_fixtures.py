@@ -1,0 +1,226 @@
+"""Writes tests/golden/float_fixtures.json: outputs of the host-compilable FLOATING-POINT fragments of the REFERENCE on the hot path --
+the scalar device functions its kernels call for the hash-grid index / fraction, the coordinate warps of `NerfCoordinate`, the activations of the NeuS alpha
+and of the albedo, the L1 / L2 ray loss, and the pixel / image choice of a training ray -- produced, like int_fixtures.json, by compiling those fragments (read
+from /root/reference at run time, never copied into this repository) with g++ in the build container and running them on seeded inputs. Tests read only the JSON.
+
+  python tests/golden/make_float_fixtures.py
+
+What is taken, verbatim (function or struct body located by its signature, braces matched):
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/common_device.h   logistic, identity_fun, pos_fract (the 3-argument-functor-free form: pos, pos_grid)
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h          clamp
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h  fast_hash, grid_index  (enum GridType restated: its three names)
+  dependencies/neus2_tcnn/dependencies/pcg32/pcg32.h             struct pcg32
+  include/neural-graphics-primitives/random_val.cuh              random_val_2d; sobol .. ld_random_val and common.h binary_search, testbed_nerf.cu sample_cdf_2d (the error-map branches of
+                                                                 image_idx / nerf_random_image_pos_training: compiled so that those two are taken unchanged, not reached -- null CDFs)
+  include/neural-graphics-primitives/bounding_box.cuh            BoundingBox::diag, ::relative_pos
+  include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
+  src/testbed_nerf.cu                                            NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
+                                                                 activation_function, network_to_rgb, network_to_rgb_derivative, warp_position, unwarp_position, warp_direction,
+                                                                 unwarp_direction, warp_dt, unwarp_dt, nerf_random_image_pos_training, image_idx
+  include/neural-graphics-primitives/common.h                    enum ELossType, enum ENerfActivation (restated: the enumerators in the file's order, checked against its text)
+The CUDA decorations are defined away, `__expf` is `expf`, Eigen comes from the reference's vendored dependencies/eigen. What the host build cannot reproduce of the
+device: nvcc contracts a * b + c to an FMA by default and its expf is not libm's -- the library and the checker are built WITHOUT contraction (-ffp-contract=off), so the
+products / sums here are the ones they compute; the expf-based values are compared with an ulp tolerance on the GPU and bit for bit against the CPU checker (same libm).
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_int_fixtures import REF, HERE, fragment  # noqa: E402
+
+
+def enum_names(path, head):
+    """The enumerators of `enum class X : int {...}` in the reference's header, in order (the restated enum below must list the same names)."""
+    src = open(os.path.join(REF, path)).read()
+    i = src.index(head)
+    body = src[src.index("{", i) + 1:src.index("}", i)]
+    return [t.strip().split("=")[0].strip() for t in body.split(",") if t.strip()]
+
+
+def build_program():
+    f = fragment
+    tn = "src/testbed_nerf.cu"
+    cd = "dependencies/neus2_tcnn/include/tiny-cuda-nn/common_device.h"
+    gh = "dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h"
+    bb = "include/neural-graphics-primitives/bounding_box.cuh"
+    rv = "include/neural-graphics-primitives/random_val.cuh"
+    src_tn = open(os.path.join(REF, tn)).read()
+    uniform_fraction = src_tn.split("static constexpr float UNIFORM_SAMPLING_FRACTION =")[1].split(";")[0].strip()
+    loss_names = enum_names("include/neural-graphics-primitives/common.h", "enum class ELossType")
+    act_names = enum_names("include/neural-graphics-primitives/common.h", "enum class ENerfActivation")
+    grid_names = enum_names(gh, "enum class GridType")
+    assert loss_names[:2] == ["L2", "L1"] and act_names == ["None", "ReLU", "Logistic", "Exponential"] and grid_names == ["Hash", "Dense", "Tiled"], (loss_names, act_names, grid_names)
+    parts = ["""
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <cassert>
+#include <vector>
+#include <Eigen/Dense>
+#define __host__
+#define __device__
+#define __restrict__
+#define TCNN_HOST_DEVICE
+#define NGP_HOST_DEVICE
+#define __expf expf
+#define NGP_PRAGMA_UNROLL
+#define PCG32_DEFAULT_STATE  0x853c49e6748fea9bULL
+#define PCG32_DEFAULT_STREAM 0xda3e39cb94b95bdbULL
+#define PCG32_MULT           0x5851f42d4c957f2dULL
+enum class ELossType : int { """ + ", ".join(loss_names) + """ };
+enum class ENerfActivation : int { """ + ", ".join(act_names) + """ };
+namespace tcnn {
+enum class GridType { """ + ", ".join(grid_names) + """ };
+template <typename T> """ + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "TCNN_HOST_DEVICE T clamp(T val, T lower, T upper)"),
+             f("dependencies/neus2_tcnn/dependencies/pcg32/pcg32.h", "struct pcg32 {") + ";",
+             "using default_rng_t = pcg32;",
+             f(cd, "__host__ __device__ inline float logistic(const float x)"),
+             f(cd, "__device__ inline float identity_fun(float val)"),
+             "template <typename F>\n" + f(cd, "__device__ inline void pos_fract(const float input, float* pos, uint32_t* pos_grid, float scale, F interpolation_fun)"),
+             "template <uint32_t N_DIMS>\n" + f(gh, "__device__ uint32_t fast_hash(const uint32_t pos_grid[N_DIMS])"),
+             "template <uint32_t N_DIMS, uint32_t N_FEATURES_PER_LEVEL>\n" + f(gh, "__device__ uint32_t grid_index(const GridType grid_type, const uint32_t feature, const uint32_t hashmap_size, const uint32_t grid_resolution, const uint32_t pos_grid[N_DIMS])"),
+             "}\nusing namespace Eigen;\nusing default_rng_t = tcnn::default_rng_t;",
+             "template <typename RNG>\n" + f("include/neural-graphics-primitives/random_val.cuh", "inline __host__ __device__ Eigen::Vector2f random_val_2d(RNG& rng)"),
+             f("include/neural-graphics-primitives/nerf.h", "inline constexpr __device__ uint32_t NERF_GRIDSIZE()"),
+             "struct BoundingBox { Eigen::Vector3f min, max;\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f diag() const") + "\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f relative_pos(const Eigen::Vector3f& pos) const") + "};",
+             # what image_idx / nerf_random_image_pos_training call when error-map CDFs are given (never here: null pointers) -- the reference's own functions, so that the two compile unchanged
+             f(rv, "inline __host__ __device__ uint32_t sobol(uint32_t index, uint32_t dim)"), f(rv, "inline __host__ __device__ uint32_t hash_combine(uint32_t seed, uint32_t v)"),
+             f(rv, "inline __host__ __device__ uint32_t reverse_bits(uint32_t x)"), f(rv, "inline __host__ __device__ uint32_t laine_karras_permutation(uint32_t x, uint32_t seed)"),
+             f(rv, "inline __host__ __device__ uint32_t nested_uniform_scramble_base2(uint32_t x, uint32_t seed)"),
+             f(rv, "inline __host__ __device__ float ld_random_val(uint32_t index, uint32_t seed, uint32_t dim = 0)"),
+             f("include/neural-graphics-primitives/common.h", "inline NGP_HOST_DEVICE uint32_t binary_search(float val, const float* data, uint32_t length)"),
+             "static constexpr float UNIFORM_SAMPLING_FRACTION = %s;" % uniform_fraction,
+             f(tn, "inline __device__ Vector2f sample_cdf_2d(")]
+    for sig in ("inline constexpr __device__ uint32_t NERF_STEPS()", "inline constexpr __device__ uint32_t NERF_CASCADES()", "inline constexpr __device__ float SQRT3()",
+                "inline constexpr __device__ float STEPSIZE()", "inline constexpr __device__ float MIN_CONE_STEPSIZE()",
+                "struct LossAndGradient {"):
+        parts.append(f(tn, sig) + (";" if sig.startswith("struct") else ""))
+    for sig in ("inline __device__ Array4f copysign(const Array4f& a, const Array4f& b)", "inline __device__ LossAndGradient mse_loss(const Array4f& target, const Array4f& prediction)",
+                "inline __device__ LossAndGradient l1_loss(const Array4f& target, const Array4f& prediction)",
+                "__device__ LossAndGradient loss_and_gradient(const Vector4f& target, const Vector4f& prediction, ELossType loss_type)",
+                "__device__ float activation_function(float val, ENerfActivation activation)", "__device__ float network_to_rgb(float val, ENerfActivation activation)",
+                "__device__ float network_to_rgb_derivative(float val, ENerfActivation activation)",
+                "__device__ Vector3f warp_position(const Vector3f& pos, const BoundingBox& aabb)", "__device__ Vector3f unwarp_position(const Vector3f& pos, const BoundingBox& aabb)",
+                "__host__ __device__ Vector3f warp_direction(const Vector3f& dir)", "__device__ Vector3f unwarp_direction(const Vector3f& dir)",
+                "__device__ float warp_dt(float dt)", "__device__ float unwarp_dt(float dt)",
+                "inline __device__ Vector2f nerf_random_image_pos_training(", "inline __device__ uint32_t image_idx("):
+        parts.append(f(tn, sig).replace("float* __restrict__ pdf = nullptr", "float* pdf = nullptr").replace("const float* __restrict__ cdf = nullptr", "const float* cdf = nullptr"))
+    parts.append(r"""
+static uint32_t fb(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float bf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static void arr_u(const char* name, const std::vector<uint32_t>& v, bool last = false) { printf("\"%s\": [", name); for (size_t i = 0; i < v.size(); ++i) printf("%u%s", v[i], i + 1 < v.size() ? "," : ""); printf("]%s\n", last ? "" : ","); }
+int main() {
+	printf("{\n");
+	tcnn::pcg32 gen{20240930};
+	auto uni = [&](float lo, float hi) { return lo + (hi - lo) * gen.next_float(); };
+	{ // ---- activations of the loss kernel (testbed_nerf.cu:968-975 ReLU / Logistic through activation_function; 1620 network_to_rgb; its derivative in the backward part)
+		std::vector<uint32_t> out;
+		std::vector<float> vals = {0.0f, -0.0f, 1.0f, -1.0f, 1e-8f, -1e-8f, 0.5f, -0.5f, 10.0f, -10.0f, 16.5f, -16.5f, 30.0f, -30.0f, 87.0f, -87.0f, 88.8f, -88.8f, 100.0f, -100.0f, 1e4f, -1e4f};
+		for (int k = 0; k < 234; ++k) vals.push_back(uni(-20.0f, 20.0f));
+		for (float v : vals) {
+			out.push_back(fb(v));
+			out.push_back(fb(activation_function(v, ENerfActivation::ReLU)));
+			out.push_back(fb(activation_function(v, ENerfActivation::Logistic)));
+			out.push_back(fb(network_to_rgb(v, ENerfActivation::Logistic)));
+			out.push_back(fb(network_to_rgb_derivative(v, ENerfActivation::Logistic)));
+		}
+		arr_u("activation_val_relu_logistic_rgb_rgbderivative", out);
+	}
+	{ // ---- NerfCoordinate warps (testbed_nerf.cu:1366-1373 writes them, 1641-1648 reads them back)
+		std::vector<uint32_t> out;
+		const float boxes[3][2] = {{0.0f, 1.0f}, {-0.5f, 1.5f}, {-1.5f, 2.5f}};
+		const float max_stepsize = MIN_CONE_STEPSIZE() * (1 << (NERF_CASCADES() - 1));
+		for (int k = 0; k < 192; ++k) {
+			const float* b = boxes[k % 3];
+			BoundingBox box{Vector3f::Constant(b[0]), Vector3f::Constant(b[1])};
+			Vector3f p{uni(b[0], b[1]), uni(b[0], b[1]), uni(b[0], b[1])};
+			Vector3f d = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized();
+			float dt = k < 8 ? (k % 2 ? max_stepsize : MIN_CONE_STEPSIZE()) : uni(MIN_CONE_STEPSIZE(), max_stepsize);
+			if (k == 8) p = Vector3f::Constant(b[0]);
+			if (k == 9) p = Vector3f::Constant(b[1]);
+			Vector3f wp = warp_position(p, box), up = unwarp_position(wp, box), wd = warp_direction(d), ud = unwarp_direction(wd);
+			float wt = warp_dt(dt), ut = unwarp_dt(wt);
+			for (float v : {b[0], b[1], p.x(), p.y(), p.z(), d.x(), d.y(), d.z(), dt, wp.x(), wp.y(), wp.z(), up.x(), up.y(), up.z(), wd.x(), wd.y(), wd.z(), ud.x(), ud.y(), ud.z(), wt, ut}) out.push_back(fb(v));
+		}
+		arr_u("warp_lo_hi_p3_d3_dt_warpedp3_unwarpedp3_warpedd3_unwarpedd3_warpeddt_unwarpeddt", out);
+	}
+	{ // ---- the ray loss (testbed_nerf.cu:1389-1394, called at 1800 with the composited rgb+ vector and its target)
+		std::vector<uint32_t> out;
+		for (int k = 0; k < 128; ++k) {
+			Vector4f t{uni(0, 1), uni(0, 1), uni(0, 1), uni(0, 3)}, p{uni(0, 1), uni(0, 1), uni(0, 1), uni(0, 3)};
+			if (k < 8) p[k % 4] = t[k % 4];            // a zero difference: copysign(1, +0)
+			if (k >= 8 && k < 12) { t[k % 4] = 0.25f; p[k % 4] = 0.25f - 0.0f; t[(k + 1) % 4] = p[(k + 1) % 4] + 0.0f; }
+			const ELossType type = (k & 1) ? ELossType::L1 : ELossType::L2;
+			LossAndGradient lg = loss_and_gradient(t, p, type);
+			out.push_back(type == ELossType::L2 ? 1u : 0u);
+			for (int c = 0; c < 4; ++c) out.push_back(fb(t[c]));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(p[c]));
+			out.push_back(fb(lg.loss));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(lg.gradient[c]));
+		}
+		arr_u("loss_isL2_target4_prediction4_loss_gradient4", out);
+	}
+	{ // ---- which image and which pixel a training ray takes (testbed_nerf.cu:1255-1262: image_idx, then the ray's generator advanced by i * 8, then the position)
+		std::vector<uint32_t> out;
+		const uint32_t shapes[4][2] = {{800, 800}, {256, 256}, {612, 512}, {1, 7}};
+		for (int k = 0; k < 256; ++k) {
+			const uint32_t n_rays = k < 4 ? 1u : 1u + gen.next_uint() % 300000u;
+			const uint32_t base = gen.next_uint() % n_rays;
+			const uint32_t total = k % 5 == 0 ? 0u : (k % 5 == 1 ? 4294967295u - gen.next_uint() % 1000u : gen.next_uint());
+			const uint32_t n_img = k % 7 == 0 ? 1u : 1u + gen.next_uint() % 100u;
+			const uint32_t w = shapes[k % 4][0], h = shapes[k % 4][1], snap = (k / 4) % 2;
+			const uint64_t seed = 1337, adv = (uint64_t)(base + total) * 8;
+			tcnn::pcg32 r{seed};
+			r.advance((int64_t)adv);
+			const uint32_t img = image_idx(base, n_rays, total, n_img);
+			Vector2f xy = nerf_random_image_pos_training(r, Vector2i{(int)w, (int)h}, snap != 0, nullptr, nullptr, Vector2i{0, 0}, img);
+			for (uint32_t v : {base, n_rays, total, n_img, w, h, snap, (uint32_t)adv, (uint32_t)(adv >> 32), img, fb(xy.x()), fb(xy.y())}) out.push_back(v);
+		}
+		arr_u("pixel_base_nrays_total_nimg_w_h_snap_advlo_advhi_img_x_y", out);
+	}
+	{ // ---- hash-grid index and fraction (grid.h:113-148, common_device.h:427-434 as called by kernel_grid with identity_fun: pos = x * scale + 0.5)
+		std::vector<uint32_t> out;
+		const uint32_t tables[8][2] = {{4096, 16}, {13824, 24}, {39304, 34}, {125000, 50}, {373248, 72}, {524288, 104}, {524288, 971}, {524288, 2049}};
+		for (int k = 0; k < 512; ++k) {
+			const uint32_t size = tables[k % 8][0], res = tables[k % 8][1];
+			uint32_t pg[3] = {gen.next_uint() % (res + 1), gen.next_uint() % (res + 1), gen.next_uint() % (res + 1)};
+			if (k < 8) { pg[0] = pg[1] = pg[2] = res; }      // the far corner of the last cell
+			if (k >= 8 && k < 16) { pg[0] = pg[1] = pg[2] = 0; }
+			const uint32_t i0 = tcnn::grid_index<3, 2>(tcnn::GridType::Hash, 0, size, res, pg), i1 = tcnn::grid_index<3, 2>(tcnn::GridType::Hash, 1, size, res, pg);
+			const float x = k % 16 == 15 ? 1.0f : (k % 16 == 14 ? 0.0f : gen.next_float()), scale = (float)(res - 1) - (k % 3 == 0 ? 0.0f : 0.37f * gen.next_float());
+			float pos; uint32_t cell;
+			tcnn::pos_fract(x, &pos, &cell, scale, tcnn::identity_fun);
+			for (uint32_t v : {size, res, pg[0], pg[1], pg[2], i0, i1, fb(x), fb(scale), fb(pos), cell}) out.push_back(v);
+		}
+		arr_u("grid_size_res_pg3_index0_index1_x_scale_pos_cell", out, true);
+	}
+	printf("}\n");
+	return 0;
+}
+""")
+    return "\n".join(parts)
+
+
+def main():
+    prog = build_program()
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "float_fixtures.cpp")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "float_fixtures")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
+        text = subprocess.check_output([exe]).decode()
+    data = json.loads(text)
+    data = {"_source": "tests/golden/make_float_fixtures.py: floating-point fragments of /root/reference compiled with g++ (-ffp-contract=off) in the build container "
+                       "(see the script's header); floats as IEEE-754 bit patterns", **data}
+    out = os.path.join(HERE, "float_fixtures.json")
+    with open(out, "w") as f:
+        json.dump(data, f, separators=(",", ":"))
+    print("wrote", out, {k: len(v) for k, v in data.items() if isinstance(v, list)}, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

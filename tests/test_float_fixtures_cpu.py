@@ -1,0 +1,23 @@
+"""The CPU checker's floating-point primitives on the hot path (hash-grid index / fraction, NerfCoordinate warps, the activations of the NeuS alpha and of the
+albedo, the L1 / L2 ray loss, image / pixel choice of a ray) against the outputs of the REFERENCE's own host-compilable fragments
+(tests/golden/float_fixtures.json, written by tests/golden/make_float_fixtures.py in the build container): bit for bit. The same items run through the HIP
+library in tests/test_gpu_parity.py."""
+from tests import float_fixture_cases, oracle_lib
+
+COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512}
+
+
+def test_oracle_float_primitives_match_the_reference_fragments():
+    c = oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10)
+    try:
+        n = float_fixture_cases.check(c, exact_exp=True)
+    finally:
+        c.close()
+    assert n == COUNTS
+
+
+def test_float_fixture_is_what_its_generator_says():
+    fx = float_fixture_cases.load()
+    assert "make_float_fixtures.py" in fx["_source"] and "-ffp-contract=off" in fx["_source"]
+    assert set(fx) == {"_source", "activation_val_relu_logistic_rgb_rgbderivative", "warp_lo_hi_p3_d3_dt_warpedp3_unwarpedp3_warpedd3_unwarpedd3_warpeddt_unwarpeddt",
+                       "loss_isL2_target4_prediction4_loss_gradient4", "pixel_base_nrays_total_nimg_w_h_snap_advlo_advhi_img_x_y", "grid_size_res_pg3_index0_index1_x_scale_pos_cell"}

@@ -106,6 +106,16 @@ def test_device_primitives_match_the_reference_fragments(pair):
     assert n == {"pcg32": 44, "morton": 64, "srgb": 256, "ray_box": 96, "march": 128}
 
 
+def test_device_float_primitives_match_the_reference_fragments(pair):
+    """The floating-point device functions the kernels call -- hash-grid index and fraction, the NerfCoordinate warps, relu / logistic (the NeuS alpha's CDFs, the
+    albedo) and the logistic's derivative, the L1 / L2 ray loss with its gradient, image and pixel of a training ray -- against what the reference's own
+    host-compilable fragments return (tests/golden/float_fixtures.json): bit for bit, except the expf-based logistic (device expf: within 4 ulp) and its derivative."""
+    from tests import float_fixture_cases
+    from tests.test_float_fixtures_cpu import COUNTS
+    gpu, _ = pair
+    assert float_fixture_cases.check(gpu, exact_exp=False) == COUNTS
+
+
 def test_density_grid_update(pair):
     gpu, cpu = pair
     for c in pair:
