@@ -348,9 +348,11 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *                                                                       pcg32{1337} advanced by `advance` (testbed_nerf.cu:1171-1214; no error-map CDFs)
  *   RNB_PRIM_GRID    in  hashmap_size, resolution, pos_grid 3, bits(x), bits(scale)   out grid_index<3,2>(Hash, feature 0, ..) / 2, and pos_fract(x, scale): pos, pos_grid
  *                                                                                                        (tcnn encodings/grid.h:113-148, common_device.h:427-434)
+ *   RNB_PRIM_READ_RGBA in w, h (w h <= 14), bits(x), bits(y), 28 words = the image, RGBA16, two words per pixel    out read_rgba(pos) r g b a, and the test
+ *                                                                       `red <= 0` of testbed_nerf.cu:1264 (common_device.cuh:621-627, 665-700)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

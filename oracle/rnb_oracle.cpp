@@ -2007,8 +2007,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_GRID) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[10] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7}, OUT_W[10] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3};
+	if (kind < 0 || kind > RNB_PRIM_READ_RGBA) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[11] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32}, OUT_W[11] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2058,6 +2058,14 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			float xy[2];
 			random_image_pos(r, a[4], a[5], a[6] != 0, xy);
 			o[0] = image_idx(a[0], a[1], a[2], a[3]); o[1] = u(xy[0]); o[2] = u(xy[1]);
+		} else if (kind == RNB_PRIM_READ_RGBA) {
+			rnb_view m{};
+			m.width = a[0]; m.height = a[1];
+			const float xy[2] = {f(a[2]), f(a[3])};
+			float cl[4];
+			read_rgba(xy, m, reinterpret_cast<const uint16_t*>(a + 4), cl); // the item's own words are the image: RGBA16, two words per pixel
+			o[0] = u(cl[0]); o[1] = u(cl[1]); o[2] = u(cl[2]); o[3] = u(cl[3]);
+			o[4] = cl[0] <= 0.0f ? 1u : 0u; // the test of testbed_nerf.cu:1264
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

@@ -2052,7 +2052,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[10] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7}, PRIM_OUT_WORDS[10] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3};
+constexpr uint32_t PRIM_IN_WORDS[11] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32}, PRIM_OUT_WORDS[11] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2104,6 +2104,14 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		float xy[2];
 		random_image_pos(r, a[4], a[5], a[6] != 0, xy);
 		o[0] = image_idx(a[0], a[1], a[2], a[3]); o[1] = u(xy[0]); o[2] = u(xy[1]);
+	} else if (kind == RNB_PRIM_READ_RGBA) {
+		ViewDev m{};
+		m.width = a[0]; m.height = a[1];
+		const float xy[2] = {f(a[2]), f(a[3])};
+		float c[4];
+		read_rgba(xy, m, reinterpret_cast<const uint16_t*>(a + 4), c); // the item's own words are the image: RGBA16, two words per pixel
+		o[0] = u(c[0]); o[1] = u(c[1]); o[2] = u(c[2]); o[3] = u(c[3]);
+		o[4] = red_is_nonpositive(xy, m, reinterpret_cast<const uint16_t*>(a + 4)) ? 1u : 0u;
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

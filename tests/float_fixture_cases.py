@@ -70,4 +70,58 @@ def check(ctx, exact_exp):
     assert np.array_equal(out[:, 0], g[:, 5] // 2), "grid_index"
     assert np.array_equal(out[:, 1], g[:, 9]) and np.array_equal(out[:, 2], g[:, 10]), "pos_fract"
     n["grid"] = len(g)
+    # ---- a pixel of a training image: position -> pixel, the sentinel word, sRGB decode (pow: 4 ulp on the GPU), alpha premultiplication, the red <= 0 test
+    rp = np.array(fx["readrgba_w_h_x_y_pixels28_rgba4_rednonpositive"], dtype=np.uint32).reshape(-1, 37)
+    out = ctx.eval_primitives("READ_RGBA", rp[:, :32])
+    assert np.array_equal(out[:, 3], rp[:, 35]) and np.array_equal(out[:, 4], rp[:, 36]), "alpha / red <= 0"
+    if exact_exp:
+        assert np.array_equal(out[:, :3], rp[:, 32:35]), "read_rgba"
+    else:
+        assert int(np.max(_ulp_distance(out[:, :3], rp[:, 32:35]))) <= 4, "read_rgba"
+        no_pow = (rp[:, 32:35].view(np.float32) <= 0.0) | (rp[:, 35:36].view(np.float32) == 0.0)  # sentinel, transparent, zero channel: exact
+        assert np.array_equal(out[:, :3][no_pow], rp[:, 32:35][no_pow])
+    assert np.count_nonzero(rp[:, 32].view(np.float32) == -1.0) >= 5 and np.count_nonzero(rp[:, 36]) >= 20  # the fixture reaches the sentinel and the red test
+    n["read_rgba"] = len(rp)
     return n
+
+
+def check_level_tables(make_context):
+    """The hash grid's parameter layout -- per level resolution, scale (this fork: resolution - 1) and table offset -- of ten encoding configurations against the level
+    loop of the reference's GridEncodingTemplated constructor (grid.h:977-1012). `make_context(**config)` -> a context of the library under test."""
+    v = np.array(load()["levels_n_base_log2hash_scalebits_offsets_resolutions_scales"], dtype=np.uint32)
+    i = n_cfg = 0
+    while i < len(v):
+        n, base, log2, pls_bits = int(v[i]), int(v[i + 1]), int(v[i + 2]), v[i + 3:i + 4]
+        off, res, sc = v[i + 4:i + 5 + n], v[i + 5 + n:i + 5 + 2 * n], v[i + 5 + 2 * n:i + 5 + 3 * n]
+        i += 5 + 3 * n
+        c = make_context(n_levels=n, base_resolution=base, log2_hashmap_size=log2, per_level_scale=float(pls_bits.view(np.float32)[0]))
+        try:
+            o, r, s = c.grid_tables()
+            assert np.array_equal(o, off), ("offsets", n, base, log2, o, off)
+            assert np.array_equal(r, res), ("resolutions", n, base, log2)
+            assert np.array_equal(s.view(np.uint32), sc), ("scales", n, base, log2)
+            assert c.n_params == 3072 + 8192 + 2 * int(off[-1]) + 4  # [sdf mlp | rgb mlp | hash grid | variance], nerf_network.h:539-583
+        finally:
+            c.close()
+        n_cfg += 1
+    return n_cfg
+
+
+def check_valid_levels(make_context):
+    """How many hash-grid levels are live at a training step (progressive training): four schedules x ~330 steps against the reference's
+    GridEncodingTemplated::set_training_step (grid.h:1430-1437), steps <= 0 included."""
+    v = np.array(load()["validlevel_n_basescale_scale_basestep_step_level"], dtype=np.uint32).reshape(-1, 6)
+    n_rows = 0
+    keys = sorted({tuple(int(x) for x in r[:4]) for r in v})
+    for key in keys:
+        rows = v[np.all(v[:, :4] == np.array(key, dtype=np.uint32), axis=1)]
+        fl = np.array(key[1:3], dtype=np.uint32).view(np.float32)
+        c = make_context(n_levels=key[0], base_valid_level_scale=float(fl[0]), valid_level_scale=float(fl[1]), base_training_step=key[3])
+        try:
+            for r in rows:
+                c.set_training_step(int(r[4]))  # (negative steps travel as their uint32 pattern, as in the ABI)
+                assert c.valid_level == int(r[5]), (key, int(np.int32(r[4])), c.valid_level, int(r[5]))
+                n_rows += 1
+        finally:
+            c.close()
+    return n_rows

@@ -8,10 +8,12 @@ from /root/reference at run time, never copied into this repository) with g++ in
 What is taken, verbatim (function or struct body located by its signature, braces matched):
   dependencies/neus2_tcnn/include/tiny-cuda-nn/common_device.h   logistic, identity_fun, pos_fract (the 3-argument-functor-free form: pos, pos_grid)
   dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h          clamp
-  dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h  fast_hash, grid_index  (enum GridType restated: its three names)
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h  fast_hash, grid_index, to_string(GridType), the level loop of GridEncodingTemplated's constructor (:977-1010;
+                                                                 its members bound as arguments) with common.h powi / next_multiple, set_training_step (:1430-1437; `override` dropped)  (enum GridType restated: its three names)
   dependencies/neus2_tcnn/dependencies/pcg32/pcg32.h             struct pcg32
   include/neural-graphics-primitives/random_val.cuh              random_val_2d; sobol .. ld_random_val and common.h binary_search, testbed_nerf.cu sample_cdf_2d (the error-map branches of
                                                                  image_idx / nerf_random_image_pos_training: compiled so that those two are taken unchanged, not reached -- null CDFs)
+  include/neural-graphics-primitives/common_device.cuh           srgb_to_linear, image_pos, pixel_idx, the body of read_rgba's `case EImageDataType::Byte` (this fork's RGBA16 pixels)
   include/neural-graphics-primitives/bounding_box.cuh            BoundingBox::diag, ::relative_pos
   include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
   src/testbed_nerf.cu                                            NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
@@ -47,6 +49,7 @@ def build_program():
     gh = "dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h"
     bb = "include/neural-graphics-primitives/bounding_box.cuh"
     rv = "include/neural-graphics-primitives/random_val.cuh"
+    cdc = "include/neural-graphics-primitives/common_device.cuh"
     src_tn = open(os.path.join(REF, tn)).read()
     uniform_fraction = src_tn.split("static constexpr float UNIFORM_SAMPLING_FRACTION =")[1].split(";")[0].strip()
     loss_names = enum_names("include/neural-graphics-primitives/common.h", "enum class ELossType")
@@ -60,6 +63,10 @@ def build_program():
 #include <cmath>
 #include <cassert>
 #include <vector>
+#include <string>
+#include <stdexcept>
+#include <limits>
+#include <algorithm>
 #include <Eigen/Dense>
 #define __host__
 #define __device__
@@ -83,9 +90,35 @@ template <typename T> """ + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/comm
              "template <typename F>\n" + f(cd, "__device__ inline void pos_fract(const float input, float* pos, uint32_t* pos_grid, float scale, F interpolation_fun)"),
              "template <uint32_t N_DIMS>\n" + f(gh, "__device__ uint32_t fast_hash(const uint32_t pos_grid[N_DIMS])"),
              "template <uint32_t N_DIMS, uint32_t N_FEATURES_PER_LEVEL>\n" + f(gh, "__device__ uint32_t grid_index(const GridType grid_type, const uint32_t feature, const uint32_t hashmap_size, const uint32_t grid_resolution, const uint32_t pos_grid[N_DIMS])"),
+             f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "inline uint32_t powi(uint32_t base, uint32_t exponent)"),
+             "template <typename T> " + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "TCNN_HOST_DEVICE T div_round_up(T val, T divisor)"),
+             "template <typename T> " + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "TCNN_HOST_DEVICE T next_multiple(T val, T divisor)"),
+             f(gh, "inline std::string to_string(GridType grid_type)"),
+             # the level loop of GridEncodingTemplated's constructor (grid.h:977-1010), verbatim, with the members it reads / writes bound as arguments
+             """template <uint32_t N_POS_DIMS>
+static void level_tables(const uint32_t m_n_levels, const float per_level_scale, const uint32_t base_resolution, const uint32_t log2_hashmap_size, const GridType grid_type,
+                         std::vector<uint32_t>& m_hashmap_offsets_table_cpu, std::vector<uint32_t>& m_resolution_table_cpu, std::vector<float>& m_scale_table_cpu) {
+	uint32_t offset = 0;
+	""" + f(gh, "for (uint32_t i = 0; i < m_n_levels; ++i) {\n\t\t\t// Compute dense params required for the given level") + """
+	m_hashmap_offsets_table_cpu[m_n_levels] = offset;
+}""",
+             # GridEncodingTemplated::set_training_step (grid.h:1430-1437), verbatim, inside a struct that declares the members it touches with the reference's types (:1477-1481)
+             """static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+struct ValidLevel {
+	uint32_t m_valid_level; int m_training_step; uint32_t m_base_training_step; float m_base_valid_level_scale; float m_valid_level_scale; uint32_t m_n_levels;
+	""" + f(gh, "void set_training_step(int training_step) override {").replace("void set_training_step(int training_step) override {", "void set_training_step(int training_step) {", 1) + """
+};""",
              "}\nusing namespace Eigen;\nusing default_rng_t = tcnn::default_rng_t;",
              "template <typename RNG>\n" + f("include/neural-graphics-primitives/random_val.cuh", "inline __host__ __device__ Eigen::Vector2f random_val_2d(RNG& rng)"),
              f("include/neural-graphics-primitives/nerf.h", "inline constexpr __device__ uint32_t NERF_GRIDSIZE()"),
+             f(cdc, "inline __host__ __device__ float srgb_to_linear(float srgb)"),
+             f(cdc, "inline NGP_HOST_DEVICE Eigen::Vector2i image_pos(const Eigen::Vector2f& pos, const Eigen::Vector2i& resolution)"),
+             f(cdc, "inline NGP_HOST_DEVICE uint64_t pixel_idx(const Eigen::Vector2i& pos, const Eigen::Vector2i& resolution, uint32_t img)"),
+             # read_rgba (common_device.cuh:665-696): the body of its `case EImageDataType::Byte` -- this fork's RGBA16 pixels -- verbatim, as a function of the same arguments
+             # (the Half case next to it is written in CUDA's __half and is not what the path's images take)
+             "static Eigen::Array4f read_rgba_byte_case(Eigen::Vector2i px, const Eigen::Vector2i& resolution, const void* pixels, uint32_t img) "
+             + f(cdc, "case EImageDataType::Byte: {")[len("case EImageDataType::Byte: "):],
              "struct BoundingBox { Eigen::Vector3f min, max;\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f diag() const") + "\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f relative_pos(const Eigen::Vector3f& pos) const") + "};",
              # what image_idx / nerf_random_image_pos_training call when error-map CDFs are given (never here: null pointers) -- the reference's own functions, so that the two compile unchanged
              f(rv, "inline __host__ __device__ uint32_t sobol(uint32_t index, uint32_t dim)"), f(rv, "inline __host__ __device__ uint32_t hash_combine(uint32_t seed, uint32_t v)"),
@@ -196,7 +229,68 @@ int main() {
 			tcnn::pos_fract(x, &pos, &cell, scale, tcnn::identity_fun);
 			for (uint32_t v : {size, res, pg[0], pg[1], pg[2], i0, i1, fb(x), fb(scale), fb(pos), cell}) out.push_back(v);
 		}
-		arr_u("grid_size_res_pg3_index0_index1_x_scale_pos_cell", out, true);
+		arr_u("grid_size_res_pg3_index0_index1_x_scale_pos_cell", out);
+	}
+	{ // ---- the level tables (grid.h:977-1012): resolution, scale (this fork: resolution - 1) and table offsets of every level -- the parameter layout of the hash grid
+		std::vector<uint32_t> out;
+		const float auto_scale = std::exp(std::log(2048.0f * 1.0f / 16.0f) / (14 - 1)); // testbed.cu:2322 with top_resolution 2048, aabb_scale 1, base 16, 14 levels
+		struct C { uint32_t n, base, log2; float pls; };
+		const C cfgs[10] = {{14, 16, 19, auto_scale}, {14, 16, 15, auto_scale}, {14, 16, 22, auto_scale}, {8, 16, 19, 1.5f}, {6, 8, 19, 2.0f}, {2, 16, 19, auto_scale},
+		                    {14, 32, 19, 1.26f}, {10, 16, 17, 1.3819129f}, {1, 16, 19, auto_scale}, {12, 4, 14, 1.7f}};
+		for (const C& c : cfgs) {
+			std::vector<uint32_t> off(c.n + 1), res(c.n);
+			std::vector<float> sc(c.n);
+			tcnn::level_tables<3>(c.n, c.pls, c.base, c.log2, tcnn::GridType::Hash, off, res, sc);
+			out.push_back(c.n); out.push_back(c.base); out.push_back(c.log2); out.push_back(fb(c.pls));
+			for (uint32_t v : off) out.push_back(v);
+			for (uint32_t v : res) out.push_back(v);
+			for (float v : sc) out.push_back(fb(v));
+		}
+		arr_u("levels_n_base_log2hash_scalebits_offsets_resolutions_scales", out);
+	}
+	{ // ---- how many levels are live at a training step (grid.h:1430-1437; the values of configs/nerf/base.json and three others)
+		std::vector<uint32_t> out;
+		struct C { uint32_t n; float base_scale, scale; uint32_t base_step; };
+		const C cfgs[4] = {{14, 0.2f, 0.02f, 100}, {14, 0.5f, 0.01f, 0}, {8, 0.1f, 0.05f, 250}, {6, 0.3f, 0.004f, 40}};
+		for (const C& c : cfgs) {
+			for (int step = -2; step <= 1500; step += (step < 130 ? 1 : 7)) {
+				tcnn::ValidLevel v{0, 0, c.base_step, c.base_scale, c.scale, c.n};
+				v.set_training_step(step);
+				out.push_back(c.n); out.push_back(fb(c.base_scale)); out.push_back(fb(c.scale)); out.push_back(c.base_step); out.push_back((uint32_t)step); out.push_back(v.m_valid_level);
+			}
+		}
+		arr_u("validlevel_n_basescale_scale_basestep_step_level", out);
+	}
+	{ // ---- a pixel of a training image (common_device.cuh:621-627, 665-700): position -> pixel, the 0x00FF00FF sentinel, sRGB decode, alpha premultiplication
+		std::vector<uint32_t> out;
+		const int shapes[4][2] = {{5, 2}, {4, 3}, {7, 2}, {2, 7}};
+		for (int k = 0; k < 256; ++k) {
+			const int w = shapes[k % 4][0], h = shapes[k % 4][1];
+			uint16_t px[14 * 4];
+			for (int q = 0; q < 14 * 4; ++q) px[q] = (uint16_t)(gen.next_uint() >> 16);
+			for (int q = 0; q < 14; ++q) {
+				const uint32_t r = gen.next_uint() % 16;
+				if (r == 0) { px[q * 4 + 0] = 0x00FF; px[q * 4 + 1] = 0x00FF; px[q * 4 + 2] = 0; px[q * 4 + 3] = 0; }   // the sentinel word
+				if (r == 1) px[q * 4 + 3] = 0;        // transparent
+				if (r == 2) px[q * 4 + 0] = 0;        // red 0: the ray is kept with probability 0.1 (testbed_nerf.cu:1264)
+				if (r == 3) px[q * 4 + 3] = 65535;
+				if (r == 4) { px[q * 4 + 0] = 0x00FF; px[q * 4 + 1] = 0x00FF; px[q * 4 + 2] = 0; px[q * 4 + 3] = 1; }   // almost the sentinel
+				if (r == 5) { px[q * 4 + 0] = 700; px[q * 4 + 1] = 2651; px[q * 4 + 2] = 2652; }                          // around the sRGB knee (0.04045 * 65535 = 2650.9)
+			}
+			float x = gen.next_float(), y = gen.next_float();
+			if (k % 16 == 1) x = 1.0f;
+			if (k % 16 == 2) y = 1.0f;
+			if (k % 16 == 3) { x = 0.0f; y = 0.0f; }
+			if (k % 16 == 4) x = -0.25f;
+			if (k % 16 == 5) y = 1.75f;
+			const Vector2i res{w, h};
+			Array4f c = read_rgba_byte_case(image_pos(Vector2f{x, y}, res), res, px, 0);
+			out.push_back((uint32_t)w); out.push_back((uint32_t)h); out.push_back(fb(x)); out.push_back(fb(y));
+			for (int q = 0; q < 14; ++q) { out.push_back((uint32_t)px[q * 4] | (uint32_t)px[q * 4 + 1] << 16); out.push_back((uint32_t)px[q * 4 + 2] | (uint32_t)px[q * 4 + 3] << 16); }
+			for (int q = 0; q < 4; ++q) out.push_back(fb(c[q]));
+			out.push_back(c.x() <= 0.0f ? 1u : 0u);
+		}
+		arr_u("readrgba_w_h_x_y_pixels28_rgba4_rednonpositive", out, true);
 	}
 	printf("}\n");
 	return 0;

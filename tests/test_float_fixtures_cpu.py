@@ -4,7 +4,7 @@ albedo, the L1 / L2 ray loss, image / pixel choice of a ray) against the outputs
 library in tests/test_gpu_parity.py."""
 from tests import float_fixture_cases, oracle_lib
 
-COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512}
+COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512, "read_rgba": 256}
 
 
 def test_oracle_float_primitives_match_the_reference_fragments():
@@ -16,8 +16,18 @@ def test_oracle_float_primitives_match_the_reference_fragments():
     assert n == COUNTS
 
 
+def test_oracle_level_tables_match_the_reference_constructor_loop():
+    assert float_fixture_cases.check_level_tables(lambda **cfg: oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 10
+
+
+def test_oracle_valid_level_schedule_matches_the_reference():
+    assert float_fixture_cases.check_valid_levels(lambda **cfg: oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 4 * 328
+
+
 def test_float_fixture_is_what_its_generator_says():
     fx = float_fixture_cases.load()
     assert "make_float_fixtures.py" in fx["_source"] and "-ffp-contract=off" in fx["_source"]
     assert set(fx) == {"_source", "activation_val_relu_logistic_rgb_rgbderivative", "warp_lo_hi_p3_d3_dt_warpedp3_unwarpedp3_warpedd3_unwarpedd3_warpeddt_unwarpeddt",
-                       "loss_isL2_target4_prediction4_loss_gradient4", "pixel_base_nrays_total_nimg_w_h_snap_advlo_advhi_img_x_y", "grid_size_res_pg3_index0_index1_x_scale_pos_cell"}
+                       "loss_isL2_target4_prediction4_loss_gradient4", "pixel_base_nrays_total_nimg_w_h_snap_advlo_advhi_img_x_y", "grid_size_res_pg3_index0_index1_x_scale_pos_cell",
+                       "levels_n_base_log2hash_scalebits_offsets_resolutions_scales", "validlevel_n_basescale_scale_basestep_step_level",
+                       "readrgba_w_h_x_y_pixels28_rgba4_rednonpositive"}

@@ -114,6 +114,9 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
     from tests.test_float_fixtures_cpu import COUNTS
     gpu, _ = pair
     assert float_fixture_cases.check(gpu, exact_exp=False) == COUNTS
+    import rnb_neus2_amd as rnb
+    assert float_fixture_cases.check_level_tables(lambda **cfg: rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 10  # the parameter layout (grid.h:977-1012)
+    assert float_fixture_cases.check_valid_levels(lambda **cfg: rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 4 * 328  # progressive levels (grid.h:1430-1437)
 
 
 def test_density_grid_update(pair):
