@@ -16,6 +16,7 @@ What is taken, verbatim (function or struct body located by its signature, brace
   include/neural-graphics-primitives/common_device.cuh           srgb_to_linear, image_pos, pixel_idx, the body of read_rgba's `case EImageDataType::Byte` (this fork's RGBA16 pixels)
   include/neural-graphics-primitives/bounding_box.cuh            BoundingBox::diag, ::relative_pos
   include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
+  include/neural-graphics-primitives/nerf_loader.h               NerfDataset::nerf_matrix_to_ngp (in a struct with the four members it reads)
   src/testbed_nerf.cu                                            NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
                                                                  activation_function, network_to_rgb, network_to_rgb_derivative, warp_position, unwarp_position, warp_direction,
                                                                  unwarp_direction, warp_dt, unwarp_dt, nerf_random_image_pos_training, image_idx
@@ -110,6 +111,8 @@ struct ValidLevel {
 	""" + f(gh, "void set_training_step(int training_step) override {").replace("void set_training_step(int training_step) override {", "void set_training_step(int training_step) {", 1) + """
 };""",
              "}\nusing namespace Eigen;\nusing default_rng_t = tcnn::default_rng_t;",
+             # NerfDataset::nerf_matrix_to_ngp (nerf_loader.h:180-201), verbatim, inside a struct with the four members it reads
+             "struct DatasetAxes { float scale; Eigen::Vector3f offset; bool from_mitsuba; bool from_na;\n" + f("include/neural-graphics-primitives/nerf_loader.h", "Eigen::Matrix<float, 3, 4> nerf_matrix_to_ngp(const Eigen::Matrix<float, 3, 4>& nerf_matrix)") + "\n};",
              "template <typename RNG>\n" + f("include/neural-graphics-primitives/random_val.cuh", "inline __host__ __device__ Eigen::Vector2f random_val_2d(RNG& rng)"),
              f("include/neural-graphics-primitives/nerf.h", "inline constexpr __device__ uint32_t NERF_GRIDSIZE()"),
              f(cdc, "inline __host__ __device__ float srgb_to_linear(float srgb)"),
@@ -290,7 +293,23 @@ int main() {
 			for (int q = 0; q < 4; ++q) out.push_back(fb(c[q]));
 			out.push_back(c.x() <= 0.0f ? 1u : 0u);
 		}
-		arr_u("readrgba_w_h_x_y_pixels28_rgba4_rednonpositive", out, true);
+		arr_u("readrgba_w_h_x_y_pixels28_rgba4_rednonpositive", out);
+	}
+	{ // ---- camera matrices of transform.json -> the training frame (nerf_loader.h:180-201): the three axis conventions, scale and offset of the position
+		std::vector<uint32_t> out;
+		for (int k = 0; k < 36; ++k) {
+			const int mode = k % 3; // 0 default (rows cycled), 1 from_na, 2 from_mitsuba
+			DatasetAxes d{mode == 2 ? 0.66f : (k % 2 ? 0.33f : uni(0.1f, 2.0f)), Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}, mode == 2, mode == 1};
+			if (mode == 2) d.offset = Vector3f::Constant(0.25f * d.scale); // what the loader sets for Mitsuba scenes (nerf_loader.cu:399-402)
+			Eigen::Matrix<float, 3, 4> m;
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m(r, c) = uni(-3, 3);
+			const Eigen::Matrix<float, 3, 4> g = d.nerf_matrix_to_ngp(m);
+			out.push_back((uint32_t)mode); out.push_back(fb(d.scale));
+			for (int c = 0; c < 3; ++c) out.push_back(fb(d.offset[c]));
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out.push_back(fb(m(r, c)));
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out.push_back(fb(g(r, c)));
+		}
+		arr_u("axes_mode_scale_offset3_matrix12_ngp12", out, true);
 	}
 	printf("}\n");
 	return 0;

@@ -117,6 +117,34 @@ def test_loader_axis_conventions(install, tmp_path):
     assert d["scale"] == 0.25 and d["offset"] == [0.25, 0.75, 1.0]
 
 
+def test_loader_axis_conventions_against_the_references_own_function(install, tmp_path):
+    """tests/golden/float_fixtures.json `axes_*`: the REFERENCE's NerfDataset::nerf_matrix_to_ngp (nerf_loader.h:180-201, compiled from its file by
+    make_float_fixtures.py) on 36 seeded camera matrices -- default (rows cycled yzx), from_na, Mitsuba; scale and offset of the position. The same matrices as frames of
+    a transform.json through the scene loader (host/dataset.hpp): every xform bit for bit."""
+    from tests import float_fixture_cases
+    v = np.array(float_fixture_cases.load()["axes_mode_scale_offset3_matrix12_ngp12"], dtype=np.uint32).reshape(-1, 29)
+    assert len(v) == 36 and sorted(set(v[:, 0].tolist())) == [0, 1, 2]
+    K = [[10, 0, 2, 0], [0, 20, 1, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+    for k, row in enumerate(v):
+        mode = int(row[0])
+        fl = row[1:].view(np.float32).astype(np.float64)
+        scale, offset, m, want = float(fl[0]), fl[1:4].tolist(), fl[4:16].reshape(3, 4), row[17:29].view(np.float32).reshape(3, 4)
+        frame = dict(normal_path="n", albedo_path="a.png", transform_matrix=m.tolist() + [[0, 0, 0, 1]], intrinsic_matrix=K)
+        meta = dict(w=4, h=4, frames=[frame])
+        if mode == 1:
+            meta.update(from_na=True, scale=scale, offset=offset)
+        elif mode == 2:
+            meta.update(normal_mts_args="-", frames=[frame])  # a Mitsuba scene: scale 0.66, offset 0.25 * scale (nerf_loader.cu:387-402) -- the fixture's values
+            assert abs(scale - 0.66) < 1e-7
+        else:
+            meta.update(scale=scale, offset=offset)
+        _write_json_scene(str(tmp_path / ("s%d" % k)), meta)
+        d = dump(install, tmp_path / ("s%d" % k))
+        assert (d["from_na"], d["from_mitsuba"]) == (int(mode == 1), int(mode == 2)), k
+        got = np.array(d["views"][0]["xform"], np.float32).reshape(3, 4)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, mode, got, want)
+
+
 def test_loader_errors(install, tmp_path):
     os.makedirs(tmp_path / "empty")
     r = subprocess.run([str(install / "build" / "dump_dataset"), str(tmp_path / "empty")], capture_output=True, text=True)
