@@ -350,9 +350,13 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *                                                                                                        (tcnn encodings/grid.h:113-148, common_device.h:427-434)
  *   RNB_PRIM_READ_RGBA in w, h (w h <= 14), bits(x), bits(y), 28 words = the image, RGBA16, two words per pixel    out read_rgba(pos) r g b a, and the test
  *                                                                       `red <= 0` of testbed_nerf.cu:1264 (common_device.cuh:621-627, 665-700)
+ *   RNB_PRIM_CAMERA_RAY in w, h, focal 2, principal point 2, position x y, camera matrix 12 (row-major 3x4)   out origin 3, direction before and after normalisation 3 + 3
+ *                                                                       (the pinhole ray of testbed_nerf.cu:1279-1305 as Eigen evaluates it)
+ *   RNB_PRIM_RAY_TARGETS in apply_no_albedo, apply_rgbplus, apply_L2, apply_light_opti, apply_relu, light index, camera matrix 12, normal texel 4, albedo texel 4,
+ *                    light_directions 9 (row-major, camera frame; nine words 0xffffffff = the context's own, testbed_nerf.cu:1537-1554)   out rgbtarget 4, the light in the world frame 3   (the loss kernel's per-ray targets, testbed_nerf.cu:1500-1592)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

@@ -70,7 +70,12 @@ static inline Vec3 v3(float x, float y, float z) { return {x, y, z}; }
 static inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static inline Vec3 operator*(float s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
-static inline float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Eigen's reduction of a fixed-size vector splits the range in halves (Redux.h, redux_novec_unroller; no SIMD under a GPU compiler): three terms are x0 + (x1 + x2), four
+// (x0 + x1) + (x2 + x3) -- what .dot(), .norm(), .normalized() and the fixed-size matrix products of the reference's kernels evaluate (pinned by tests/golden/float_fixtures.json,
+// which runs the kernel's own statements through the reference's vendored Eigen). Sums the reference spells out term by term stay left to right.
+static inline float esum3(float x0, float x1, float x2) { return x0 + (x1 + x2); }
+static inline float esum4(float x0, float x1, float x2, float x3) { return (x0 + x1) + (x2 + x3); }
+static inline float dot(Vec3 a, Vec3 b) { return esum3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline float norm(Vec3 a) { return sqrtf(dot(a, a)); }
 static inline Vec3 normalized(Vec3 a) { float n = norm(a); return {a.x / n, a.y / n, a.z / n}; }
 
@@ -802,6 +807,21 @@ static inline void read_rgba(const float xy[2], const rnb_view& m, const uint16_
 	rgba[2] = srgb_to_linear((float)v[2] * (1.0f / 65535.0f)) * alpha;
 	rgba[3] = alpha;
 }
+// The ray of an image position (testbed_nerf.cu:1279-1305; no lens distortion, no rolling shutter): Eigen's fixed-size 3x3 * 3 product (esum3 per row),
+// normalized() divides by the norm.
+static inline void camera_ray(const rnb_view& m, const float xy[2], Vec3& o, Vec3& d_unnorm, Vec3& dir) {
+	const float* X = m.xform;
+	o = v3(X[3], X[7], X[11]);
+	Vec3 dcam = {
+		(xy[0] - m.principal_point[0]) * (float)m.width / m.focal_length[0],
+		(xy[1] - m.principal_point[1]) * (float)m.height / m.focal_length[1],
+		1.0f,
+	};
+	d_unnorm = v3(esum3(X[0] * dcam.x, X[1] * dcam.y, X[2] * dcam.z),
+	              esum3(X[4] * dcam.x, X[5] * dcam.y, X[6] * dcam.z),
+	              esum3(X[8] * dcam.x, X[9] * dcam.y, X[10] * dcam.z));
+	dir = normalized(d_unnorm);
+}
 // nerf_random_image_pos_training (testbed_nerf.cu:1171-1192), no error-map CDF (default off, testbed.h:663-664)
 static inline void random_image_pos(Pcg32& rng, uint32_t w, uint32_t h, bool snap, float xy[2]) {
 	xy[0] = rng.next_float(); xy[1] = rng.next_float();
@@ -851,17 +871,7 @@ RaySetup setup_ray(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_r
 	if (rgba[0] <= 0.0f && rng.next_float() >= 0.9) return r; // testbed_nerf.cu:1264 (short-circuit draw)
 	// max_level_rand_training = false (testbed.h:460): no draw
 	float motionblur_time = rng.next_float(); (void)motionblur_time; // testbed_nerf.cu:1270
-	const float* X = m.xform;
-	r.o = v3(X[3], X[7], X[11]);
-	Vec3 dcam = {
-		(xy[0] - m.principal_point[0]) * (float)m.width / m.focal_length[0],
-		(xy[1] - m.principal_point[1]) * (float)m.height / m.focal_length[1],
-		1.0f,
-	};
-	r.d_unnorm = v3(X[0] * dcam.x + X[1] * dcam.y + X[2] * dcam.z,
-	                X[4] * dcam.x + X[5] * dcam.y + X[6] * dcam.z,
-	                X[8] * dcam.x + X[9] * dcam.y + X[10] * dcam.z);
-	r.dir = normalized(r.d_unnorm);
+	camera_ray(m, xy, r.o, r.d_unnorm, r.dir);
 	// first_frame_offset = 0; predict_global_movement: identity rotation, zero translation (testbed_nerf.cu:1312-1320)
 	float tmin, tmax;
 	ray_intersect(c, r.o, r.dir, &tmin, &tmax);
@@ -993,6 +1003,51 @@ static inline void albedo_from_output(const orc_ctx_s* c, const half_t* o, float
 	} else albedo[3] = 0.f;
 }
 
+// The loss kernel's per-ray targets from the two texels (testbed_nerf.cu:1500-1592): target normal, target albedo, the step's light in the camera and the world frame, the shading
+// target and rgbtarget; every Eigen reduction as Eigen evaluates it (esum3). tests/golden/float_fixtures.json runs the kernel's own statements.
+static inline void ray_targets(const rnb_config& F, const float* X, const float tex_normal[4], const float tex_albedo[4], const float* light_dirs, const int random_light,
+                               float rgbtarget[4], float light[3]) {
+	// exposure = 0 -> exposure_scale = exp(0) = 1 (testbed_nerf.cu:1503)
+	const float exposure_scale = expf(0.6931471805599453f * 0.f);
+	float nv[3];
+	for (int k = 0; k < 3; ++k) nv[k] = linear_to_srgb(exposure_scale * tex_normal[k]) * 2.0f - 1.0f; // testbed_nerf.cu:1507
+	nv[1] *= -1; nv[2] *= -1;
+	{ float n = sqrtf(esum3(nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2])); for (int k = 0; k < 3; ++k) nv[k] /= n; } // .matrix().norm()
+	float albedo_value[4];
+	if (F.apply_no_albedo) { albedo_value[0] = albedo_value[1] = albedo_value[2] = 1.f; albedo_value[3] = 0.f; }
+	else {
+		float a[3];
+		for (int k = 0; k < 3; ++k) a[k] = linear_to_srgb(exposure_scale * tex_albedo[k]);
+		albedo_value[0] = a[0]; albedo_value[1] = a[1]; albedo_value[2] = a[2];
+		if (F.apply_rgbplus) {
+			if (F.apply_L2) albedo_value[3] = sqrtf(std::max(0.0f, 3 - a[0] * a[0] - a[1] * a[1] - a[2] * a[2]));
+			else albedo_value[3] = 3 - fabsf(a[0]) - fabsf(a[1]) - fabsf(a[2]);
+		} else albedo_value[3] = 0.f;
+	}
+	// light triplet (testbed_nerf.cu:1537-1583)
+	float Ld[9];
+	for (int k = 0; k < 9; ++k) Ld[k] = light_dirs[k];
+	if (F.apply_light_opti) { // testbed_nerf.cu:1563-1581
+		float k3[3] = {-nv[1], nv[0], 0.f};
+		float kn = sqrtf(esum3(k3[0] * k3[0], k3[1] * k3[1], k3[2] * k3[2]));
+		for (int a = 0; a < 3; ++a) k3[a] /= kn;
+		float cos_theta = nv[2];
+		float sin_theta = std::sqrt(1 - cos_theta * cos_theta);
+		float K[9] = {0, -k3[2], k3[1], k3[2], 0, -k3[0], -k3[1], k3[0], 0};
+		float Rm[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+			Rm[r * 3 + q] = cos_theta * (r == q ? 1.f : 0.f) + sin_theta * K[r * 3 + q] + (1 - cos_theta) * (k3[r] * k3[q]);
+		float out[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+			out[r * 3 + q] = esum3((-Rm[r * 3 + 0]) * Ld[0 * 3 + q], (-Rm[r * 3 + 1]) * Ld[1 * 3 + q], (-Rm[r * 3 + 2]) * Ld[2 * 3 + q]); // -R * light_directions
+		for (int k = 0; k < 9; ++k) Ld[k] = out[k];
+	}
+	float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
+	for (int r = 0; r < 3; ++r) light[r] = esum3(X[r * 4 + 0] * light_cam[0], X[r * 4 + 1] * light_cam[1], X[r * 4 + 2] * light_cam[2]); // Rt * light_cam
+	float shading_target = esum3(nv[0] * light_cam[0], nv[1] * light_cam[1], nv[2] * light_cam[2]);                                         // .dot(light_cam)
+	if (F.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
+	for (int k = 0; k < 4; ++k) rgbtarget[k] = albedo_value[k] * shading_target;
+}
 struct AlphaTerms {
 	float inv_s, sdf_value, true_cos, iter_cos, est_next, p_div_c, alpha, dt;
 	float g[3];
@@ -1038,53 +1093,11 @@ void loss_pass1(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_rays
 	float tex_albedo[4], tex_normal[4];
 	read_rgba(xy, m, view.albedo.data(), tex_albedo);
 	read_rgba(xy, m, view.normal.data(), tex_normal);
-	// exposure = 0 -> exposure_scale = exp(0) = 1 (testbed_nerf.cu:1503)
-	const float exposure_scale = expf(0.6931471805599453f * 0.f);
-	float nv[3];
-	for (int k = 0; k < 3; ++k) nv[k] = linear_to_srgb(exposure_scale * tex_normal[k]) * 2.0f - 1.0f; // testbed_nerf.cu:1507
-	nv[1] *= -1; nv[2] *= -1;
-	{ float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]); for (int k = 0; k < 3; ++k) nv[k] /= n; }
-	float albedo_value[4];
-	if (c->cfg.apply_no_albedo) { albedo_value[0] = albedo_value[1] = albedo_value[2] = 1.f; albedo_value[3] = 0.f; }
-	else {
-		float a[3];
-		for (int k = 0; k < 3; ++k) a[k] = linear_to_srgb(exposure_scale * tex_albedo[k]);
-		albedo_value[0] = a[0]; albedo_value[1] = a[1]; albedo_value[2] = a[2];
-		if (c->cfg.apply_rgbplus) {
-			if (c->cfg.apply_L2) albedo_value[3] = sqrtf(std::max(0.0f, 3 - a[0] * a[0] - a[1] * a[1] - a[2] * a[2]));
-			else albedo_value[3] = 3 - fabsf(a[0]) - fabsf(a[1]) - fabsf(a[2]);
-		} else albedo_value[3] = 0.f;
-	}
-	// light triplet (testbed_nerf.cu:1537-1583)
-	float Ld[9];
-	for (int k = 0; k < 9; ++k) Ld[k] = c->light_dirs[k];
 	// deviation D4: deterministic light pick = draw #7 of the ray's PCG32 stream
 	Pcg32 lrng = c->rng;
 	lrng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY + 7);
 	const int random_light = (int)(lrng.next_uint() % 3u);
-	if (c->cfg.apply_light_opti) { // testbed_nerf.cu:1563-1581
-		float k3[3] = {-nv[1], nv[0], 0.f};
-		float kn = sqrtf(k3[0] * k3[0] + k3[1] * k3[1] + k3[2] * k3[2]);
-		for (int a = 0; a < 3; ++a) k3[a] /= kn;
-		float cos_theta = nv[2];
-		float sin_theta = std::sqrt(1 - cos_theta * cos_theta);
-		float K[9] = {0, -k3[2], k3[1], k3[2], 0, -k3[0], -k3[1], k3[0], 0};
-		float Rm[9];
-		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
-			Rm[r * 3 + q] = cos_theta * (r == q ? 1.f : 0.f) + sin_theta * K[r * 3 + q] + (1 - cos_theta) * (k3[r] * k3[q]);
-		float out[9];
-		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-			float s = 0.f;
-			for (int t = 0; t < 3; ++t) s += (-Rm[r * 3 + t]) * Ld[t * 3 + q];
-			out[r * 3 + q] = s;
-		}
-		for (int k = 0; k < 9; ++k) Ld[k] = out[k];
-	}
-	float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
-	for (int r = 0; r < 3; ++r) R.light[r] = X[r * 4 + 0] * light_cam[0] + X[r * 4 + 1] * light_cam[1] + X[r * 4 + 2] * light_cam[2];
-	float shading_target = nv[0] * light_cam[0] + nv[1] * light_cam[1] + nv[2] * light_cam[2];
-	if (c->cfg.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
-	for (int k = 0; k < 4; ++k) R.rgbtarget[k] = albedo_value[k] * shading_target;
+	ray_targets(c->cfg, X, tex_normal, tex_albedo, c->light_dirs, random_light, R.rgbtarget, R.light);
 
 	// pass 1 (testbed_nerf.cu:1608-1697)
 	float T = 1.f;
@@ -1104,7 +1117,7 @@ void loss_pass1(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_rays
 		}
 		AlphaTerms a = alpha_terms(o, dt, dir, 1.0f);
 		const float weight = a.alpha * T;
-		float shading = a.g[0] * R.light[0] + a.g[1] * R.light[1] + a.g[2] * R.light[2];
+		float shading = esum3(a.g[0] * R.light[0], a.g[1] * R.light[1], a.g[2] * R.light[2]); // normal.dot(light)
 		if (c->cfg.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		for (int k = 0; k < 4; ++k) rgb_ray[k] += weight * albedo[k] * shading;
 		weight_sum += weight;
@@ -1166,7 +1179,7 @@ void loss_pass2(orc_ctx_s* c, uint32_t i, uint32_t n_rays, const RayLoss& R, uin
 		AlphaTerms a = alpha_terms(o, dt, dir, 1.0f);
 		const float alpha = a.alpha;
 		const float weight = alpha * T;
-		float shading = a.g[0] * R.light[0] + a.g[1] * R.light[1] + a.g[2] * R.light[2];
+		float shading = esum3(a.g[0] * R.light[0], a.g[1] * R.light[1], a.g[2] * R.light[2]); // normal.dot(light)
 		if (c->cfg.apply_relu) shading = shading > 0.f ? shading : 0.f;
 		for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * albedo[k] * shading;
 		weight_sum2 += weight;
@@ -2007,8 +2020,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_READ_RGBA) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[11] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32}, OUT_W[11] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5};
+	if (kind < 0 || kind > RNB_PRIM_RAY_TARGETS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[13] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35}, OUT_W[13] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2066,6 +2079,25 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			read_rgba(xy, m, reinterpret_cast<const uint16_t*>(a + 4), cl); // the item's own words are the image: RGBA16, two words per pixel
 			o[0] = u(cl[0]); o[1] = u(cl[1]); o[2] = u(cl[2]); o[3] = u(cl[3]);
 			o[4] = cl[0] <= 0.0f ? 1u : 0u; // the test of testbed_nerf.cu:1264
+		} else if (kind == RNB_PRIM_CAMERA_RAY) {
+			rnb_view m{};
+			m.width = a[0]; m.height = a[1]; m.focal_length[0] = f(a[2]); m.focal_length[1] = f(a[3]); m.principal_point[0] = f(a[4]); m.principal_point[1] = f(a[5]);
+			for (int k = 0; k < 12; ++k) m.xform[k] = f(a[8 + k]);
+			const float xy[2] = {f(a[6]), f(a[7])};
+			Vec3 ro, du, dir;
+			camera_ray(m, xy, ro, du, dir);
+			o[0] = u(ro.x); o[1] = u(ro.y); o[2] = u(ro.z); o[3] = u(du.x); o[4] = u(du.y); o[5] = u(du.z); o[6] = u(dir.x); o[7] = u(dir.y); o[8] = u(dir.z);
+		} else if (kind == RNB_PRIM_RAY_TARGETS) {
+			rnb_config F{};
+			F.apply_no_albedo = a[0]; F.apply_rgbplus = a[1]; F.apply_L2 = a[2]; F.apply_light_opti = a[3]; F.apply_relu = a[4];
+			float X[12], tn[4], ta[4], ld[9], tgt[4], lw[3];
+			for (int k = 0; k < 12; ++k) X[k] = f(a[6 + k]);
+			for (int k = 0; k < 4; ++k) { tn[k] = f(a[18 + k]); ta[k] = f(a[22 + k]); }
+			bool own = true; // nine words 0xffffffff = the context's own light directions (build_light_dirs)
+			for (int k = 0; k < 9; ++k) { ld[k] = f(a[26 + k]); own = own && a[26 + k] == 0xffffffffu; }
+			if (own) std::memcpy(ld, c->light_dirs, 36);
+			ray_targets(F, X, tn, ta, ld, (int)a[5], tgt, lw);
+			o[0] = u(tgt[0]); o[1] = u(tgt[1]); o[2] = u(tgt[2]); o[3] = u(tgt[3]); o[4] = u(lw[0]); o[5] = u(lw[1]); o[6] = u(lw[2]);
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

@@ -362,7 +362,12 @@ __device__ __forceinline__ Vec3 v3(float x, float y, float z) { return {x, y, z}
 __device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ Vec3 operator*(float s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Eigen's reduction of a fixed-size vector splits the range in halves (Redux.h, redux_novec_unroller; no SIMD under a GPU compiler): three terms are x0 + (x1 + x2), four
+// (x0 + x1) + (x2 + x3). That is what .dot(), .norm(), .normalized() and the fixed-size matrix products of the reference's kernels evaluate (tests/golden/float_fixtures.json
+// runs the kernel's own statements through its vendored Eigen); sums the reference spells out term by term stay left to right.
+__device__ __forceinline__ float esum3(float x0, float x1, float x2) { return x0 + (x1 + x2); }
+__device__ __forceinline__ float esum4(float x0, float x1, float x2, float x3) { return (x0 + x1) + (x2 + x3); }
+__device__ __forceinline__ float dot(Vec3 a, Vec3 b) { return esum3(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ Vec3 normalized(Vec3 a) { float n = sqrtf(dot(a, a)); return {a.x / n, a.y / n, a.z / n}; }
 
 __device__ __forceinline__ int mip_from_pos(const Vec3& pos, uint32_t max_cascade = N_CASCADES - 1) {

@@ -386,6 +386,20 @@ __device__ __forceinline__ void random_image_pos(Pcg32& rng, const uint32_t w, c
 		}
 	}
 }
+// The ray of an image position (testbed_nerf.cu:1279-1305, no lens distortion, no rolling shutter): origin = the camera matrix's last column, direction = its 3x3 block
+// applied to ((x - cx) w / fx, (y - cy) h / fy, 1) -- Eigen's fixed-size product: a row's three terms as x0 + (x1 + x2), esum3 -- and normalised by a division by the norm.
+__device__ __forceinline__ void camera_ray(const ViewDev& m, const float xy[2], Vec3& o, Vec3& du, Vec3& dir) {
+	o = v3(m.xform[3], m.xform[7], m.xform[11]);
+	const Vec3 dcam = {
+		(xy[0] - m.principal[0]) * (float)m.width / m.focal[0],
+		(xy[1] - m.principal[1]) * (float)m.height / m.focal[1],
+		1.0f,
+	};
+	du = v3(esum3(m.xform[0] * dcam.x, m.xform[1] * dcam.y, m.xform[2] * dcam.z),
+	        esum3(m.xform[4] * dcam.x, m.xform[5] * dcam.y, m.xform[6] * dcam.z),
+	        esum3(m.xform[8] * dcam.x, m.xform[9] * dcam.y, m.xform[10] * dcam.z));
+	dir = normalized(du);
+}
 __device__ __forceinline__ uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_rays_total, uint32_t n_images) { // testbed_nerf.cu:1194-1214
 	return (((base_idx + n_rays_total) * n_images) / n_rays) % n_images;
 }
@@ -485,16 +499,7 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 	}
 	if (!dead) {
 		(void)rng.next_float(); // motionblur_time, testbed_nerf.cu:1270
-		o = v3(m.xform[3], m.xform[7], m.xform[11]);
-		const Vec3 dcam = {
-			(xy[0] - m.principal[0]) * (float)m.width / m.focal[0],
-			(xy[1] - m.principal[1]) * (float)m.height / m.focal[1],
-			1.0f,
-		};
-		du = v3(m.xform[0] * dcam.x + m.xform[1] * dcam.y + m.xform[2] * dcam.z,
-		        m.xform[4] * dcam.x + m.xform[5] * dcam.y + m.xform[6] * dcam.z,
-		        m.xform[8] * dcam.x + m.xform[9] * dcam.y + m.xform[10] * dcam.z);
-		dir = normalized(du);
+		camera_ray(m, xy, o, du, dir);
 		float tmin, tmax;
 		ray_intersect(a.A, o, dir, &tmin, &tmax);
 		tmin = fmaxf(tmin, 0.0f);
@@ -550,16 +555,7 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 		}
 		if (!dead) {
 			(void)rng.next_float(); // motionblur_time
-			o = v3(m.xform[3], m.xform[7], m.xform[11]);
-			const Vec3 dcam = {
-				(xy[0] - m.principal[0]) * (float)m.width / m.focal[0],
-				(xy[1] - m.principal[1]) * (float)m.height / m.focal[1],
-				1.0f,
-			};
-			du = v3(m.xform[0] * dcam.x + m.xform[1] * dcam.y + m.xform[2] * dcam.z,
-			        m.xform[4] * dcam.x + m.xform[5] * dcam.y + m.xform[6] * dcam.z,
-			        m.xform[8] * dcam.x + m.xform[9] * dcam.y + m.xform[10] * dcam.z);
-			dir = normalized(du);
+			camera_ray(m, xy, o, du, dir);
 			idir = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 			float tmin, tmax;
 			ray_intersect(a.A, o, dir, &tmin, &tmax);
@@ -1168,6 +1164,56 @@ __device__ __forceinline__ void load_out16(const half_t* __restrict__ p, half_t 
 	for (int j = 0; j < 8; ++j) { o[j] = o0[j]; o[8 + j] = o1[j]; }
 }
 
+// The loss kernel's per-ray targets from the two texels (testbed_nerf.cu:1500-1592): target normal (sRGB-encoded, y / z flipped, normalised), target albedo (+ its rgb+
+// fourth channel), the light of the step in the camera frame (optionally rotated onto the target normal, apply_light_opti) and in the world frame, the shading target and
+// rgbtarget. Every Eigen reduction as Eigen evaluates it (esum3). tests/golden/float_fixtures.json runs the kernel's own statements.
+__device__ __forceinline__ void ray_targets(const LossFlags& F, const float (&xform)[12], const float (&tex_normal)[4], const float (&tex_albedo)[4], const float* __restrict__ light_dirs,
+                                            const int random_light, float (&rgbtarget)[4], float (&light)[3]) {
+	const float exposure_scale = expf(0.6931471805599453f * 0.f);
+	float nv[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) nv[k] = linear_to_srgb(exposure_scale * tex_normal[k]) * 2.0f - 1.0f;
+	nv[1] *= -1; nv[2] *= -1;
+	{ const float nn = sqrtf(esum3(nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2])); nv[0] /= nn; nv[1] /= nn; nv[2] /= nn; } // .matrix().norm()
+	float albedo_value[4];
+	if (F.apply_no_albedo) { albedo_value[0] = albedo_value[1] = albedo_value[2] = 1.f; albedo_value[3] = 0.f; }
+	else {
+		float al[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) al[k] = linear_to_srgb(exposure_scale * tex_albedo[k]);
+		albedo_value[0] = al[0]; albedo_value[1] = al[1]; albedo_value[2] = al[2];
+		if (F.apply_rgbplus) {
+			if (F.apply_L2) albedo_value[3] = sqrtf(fmaxf(0.0f, 3 - al[0] * al[0] - al[1] * al[1] - al[2] * al[2]));
+			else albedo_value[3] = 3 - fabsf(al[0]) - fabsf(al[1]) - fabsf(al[2]);
+		} else albedo_value[3] = 0.f;
+	}
+	float Ld[9];
+#pragma unroll
+	for (int k = 0; k < 9; ++k) Ld[k] = light_dirs[k];
+	if (F.apply_light_opti) { // testbed_nerf.cu:1563-1581
+		float k3[3] = {-nv[1], nv[0], 0.f};
+		const float kn = sqrtf(esum3(k3[0] * k3[0], k3[1] * k3[1], k3[2] * k3[2]));
+		k3[0] /= kn; k3[1] /= kn; k3[2] /= kn;
+		const float cos_theta = nv[2];
+		const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+		const float K[9] = {0, -k3[2], k3[1], k3[2], 0, -k3[0], -k3[1], k3[0], 0};
+		float Rm[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+			Rm[r * 3 + q] = cos_theta * (r == q ? 1.f : 0.f) + sin_theta * K[r * 3 + q] + (1 - cos_theta) * (k3[r] * k3[q]);
+		float outm[9];
+		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
+			outm[r * 3 + q] = esum3((-Rm[r * 3 + 0]) * Ld[0 * 3 + q], (-Rm[r * 3 + 1]) * Ld[1 * 3 + q], (-Rm[r * 3 + 2]) * Ld[2 * 3 + q]); // -R * light_directions
+		for (int k = 0; k < 9; ++k) Ld[k] = outm[k];
+	}
+	const float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
+#pragma unroll
+	for (int r = 0; r < 3; ++r) light[r] = esum3(xform[r * 4 + 0] * light_cam[0], xform[r * 4 + 1] * light_cam[1], xform[r * 4 + 2] * light_cam[2]); // Rt * light_cam
+	float shading_target = esum3(nv[0] * light_cam[0], nv[1] * light_cam[1], nv[2] * light_cam[2]);                                                          // .dot(light_cam)
+	if (F.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) rgbtarget[k] = albedo_value[k] * shading_target;
+}
+
 // Per-ray constants of the loss kernel (testbed_nerf.cu:1485-1593): pixel, target normal, light triplet, shading target.
 struct RayConstIn { Pcg32 rng; uint32_t ray_offset, n_rays_global, n_rays_total, n_images; const ViewDev* views; LossFlags F; const float* light_dirs; };
 
@@ -1183,55 +1229,10 @@ __device__ __forceinline__ void ray_constants_core(const RayConstIn& a, const ui
 	float tex_albedo[4], tex_normal[4];
 	read_rgba(xy, m, m.albedo, tex_albedo);
 	read_rgba(xy, m, m.normal, tex_normal);
-	const float exposure_scale = expf(0.6931471805599453f * 0.f);
-	float nv[3];
-#pragma unroll
-	for (int k = 0; k < 3; ++k) nv[k] = linear_to_srgb(exposure_scale * tex_normal[k]) * 2.0f - 1.0f;
-	nv[1] *= -1; nv[2] *= -1;
-	{ const float nn = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]); nv[0] /= nn; nv[1] /= nn; nv[2] /= nn; }
-	float albedo_value[4];
-	if (a.F.apply_no_albedo) { albedo_value[0] = albedo_value[1] = albedo_value[2] = 1.f; albedo_value[3] = 0.f; }
-	else {
-		float al[3];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) al[k] = linear_to_srgb(exposure_scale * tex_albedo[k]);
-		albedo_value[0] = al[0]; albedo_value[1] = al[1]; albedo_value[2] = al[2];
-		if (a.F.apply_rgbplus) {
-			if (a.F.apply_L2) albedo_value[3] = sqrtf(fmaxf(0.0f, 3 - al[0] * al[0] - al[1] * al[1] - al[2] * al[2]));
-			else albedo_value[3] = 3 - fabsf(al[0]) - fabsf(al[1]) - fabsf(al[2]);
-		} else albedo_value[3] = 0.f;
-	}
-	float Ld[9];
-#pragma unroll
-	for (int k = 0; k < 9; ++k) Ld[k] = a.light_dirs[k];
 	Pcg32 lrng = a.rng; // deterministic light pick: draw #7 of the ray's stream (the reference seeds curand with clock64())
 	lrng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY + 7);
 	const int random_light = (int)(lrng.next_uint() % 3u);
-	if (a.F.apply_light_opti) { // testbed_nerf.cu:1563-1581
-		float k3[3] = {-nv[1], nv[0], 0.f};
-		const float kn = sqrtf(k3[0] * k3[0] + k3[1] * k3[1] + k3[2] * k3[2]);
-		k3[0] /= kn; k3[1] /= kn; k3[2] /= kn;
-		const float cos_theta = nv[2];
-		const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-		const float K[9] = {0, -k3[2], k3[1], k3[2], 0, -k3[0], -k3[1], k3[0], 0};
-		float Rm[9];
-		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q)
-			Rm[r * 3 + q] = cos_theta * (r == q ? 1.f : 0.f) + sin_theta * K[r * 3 + q] + (1 - cos_theta) * (k3[r] * k3[q]);
-		float outm[9];
-		for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-			float sacc = 0.f;
-			for (int t = 0; t < 3; ++t) sacc += (-Rm[r * 3 + t]) * Ld[t * 3 + q];
-			outm[r * 3 + q] = sacc;
-		}
-		for (int k = 0; k < 9; ++k) Ld[k] = outm[k];
-	}
-	const float light_cam[3] = {Ld[0 * 3 + random_light], Ld[1 * 3 + random_light], Ld[2 * 3 + random_light]};
-#pragma unroll
-	for (int r = 0; r < 3; ++r) R.light[r] = m.xform[r * 4 + 0] * light_cam[0] + m.xform[r * 4 + 1] * light_cam[1] + m.xform[r * 4 + 2] * light_cam[2];
-	float shading_target = nv[0] * light_cam[0] + nv[1] * light_cam[1] + nv[2] * light_cam[2];
-	if (a.F.apply_relu) shading_target = shading_target > 0.f ? shading_target : 0.f;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) R.rgbtarget[k] = albedo_value[k] * shading_target;
+	ray_targets(a.F, m.xform, tex_normal, tex_albedo, a.light_dirs, random_light, R.rgbtarget, R.light);
 	R.mask_certainty = (float)(tex_albedo[3] > 0.99);
 	R.mask_gt = (float)(tex_normal[3] > 0.99);
 }
@@ -1418,7 +1419,7 @@ __device__ __forceinline__ uint32_t loss_pass1_ray(const LossArgs& a, const uint
 			const float dt = unwarp_dt(coords_in[(size_t)j * 7 + 3]);
 			const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
 			alpha = at.alpha;
-			shading = at.g[0] * R.light[0] + at.g[1] * R.light[1] + at.g[2] * R.light[2];
+			shading = esum3(at.g[0] * R.light[0], at.g[1] * R.light[1], at.g[2] * R.light[2]); // normal.dot(light)
 			if (a.F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 			if (a.chain_rec) {
 				const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
@@ -1590,7 +1591,7 @@ __device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& 
 	albedo_from_output(F, o, albedo);
 	const float dir[3] = {G.dir[0], G.dir[1], G.dir[2]};
 	const AlphaTerms at = alpha_terms(o, dt, dir, 1.0f);
-	float shading = at.g[0] * G.light[0] + at.g[1] * G.light[1] + at.g[2] * G.light[2];
+	float shading = esum3(at.g[0] * G.light[0], at.g[1] * G.light[1], at.g[2] * G.light[2]); // normal.dot(light)
 	if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 	const float gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
 	const float* grad = G.grad;
@@ -1730,7 +1731,7 @@ __global__ __launch_bounds__(256) void k_loss_pass2(const LossArgs a) {
 				albedo_from_output(F, o, albedo);
 				const AlphaTerms at = alpha_terms(o, dt, G.dir, 1.0f);
 				alpha = at.alpha;
-				shading = at.g[0] * G.light[0] + at.g[1] * G.light[1] + at.g[2] * G.light[2];
+				shading = esum3(at.g[0] * G.light[0], at.g[1] * G.light[1], at.g[2] * G.light[2]); // normal.dot(light)
 				if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
 				gradient_norm = (float)sqrt((double)(at.g[0] * at.g[0] + at.g[1] * at.g[1] + at.g[2] * at.g[2]) + 1e-6);
 			}
@@ -2052,7 +2053,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[11] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32}, PRIM_OUT_WORDS[11] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5};
+constexpr uint32_t PRIM_IN_WORDS[13] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35}, PRIM_OUT_WORDS[13] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2112,6 +2113,23 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		read_rgba(xy, m, reinterpret_cast<const uint16_t*>(a + 4), c); // the item's own words are the image: RGBA16, two words per pixel
 		o[0] = u(c[0]); o[1] = u(c[1]); o[2] = u(c[2]); o[3] = u(c[3]);
 		o[4] = red_is_nonpositive(xy, m, reinterpret_cast<const uint16_t*>(a + 4)) ? 1u : 0u;
+	} else if (kind == RNB_PRIM_CAMERA_RAY) {
+		ViewDev m{};
+		m.width = a[0]; m.height = a[1]; m.focal[0] = f(a[2]); m.focal[1] = f(a[3]); m.principal[0] = f(a[4]); m.principal[1] = f(a[5]);
+		for (int k = 0; k < 12; ++k) m.xform[k] = f(a[8 + k]);
+		const float xy[2] = {f(a[6]), f(a[7])};
+		Vec3 ro, du, dir;
+		camera_ray(m, xy, ro, du, dir);
+		o[0] = u(ro.x); o[1] = u(ro.y); o[2] = u(ro.z); o[3] = u(du.x); o[4] = u(du.y); o[5] = u(du.z); o[6] = u(dir.x); o[7] = u(dir.y); o[8] = u(dir.z);
+	} else if (kind == RNB_PRIM_RAY_TARGETS) {
+		LossFlags F{};
+		F.apply_no_albedo = a[0]; F.apply_rgbplus = a[1]; F.apply_L2 = a[2]; F.apply_light_opti = a[3]; F.apply_relu = a[4];
+		float X[12], tn[4], ta[4], ld[9], tgt[4], lw[3];
+		for (int k = 0; k < 12; ++k) X[k] = f(a[6 + k]);
+		for (int k = 0; k < 4; ++k) { tn[k] = f(a[18 + k]); ta[k] = f(a[22 + k]); }
+		for (int k = 0; k < 9; ++k) ld[k] = f(a[26 + k]);
+		ray_targets(F, X, tn, ta, ld, (int)a[5], tgt, lw);
+		o[0] = u(tgt[0]); o[1] = u(tgt[1]); o[2] = u(tgt[2]); o[3] = u(tgt[3]); o[4] = u(lw[0]); o[5] = u(lw[1]); o[6] = u(lw[2]);
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

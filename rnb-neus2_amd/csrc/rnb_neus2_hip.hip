@@ -2139,7 +2139,7 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_READ_RGBA) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_RAY_TARGETS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
 	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
 	uint32_t *in = nullptr, *out = nullptr;
@@ -2147,6 +2147,17 @@ int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t 
 	int rc = RNB_OK;
 	if (hipMalloc((void**)&in, n_in * 4) != hipSuccess || hipMalloc((void**)&out, n_out * 4) != hipSuccess || (kind == RNB_PRIM_MARCH && hipMalloc((void**)&bf, n_bf) != hipSuccess))
 		rc = fail(RNB_ERR_NOMEM, "hipMalloc failed for the primitive self-test");
+	std::vector<uint32_t> own; // RNB_PRIM_RAY_TARGETS: nine words 0xffffffff for the light directions = "the context's own" (build_light_dirs)
+	if (kind == RNB_PRIM_RAY_TARGETS) {
+		own.assign(in_host, in_host + n_in);
+		for (uint32_t i = 0; i < n_items; ++i) {
+			uint32_t* ld = own.data() + (size_t)i * PRIM_IN_WORDS[kind] + 26;
+			bool all = true;
+			for (int k = 0; k < 9; ++k) all = all && ld[k] == 0xffffffffu;
+			if (all) std::memcpy(ld, c->light_dirs, 36);
+		}
+		in_host = own.data();
+	}
 	if (rc == RNB_OK && hipMemcpy(in, in_host, n_in * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: copy in failed");
 	if (rc == RNB_OK) {
 		if (bf) hipLaunchKernelGGL(k_prim_bitfield, dim3((uint32_t)((n_bf + 255) / 256)), dim3(256), 0, 0, bf, (uint32_t)n_bf);

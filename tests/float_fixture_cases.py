@@ -82,6 +82,39 @@ def check(ctx, exact_exp):
         assert np.array_equal(out[:, :3][no_pow], rp[:, 32:35][no_pow])
     assert np.count_nonzero(rp[:, 32].view(np.float32) == -1.0) >= 5 and np.count_nonzero(rp[:, 36]) >= 20  # the fixture reaches the sentinel and the red test
     n["read_rgba"] = len(rp)
+    # ---- the ray of an image position: the kernel's own statements as Eigen evaluates them (row sums left to right, division by the norm)
+    cr = np.array(fx["cameraray_w_h_focal2_pp2_xy2_xform12_o3_d3_dir3"], dtype=np.uint32).reshape(-1, 29)
+    out = ctx.eval_primitives("CAMERA_RAY", cr[:, :20])
+    assert np.array_equal(out[:, 0:3], cr[:, 20:23]), "origin"
+    assert np.array_equal(out[:, 3:6], cr[:, 23:26]), "direction before normalisation"
+    if exact_exp:
+        assert np.array_equal(out[:, 6:9], cr[:, 26:29]), "direction"
+    else:
+        assert int(np.max(_ulp_distance(out[:, 6:9], cr[:, 26:29]))) <= 1, "direction"  # (device sqrtf / division are correctly rounded too; one ulp allowed)
+    n["camera_ray"] = len(cr)
+    # ---- the loss kernel's per-ray targets: its own statements (all but the texel fetches and the curand lines) through the reference's Eigen
+    rt = np.array(fx["raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal"], dtype=np.uint32).reshape(-1, 47)
+    out = ctx.eval_primitives("RAY_TARGETS", rt[:, :35])
+    if exact_exp:
+        assert np.array_equal(out[:, 0:4], rt[:, 35:39]), "rgbtarget"
+        assert np.array_equal(out[:, 4:7], rt[:, 39:42]), "light"
+    else:  # linear_to_srgb's powf and sinf / cosf of the light rotation are the device's: a few ulp of the largest component
+        for got, want, what in ((out[:, 0:4], rt[:, 35:39], "rgbtarget"), (out[:, 4:7], rt[:, 39:42], "light")):
+            g, w = got.view(np.float32).astype(np.float64), want.view(np.float32).astype(np.float64)
+            scale = np.maximum(np.max(np.abs(w), axis=1, keepdims=True), 1e-3)
+            assert np.max(np.abs(g - w) / scale) <= 16 * float(np.spacing(np.float32(1.0))), (what, float(np.max(np.abs(g - w) / scale)))
+    assert np.count_nonzero(rt[:, 3]) >= 30 and np.count_nonzero(rt[:, 46]) >= 10  # light_opti and supernormal cases are in
+    # the context's own light triplet (tilt 0 / 120 / 240 degrees, slant 54.74: testbed_nerf.cu:1537-1554) in place of the fixture's: the same targets
+    plain = rt[rt[:, 46] == 0]
+    own = plain[:, :35].copy()
+    own[:, 26:35] = 0xffffffff
+    out2 = ctx.eval_primitives("RAY_TARGETS", own)
+    ref2 = ctx.eval_primitives("RAY_TARGETS", plain[:, :35])
+    if exact_exp:
+        assert np.array_equal(out2, ref2), "the context's light directions are the reference's"
+    else:
+        assert np.max(np.abs(out2.view(np.float32).astype(np.float64) - ref2.view(np.float32).astype(np.float64))) <= 4e-7
+    n["ray_targets"] = len(rt)
     return n
 
 

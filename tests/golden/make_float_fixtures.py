@@ -17,7 +17,10 @@ What is taken, verbatim (function or struct body located by its signature, brace
   include/neural-graphics-primitives/bounding_box.cuh            BoundingBox::diag, ::relative_pos
   include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
   include/neural-graphics-primitives/nerf_loader.h               NerfDataset::nerf_matrix_to_ngp (in a struct with the four members it reads)
-  src/testbed_nerf.cu                                            NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
+  include/neural-graphics-primitives/common.h                    struct Ray
+  src/testbed_nerf.cu                                            the per-ray targets of the loss kernel (:1500-1592, three runs of its lines: all but the texel fetches and curand),
+                                                                 the pinhole-ray statements of generate_training_samples_nerf (:1279-1305, located by their text),
+                                                                 NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
                                                                  activation_function, network_to_rgb, network_to_rgb_derivative, warp_position, unwarp_position, warp_direction,
                                                                  unwarp_direction, warp_dt, unwarp_dt, nerf_random_image_pos_training, image_idx
   include/neural-graphics-primitives/common.h                    enum ELossType, enum ENerfActivation (restated: the enumerators in the file's order, checked against its text)
@@ -32,7 +35,9 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from make_int_fixtures import REF, HERE, fragment  # noqa: E402
+from make_int_fixtures import REF, HERE, fragment, _block  # noqa: E402
+
+LOSS_KERNEL = "__global__ void compute_loss_kernel_train_nerf_with_global_movement("
 
 
 def enum_names(path, head):
@@ -41,6 +46,22 @@ def enum_names(path, head):
     i = src.index(head)
     body = src[src.index("{", i) + 1:src.index("}", i)]
     return [t.strip().split("=")[0].strip() for t in body.split(",") if t.strip()]
+
+
+def statement(path, text):
+    """A statement of the reference located by its exact text (asserted to be there, once or more -- the training and the inference sampler hold the same lines)."""
+    src = open(os.path.join(REF, path)).read()
+    assert text in src, text
+    return text
+
+
+def span(path, first, last, after=None):
+    """The reference's text from the statement `first` through the statement `last` (both asserted present), searched from the text `after` on: a run of a kernel's own lines."""
+    src = open(os.path.join(REF, path)).read()
+    base = src.index(after) if after else 0
+    i = src.index(first, base)
+    j = src.index(last, i)
+    return src[i:j + len(last)]
 
 
 def build_program():
@@ -111,6 +132,36 @@ struct ValidLevel {
 	""" + f(gh, "void set_training_step(int training_step) override {").replace("void set_training_step(int training_step) override {", "void set_training_step(int training_step) {", 1) + """
 };""",
              "}\nusing namespace Eigen;\nusing default_rng_t = tcnn::default_rng_t;",
+             f("include/neural-graphics-primitives/common.h", "struct Ray {") + ";",
+             # the pinhole ray of generate_training_samples_nerf (testbed_nerf.cu:1279-1305): the kernel's own statements, located by their text, in its order, between the
+             # declarations of the names they use (distortion modes other than None, rolling shutter and global movement are off on this path)
+             """static void camera_ray_statements(const Vector2f& xy, const Vector2f& principal_point, const Vector2i& resolution, const Vector2f& focal_length, const Matrix<float, 3, 4>& xform,
+                                  Vector3f& o_out, Vector3f& d_out, Vector3f& dir_out) {
+	Ray ray_unnormalized;
+	""" + statement(tn, "ray_unnormalized.o = xform.col(3);") + "\n\t" + _block(open(os.path.join(REF, tn)).read(), open(os.path.join(REF, tn)).read().index("ray_unnormalized.d = {\n\t\t\t(xy.x()-principal_point.x())*resolution.x() / focal_length.x(),")) + ";\n\t"
+             + statement(tn, "ray_unnormalized.d = (xform.block<3, 3>(0, 0) * ray_unnormalized.d);") + "\n\t" + statement(tn, "Eigen::Vector3f dir = ray_unnormalized.d.normalized();") + """
+	o_out = ray_unnormalized.o; d_out = ray_unnormalized.d; dir_out = dir;
+}""",
+             f(cdc, "inline __host__ __device__ float linear_to_srgb(float linear)"),
+             f(cdc, "inline __host__ __device__ Eigen::Array3f linear_to_srgb(const Eigen::Array3f& x)"),
+             # the per-ray targets of compute_loss_kernel_train_nerf_with_global_movement (testbed_nerf.cu:1500-1592): the kernel's own lines in three runs -- everything between
+             # `xform` and `rgbtarget` except the two read_rgba calls (the texels are arguments here) and the three curand lines (the light index is an argument: deviation D4)
+             """static inline float max(float a, float b) { return fmaxf(a, b); }
+using std::abs;
+float activation_function(float val, ENerfActivation activation); // (the reference's, defined below from its file)
+struct RayTargets { Array3f normal_value; Array4f albedo_value; Matrix3f light_directions_before; Vector3f light; float shading_target; Array4f rgbtarget; };
+static RayTargets ray_target_statements(const Matrix<float, 3, 4>& xform_in, const Array4f& texsamp_albedo, const Array4f& texsamp_normal, const bool apply_no_albedo, const bool apply_rgbplus,
+                                        const bool apply_L2, const bool apply_supernormal, const bool apply_light_opti, const bool apply_relu, const int random_light) {
+	const uint32_t img = 0;
+	const Array3f exposure_values[1] = {Array3f::Zero()};
+	const Array3f* exposure = exposure_values;
+	struct { Matrix<float, 3, 4> start; } training_xforms[1] = {{xform_in}};
+	""" + span(tn, "const Matrix<float, 3, 4>& xform = training_xforms[img].start;", "Array3f exposure_scale = (0.6931471805599453f * exposure[img]).exp();", LOSS_KERNEL) + "\n\t"
+             + span(tn, "Array3f normal_value = linear_to_srgb(exposure_scale * texsamp_normal.head<3>())*2.0f - 1.0f;", "light_directions = Eigen::Matrix3f::Identity(); \n\t}", LOSS_KERNEL) + """
+	const Matrix3f light_directions_before = light_directions;
+	""" + span(tn, "if (apply_light_opti){", "Array4f rgbtarget = albedo_value * shading_target;", LOSS_KERNEL) + """
+	return {normal_value, albedo_value, light_directions_before, light, shading_target, rgbtarget};
+}""",
              # NerfDataset::nerf_matrix_to_ngp (nerf_loader.h:180-201), verbatim, inside a struct with the four members it reads
              "struct DatasetAxes { float scale; Eigen::Vector3f offset; bool from_mitsuba; bool from_na;\n" + f("include/neural-graphics-primitives/nerf_loader.h", "Eigen::Matrix<float, 3, 4> nerf_matrix_to_ngp(const Eigen::Matrix<float, 3, 4>& nerf_matrix)") + "\n};",
              "template <typename RNG>\n" + f("include/neural-graphics-primitives/random_val.cuh", "inline __host__ __device__ Eigen::Vector2f random_val_2d(RNG& rng)"),
@@ -309,7 +360,58 @@ int main() {
 			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out.push_back(fb(m(r, c)));
 			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out.push_back(fb(g(r, c)));
 		}
-		arr_u("axes_mode_scale_offset3_matrix12_ngp12", out, true);
+		arr_u("axes_mode_scale_offset3_matrix12_ngp12", out);
+	}
+	{ // ---- the ray of an image position (testbed_nerf.cu:1279-1305)
+		std::vector<uint32_t> out;
+		const int shapes[3][2] = {{800, 800}, {256, 256}, {612, 512}};
+		for (int k = 0; k < 192; ++k) {
+			const int w = shapes[k % 3][0], h = shapes[k % 3][1];
+			const Vector2f focal{uni(200, 1600), uni(200, 1600)}, pp{uni(0.4f, 0.6f), uni(0.4f, 0.6f)};
+			Vector2f xy{gen.next_float(), gen.next_float()};
+			if (k % 16 == 0) xy = pp;                       // the principal ray
+			if (k % 16 == 1) xy = Vector2f{0.0f, 0.0f};
+			Matrix<float, 3, 4> X;
+			Vector3f a = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized(), b = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)};
+			b = (b - a * a.dot(b)).normalized();
+			X.col(0) = a; X.col(1) = b; X.col(2) = a.cross(b); X.col(3) = Vector3f{uni(-2, 3), uni(-2, 3), uni(-2, 3)};
+			if (k % 4 == 3) X.block<3, 3>(0, 0) *= uni(0.5f, 2.0f);   // a scaled camera frame (n2w): the direction is normalised after the product
+			Vector3f o, d, dir;
+			camera_ray_statements(xy, pp, Vector2i{w, h}, focal, X, o, d, dir);
+			out.push_back((uint32_t)w); out.push_back((uint32_t)h);
+			for (float v : {focal.x(), focal.y(), pp.x(), pp.y(), xy.x(), xy.y()}) out.push_back(fb(v));
+			for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out.push_back(fb(X(r, c)));
+			for (float v : {o.x(), o.y(), o.z(), d.x(), d.y(), d.z(), dir.x(), dir.y(), dir.z()}) out.push_back(fb(v));
+		}
+		arr_u("cameraray_w_h_focal2_pp2_xy2_xform12_o3_d3_dir3", out);
+	}
+	{ // ---- the loss kernel's per-ray targets (testbed_nerf.cu:1500-1592)
+		std::vector<uint32_t> out;
+		for (int k = 0; k < 192; ++k) {
+			const bool no_albedo = k % 4 == 1, rgbplus = k % 8 < 6, L2 = k % 3 != 2, supernormal = k % 16 == 5, light_opti = k % 5 == 2, relu_ = k % 7 == 3;
+			const int random_light = k % 3;
+			Matrix<float, 3, 4> X;
+			Vector3f a = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized(), b = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)};
+			b = (b - a * a.dot(b)).normalized();
+			X.col(0) = a; X.col(1) = b; X.col(2) = a.cross(b); X.col(3) = Vector3f{uni(-2, 3), uni(-2, 3), uni(-2, 3)};
+			// texels as read_rgba returns them: linear colour x alpha, alpha (a normal map pointing roughly at the camera; an albedo)
+			const float an = k % 9 == 0 ? 0.5f : 1.0f, aa = k % 11 == 0 ? 0.25f : 1.0f;
+			Vector3f nrm = Vector3f{uni(-0.6f, 0.6f), uni(-0.6f, 0.6f), 1.0f}.normalized();
+			auto enc = [](float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 0.41666f) - 0.055f; }; (void)enc;
+			Array4f tn_{srgb_to_linear(nrm.x() * 0.5f + 0.5f) * an, srgb_to_linear(-nrm.y() * 0.5f + 0.5f) * an, srgb_to_linear(-nrm.z() * 0.5f + 0.5f) * an, an};
+			Array4f ta_{uni(0.02f, 0.9f) * aa, uni(0.02f, 0.9f) * aa, uni(0.02f, 0.9f) * aa, aa};
+			const RayTargets r = ray_target_statements(X, ta_, tn_, no_albedo, rgbplus, L2, supernormal, light_opti, relu_, random_light);
+			for (uint32_t v : {(uint32_t)no_albedo, (uint32_t)rgbplus, (uint32_t)L2, (uint32_t)light_opti, (uint32_t)relu_, (uint32_t)random_light}) out.push_back(v);
+			for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 4; ++c) out.push_back(fb(X(rr, c)));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(tn_[c]));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(ta_[c]));
+			for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 3; ++c) out.push_back(fb(r.light_directions_before(rr, c)));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(r.rgbtarget[c]));
+			for (int c = 0; c < 3; ++c) out.push_back(fb(r.light[c]));
+			for (int c = 0; c < 3; ++c) out.push_back(fb(r.normal_value[c]));
+			out.push_back(fb(r.shading_target)); out.push_back((uint32_t)supernormal);
+		}
+		arr_u("raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal", out, true);
 	}
 	printf("}\n");
 	return 0;
@@ -324,7 +426,7 @@ def main():
         src = os.path.join(d, "float_fixtures.cpp")
         open(src, "w").write(prog)
         exe = os.path.join(d, "float_fixtures")
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
         text = subprocess.check_output([exe]).decode()
     data = json.loads(text)
     data = {"_source": "tests/golden/make_float_fixtures.py: floating-point fragments of /root/reference compiled with g++ (-ffp-contract=off) in the build container "

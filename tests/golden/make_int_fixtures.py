@@ -200,7 +200,7 @@ def main():
         open(src, "w").write("#include <cstring>\n#include <vector>\n" + prog)
         exe = os.path.join(d, "int_fixtures")
         # -ffp-contract=off: nvcc contracts to FMA on the device, g++ on x86-64 does not by default either way; the library and the checker are built without contraction
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
         text = subprocess.check_output([exe]).decode()
     data = json.loads(text)
     data = {"_source": "tests/golden/make_int_fixtures.py: fragments of /root/reference compiled with g++ in the build container (see the script's header); floats as IEEE-754 bit patterns",

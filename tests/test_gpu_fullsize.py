@@ -376,8 +376,15 @@ def test_data_parallel_trainer_over_rccl_single_rank(scene, trained, monkeypatch
         phase("20 steps x 3")
         for st in got:
             assert st.training_step == ref.training_step
-            assert abs(st.loss - ref.loss) <= 0.05 * abs(ref.loss), history  # measured spread between the variants: 0.3 %
             assert abs(st.rays_per_batch - ref.rays_per_batch) <= max(256, 0.02 * ref.rays_per_batch), history  # the controller rounds to multiples of 128
+        # Three trajectories: while their batches have the same shape they draw the same rays and their losses agree (measured spread 0.3 %); once a controller has rounded
+        # to another multiple of 128 every ray of the batch is another pixel and a step's loss is another sample of the +-30 % step-to-step spread -- the mean still agrees.
+        h = np.array(history)
+        same = (h[:, 3] == h[:, 4]) & (h[:, 3] == h[:, 5])
+        assert same[:3].all(), history
+        for k in (1, 2):
+            assert np.all(np.abs(h[same, k] - h[same, 0]) <= 0.05 * np.abs(h[same, 0])), history
+            assert abs(h[:, k].mean() - h[:, 0].mean()) <= 0.15 * h[:, 0].mean(), history
     finally:
         dist.destroy_process_group()
         phase("destroy_process_group")
