@@ -354,9 +354,14 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *                                                                       (the pinhole ray of testbed_nerf.cu:1279-1305 as Eigen evaluates it)
  *   RNB_PRIM_RAY_TARGETS in apply_no_albedo, apply_rgbplus, apply_L2, apply_light_opti, apply_relu, light index, camera matrix 12, normal texel 4, albedo texel 4,
  *                    light_directions 9 (row-major, camera frame; nine words 0xffffffff = the context's own, testbed_nerf.cu:1537-1554)   out rgbtarget 4, the light in the world frame 3   (the loss kernel's per-ray targets, testbed_nerf.cu:1500-1592)
+ *   RNB_PRIM_LOSS_SAMPLE in apply_no_albedo, apply_rgbplus, apply_L2, apply_relu, the sample's network output (16 halves = 8 words), dt, ray direction 3, light 3, the ray's loss
+ *                    gradient 4, rgb_ray 4, then the running values BEFORE the sample: rgb_ray2 4, (clamped) weight_sum, weight_sum2, T, then gradient_weight_sum, loss_scale,
+ *                    ek_loss_weight   out alpha, and AFTER the sample T, weight_sum2, rgb_ray2 4, then dL/d(network output)[0..10] as half bit patterns, then the float values behind
+ *                    them: dloss_by_drgb 3, dloss_dn 3, dloss_dalpha, dloss_dsdf, dloss_dvariance, dloss_dnormal_norm
+ *                    (one iteration of the loss kernel's second loop, testbed_nerf.cu:1855-2085; cos_anneal_ratio 1, rgb_activation Logistic)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

@@ -1131,6 +1131,75 @@ void loss_pass1(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_rays
 	R.mask_gt = (float)(tex_normal[3] > 0.99);
 }
 
+// dL/d(network output) of one compacted sample (testbed_nerf.cu:1920-2085) from the ray's terms, the sample's network output `o`, its step `dt`, and the running values of the
+// compositing recurrence right AFTER the sample: its weight, the transmittance T, the weight sum weight_sum2, the colour sums rgb_ray2. Returns the sample's gradient norm
+// (the Eikonal term is formed from it). tests/golden/float_fixtures.json runs the kernel's own lines for one sample.
+static inline float pass2_sample(const rnb_config& F, const float grad[4], const float rgb_ray[4], const float weight_sum, const float gradient_weight_sum, const float light[3], const Vec3& dir,
+                                 const float loss_scale, const half_t* o, const float dt, const float albedo[4], const AlphaTerms& a, const float shading, const float weight, const float T,
+                                 const float weight_sum2, const float rgb_ray2[4], half_t dl[16], float* inter = nullptr) {
+	const float alpha = a.alpha;
+	float suffix[4];
+	for (int k = 0; k < 4; ++k) suffix[k] = rgb_ray[k] - rgb_ray2[k];
+	// dloss_dn = weight * (light * albedo^T) * lg.gradient (testbed_nerf.cu:1924-1926): Eigen forms every coefficient of the scaled 3x4 matrix, then sums a row's four terms as
+	// (x0 + x1) + (x2 + x3)
+	float dloss_dn[3];
+	for (int d = 0; d < 3; ++d)
+		dloss_dn[d] = esum4((weight * (light[d] * albedo[0])) * grad[0], (weight * (light[d] * albedo[1])) * grad[1], (weight * (light[d] * albedo[2])) * grad[2], (weight * (light[d] * albedo[3])) * grad[3]);
+	// jac_rgb (testbed_nerf.cu:1928-1949)
+	float J3[3] = {0, 0, 0};
+	if (F.apply_rgbplus) {
+		if (F.apply_L2) for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5));
+		else for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]);
+	}
+	float drgb[3]; // (weight * shading) * jac_rgb * lg.gradient with jac_rgb = [I | J3] (testbed_nerf.cu:1928-1952): the scaled matrix's zero entries are signed zeros and stay in the sums
+	const float ws = weight * shading;
+	for (int d = 0; d < 3; ++d)
+		drgb[d] = esum4((ws * (d == 0 ? 1.0f : 0.0f)) * grad[0], (ws * (d == 1 ? 1.0f : 0.0f)) * grad[1], (ws * (d == 2 ? 1.0f : 0.0f)) * grad[2], (ws * J3[d]) * grad[3]);
+	for (int q = 0; q < 16; ++q) dl[q] = 0;
+	const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
+	for (int d = 0; d < 3; ++d) {
+		float sg = logistic(h2f(o[d]));
+		dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
+	}
+	const float sum_weight_suffix = weight_sum - weight_sum2;
+	const float dot_term = esum4(grad[0] * (T * albedo[0] * shading - suffix[0]), grad[1] * (T * albedo[1] * shading - suffix[1]), grad[2] * (T * albedo[2] * shading - suffix[2]),
+	                             grad[3] * (T * albedo[3] * shading - suffix[3])); // lg.gradient.matrix().dot(...)
+	float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (T - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
+	float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
+	if (!(a.p_div_c <= 0.0f || a.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
+		float plus_sigmoid_x = a.inv_s * a.iter_cos * dt;
+		float plus_e = expf(plus_sigmoid_x);
+		float e_minus = expf(-a.est_next * a.inv_s);
+		dE_dsdf = -a.inv_s * e_minus;
+		dE_dinvs = -a.est_next * e_minus;
+		float aa = 1 + e_minus;
+		float bb = 1 + plus_e * e_minus;
+		float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
+		float delta = aa * (bb * bb) * (cc * cc);
+		dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
+		dalpha_dEp = -e_minus / (delta);
+		dEp_dinvs = plus_e * a.iter_cos * dt;
+		dEp_ditc = plus_e * a.inv_s * dt;
+		dE_ditc = (float)(-a.inv_s * e_minus * dt * 0.5);
+	}
+	float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
+	float dloss_dvariance = dloss_dinvs * a.inv_s * 10;
+	float d_iter_cos_true_cos = (a.true_cos >= 0) ? 0.0f : 1.0f;
+	float gradient_norm = (float)std::sqrt(a.g[0] * a.g[0] + a.g[1] * a.g[1] + a.g[2] * a.g[2] + 1e-6);
+	float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
+	float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
+	float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
+	dl[3] = f2h(loss_scale * dloss_dsdf);
+	for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(F.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * a.g[d]);
+	dl[7] = f2h(loss_scale * dloss_dvariance);
+	const float dirv[3] = {dir.x, dir.y, dir.z};
+	for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dirv[d]));
+	if (inter) {
+		for (int d = 0; d < 3; ++d) { inter[d] = drgb[d]; inter[3 + d] = dloss_dn[d]; }
+		inter[6] = dloss_dalpha; inter[7] = dloss_dsdf; inter[8] = dloss_dvariance; inter[9] = dloss_dnormal_norm;
+	}
+	return gradient_norm;
+}
 void loss_pass2(orc_ctx_s* c, uint32_t i, uint32_t n_rays, const RayLoss& R, uint32_t compacted_base, uint32_t compacted_numsteps) {
 	const uint32_t base = c->numsteps[(size_t)i * 2 + 1];
 	const float* coords_in = &c->coords[(size_t)base * 7];
@@ -1184,61 +1253,9 @@ void loss_pass2(orc_ctx_s* c, uint32_t i, uint32_t n_rays, const RayLoss& R, uin
 		for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * albedo[k] * shading;
 		weight_sum2 += weight;
 		T *= (1.f - alpha);
-		float suffix[4];
-		for (int k = 0; k < 4; ++k) suffix[k] = R.rgb_ray[k] - rgb_ray2[k];
-		// dloss_dn = weight * light * (albedo · G) (testbed_nerf.cu:1924-1926)
-		float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
-		float dloss_dn[3];
-		for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (R.light[d] * aG);
-		// jac_rgb (testbed_nerf.cu:1928-1949)
-		float J3[3] = {0, 0, 0};
-		if (c->cfg.apply_rgbplus) {
-			if (c->cfg.apply_L2) for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5));
-			else for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]);
-		}
-		float drgb[3];
-		for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
 		half_t dl[16];
-		for (int q = 0; q < 16; ++q) dl[q] = 0;
-		const float opti_rgb = c->cfg.apply_no_albedo ? 0.0f : 1.0f;
-		for (int d = 0; d < 3; ++d) {
-			float sg = logistic(h2f(o[d]));
-			dl[d] = f2h(opti_rgb * loss_scale * (drgb[d] * (sg * (1 - sg))));
-		}
-		const float sum_weight_suffix = weight_sum - weight_sum2;
-		float dot_term = 0.f;
-		for (int k = 0; k < 4; ++k) dot_term += grad[k] * (T * albedo[k] * shading - suffix[k]);
-		float dloss_dalpha = (float)((dot_term + (gradient_weight_sum * (T - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
-		float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
-		if (!(a.p_div_c <= 0.0f || a.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
-			float plus_sigmoid_x = a.inv_s * a.iter_cos * dt;
-			float plus_e = expf(plus_sigmoid_x);
-			float e_minus = expf(-a.est_next * a.inv_s);
-			dE_dsdf = -a.inv_s * e_minus;
-			dE_dinvs = -a.est_next * e_minus;
-			float aa = 1 + e_minus;
-			float bb = 1 + plus_e * e_minus;
-			float cc = (float)(1e-5 + 1 / (1 + plus_e * e_minus));
-			float delta = aa * (bb * bb) * (cc * cc);
-			dalpha_dE = -(plus_e / (delta)-1 / (aa * aa * cc));
-			dalpha_dEp = -e_minus / (delta);
-			dEp_dinvs = plus_e * a.iter_cos * dt;
-			dEp_ditc = plus_e * a.inv_s * dt;
-			dE_ditc = (float)(-a.inv_s * e_minus * dt * 0.5);
-		}
-		float dloss_dinvs = dloss_dalpha * (dalpha_dE * dE_dinvs + dalpha_dEp * dEp_dinvs);
-		float dloss_dvariance = dloss_dinvs * a.inv_s * 10;
-		float d_iter_cos_true_cos = (a.true_cos >= 0) ? 0.0f : 1.0f;
-		float gradient_norm = (float)std::sqrt(a.g[0] * a.g[0] + a.g[1] * a.g[1] + a.g[2] * a.g[2] + 1e-6);
-		float pos_gradient_norm_inv = 1 - 1 / gradient_norm;
-		float dloss_dnormal_norm = dloss_dalpha * (dalpha_dE * dE_ditc + dEp_ditc * dalpha_dEp) * d_iter_cos_true_cos;
-		float dloss_dsdf = dloss_dalpha * dalpha_dE * dE_dsdf;
-		dl[3] = f2h(loss_scale * dloss_dsdf);
+		const float gradient_norm = pass2_sample(c->cfg, grad, R.rgb_ray, weight_sum, gradient_weight_sum, R.light, dir, loss_scale, o, dt, albedo, a, shading, weight, T, weight_sum2, rgb_ray2, dl);
 		ek += (gradient_norm - 1.0f) * (gradient_norm - 1.0f);
-		for (int d = 0; d < 3; ++d) dl[4 + d] = f2h(c->cfg.ek_loss_weight * 2 * LOSS_SCALE * pos_gradient_norm_inv * a.g[d]);
-		dl[7] = f2h(loss_scale * dloss_dvariance);
-		const float dirv[3] = {dir.x, dir.y, dir.z};
-		for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dirv[d]));
 		for (int q = 0; q < 16; ++q) dloss[(size_t)j * 16 + q] = dl[q];
 	}
 	c->ek_loss[i] = ek / ((float)compacted_numsteps * (float)gn);
@@ -2020,8 +2037,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_RAY_TARGETS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[13] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35}, OUT_W[13] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7};
+	if (kind < 0 || kind > RNB_PRIM_LOSS_SAMPLE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[14] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37}, OUT_W[14] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2098,6 +2115,37 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			if (own) std::memcpy(ld, c->light_dirs, 36);
 			ray_targets(F, X, tn, ta, ld, (int)a[5], tgt, lw);
 			o[0] = u(tgt[0]); o[1] = u(tgt[1]); o[2] = u(tgt[2]); o[3] = u(tgt[3]); o[4] = u(lw[0]); o[5] = u(lw[1]); o[6] = u(lw[2]);
+		} else if (kind == RNB_PRIM_LOSS_SAMPLE) {
+			rnb_config F{};
+			F.apply_no_albedo = a[0]; F.apply_rgbplus = a[1]; F.apply_L2 = a[2]; F.apply_relu = a[3];
+			half_t oh[16];
+			std::memcpy(oh, a + 4, 32);
+			const float dt = f(a[12]);
+			const Vec3 dir = {f(a[13]), f(a[14]), f(a[15])};
+			const float light[3] = {f(a[16]), f(a[17]), f(a[18])}, grad[4] = {f(a[19]), f(a[20]), f(a[21]), f(a[22])}, rgb_ray[4] = {f(a[23]), f(a[24]), f(a[25]), f(a[26])};
+			float rgb_ray2[4] = {f(a[27]), f(a[28]), f(a[29]), f(a[30])};
+			const float weight_sum = f(a[31]);
+			float weight_sum2 = f(a[32]), T = f(a[33]);
+			const float gws = f(a[34]), loss_scale = f(a[35]);
+			F.ek_loss_weight = f(a[36]);
+			// the forward part of the loop body (testbed_nerf.cu:1866-1917), as loss_pass2 runs it
+			orc_ctx_s tmp; tmp.cfg = F;
+			float albedo[4];
+			albedo_from_output(&tmp, oh, albedo);
+			const AlphaTerms at = alpha_terms(oh, dt, dir, 1.0f);
+			const float weight = at.alpha * T;
+			float shading = esum3(at.g[0] * light[0], at.g[1] * light[1], at.g[2] * light[2]);
+			if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+			for (int k = 0; k < 4; ++k) rgb_ray2[k] += weight * albedo[k] * shading;
+			weight_sum2 += weight;
+			T *= (1.f - at.alpha);
+			half_t dl[16];
+			float inter[10];
+			(void)pass2_sample(F, grad, rgb_ray, weight_sum, gws, light, dir, loss_scale, oh, dt, albedo, at, shading, weight, T, weight_sum2, rgb_ray2, dl, inter);
+			for (int k = 0; k < 10; ++k) o[18 + k] = u(inter[k]);
+			o[0] = u(at.alpha); o[1] = u(T); o[2] = u(weight_sum2);
+			for (int k = 0; k < 4; ++k) o[3 + k] = u(rgb_ray2[k]);
+			for (int k = 0; k < 11; ++k) { uint16_t hb; std::memcpy(&hb, &dl[k], 2); o[7 + k] = hb; }
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

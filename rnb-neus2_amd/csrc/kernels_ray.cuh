@@ -1585,8 +1585,10 @@ __device__ __forceinline__ void pass2_ray_terms(const LossFlags& F, const RayLos
 
 // dL/d(network output) of one compacted sample (testbed_nerf.cu:1893-2075) from the ray's terms, the sample's network output `o`, its step `dt` and the
 // running values of the compositing recurrence right after it: its weight, the transmittance Tj, the weight sum w2, the colour sums rgb2.
+// Eigen evaluates `weight * light_albedo * g` and `weight * shading * jac_rgb * g` as fixed-size products of a scaled 3x4 matrix with a 4-vector: every coefficient of the
+// scaled matrix first, then a row's four terms as (x0 + x1) + (x2 + x3); the .dot() of two 4-vectors the same way (esum4). `inter` (tests): the float values behind dl.
 __device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& G, const float loss_scale, const half_t (&o)[16], const float dt,
-                                             const float my_weight, const float Tj, const float my_w2, const float (&my_rgb2)[4], half_t (&dl)[16]) {
+                                             const float my_weight, const float Tj, const float my_w2, const float (&my_rgb2)[4], half_t (&dl)[16], float* inter = nullptr) {
 	float albedo[4];
 	albedo_from_output(F, o, albedo);
 	const float dir[3] = {G.dir[0], G.dir[1], G.dir[2]};
@@ -1600,22 +1602,24 @@ __device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& 
 	float suffix[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) suffix[k] = G.rgb_ray[k] - my_rgb2[k];
-	const float aG = albedo[0] * grad[0] + albedo[1] * grad[1] + albedo[2] * grad[2] + albedo[3] * grad[3];
-	float dloss_dn[3];
+	float dloss_dn[3]; // weight * (light * albedo^T) * lg.gradient
 #pragma unroll
-	for (int d = 0; d < 3; ++d) dloss_dn[d] = weight * (G.light[d] * aG);
+	for (int d = 0; d < 3; ++d)
+		dloss_dn[d] = esum4((weight * (G.light[d] * albedo[0])) * grad[0], (weight * (G.light[d] * albedo[1])) * grad[1], (weight * (G.light[d] * albedo[2])) * grad[2], (weight * (G.light[d] * albedo[3])) * grad[3]);
 	float J3[3] = {0, 0, 0};
 	if (F.apply_rgbplus) {
 		if (F.apply_L2) { for (int d = 0; d < 3; ++d) J3[d] = (float)(-2 * albedo[d] / (albedo[3] + 1e-5)); }
 		else { for (int d = 0; d < 3; ++d) J3[d] = -sign1(albedo[d]); }
 	}
-	float drgb[3];
+	float drgb[3]; // (weight * shading) * jac_rgb * lg.gradient, jac_rgb = [I | J3]: the zero entries of the scaled matrix are signed zeros and stay in the sums
+	const float ws = weight * shading;
 #pragma unroll
-	for (int d = 0; d < 3; ++d) drgb[d] = weight * shading * (grad[d] + J3[d] * grad[3]);
+	for (int d = 0; d < 3; ++d)
+		drgb[d] = esum4((ws * (d == 0 ? 1.0f : 0.0f)) * grad[0], (ws * (d == 1 ? 1.0f : 0.0f)) * grad[1], (ws * (d == 2 ? 1.0f : 0.0f)) * grad[2], (ws * J3[d]) * grad[3]);
 #pragma unroll
 	for (int q = 0; q < 16; ++q) dl[q] = (half_t)0.f;
 	const float opti_rgb = F.apply_no_albedo ? 0.0f : 1.0f;
-	if (F.apply_no_albedo) { // 0 x loss_scale x (drgb x a factor in [0, 1/4]): a zero with the sign of drgb (round 4: three exp and three divisions per sample for it before)
+	if (F.apply_no_albedo) { // 0 x loss_scale x (drgb x a factor in (0, 1/4]): a zero with the sign of drgb (round 4: three exp and three divisions per sample for it before)
 #pragma unroll
 		for (int d = 0; d < 3; ++d) dl[d] = f2h(copysignf(0.f, drgb[d]));
 	} else {
@@ -1626,9 +1630,8 @@ __device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& 
 		}
 	}
 	const float sum_weight_suffix = G.weight_sum - my_w2;
-	float dot_term = 0.f;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) dot_term += grad[k] * (Tj * albedo[k] * shading - suffix[k]);
+	const float dot_term = esum4(grad[0] * (Tj * albedo[0] * shading - suffix[0]), grad[1] * (Tj * albedo[1] * shading - suffix[1]), grad[2] * (Tj * albedo[2] * shading - suffix[2]),
+	                             grad[3] * (Tj * albedo[3] * shading - suffix[3])); // lg.gradient.matrix().dot(...)
 	const float dloss_dalpha = (float)((dot_term + (G.gradient_weight_sum * (Tj - sum_weight_suffix))) / (1.0f - alpha + 1e-5));
 	float dalpha_dE = 0.f, dE_dsdf = 0.f, dE_dinvs = 0.f, dalpha_dEp = 0.f, dEp_dinvs = 0.f, dEp_ditc = 0.f, dE_ditc = 0.f;
 	if (!(at.p_div_c <= 0.0f || at.p_div_c >= 1.0f)) { // testbed_nerf.cu:1982-2014
@@ -1659,6 +1662,10 @@ __device__ __forceinline__ void pass2_sample(const LossFlags& F, const RayGrad& 
 	dl[7] = f2h(loss_scale * dloss_dvariance);
 #pragma unroll
 	for (int d = 0; d < 3; ++d) dl[8 + d] = f2h(loss_scale * (dloss_dn[d] + dloss_dnormal_norm * dir[d]));
+	if (inter) {
+		for (int d = 0; d < 3; ++d) { inter[d] = drgb[d]; inter[3 + d] = dloss_dn[d]; }
+		inter[6] = dloss_dalpha; inter[7] = dloss_dsdf; inter[8] = dloss_dvariance; inter[9] = dloss_dnormal_norm;
+	}
 }
 
 // One launch, LR lanes per ray (64: one wavefront per ray; 16: four rays per wavefront): lanes own samples. REC: the running values of the recurrence come from
@@ -2053,7 +2060,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[13] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35}, PRIM_OUT_WORDS[13] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7};
+constexpr uint32_t PRIM_IN_WORDS[14] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37}, PRIM_OUT_WORDS[14] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2130,6 +2137,38 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		for (int k = 0; k < 9; ++k) ld[k] = f(a[26 + k]);
 		ray_targets(F, X, tn, ta, ld, (int)a[5], tgt, lw);
 		o[0] = u(tgt[0]); o[1] = u(tgt[1]); o[2] = u(tgt[2]); o[3] = u(tgt[3]); o[4] = u(lw[0]); o[5] = u(lw[1]); o[6] = u(lw[2]);
+	} else if (kind == RNB_PRIM_LOSS_SAMPLE) {
+		LossFlags F{};
+		F.apply_no_albedo = a[0]; F.apply_rgbplus = a[1]; F.apply_L2 = a[2]; F.apply_relu = a[3];
+		half_t oh[16];
+		for (int k = 0; k < 8; ++k) { const h2 p2 = unpack_h2(a[4 + k]); oh[2 * k] = p2[0]; oh[2 * k + 1] = p2[1]; }
+		const float dt = f(a[12]);
+		RayGrad G;
+		for (int k = 0; k < 3; ++k) { G.dir[k] = f(a[13 + k]); G.light[k] = f(a[16 + k]); }
+		for (int k = 0; k < 4; ++k) { G.grad[k] = f(a[19 + k]); G.rgb_ray[k] = f(a[23 + k]); }
+		float rgb2[4] = {f(a[27]), f(a[28]), f(a[29]), f(a[30])};
+		G.weight_sum = f(a[31]);
+		float w2 = f(a[32]), T = f(a[33]);
+		G.gradient_weight_sum = f(a[34]);
+		const float loss_scale = f(a[35]);
+		F.ek_loss_weight = f(a[36]);
+		// the forward part of the loop body (testbed_nerf.cu:1866-1917) with the compositing recurrence as replay_chain states it (chain.cuh)
+		float albedo[4];
+		albedo_from_output(F, oh, albedo);
+		const AlphaTerms at = alpha_terms(oh, dt, G.dir, 1.0f);
+		float shading = esum3(at.g[0] * G.light[0], at.g[1] * G.light[1], at.g[2] * G.light[2]);
+		if (F.apply_relu) shading = shading > 0.f ? shading : 0.f;
+		const float w = at.alpha * T;
+		T = T * (1.f - at.alpha);
+		w2 = w2 + w;
+		for (int k = 0; k < 4; ++k) rgb2[k] = rgb2[k] + w * albedo[k] * shading;
+		half_t dl[16];
+		float inter[10];
+		pass2_sample(F, G, loss_scale, oh, dt, w, T, w2, rgb2, dl, inter);
+		for (int k = 0; k < 10; ++k) o[18 + k] = u(inter[k]);
+		o[0] = u(at.alpha); o[1] = u(T); o[2] = u(w2);
+		for (int k = 0; k < 4; ++k) o[3 + k] = u(rgb2[k]);
+		for (int k = 0; k < 11; ++k) o[7 + k] = (uint32_t)__builtin_bit_cast(uint16_t, dl[k]);
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

