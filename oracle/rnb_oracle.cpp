@@ -1131,6 +1131,32 @@ void loss_pass1(const orc_ctx_s* c, uint32_t i, uint32_t n_rays, uint32_t n_rays
 	R.mask_gt = (float)(tex_normal[3] > 0.99);
 }
 
+// The ray's loss terms between the loss kernel's two loops (testbed_nerf.cu:1735-1800): loss and gradient (halved for rgb+, gated by the albedo's alpha), the clamped weight sum, the
+// gradient of the mask term, the two loss rows. Returns the ray's loss. tests/golden/float_fixtures.json runs the kernel's own lines.
+static inline float pass2_ray_terms(const rnb_config& F, const float rgbtarget[4], const float rgb_ray[4], const float mask_certainty, const float mask_gt, const float weight_sum_raw,
+                                    const float gn, float grad[4], float* weight_sum_out, float* gradient_weight_sum_out, float* loss_row, float* mask_row) {
+	float loss = loss_and_gradient(F.apply_L2 != 0, rgbtarget, rgb_ray, grad);
+	if (F.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) grad[k] /= 2; }
+	loss *= mask_certainty;
+	for (int k = 0; k < 4; ++k) grad[k] *= mask_certainty;
+	float weight_sum = weight_sum_raw;
+	float gradient_weight_sum;
+	if (weight_sum >= 1.0 - 1e-4) { weight_sum = (float)(1.0 - 1e-4); gradient_weight_sum = 0.0f; }
+	else if (weight_sum <= 1e-4) { weight_sum = 1e-4; gradient_weight_sum = 0.0f; }
+	else {
+		float sig = 1.0f / (1.0f + expf(-weight_sum));
+		if (F.apply_bce) gradient_weight_sum = ((1 - mask_gt) / (1 - weight_sum) - mask_gt / weight_sum) * F.mask_loss_weight;
+		else gradient_weight_sum = (sig - mask_gt) * F.mask_loss_weight;
+	}
+	*loss_row = loss / gn;
+	{
+		float sig = 1.0f / (1.0f + expf(-weight_sum));
+		if (F.apply_bce) *mask_row = -(mask_gt * logf(weight_sum) + (1 - mask_gt) * logf(1 - weight_sum));
+		else *mask_row = -(mask_gt * logf(sig) + (1 - mask_gt) * logf(1 - sig));
+	}
+	*weight_sum_out = weight_sum; *gradient_weight_sum_out = gradient_weight_sum;
+	return loss;
+}
 // dL/d(network output) of one compacted sample (testbed_nerf.cu:1920-2085) from the ray's terms, the sample's network output `o`, its step `dt`, and the running values of the
 // compositing recurrence right AFTER the sample: its weight, the transmittance T, the weight sum weight_sum2, the colour sums rgb_ray2. Returns the sample's gradient norm
 // (the Eikonal term is formed from it). tests/golden/float_fixtures.json runs the kernel's own lines for one sample.
@@ -1211,26 +1237,8 @@ void loss_pass2(orc_ctx_s* c, uint32_t i, uint32_t n_rays, const RayLoss& R, uin
 	if (compacted_numsteps == 0) return; // testbed_nerf.cu:1726-1728: returns before any loss output is written
 
 	// loss (testbed_nerf.cu:1737-1802)
-	float grad[4];
-	float loss = loss_and_gradient(c->cfg.apply_L2 != 0, R.rgbtarget, R.rgb_ray, grad);
-	if (c->cfg.apply_rgbplus) { loss /= 2; for (int k = 0; k < 4; ++k) grad[k] /= 2; }
-	loss *= R.mask_certainty;
-	for (int k = 0; k < 4; ++k) grad[k] *= R.mask_certainty;
-	float weight_sum = R.weight_sum_raw;
-	float gradient_weight_sum;
-	if (weight_sum >= 1.0 - 1e-4) { weight_sum = (float)(1.0 - 1e-4); gradient_weight_sum = 0.0f; }
-	else if (weight_sum <= 1e-4) { weight_sum = 1e-4; gradient_weight_sum = 0.0f; }
-	else {
-		float sig = 1.0f / (1.0f + expf(-weight_sum));
-		if (c->cfg.apply_bce) gradient_weight_sum = ((1 - R.mask_gt) / (1 - weight_sum) - R.mask_gt / weight_sum) * c->cfg.mask_loss_weight;
-		else gradient_weight_sum = (sig - R.mask_gt) * c->cfg.mask_loss_weight;
-	}
-	c->loss[i] = loss / (float)gn;
-	{
-		float sig = 1.0f / (1.0f + expf(-weight_sum));
-		if (c->cfg.apply_bce) c->mask_loss[i] = -(R.mask_gt * logf(weight_sum) + (1 - R.mask_gt) * logf(1 - weight_sum));
-		else c->mask_loss[i] = -(R.mask_gt * logf(sig) + (1 - R.mask_gt) * logf(1 - sig));
-	}
+	float grad[4], weight_sum, gradient_weight_sum;
+	(void)pass2_ray_terms(c->cfg, R.rgbtarget, R.rgb_ray, R.mask_certainty, R.mask_gt, R.weight_sum_raw, (float)gn, grad, &weight_sum, &gradient_weight_sum, &c->loss[i], &c->mask_loss[i]);
 	c->ek_loss[i] = 0.f;
 
 	const float loss_scale = LOSS_SCALE / (float)gn; // testbed_nerf.cu:1832
@@ -2037,8 +2045,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_LOSS_SAMPLE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[14] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37}, OUT_W[14] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28};
+	if (kind < 0 || kind > RNB_PRIM_RAY_LOSS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[15] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16}, OUT_W[15] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2146,6 +2154,13 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			o[0] = u(at.alpha); o[1] = u(T); o[2] = u(weight_sum2);
 			for (int k = 0; k < 4; ++k) o[3 + k] = u(rgb_ray2[k]);
 			for (int k = 0; k < 11; ++k) { uint16_t hb; std::memcpy(&hb, &dl[k], 2); o[7 + k] = hb; }
+		} else if (kind == RNB_PRIM_RAY_LOSS) {
+			rnb_config F{};
+			F.apply_L2 = a[0]; F.apply_rgbplus = a[1]; F.apply_bce = a[2]; F.mask_loss_weight = f(a[3]);
+			const float tgt[4] = {f(a[5]), f(a[6]), f(a[7]), f(a[8])}, ray[4] = {f(a[9]), f(a[10]), f(a[11]), f(a[12])};
+			float grad[4], ws, gws, lrow, mrow;
+			const float loss = pass2_ray_terms(F, tgt, ray, (float)(f(a[13]) > 0.99), (float)(f(a[14]) > 0.99), f(a[15]), (float)a[4], grad, &ws, &gws, &lrow, &mrow);
+			o[0] = u(loss); o[1] = u(grad[0]); o[2] = u(grad[1]); o[3] = u(grad[2]); o[4] = u(grad[3]); o[5] = u(ws); o[6] = u(gws); o[7] = u(lrow); o[8] = u(mrow);
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

@@ -2060,7 +2060,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[14] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37}, PRIM_OUT_WORDS[14] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28};
+constexpr uint32_t PRIM_IN_WORDS[15] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16}, PRIM_OUT_WORDS[15] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2169,6 +2169,18 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		o[0] = u(at.alpha); o[1] = u(T); o[2] = u(w2);
 		for (int k = 0; k < 4; ++k) o[3 + k] = u(rgb2[k]);
 		for (int k = 0; k < 11; ++k) o[7 + k] = (uint32_t)__builtin_bit_cast(uint16_t, dl[k]);
+	} else if (kind == RNB_PRIM_RAY_LOSS) {
+		LossFlags F{};
+		F.apply_L2 = a[0]; F.apply_rgbplus = a[1]; F.apply_bce = a[2]; F.mask_loss_weight = f(a[3]);
+		RayLoss R{};
+		for (int k = 0; k < 4; ++k) { R.rgbtarget[k] = f(a[5 + k]); R.rgb_ray[k] = f(a[9 + k]); }
+		R.mask_certainty = (float)(f(a[13]) > 0.99); R.mask_gt = (float)(f(a[14]) > 0.99); // as ray_constants_core forms them from the texels' alpha
+		R.weight_sum_raw = f(a[15]);
+		RayGrad G;
+		float lrow, mrow;
+		pass2_ray_terms(F, R, (float)a[4], G, lrow, mrow);
+		o[0] = u(lrow * (float)a[4]); // (the ray's loss itself is not kept by the kernels: row x n_rays, compared as such)
+		o[1] = u(G.grad[0]); o[2] = u(G.grad[1]); o[3] = u(G.grad[2]); o[4] = u(G.grad[3]); o[5] = u(G.weight_sum); o[6] = u(G.gradient_weight_sum); o[7] = u(lrow); o[8] = u(mrow);
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

@@ -116,6 +116,19 @@ def check(ctx, exact_exp):
         assert np.max(np.abs(out2.view(np.float32).astype(np.float64) - ref2.view(np.float32).astype(np.float64))) <= 4e-7
     n["ray_targets"] = len(rt)
     n["loss_sample"], _ = check_loss_sample(ctx, exact_exp)
+    # ---- the ray's loss terms between the loss kernel's two loops
+    rl = np.array(fx["rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow"], dtype=np.uint32).reshape(-1, 25)
+    out = ctx.eval_primitives("RAY_LOSS", rl[:, :16])
+    assert np.array_equal(out[:, 1:6], rl[:, 17:22]), "gradient / clamped weight sum"
+    assert np.array_equal(out[:, 7], rl[:, 23]), "loss row"
+    if exact_exp:
+        assert np.array_equal(out[:, 6], rl[:, 22]) and np.array_equal(out[:, 8], rl[:, 24]), "mask gradient / mask row"
+        assert np.array_equal(out[:, 0], rl[:, 16]), "loss"
+    else:
+        for col_g, col_w in ((6, 22), (8, 24), (0, 16)):  # expf / logf of the device; the HIP kernels keep the row, the loss is row x n_rays again
+            g, w = out[:, col_g].view(np.float32).astype(np.float64), rl[:, col_w].view(np.float32).astype(np.float64)
+            assert np.all(np.abs(g - w) <= 4e-6 * np.maximum(np.abs(w), 1.0)), (col_g, float(np.max(np.abs(g - w))))
+    n["ray_loss"] = len(rl)
     return n
 
 

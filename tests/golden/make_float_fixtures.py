@@ -161,7 +161,7 @@ struct ValidLevel {
              # the per-ray targets of compute_loss_kernel_train_nerf_with_global_movement (testbed_nerf.cu:1500-1592): the kernel's own lines in three runs -- everything between
              # `xform` and `rgbtarget` except the two read_rgba calls (the texels are arguments here) and the three curand lines (the light index is an argument: deviation D4)
              """static inline float max(float a, float b) { return fmaxf(a, b); }
-using std::abs;
+using std::abs; using std::exp; using std::log; // CUDA's global overload set: abs / exp / log of a float are the float functions (the C library's global names are the double ones)
 float activation_function(float val, ENerfActivation activation); // (the reference's, defined below from its file)
 struct RayTargets { Array3f normal_value; Array4f albedo_value; Matrix3f light_directions_before; Vector3f light; float shading_target; Array4f rgbtarget; };
 static RayTargets ray_target_statements(const Matrix<float, 3, 4>& xform_in, const Array4f& texsamp_albedo, const Array4f& texsamp_normal, const bool apply_no_albedo, const bool apply_rgbplus,
@@ -232,6 +232,19 @@ static SampleBackward backward_sample_statements(const __half* network_output, c
 	                                                                              dloss_dvariance, dloss_dnormal_norm}};
 	for (int q = 0; q < 11; ++q) r.dl[q] = local_dL_doutput[q];
 	return r;
+}""")
+    # the loss kernel between its two loops (testbed_nerf.cu:1735-1800): the ray's loss and gradient, the clamped weight sum and the mask term's gradient, the two loss rows
+    parts.append("""struct RayLossTerms { float loss; Array4f gradient; float weight_sum, gradient_weight_sum, loss_row, mask_row; };
+static RayLossTerms ray_loss_statements(const Array4f rgbtarget, const Array4f rgb_ray, const Array4f texsamp_albedo, const Array4f texsamp_normal, float weight_sum, const bool apply_L2,
+                                        const bool apply_rgbplus, const bool apply_bce, const float mask_loss_weight, const uint32_t n_rays) {
+	ELossType loss_type;
+	const float img_pdf = 1.0f, xy_pdf = 1.0f; // no error-map sampling
+	float loss_row = 0.f, mask_row = 0.f;
+	float* loss_output = &loss_row;
+	float* mask_loss_output = &mask_row;
+	const uint32_t i = 0;
+	""" + span_until(tn, "float mask_certainty = (float) (texsamp_albedo.w() > 0.99);", "if (ek_loss_output) {\n\t\tek_loss_output[i] = 0.f;", LOSS_KERNEL) + """
+	return {lg.loss, lg.gradient, weight_sum, gradient_weight_sum, loss_row, mask_row};
 }""")
     parts.append(r"""
 static uint32_t fb(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -487,7 +500,33 @@ int main() {
 			out.push_back(fb(r.shading)); out.push_back(fb(r.ek_term));
 			for (int q = 0; q < 10; ++q) out.push_back(fb(r.inter[q]));
 		}
-		arr_u("losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10", out, true);
+		arr_u("losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10", out);
+	}
+	{ // ---- the ray's loss terms between the two loops (testbed_nerf.cu:1735-1800)
+		std::vector<uint32_t> out;
+		for (int k = 0; k < 192; ++k) {
+			const bool L2 = k % 3 != 2, rgbplus = k % 8 < 6, bce = k % 5 == 4;
+			const Array4f target{uni(0, 1), uni(0, 1), uni(0, 1), uni(0, 2)};
+			Array4f ray{uni(0, 1), uni(0, 1), uni(0, 1), uni(0, 2)};
+			if (k % 16 == 3) ray[k % 4] = target[k % 4];
+			const float aa = k % 6 == 0 ? 0.5f : (k % 6 == 1 ? 0.99f : 1.0f), an = k % 7 == 0 ? 0.0f : 1.0f;
+			float ws = uni(0.0f, 1.05f);
+			if (k % 16 == 5) ws = 0.0f;
+			if (k % 16 == 6) ws = (float)(1.0 - 1e-4);
+			if (k % 16 == 7) ws = 1e-4f;
+			if (k % 16 == 8) ws = 0.99995f;
+			const float mw = k % 2 ? 1.0f : 0.1f;
+			const uint32_t n_rays = 4096 + 128 * (uint32_t)k;
+			const RayLossTerms r = ray_loss_statements(target, ray, Array4f{0, 0, 0, aa}, Array4f{0, 0, 0, an}, ws, L2, rgbplus, bce, mw, n_rays);
+			for (uint32_t v : {(uint32_t)L2, (uint32_t)rgbplus, (uint32_t)bce, fb(mw), n_rays}) out.push_back(v);
+			for (int c = 0; c < 4; ++c) out.push_back(fb(target[c]));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(ray[c]));
+			out.push_back(fb(aa)); out.push_back(fb(an)); out.push_back(fb(ws));
+			out.push_back(fb(r.loss));
+			for (int c = 0; c < 4; ++c) out.push_back(fb(r.gradient[c]));
+			for (float v : {r.weight_sum, r.gradient_weight_sum, r.loss_row, r.mask_row}) out.push_back(fb(v));
+		}
+		arr_u("rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow", out, true);
 	}
 	printf("}\n");
 	return 0;

@@ -4,7 +4,7 @@ albedo, the L1 / L2 ray loss, image / pixel choice of a ray) against the outputs
 library in tests/test_gpu_parity.py."""
 from tests import float_fixture_cases, oracle_lib
 
-COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512, "read_rgba": 256, "camera_ray": 192, "ray_targets": 192, "loss_sample": 384}
+COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512, "read_rgba": 256, "camera_ray": 192, "ray_targets": 192, "loss_sample": 384, "ray_loss": 192}
 
 
 def test_oracle_float_primitives_match_the_reference_fragments():
@@ -32,4 +32,5 @@ def test_float_fixture_is_what_its_generator_says():
                        "levels_n_base_log2hash_scalebits_offsets_resolutions_scales", "validlevel_n_basescale_scale_basestep_step_level",
                        "readrgba_w_h_x_y_pixels28_rgba4_rednonpositive", "axes_mode_scale_offset3_matrix12_ngp12", "cameraray_w_h_focal2_pp2_xy2_xform12_o3_d3_dir3",
                        "raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal",
-                       "losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10"}
+                       "losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10",
+                       "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow"}
