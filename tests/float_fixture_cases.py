@@ -207,3 +207,57 @@ def check_valid_levels(make_context):
         finally:
             c.close()
     return n_rows
+
+
+def check_optimizer(ctx, exact_pow):
+    """tcnn's Adam and half-precision EMA on 256 single parameters (the reference's own kernel bodies behind their index lines, run in the build container) against ONE call of the
+    library's optimizer per distinct optimizer step count: the rows' values are written into the context's buffers at the rows' parameter indices, rnb_optimizer_step runs, the same
+    indices are read back. exact_pow: the CPU checker shares libm's powf with the fixture (bit for bit); the device has its own (bias correction within 2e-6)."""
+    v = np.array(load()["adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16"], dtype=np.uint32)
+    lr, beta1, beta2, eps, l2, loss_scale, ema_decay = [float(x) for x in v[:7].view(np.float32)]
+    n_matrix = int(v[7])
+    cfg = ctx.cfg
+    assert (np.float32(cfg.learning_rate), np.float32(cfg.beta1), np.float32(cfg.beta2), np.float32(cfg.epsilon), np.float32(cfg.l2_reg), np.float32(cfg.ema_decay)) == \
+        (np.float32(lr), np.float32(beta1), np.float32(beta2), np.float32(eps), np.float32(l2), np.float32(ema_decay)), "the context runs the optimizer of configs/nerf/base.json"
+    assert loss_scale == 128.0 and n_matrix == 3072 + 8192
+    ctx.update_config(lr_decay_start=4000000000)  # the rows are single Adam steps at the base learning rate: no ExponentialDecay event behind any optimizer step count used here
+    rows = v[8:].reshape(-1, 15)
+    idx = np.where(rows[:, 0] == 1, np.arange(len(rows)), n_matrix + np.arange(len(rows))).astype(np.int64)
+    n = ctx.n_params
+    assert idx.max() < n
+    h = lambda col: rows[:, col].astype(np.uint16).view(np.float16)
+    f = lambda col: rows[:, col].view(np.float32)
+    base_w = ctx.get("PARAMS_FP32").copy()
+    n_checked = 0
+    for opt_step in sorted(set(rows[:, 2].tolist())):
+        sel = rows[:, 2] == opt_step
+        i = idx[sel]
+        w = base_w.copy(); w[i] = f(3)[sel]
+        ctx.set_params(w)  # masters and their half copies (the fixture's w16 is (half)w)
+        assert np.array_equal(ctx.get("PARAMS_FP16")[i].view(np.uint16), h(4)[sel].view(np.uint16))
+        steps = np.zeros(n, np.uint32); steps[i] = rows[sel, 1]
+        m = np.zeros(n, np.float32); m[i] = f(6)[sel]
+        vv = np.zeros(n, np.float32); vv[i] = f(7)[sel]
+        ema = np.zeros(n, np.float16); ema[i] = h(8)[sel]
+        g = np.zeros(n, np.float32); g[i] = h(5)[sel].astype(np.float32)  # the accumulators hold loss-scaled sums; the optimizer narrows them to half first (exact here)
+        ctx.put("ADAM_STEPS", steps); ctx.put("ADAM_M", m); ctx.put("ADAM_V", vv); ctx.put("PARAMS_EMA", ema)
+        ctx.set_optimizer_step(int(opt_step) - 1)
+        ctx.put("GRADS_FP32", g)
+        ctx.optimizer_step()
+        got = dict(w=ctx.get("PARAMS_FP32")[i], w16=ctx.get("PARAMS_FP16")[i], m=ctx.get("ADAM_M")[i], v=ctx.get("ADAM_V")[i], steps=ctx.get("ADAM_STEPS")[i], ema=ctx.get("PARAMS_EMA")[i])
+        assert np.array_equal(got["steps"], rows[sel, 13]), ("step counts", opt_step)
+        assert np.array_equal(got["m"].view(np.uint32), rows[sel, 11]) and np.array_equal(got["v"].view(np.uint32), rows[sel, 12]), ("moments", opt_step)
+        if exact_pow:
+            assert np.array_equal(got["w"].view(np.uint32), rows[sel, 9]), ("masters", opt_step)
+            assert np.array_equal(got["w16"].view(np.uint16), rows[sel, 10].astype(np.uint16)), ("half weights", opt_step)
+            assert np.array_equal(got["ema"].view(np.uint16), rows[sel, 14].astype(np.uint16)), ("EMA", opt_step)
+        else:
+            want_w = f(9)[sel].astype(np.float64)
+            assert np.all(np.abs(got["w"].astype(np.float64) - want_w) <= 2e-6 * np.abs(want_w - f(3)[sel]) + 1e-9), ("masters", opt_step)
+            for name, col in (("w16", 10), ("ema", 14)):
+                a, b = got[name].astype(np.float64), h(col)[sel].astype(np.float64)
+                assert np.all(np.abs(a - b) <= 1.1e-3 * np.abs(b) + 1e-7), (name, opt_step)
+        n_checked += int(sel.sum())
+    untouched = (rows[:, 0] == 0) & (h(5) == 0)
+    assert untouched.sum() >= 20 and np.array_equal(rows[untouched, 13], rows[untouched, 1]) and np.array_equal(rows[untouched, 9], rows[untouched, 3])  # hash-grid entries without gradient
+    return n_checked

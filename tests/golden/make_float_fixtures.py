@@ -18,6 +18,7 @@ What is taken, verbatim (function or struct body located by its signature, brace
   include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
   include/neural-graphics-primitives/nerf_loader.h               NerfDataset::nerf_matrix_to_ngp (in a struct with the four members it reads)
   include/neural-graphics-primitives/common.h                    struct Ray
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/*.h    adam_step's body behind its index lines, ema_step_half_precision's arithmetic line + EmaOptimizer::step's debias statements
   src/testbed_nerf.cu                                            the per-ray targets of the loss kernel (:1500-1592, three runs of its lines: all but the texel fetches and curand),
                                                                  the pinhole-ray statements of generate_training_samples_nerf (:1279-1305, located by their text),
                                                                  NERF_STEPS .. MIN_CONE_STEPSIZE, struct LossAndGradient, copysign(Array4f), mse_loss, l1_loss, loss_and_gradient,
@@ -47,6 +48,28 @@ def enum_names(path, head):
     i = src.index(head)
     body = src[src.index("{", i) + 1:src.index("}", i)]
     return [t.strip().split("=")[0].strip() for t in body.split(",") if t.strip()]
+
+
+def block_ignoring_comments(path, signature):
+    """fragment() for code whose // comments hold braces: the text from `signature` through the brace that closes its first '{', braces behind `//` not counted."""
+    src = open(os.path.join(REF, path)).read()
+    start = src.index(signature)
+    i = src.index("{", start)
+    depth, j, in_comment = 0, i, False
+    while True:
+        c = src[j]
+        if c == "\n":
+            in_comment = False
+        elif src.startswith("//", j):
+            in_comment = True
+        elif not in_comment:
+            if c == "{":
+                depth += 1
+            elif c == "}":
+                depth -= 1
+                if depth == 0:
+                    return src[start:j + 1]
+        j += 1
 
 
 def statement(path, text):
@@ -246,6 +269,35 @@ static RayLossTerms ray_loss_statements(const Array4f rgbtarget, const Array4f r
 	""" + span_until(tn, "float mask_certainty = (float) (texsamp_albedo.w() > 0.99);", "if (ek_loss_output) {\n\t\tek_loss_output[i] = 0.f;", LOSS_KERNEL) + """
 	return {lg.loss, lg.gradient, weight_sum, gradient_weight_sum, loss_row, mask_row};
 }""")
+    # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
+    # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
+    adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
+    ema_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/ema.h"
+    adam_kernel = block_ignoring_comments(adam_h, "__global__ void adam_step(")
+    adam_body = adam_kernel[adam_kernel.index("float gradient = (float)gradients[i] / loss_scale;"):adam_kernel.rindex("}")]
+    parts.append("#include <utility>\nnamespace tcnn {\n" + f(cd, "__device__ inline float weight_decay(float relative_weight_decay, float absolute_weight_decay, float weight)") + """
+template <typename T>
+static void adam_step_element(const uint32_t i, const uint32_t n_components, const uint32_t n_weights_delta, const uint32_t n_weights_canonical_covered_by_matrices,
+	const uint32_t n_weights_delta_covered_by_matrices, const float relative_weight_decay, const float absolute_weight_decay, const float loss_scale, float learning_rate,
+	const float non_matrix_learning_rate_factor, const bool optimize_matrix_params, const bool optimize_non_matrix_params, const bool optimize_canonical_params, const bool optimize_delta_params,
+	const float beta1, const float beta2, const float epsilon, const float lower_lr_bound, const float upper_lr_bound, const float l2_reg, float* weights_full_precision, T* weights,
+	const T* gradients, float* first_moments, float* second_moments, uint32_t* param_steps, std::pair<uint32_t, bool>* n_weights_optimize, const bool only_sdf_training,
+	const bool only_reflectance_training) {
+	""" + adam_body + """
+}
+template <typename T>
+static void ema_step_element(const uint32_t i, const float m_ema_decay, const uint32_t current_step, const T* weights, T* weights_ema) {
+	const float ema_decay = m_ema_decay;
+	""" + statement(ema_h, "float ema_debias_old = 1 - (float)std::pow(m_ema_decay, current_step-1);") + "\n\t" + statement(ema_h, "float ema_debias_new = 1.0f / (1 - (float)std::pow(m_ema_decay, current_step));") + "\n\t"
+                 + statement(ema_h, "float filtered_val = ((float)weights_ema[i] * ema_decay * ema_debias_old + (float)weights[i] * (1 - ema_decay)) * ema_debias_new;") + "\n\t"
+                 + statement(ema_h, "weights_ema[i] = (T)filtered_val;") + """
+}
+}""")
+    base = json.load(open(os.path.join(REF, "configs", "nerf", "base.json")))["optimizer"]
+    adam_cfg = base["nested"]["nested"]
+    assert base["otype"] == "Ema" and base["nested"]["otype"] == "ExponentialDecay" and adam_cfg["otype"] == "Adam"
+    opt = {k: repr(float(adam_cfg[k])) + "f" for k in ("learning_rate", "beta1", "beta2", "epsilon", "l2_reg")}
+    opt["ema_decay"] = repr(float(base["decay"])) + "f"
     parts.append(r"""
 static uint32_t fb(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float bf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -526,7 +578,33 @@ int main() {
 			for (int c = 0; c < 4; ++c) out.push_back(fb(r.gradient[c]));
 			for (float v : {r.weight_sum, r.gradient_weight_sum, r.loss_row, r.mask_row}) out.push_back(fb(v));
 		}
-		arr_u("rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow", out, true);
+		arr_u("rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow", out);
+	}
+	{ // ---- the optimizer on single parameters: Adam (adam.h:52-202) then the EMA of the half weights (ema.h:63-78, 115-116), with the values of configs/nerf/base.json
+		std::vector<uint32_t> out;
+		auto hb = [](__half h) { uint16_t u; memcpy(&u, &h, 2); return (uint32_t)u; };
+		const uint32_t n_matrix = 3072 + 8192;
+		const float lr = """ + opt["learning_rate"] + r""", beta1 = """ + opt["beta1"] + r""", beta2 = """ + opt["beta2"] + r""", eps = """ + opt["epsilon"] + r""", l2 = """ + opt["l2_reg"] + r""", loss_scale = 128.0f, ema_decay = """ + opt["ema_decay"] + r"""; // configs/nerf/base.json
+		for (uint32_t v : {fb(lr), fb(beta1), fb(beta2), fb(eps), fb(l2), fb(loss_scale), fb(ema_decay), n_matrix}) out.push_back(v);
+		for (int k = 0; k < 256; ++k) {
+			const bool is_matrix = k % 2 == 0;
+			const uint32_t i = is_matrix ? (uint32_t)k : n_matrix + (uint32_t)k;
+			const uint32_t steps_before[8] = {0, 1, 2, 9, 99, 2999, 65534, 70000};
+			uint32_t step = steps_before[(k / 2) % 8];
+			const uint32_t current_step = k % 16 == 0 ? 1u : step + 1 + (uint32_t)(gen.next_uint() % 50);   // the optimizer's own step count (>= any parameter's)
+			float w = uni(-0.5f, 0.5f) * (is_matrix ? 1.0f : 1e-2f);
+			__half g = (__half)(uni(-1, 1) * (k % 3 == 0 ? 60000.0f : (k % 3 == 1 ? 1.0f : 1e-4f)));
+			if (k % 8 == 5 || k % 8 == 4) g = (__half)0.0f;                         // a hash-grid entry without gradient is left alone; an MLP weight still decays
+			float m = step ? uni(-1e-3f, 1e-3f) : 0.0f, v = step ? uni(0, 1e-5f) : 0.0f;
+			__half w16 = (__half)w, ema = (__half)(current_step > 1 ? w * uni(0.8f, 1.2f) : 0.0f);
+			const uint32_t step0 = step; const float w0 = w, m0 = m, v0 = v; const __half w160 = w16, ema0 = ema;
+			// arrays of one element addressed as element i
+			tcnn::adam_step_element<__half>(i, 0, 0, n_matrix, 0, 0.0f, 0.0f, loss_scale, lr, 1.0f, true, true, true, true, beta1, beta2, eps, 0.0f, std::numeric_limits<float>::max(), l2,
+			                                &w - i, &w16 - i, &g - i, &m - i, &v - i, &step - i, nullptr, false, false);
+			tcnn::ema_step_element<__half>(i, ema_decay, current_step, &w16 - i, &ema - i);
+			for (uint32_t x : {(uint32_t)is_matrix, step0, current_step, fb(w0), hb(w160), hb(g), fb(m0), fb(v0), hb(ema0), fb(w), hb(w16), fb(m), fb(v), step, hb(ema)}) out.push_back(x);
+		}
+		arr_u("adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16", out, true);
 	}
 	printf("}\n");
 	return 0;

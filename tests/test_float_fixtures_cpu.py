@@ -24,6 +24,15 @@ def test_oracle_valid_level_schedule_matches_the_reference():
     assert float_fixture_cases.check_valid_levels(lambda **cfg: oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 4 * 328
 
 
+def test_oracle_optimizer_matches_the_reference_kernels():
+    c = oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, n_levels=2)
+    try:
+        c.init_params()
+        assert float_fixture_cases.check_optimizer(c, exact_pow=True) == 256
+    finally:
+        c.close()
+
+
 def test_float_fixture_is_what_its_generator_says():
     fx = float_fixture_cases.load()
     assert "make_float_fixtures.py" in fx["_source"] and "-ffp-contract=off" in fx["_source"]
@@ -33,4 +42,5 @@ def test_float_fixture_is_what_its_generator_says():
                        "readrgba_w_h_x_y_pixels28_rgba4_rednonpositive", "axes_mode_scale_offset3_matrix12_ngp12", "cameraray_w_h_focal2_pp2_xy2_xform12_o3_d3_dir3",
                        "raytargets_flags5_light_xform12_texnormal4_texalbedo4_lightdirs9_rgbtarget4_light3_normal3_shading_supernormal",
                        "losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10",
-                       "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow"}
+                       "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow",
+                       "adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16"}

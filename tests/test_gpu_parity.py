@@ -117,6 +117,12 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
     import rnb_neus2_amd as rnb
     assert float_fixture_cases.check_level_tables(lambda **cfg: rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 10  # the parameter layout (grid.h:977-1012)
     assert float_fixture_cases.check_valid_levels(lambda **cfg: rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, **cfg)) == 4 * 328  # progressive levels (grid.h:1430-1437)
+    c = rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, n_levels=2)
+    try:  # tcnn's Adam and EMA kernel bodies on 256 single parameters against rnb_optimizer_step (k_adam_ema: records, bias-correction table, in-place fallback beyond it)
+        c.init_params()
+        assert float_fixture_cases.check_optimizer(c, exact_pow=False) == 256
+    finally:
+        c.close()
 
 
 def test_density_grid_update(pair):
