@@ -362,9 +362,12 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *   RNB_PRIM_RAY_LOSS in apply_L2, apply_rgbplus, apply_bce, bits(mask_loss_weight), n_rays, rgbtarget 4, rgb_ray 4, the albedo texel's alpha, the normal texel's alpha, weight_sum
  *                    out the ray's loss, its gradient 4, the clamped weight_sum, gradient_weight_sum, the loss row (loss / n_rays), the mask-loss row
  *                    (the loss kernel between its two loops, testbed_nerf.cu:1735-1800)
+ *   RNB_PRIM_ENCODE  in  table entries (<= 256), resolution, bits(scale), x y z, then 257 words = the level's table (half2 per entry, + one readable word)
+ *                    out features f0 f1 (half bits), d f0 / d xyz 3, d f1 / d xyz 3 -- twice: the training kernels' form, then the evaluation kernels' pipelined form
+ *                    (one sample, one level of kernel_grid, tcnn encodings/grid.h:168-364)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

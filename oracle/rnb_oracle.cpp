@@ -2045,8 +2045,8 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_RAY_LOSS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[15] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16}, OUT_W[15] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9};
+	if (kind < 0 || kind > RNB_PRIM_ENCODE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[16] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263}, OUT_W[16] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2161,6 +2161,17 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			float grad[4], ws, gws, lrow, mrow;
 			const float loss = pass2_ray_terms(F, tgt, ray, (float)(f(a[13]) > 0.99), (float)(f(a[14]) > 0.99), f(a[15]), (float)a[4], grad, &ws, &gws, &lrow, &mrow);
 			o[0] = u(loss); o[1] = u(grad[0]); o[2] = u(grad[1]); o[3] = u(grad[2]); o[4] = u(grad[3]); o[5] = u(ws); o[6] = u(gws); o[7] = u(lrow); o[8] = u(mrow);
+		} else if (kind == RNB_PRIM_ENCODE) {
+			orc_ctx_s lv; // a one-level encoding over the item's own table
+			lv.cfg.n_levels = 1; lv.valid_level = 0;
+			lv.offsets[0] = 0; lv.offsets[1] = a[0]; lv.resolution[0] = a[1]; lv.scale[0] = f(a[2]);
+			const float x3[3] = {f(a[3]), f(a[4]), f(a[5])};
+			half_t feat[28];
+			float dy[28][3];
+			encode_sample(&lv, reinterpret_cast<const half_t*>(a + 6), x3, feat, dy);
+			uint16_t h0, h1; std::memcpy(&h0, &feat[0], 2); std::memcpy(&h1, &feat[1], 2);
+			o[0] = o[8] = h0; o[1] = o[9] = h1; // (the checker has one form of the encoding; the library's second form fills words 8-15)
+			for (int d = 0; d < 3; ++d) { o[2 + d] = o[10 + d] = u(dy[0][d]); o[5 + d] = o[13 + d] = u(dy[1][d]); }
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

@@ -2060,13 +2060,41 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[15] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16}, PRIM_OUT_WORDS[15] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9};
+constexpr uint32_t PRIM_IN_WORDS[16] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263}, PRIM_OUT_WORDS[16] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	Pcg32 q{5};
 	q.advance((int64_t)i);
 	bitfield[i] = (uint8_t)(q.next_uint() >> 24);
+}
+// RNB_PRIM_ENCODE: one (sample, level) of the hash-grid encoding from a table of <= 256 entries that travels with the item -- through encode_level_core (the training kernels' form)
+// AND through level_issue / level_consume (the evaluation kernels' pipelined form). One WAVEFRONT per item: both read their level's constants with readfirstlane.
+__global__ __launch_bounds__(64) void k_prim_encode(const uint32_t* __restrict__ in, const uint32_t n, uint32_t* __restrict__ out) {
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	const uint32_t i = blockIdx.x;
+	if (i >= n) return;
+	const uint32_t* a = in + (size_t)i * PRIM_IN_WORDS[RNB_PRIM_ENCODE];
+	GridMeta G{};
+	G.n_levels = 1; G.valid_level = 0;
+	for (uint32_t l = 1; l <= RNB_MAX_LEVELS; ++l) G.offsets[l] = a[0];
+	G.resolution[0] = a[1]; G.scale[0] = __uint_as_float(a[2]);
+	fill_level_meta(lm, G, (int)threadIdx.x);
+	__syncthreads();
+	const float x = __uint_as_float(a[3]), y = __uint_as_float(a[4]), z = __uint_as_float(a[5]);
+	const uint32_t* table = a + 6; // half2 per entry; entry `size` is readable (257 words)
+	half_t f0, f1, g0, g1;
+	float dy0[3], dy1[3], ey0[3], ey1[3];
+	encode_level_core<true>(table, a[0], a[1], __uint_as_float(a[2]), x, y, z, f0, f1, dy0, dy1);
+	uint32_t v[8];
+	level_issue(lm, table, 0, x, y, z, v);
+	level_consume<true>(lm, 0, x, y, z, v, g0, g1, ey0, ey1);
+	if (threadIdx.x == 0) {
+		uint32_t* o = out + (size_t)i * PRIM_OUT_WORDS[RNB_PRIM_ENCODE];
+		o[0] = (uint32_t)__builtin_bit_cast(uint16_t, f0); o[1] = (uint32_t)__builtin_bit_cast(uint16_t, f1);
+		o[8] = (uint32_t)__builtin_bit_cast(uint16_t, g0); o[9] = (uint32_t)__builtin_bit_cast(uint16_t, g1);
+		for (int d = 0; d < 3; ++d) { o[2 + d] = __float_as_uint(dy0[d]); o[5 + d] = __float_as_uint(dy1[d]); o[10 + d] = __float_as_uint(ey0[d]); o[13 + d] = __float_as_uint(ey1[d]); }
+	}
 }
 __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, const uint32_t n, uint32_t* __restrict__ out, const uint8_t* __restrict__ bitfield) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

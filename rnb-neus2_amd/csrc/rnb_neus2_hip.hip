@@ -2139,7 +2139,7 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_RAY_LOSS) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_ENCODE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
 	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
 	uint32_t *in = nullptr, *out = nullptr;
@@ -2161,7 +2161,8 @@ int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t 
 	if (rc == RNB_OK && hipMemcpy(in, in_host, n_in * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: copy in failed");
 	if (rc == RNB_OK) {
 		if (bf) hipLaunchKernelGGL(k_prim_bitfield, dim3((uint32_t)((n_bf + 255) / 256)), dim3(256), 0, 0, bf, (uint32_t)n_bf);
-		hipLaunchKernelGGL(k_primitives, dim3((n_items + 127) / 128), dim3(128), 0, 0, kind, in, n_items, out, bf);
+		if (kind == RNB_PRIM_ENCODE) hipLaunchKernelGGL(k_prim_encode, dim3(n_items), dim3(64), 0, 0, in, n_items, out);
+		else hipLaunchKernelGGL(k_primitives, dim3((n_items + 127) / 128), dim3(128), 0, 0, kind, in, n_items, out, bf);
 		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_host, out, n_out * 4, hipMemcpyDeviceToHost) != hipSuccess)
 			rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: kernel or copy out failed");
 	}

@@ -129,6 +129,14 @@ def check(ctx, exact_exp):
             g, w = out[:, col_g].view(np.float32).astype(np.float64), rl[:, col_w].view(np.float32).astype(np.float64)
             assert np.all(np.abs(g - w) <= 4e-6 * np.maximum(np.abs(w), 1.0)), (col_g, float(np.max(np.abs(g - w))))
     n["ray_loss"] = len(rl)
+    # ---- one (sample, level) of the hash-grid encoding: kernel_grid's own body; features are half sums, dy/dx float sums: IEEE arithmetic only, bit for bit everywhere,
+    # through both forms of the library's encode (words 0-7: encode_level_core, 8-15: level_issue / level_consume)
+    en = np.array(fx["encode_size_res_scale_xyz_table257_f0_f1_dydx6"], dtype=np.uint32).reshape(-1, 271)
+    out = ctx.eval_primitives("ENCODE", en[:, :263])
+    assert np.array_equal(out[:, 0:8], en[:, 263:271]), "encode_level_core"
+    assert np.array_equal(out[:, 8:16], en[:, 263:271]), "level_issue / level_consume"
+    assert np.count_nonzero(en[:, 263]) > 300 and len(set(en[:, 0].tolist())) == 5
+    n["encode"] = len(en)
     return n
 
 

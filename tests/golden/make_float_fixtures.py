@@ -18,6 +18,7 @@ What is taken, verbatim (function or struct body located by its signature, brace
   include/neural-graphics-primitives/nerf.h                      NERF_GRIDSIZE
   include/neural-graphics-primitives/nerf_loader.h               NerfDataset::nerf_matrix_to_ngp (in a struct with the four members it reads)
   include/neural-graphics-primitives/common.h                    struct Ray
+  dependencies/neus2_tcnn/include/tiny-cuda-nn/encodings/grid.h  kernel_grid's body behind its index lines (one sample, one level), gpu_matrix.h MatrixView, common_device.h pos_fract / smoothstep
   dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/*.h    adam_step's body behind its index lines, ema_step_half_precision's arithmetic line + EmaOptimizer::step's debias statements
   src/testbed_nerf.cu                                            the per-ray targets of the loss kernel (:1500-1592, three runs of its lines: all but the texel fetches and curand),
                                                                  the pinhole-ray statements of generate_training_samples_nerf (:1279-1305, located by their text),
@@ -268,6 +269,23 @@ static RayLossTerms ray_loss_statements(const Array4f rgbtarget, const Array4f r
 	const uint32_t i = 0;
 	""" + span_until(tn, "float mask_certainty = (float) (texsamp_albedo.w() > 0.99);", "if (ek_loss_output) {\n\t\tek_loss_output[i] = 0.f;", LOSS_KERNEL) + """
 	return {lg.loss, lg.gradient, weight_sum, gradient_weight_sum, loss_row, mask_row};
+}""")
+    # one (sample, level) of tcnn's kernel_grid (encodings/grid.h:168-364): the kernel's body behind its three index lines (`i` and `level` bound as arguments): interpolated
+    # features accumulated in half, dy/dx in float
+    itp = enum_names("dependencies/neus2_tcnn/include/tiny-cuda-nn/encoding.h", "enum class InterpolationType")
+    assert itp == ["Nearest", "Linear", "Smoothstep"]
+    grid_kernel = block_ignoring_comments(gh, "__global__ void kernel_grid(")
+    grid_body = grid_kernel[grid_kernel.index("if (level > valid_level) {"):grid_kernel.rindex("}")]
+    parts.append("namespace tcnn {\nenum class InterpolationType { " + ", ".join(itp) + " };\n" + statement("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "template <uint32_t N_FLOATS>\nusing vector_fullp_t = vector_t<float, N_FLOATS>;")
+                 + "\ntemplate <typename T>\n" + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/gpu_matrix.h", "struct MatrixView {") + ";\n"
+                 + f(cd, "__device__ inline float smoothstep(float val)") + "\n" + f(cd, "__device__ inline float smoothstep_derivative(float val)") + "\n" + f(cd, "__device__ inline float identity_derivative(float val)") + "\n"
+                 + "template <typename F, typename FPRIME>\n" + f(cd, "__device__ inline void pos_fract(const float input, float* pos, float* pos_derivative, uint32_t* pos_grid, float scale, F interpolation_fun, FPRIME interpolation_fun_derivative)") + """
+template <typename T, uint32_t N_POS_DIMS, uint32_t N_FEATURES_PER_LEVEL>
+static void kernel_grid_element(const uint32_t i, const uint32_t level, const uint32_t num_elements, const uint32_t num_grid_features, const uint32_t* hashmap_offset_table,
+	const uint32_t* resolution_table, const float* scale_table, const uint32_t valid_level, const float quantize_threshold, float max_level, const float* max_level_gpu,
+	const InterpolationType interpolation_type, const GridType grid_type, const T* grid, MatrixView<const float> positions_in, T* encoded_positions, float* dy_dx) {
+	""" + grid_body + """
+}
 }""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
@@ -604,7 +622,31 @@ int main() {
 			tcnn::ema_step_element<__half>(i, ema_decay, current_step, &w16 - i, &ema - i);
 			for (uint32_t x : {(uint32_t)is_matrix, step0, current_step, fb(w0), hb(w160), hb(g), fb(m0), fb(v0), hb(ema0), fb(w), hb(w16), fb(m), fb(v), step, hb(ema)}) out.push_back(x);
 		}
-		arr_u("adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16", out, true);
+		arr_u("adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16", out);
+	}
+	{ // ---- one (sample, level) of the hash-grid encoding (grid.h:168-364): features (half sums) and dy/dx (float) from a small table that travels with the item
+		std::vector<uint32_t> out;
+		auto hb = [](__half h) { uint16_t u; memcpy(&u, &h, 2); return (uint32_t)u; };
+		const uint32_t shapes[8][2] = {{32, 3}, {216, 6}, {128, 5}, {64, 151}, {128, 971}, {256, 2049}, {256, 50}, {64, 4}}; // table entries, resolution: dense (27 -> 32, 216, 125 -> 128, 64) and hashed
+		for (int k = 0; k < 384; ++k) {
+			const uint32_t size = shapes[k % 8][0], res = shapes[k % 8][1];
+			const float scale = (float)(res - 1);
+			__half table[257 * 2];
+			for (int q = 0; q < 257 * 2; ++q) table[q] = (__half)(q < (int)size * 2 ? uni(-1, 1) * (k % 3 == 0 ? 1e-4f : (k % 3 == 1 ? 0.1f : 4.0f)) : 0.0f);
+			float xyz[3] = {gen.next_float(), gen.next_float(), gen.next_float()};
+			if (k % 32 == 31) xyz[0] = 1.0f;
+			if (k % 32 == 30) { xyz[1] = 0.0f; xyz[2] = 1.0f; }
+			const uint32_t offsets[2] = {0, size};
+			__half feat[2] = {(__half)7.0f, (__half)7.0f};
+			float dydx[6] = {7, 7, 7, 7, 7, 7};
+			tcnn::kernel_grid_element<__half, 3, 2>(0, 0, 1, 2, offsets, &res, &scale, 0, 0.0f, 1.0f, nullptr, tcnn::InterpolationType::Linear, tcnn::GridType::Hash, table,
+			                                         tcnn::MatrixView<const float>(xyz, 1, 3), feat, dydx);
+			for (uint32_t v : {size, res, fb(scale), fb(xyz[0]), fb(xyz[1]), fb(xyz[2])}) out.push_back(v);
+			for (int q = 0; q < 257; ++q) out.push_back(hb(table[2 * q]) | hb(table[2 * q + 1]) << 16);
+			out.push_back(hb(feat[0])); out.push_back(hb(feat[1]));
+			for (int q = 0; q < 6; ++q) out.push_back(fb(dydx[q]));
+		}
+		arr_u("encode_size_res_scale_xyz_table257_f0_f1_dydx6", out, true);
 	}
 	printf("}\n");
 	return 0;
