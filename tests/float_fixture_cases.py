@@ -269,3 +269,29 @@ def check_optimizer(ctx, exact_pow):
     untouched = (rows[:, 0] == 0) & (h(5) == 0)
     assert untouched.sum() >= 20 and np.array_equal(rows[untouched, 13], rows[untouched, 1]) and np.array_equal(rows[untouched, 9], rows[untouched, 3])  # hash-grid entries without gradient
     return n_checked
+
+
+def check_grid_samples(ctx):
+    """The samples of two occupancy updates -- generate_grid_samples_nerf_nonuniform's own body (testbed_nerf.cu:585-614) as update_density_grid_nerf drives it (:3424-3494) -- against
+    the library's updates through the ABI: the first update of a fresh context (every cell of the zeroed grid), then, over a grid pattern written through RNB_BUF_DENSITY_GRID, an
+    update past training step 256 (n/4 samples anywhere, n/4 in cells above NERF_MIN_OPTICAL_THICKNESS). Cell indices and warped positions bit for bit. `ctx`: fresh, with a dataset."""
+    v = np.array(load()["gridsamples_call_slot_idx_pos3"], dtype=np.uint32).reshape(-1, 6)
+    cells = 128 ** 3
+    ctx.set_training_step(0)
+    ctx.update_density_grid()
+    idx, pos = ctx.get("GRID_SAMPLE_IDX"), ctx.get("GRID_SAMPLE_POS").view(np.uint32).reshape(-1, 3)
+    r = v[v[:, 0] == 0]
+    assert len(idx) == cells and np.array_equal(idx[r[:, 1]], r[:, 2]) and np.array_equal(pos[r[:, 1]], r[:, 3:6]), "first update"
+    c = np.arange(cells, dtype=np.uint32)
+    grid = np.where(((c * np.uint32(2654435761)) >> np.uint32(29)) == 0, np.float32(0.5), np.float32(0.0)).astype(np.float32)
+    ctx.put("DENSITY_GRID", grid)
+    ctx.set_training_step(4096)
+    ctx.update_density_grid()
+    idx, pos = ctx.get("GRID_SAMPLE_IDX"), ctx.get("GRID_SAMPLE_POS").view(np.uint32).reshape(-1, 3)
+    assert len(idx) == cells // 2
+    for call in (1, 2):
+        r = v[v[:, 0] == call]
+        assert np.array_equal(idx[r[:, 1]], r[:, 2]) and np.array_equal(pos[r[:, 1]], r[:, 3:6]), "second update, launch %d" % call
+    occupied = grid[v[v[:, 0] == 2][:, 2]] > 0.1
+    assert occupied.mean() > 0.7  # ten tries at 1 / 8 occupied cells: 74 % land in one
+    return len(v)

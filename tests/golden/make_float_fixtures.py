@@ -287,6 +287,19 @@ static void kernel_grid_element(const uint32_t i, const uint32_t level, const ui
 	""" + grid_body + """
 }
 }""")
+    # one sample of an occupancy update: generate_grid_samples_nerf_nonuniform's body behind its two index lines (testbed_nerf.cu:585-614), with NERF_MIN_OPTICAL_THICKNESS as the
+    # file's `#if SDF_GRID` selects it
+    sdf_grid = src_tn.split("#define SDF_GRID")[1].split("\n")[0].strip()
+    gs_kernel = block_ignoring_comments(tn, "__global__ void generate_grid_samples_nerf_nonuniform(")
+    gs_body = gs_kernel[gs_kernel.index("// 1 random number to select the level, 3 to select the position."):gs_kernel.rindex("}")]
+    parts.append("#define SDF_GRID " + sdf_grid + "\n" + span(tn, "#if SDF_GRID\ninline constexpr __device__ float NERF_MIN_OPTICAL_THICKNESS()", "#endif") + "\n"
+                 + f("include/neural-graphics-primitives/nerf.h", "struct NerfPosition {") + ";\n"
+                 + "template <typename RNG>\n" + f(rv, "inline __host__ __device__ float random_val(RNG& rng)") + "\ntemplate <typename RNG>\n" + f(rv, "inline __host__ __device__ Eigen::Vector3f random_val_3d(RNG& rng)") + """
+namespace tcnn { """ + f(cd, "__host__ __device__ inline uint32_t expand_bits(uint32_t v)") + f(cd, "__host__ __device__ inline uint32_t morton3D_invert(uint32_t x)") + """ }
+static void grid_sample_element(const uint32_t i, const uint32_t n_elements, default_rng_t rng, const uint32_t step, BoundingBox aabb, const float* grid_in, NerfPosition* out, uint32_t* indices,
+                                uint32_t n_cascades, float thresh) {
+	""" + gs_body + """
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -646,7 +659,33 @@ int main() {
 			out.push_back(hb(feat[0])); out.push_back(hb(feat[1]));
 			for (int q = 0; q < 6; ++q) out.push_back(fb(dydx[q]));
 		}
-		arr_u("encode_size_res_scale_xyz_table257_f0_f1_dydx6", out, true);
+		arr_u("encode_size_res_scale_xyz_table257_f0_f1_dydx6", out);
+	}
+	{ // ---- the samples of two occupancy updates (testbed_nerf.cu:3424-3494 drives generate_grid_samples_nerf_nonuniform): the first update of a run (every cell of the zeroed grid)
+	  //      and a later one (n/4 samples anywhere, then n/4 in cells above NERF_MIN_OPTICAL_THICKNESS) over the grid pattern cell c -> 0.5 if (c * 2654435761 >> 29) == 0 else 0
+		std::vector<uint32_t> out;
+		const uint32_t cells = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE();
+		std::vector<float> grid(cells, 0.0f);
+		tcnn::pcg32 m_rng{1337};                                        // Testbed::reset_network (testbed.cu:2223-2237): seed 1337, the grid's generator seeded with its first draw
+		tcnn::pcg32 density_grid_rng{m_rng.next_uint()};
+		BoundingBox box{Vector3f::Constant(0.0f), Vector3f::Constant(1.0f)};
+		// the kernel advances its generator by i * 4 itself and indexes out[i] / indices[i]: call it with the true i and arrays shifted by -i
+		auto run_true = [&](const uint32_t n_elements, const uint32_t step, const float thresh, const uint32_t offset, const uint32_t call) {
+			for (int k = 0; k < 512; ++k) {
+				const uint32_t i = k < 4 ? (uint32_t)k : (k < 8 ? n_elements - 1 - (uint32_t)(k - 4) : gen.next_uint() % n_elements);
+				NerfPosition p{Vector3f::Zero(), 0.0f};
+				uint32_t idx = 0;
+				grid_sample_element(i, n_elements, density_grid_rng, step, box, grid.data(), &p - i, &idx - i, 1, thresh);
+				out.push_back(call); out.push_back(offset + i); out.push_back(idx); out.push_back(fb(p.p.x())); out.push_back(fb(p.p.y())); out.push_back(fb(p.p.z()));
+			}
+		};
+		run_true(cells, 0, -0.01f, 0, 0);                                 // update 1 (training step 0): n_uniform = all cells, n_nonuniform = 0; density_grid_ema_step 0
+		density_grid_rng.advance(); density_grid_rng.advance();           // (both launches are followed by an advance, the empty one too)
+		for (uint32_t c = 0; c < cells; ++c) grid[c] = ((c * 2654435761u) >> 29) == 0 ? 0.5f : 0.0f;
+		run_true(cells / 4, 1, -0.01f, 0, 1);                             // update 2 (training step >= 256): density_grid_ema_step 1
+		density_grid_rng.advance();
+		run_true(cells / 4, 1, NERF_MIN_OPTICAL_THICKNESS(), cells / 4, 2);
+		arr_u("gridsamples_call_slot_idx_pos3", out, true);
 	}
 	printf("}\n");
 	return 0;

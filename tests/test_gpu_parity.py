@@ -123,6 +123,14 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
         assert float_fixture_cases.check_optimizer(c, exact_pow=False) == 256
     finally:
         c.close()
+    from rnb_neus2_amd import synthetic
+    c = rnb.Context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, n_levels=2)
+    try:  # the samples of two occupancy updates against generate_grid_samples_nerf_nonuniform's own body (a grid written through the ABI between them)
+        c.init_params()
+        c.set_dataset(*synthetic.make_scene(2, 16, 28.0))
+        assert float_fixture_cases.check_grid_samples(c) == 3 * 512
+    finally:
+        c.close()
 
 
 def test_density_grid_update(pair):
