@@ -295,3 +295,28 @@ def check_grid_samples(ctx):
     occupied = grid[v[v[:, 0] == 2][:, 2]] > 0.1
     assert occupied.mean() > 0.7  # ten tries at 1 / 8 occupied cells: 74 % land in one
     return len(v)
+
+
+def check_bitfield(ctx):
+    """Occupancy grid -> bitfield and its seven max-pooled mips: the bodies of grid_to_bitfield / bitfield_max_pool (testbed_nerf.cu:693-740) as update_density_grid_mean_and_bitfield
+    drives them, against rnb_update_density_bitfield on two grid patterns written through RNB_BUF_DENSITY_GRID: the mean bit for bit (the patterns' sums are exact in any order),
+    every mip's set-bit count and a position-weighted checksum of its bytes."""
+    v = np.array(load()["bitfield_pattern_mean_table8_then_setbits_checksum_per_mip"], dtype=np.uint32).reshape(2, 26)
+    cells = 128 ** 3
+    c = np.arange(cells, dtype=np.uint32)
+    sel = (c * np.uint32(2654435761)) >> np.uint32(29)
+    w = (np.arange(cells // 8, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(1)).astype(np.uint32)
+    for row in v:
+        table = row[2:10].view(np.float32)
+        ctx.put("DENSITY_GRID", table[sel].astype(np.float32))
+        ctx.update_density_bitfield()
+        assert ctx.get("DENSITY_MEAN")[:1].view(np.uint32)[0] == row[1], ("mean", int(row[0]))
+        bits = ctx.get("DENSITY_BITFIELD")
+        assert len(bits) == 8 * cells // 8
+        for mip in range(8):
+            b = bits[mip * (cells // 8):(mip + 1) * (cells // 8)]
+            set_bits = int(np.unpackbits(b).sum())
+            chk = int((b.astype(np.uint32) * w).sum(dtype=np.uint64) & 0xffffffff)  # uint32 products, summed modulo 2^32
+            assert (set_bits, chk) == (int(row[10 + 2 * mip]), int(row[11 + 2 * mip])), ("mip", int(row[0]), mip, set_bits, int(row[10 + 2 * mip]))
+    assert v[0][1:2].view(np.float32)[0] < 0.1 < v[1][1:2].view(np.float32)[0]  # both thresholds are exercised
+    return 16

@@ -300,6 +300,17 @@ static void grid_sample_element(const uint32_t i, const uint32_t n_elements, def
                                 uint32_t n_cascades, float thresh) {
 	""" + gs_body + """
 }""")
+    # occupancy grid -> bitfield and its seven max-pooled mips: the bodies of grid_to_bitfield and bitfield_max_pool behind their index lines (testbed_nerf.cu:693-740), driven as
+    # update_density_grid_mean_and_bitfield drives them (:3496-3517)
+    g2b = block_ignoring_comments(tn, "__global__ void grid_to_bitfield(")
+    bmp = block_ignoring_comments(tn, "__global__ void bitfield_max_pool(")
+    parts.append("namespace tcnn { " + f(cd, "__host__ __device__ inline uint32_t morton3D(uint32_t x, uint32_t y, uint32_t z)") + " }\n" + f(tn, "inline __host__ __device__ uint32_t grid_mip_offset(uint32_t mip)") + """
+static void grid_to_bitfield_element(const uint32_t i, const uint32_t n_nonzero_elements, const float* grid, uint8_t* grid_bitfield, const float* mean_density_ptr) {
+	""" + g2b[g2b.index("if (i >= n_nonzero_elements) {"):g2b.rindex("}")] + """
+}
+static void bitfield_max_pool_element(const uint32_t i, const uint8_t* prev_level, uint8_t* next_level) {
+	""" + bmp[bmp.index("uint8_t bits = 0;"):bmp.rindex("}")] + """
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -685,7 +696,32 @@ int main() {
 		run_true(cells / 4, 1, -0.01f, 0, 1);                             // update 2 (training step >= 256): density_grid_ema_step 1
 		density_grid_rng.advance();
 		run_true(cells / 4, 1, NERF_MIN_OPTICAL_THICKNESS(), cells / 4, 2);
-		arr_u("gridsamples_call_slot_idx_pos3", out, true);
+		arr_u("gridsamples_call_slot_idx_pos3", out);
+	}
+	{ // ---- occupancy grid -> bitfield + 7 mips (testbed_nerf.cu:3496-3517), two grid patterns whose mean is exact in any summation order (values are multiples of 2^-10):
+	  //      cell c -> table[(c * 2654435761) >> 29], sparse (mean < 0.1: the threshold is the mean) and dense (mean > 0.1: the threshold is NERF_MIN_OPTICAL_THICKNESS)
+		std::vector<uint32_t> out;
+		const uint32_t n_elements = NERF_GRIDSIZE() * NERF_GRIDSIZE() * NERF_GRIDSIZE();
+		const float tables[2][8] = {{0.5f, 0.0f, 0.0f, -1.0f, 0.0625f, 0.0f, 0.0f, 0.0f}, {0.5f, 0.5f, 0.09765625f, -1.0f, 0.1015625f, 0.5f, 0.5f, 0.0f}};
+		for (int pat = 0; pat < 2; ++pat) {
+			std::vector<float> grid(n_elements);
+			double sum = 0.0;
+			for (uint32_t c = 0; c < n_elements; ++c) { grid[c] = tables[pat][(c * 2654435761u) >> 29]; sum += fmaxf(grid[c], 0.f) / (n_elements); }
+			const float mean = (float)sum; // = what reduce_sum leaves in any order: every term and every partial sum is exact
+			std::vector<uint8_t> bits(grid_mip_offset(NERF_CASCADES()) / 8, 0);
+			for (uint32_t i = 0; i < n_elements / 8 * NERF_CASCADES(); ++i) grid_to_bitfield_element(i, n_elements / 8 * 1, grid.data(), bits.data(), &mean);
+			for (uint32_t level = 1; level < NERF_CASCADES(); ++level)
+				for (uint32_t i = 0; i < n_elements / 64; ++i) bitfield_max_pool_element(i, bits.data() + grid_mip_offset(level - 1) / 8, bits.data() + grid_mip_offset(level) / 8);
+			out.push_back((uint32_t)pat); out.push_back(fb(mean));
+			for (int q = 0; q < 8; ++q) out.push_back(fb(tables[pat][q]));
+			for (uint32_t level = 0; level < NERF_CASCADES(); ++level) { // per mip: set bits, and a position-weighted checksum of its bytes
+				uint32_t set = 0, chk = 0;
+				const uint8_t* b = bits.data() + grid_mip_offset(level) / 8;
+				for (uint32_t i = 0; i < n_elements / 8; ++i) { set += (uint32_t)__builtin_popcount(b[i]); chk += (uint32_t)b[i] * (i * 2654435761u + 1u); }
+				out.push_back(set); out.push_back(chk);
+			}
+		}
+		arr_u("bitfield_pattern_mean_table8_then_setbits_checksum_per_mip", out, true);
 	}
 	printf("}\n");
 	return 0;

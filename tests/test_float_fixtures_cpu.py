@@ -40,6 +40,7 @@ def test_oracle_occupancy_update_samples_match_the_reference_kernel():
         c.init_params()
         c.set_dataset(*synthetic.make_scene(2, 16, 28.0))
         assert float_fixture_cases.check_grid_samples(c) == 3 * 512
+        assert float_fixture_cases.check_bitfield(c) == 16
     finally:
         c.close()
 
@@ -55,4 +56,4 @@ def test_float_fixture_is_what_its_generator_says():
                        "losssample_flags4_out8_in25_alpha_T_w2_rgb4_dl11_shading_ek_inter10",
                        "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow",
                        "adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16",
-                       "encode_size_res_scale_xyz_table257_f0_f1_dydx6", "gridsamples_call_slot_idx_pos3"}
+                       "encode_size_res_scale_xyz_table257_f0_f1_dydx6", "gridsamples_call_slot_idx_pos3", "bitfield_pattern_mean_table8_then_setbits_checksum_per_mip"}

@@ -129,6 +129,7 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
         c.init_params()
         c.set_dataset(*synthetic.make_scene(2, 16, 28.0))
         assert float_fixture_cases.check_grid_samples(c) == 3 * 512
+        assert float_fixture_cases.check_bitfield(c) == 16  # grid_to_bitfield / bitfield_max_pool's own bodies: mean, 8 mips
     finally:
         c.close()
 
