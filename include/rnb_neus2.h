@@ -365,9 +365,12 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *   RNB_PRIM_ENCODE  in  table entries (<= 256), resolution, bits(scale), x y z, then 257 words = the level's table (half2 per entry, + one readable word)
  *                    out features f0 f1 (half bits), d f0 / d xyz 3, d f1 / d xyz 3 -- twice: the training kernels' form, then the evaluation kernels' pipelined form
  *                    (one sample, one level of kernel_grid, tcnn encodings/grid.h:168-364)
+ *   RNB_PRIM_MARCH_RAY in box lo hi, cone_angle, origin 3, direction 3, start t    out the number of samples the march takes through the RNB_PRIM_MARCH bitfield, the sum of the bit
+ *                    patterns of every NerfCoordinate word it writes (7 per sample: warped position, warped dt, warped direction), the first two samples' 14 words, the last one's 7
+ *                    (the sampler's two march loops, testbed_nerf.cu:1330-1380)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15, RNB_PRIM_MARCH_RAY = 16 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

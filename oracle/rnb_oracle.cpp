@@ -2045,12 +2045,12 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_ENCODE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[16] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263}, OUT_W[16] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16};
+	if (kind < 0 || kind > RNB_PRIM_MARCH_RAY) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	static const uint32_t IN_W[17] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10}, OUT_W[17] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
-	if (kind == RNB_PRIM_MARCH) {
+	if (kind == RNB_PRIM_MARCH || kind == RNB_PRIM_MARCH_RAY) {
 		bf.resize((size_t)GRID_CELLS / 8 * N_CASCADES);
 		Pcg32 q{5};
 		for (auto& b : bf) b = (uint8_t)(q.next_uint() >> 24);
@@ -2172,6 +2172,21 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			uint16_t h0, h1; std::memcpy(&h0, &feat[0], 2); std::memcpy(&h1, &feat[1], 2);
 			o[0] = o[8] = h0; o[1] = o[9] = h1; // (the checker has one form of the encoding; the library's second form fills words 8-15)
 			for (int d = 0; d < 3; ++d) { o[2 + d] = o[10 + d] = u(dy[0][d]); o[5 + d] = o[13 + d] = u(dy[1][d]); }
+		} else if (kind == RNB_PRIM_MARCH_RAY) {
+			orc_ctx_s mc; // the box, the cone angle and the bitfield the march reads from a context
+			mc.aabb_min = f(a[0]); mc.aabb_max = f(a[1]); mc.cone_angle = f(a[2]);
+			mc.bitfield = bf;
+			RaySetup r; r.alive = true; r.o = {f(a[3]), f(a[4]), f(a[5])}; r.dir = {f(a[6]), f(a[7]), f(a[8])}; r.d_unnorm = r.dir; r.startt = f(a[9]);
+			const Vec3 wd = warp_direction(r.dir);
+			uint32_t chk = 0, last[7] = {0, 0, 0, 0, 0, 0, 0};
+			for (int q = 0; q < 23; ++q) o[q] = 0u;
+			const uint32_t n = march(&mc, r, RNB_MAX_STEPS, [&](uint32_t j, const Vec3& pos, float dt) {
+				const Vec3 wp = warp_position(&mc, pos);
+				const uint32_t c7[7] = {u(wp.x), u(wp.y), u(wp.z), u(warp_dt(dt)), u(wd.x), u(wd.y), u(wd.z)}; // a NerfCoordinate (nerf.h:76-104): position, dt, direction
+				for (int q = 0; q < 7; ++q) { chk += c7[q]; last[q] = c7[q]; if (j < 2) o[2 + j * 7 + q] = c7[q]; }
+			});
+			o[0] = n; o[1] = chk;
+			for (int q = 0; q < 7; ++q) o[16 + q] = last[q];
 		} else if (kind == RNB_PRIM_GRID) {
 			float pos; uint32_t cell;
 			pos_fract(f(a[5]), &pos, &cell, f(a[6]));

@@ -2060,7 +2060,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[16] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263}, PRIM_OUT_WORDS[16] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16};
+constexpr uint32_t PRIM_IN_WORDS[17] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10}, PRIM_OUT_WORDS[17] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2209,6 +2209,20 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		pass2_ray_terms(F, R, (float)a[4], G, lrow, mrow);
 		o[0] = u(lrow * (float)a[4]); // (the ray's loss itself is not kept by the kernels: row x n_rays, compared as such)
 		o[1] = u(G.grad[0]); o[2] = u(G.grad[1]); o[3] = u(G.grad[2]); o[4] = u(G.grad[3]); o[5] = u(G.weight_sum); o[6] = u(G.gradient_weight_sum); o[7] = u(lrow); o[8] = u(mrow);
+	} else if (kind == RNB_PRIM_MARCH_RAY) {
+		SceneAabb A; A.mn = f(a[0]); A.mx = f(a[1]); A.cone_angle = f(a[2]); A.max_cascade = 0;
+		const Vec3 ro = {f(a[3]), f(a[4]), f(a[5])}, dir = {f(a[6]), f(a[7]), f(a[8])};
+		const Vec3 wd = warp_direction(dir);
+		uint32_t chk = 0;
+		for (int q = 0; q < 23; ++q) o[q] = 0u;
+		uint32_t last[7] = {0, 0, 0, 0, 0, 0, 0};
+		const uint32_t n = march<false>(A, bitfield, nullptr, 0u, ro, dir, f(a[9]), RNB_MAX_STEPS, [&](uint32_t j, const Vec3& pos, float dt, float) {
+			const Vec3 wp = warp_position(A, pos);
+			const uint32_t c7[7] = {u(wp.x), u(wp.y), u(wp.z), u(warp_dt(dt)), u(wd.x), u(wd.y), u(wd.z)}; // a NerfCoordinate (nerf.h:76-104): position, dt, direction
+			for (int q = 0; q < 7; ++q) { chk += c7[q]; last[q] = c7[q]; if (j < 2) o[2 + j * 7 + q] = c7[q]; }
+		});
+		o[0] = n; o[1] = chk;
+		for (int q = 0; q < 7; ++q) o[16 + q] = last[q];
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

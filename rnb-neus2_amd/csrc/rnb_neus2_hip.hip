@@ -2139,13 +2139,13 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_ENCODE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_MARCH_RAY) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
 	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
 	uint32_t *in = nullptr, *out = nullptr;
 	uint8_t* bf = nullptr;
 	int rc = RNB_OK;
-	if (hipMalloc((void**)&in, n_in * 4) != hipSuccess || hipMalloc((void**)&out, n_out * 4) != hipSuccess || (kind == RNB_PRIM_MARCH && hipMalloc((void**)&bf, n_bf) != hipSuccess))
+	if (hipMalloc((void**)&in, n_in * 4) != hipSuccess || hipMalloc((void**)&out, n_out * 4) != hipSuccess || ((kind == RNB_PRIM_MARCH || kind == RNB_PRIM_MARCH_RAY) && hipMalloc((void**)&bf, n_bf) != hipSuccess))
 		rc = fail(RNB_ERR_NOMEM, "hipMalloc failed for the primitive self-test");
 	std::vector<uint32_t> own; // RNB_PRIM_RAY_TARGETS: nine words 0xffffffff for the light directions = "the context's own" (build_light_dirs)
 	if (kind == RNB_PRIM_RAY_TARGETS) {

@@ -137,6 +137,14 @@ def check(ctx, exact_exp):
     assert np.array_equal(out[:, 8:16], en[:, 263:271]), "level_issue / level_consume"
     assert np.count_nonzero(en[:, 263]) > 300 and len(set(en[:, 0].tolist())) == 5
     n["encode"] = len(en)
+    # ---- a ray through the occupancy bitfield: the sampler's two march loops (its own lines, writing the reference's NerfCoordinate) -- how many samples, and all of them (a checksum
+    # over every word, the first two and the last sample in full); IEEE arithmetic and integer logic only: bit for bit everywhere
+    mr = np.array(fx["marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7"], dtype=np.uint32).reshape(-1, 33)
+    out = ctx.eval_primitives("MARCH_RAY", mr[:, :10])
+    assert np.array_equal(out[:, 0], mr[:, 10]), "number of samples"
+    assert np.array_equal(out[:, 1:], mr[:, 11:]), "NerfCoordinates"
+    assert mr[:, 10].max() > 400 and (mr[:, 10] == 0).any()
+    n["march_ray"] = len(mr)
     return n
 
 

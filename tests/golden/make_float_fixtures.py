@@ -311,6 +311,31 @@ static void grid_to_bitfield_element(const uint32_t i, const uint32_t n_nonzero_
 static void bitfield_max_pool_element(const uint32_t i, const uint8_t* prev_level, uint8_t* next_level) {
 	""" + bmp[bmp.index("uint8_t bits = 0;"):bmp.rindex("}")] + """
 }""")
+    # the sampler's two march loops (testbed_nerf.cu:1330-1380): the counting loop and the loop that writes the NerfCoordinates, the kernel's own lines, with the functions they call
+    # (calc_dt .. mip_from_dt, the int fixtures' fragments) and the reference's NerfCoordinate / PitchedPtr
+    parts.append("""static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline float min(float a, float b) { return fminf(a, b); }
+static inline unsigned int min(unsigned int a, unsigned int b) { return a < b ? a : b; }
+static inline unsigned int min(unsigned int a, int b) { return min(a, (unsigned int)b); }
+static inline unsigned int min(int a, unsigned int b) { return min((unsigned int)a, b); }
+namespace tcnn { template <typename T>\n""" + f("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "struct PitchedPtr {") + "; }\n"
+                 + f("include/neural-graphics-primitives/nerf.h", "struct NerfDirection {") + ";\n" + f("include/neural-graphics-primitives/nerf.h", "struct NerfCoordinate {") + ";\n"
+                 + "\n".join(f(tn, sig) for sig in ("inline constexpr __device__ float MAX_CONE_STEPSIZE()", "inline __host__ __device__ float calc_dt(float t, float cone_angle)",
+                                                     "inline __device__ float distance_to_next_voxel(", "inline __device__ float advance_to_next_voxel(",
+                                                     "__device__ uint32_t cascaded_grid_idx_at(Vector3f pos, uint32_t mip)", "__device__ bool density_grid_occupied_at(",
+                                                     "inline __device__ int mip_from_pos(", "inline __device__ int mip_from_dt(")) + """
+struct MarchResult { uint32_t numsteps; std::vector<float> coords; };
+static MarchResult march_statements(const Vector3f ray_o, const Vector3f dir, const float startt, const float cone_angle, const BoundingBox aabb, const uint8_t* density_grid) {
+	std::vector<float> storage(7 * NERF_STEPS());
+	tcnn::PitchedPtr<NerfCoordinate> coords_out((NerfCoordinate*)storage.data(), 1, 0, 0);
+	const float* extra_dims = nullptr;
+	""" + span_until(tn, "Vector3f idir = dir.cwiseInverse();", "if (j == 0 && !train_envmap) {", "__global__ void generate_training_samples_nerf_with_global_movement(") + """
+	uint32_t numsteps = j;
+	""" + span_until(tn, "Vector3f warped_dir = warp_direction(dir);", "if (max_level_rand_training) {\n\t\tmax_level_ptr += base;", "__global__ void generate_training_samples_nerf_with_global_movement(") + """
+	storage.resize(7 * (size_t)numsteps);
+	return {numsteps, storage};
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -721,7 +746,32 @@ int main() {
 				out.push_back(set); out.push_back(chk);
 			}
 		}
-		arr_u("bitfield_pattern_mean_table8_then_setbits_checksum_per_mip", out, true);
+		arr_u("bitfield_pattern_mean_table8_then_setbits_checksum_per_mip", out);
+	}
+	{ // ---- a ray through the occupancy bitfield (testbed_nerf.cu:1330-1380): how many samples, and the NerfCoordinates written (7 floats each: warped position, warped dt, warped direction);
+	  //      bitfield byte i = pcg32{5} draw i >> 24, as for the int fixtures' march items
+		std::vector<uint32_t> out;
+		static_assert(sizeof(NerfCoordinate) == 28, "NerfCoordinate is seven floats");
+		std::vector<uint8_t> bf(grid_mip_offset(NERF_CASCADES()) / 8);
+		{ tcnn::pcg32 q{5}; for (auto& b : bf) b = (uint8_t)(q.next_uint() >> 24); }
+		for (int k = 0; k < 192; ++k) {
+			const float lo = k % 3 == 2 ? -1.5f : 0.0f, hi = k % 3 == 2 ? 2.5f : 1.0f, cone = k % 3 == 2 ? 1.0f / 256.0f : 0.0f;   // one cascade with the constant step; four with cone stepping
+			BoundingBox box{Vector3f::Constant(lo), Vector3f::Constant(hi)};
+			Vector3f o{uni(lo, hi), uni(lo, hi), uni(lo, hi)};
+			Vector3f d = Vector3f{uni(-1, 1), uni(-1, 1), uni(-1, 1)}.normalized();
+			if (k % 16 == 7) d = Vector3f{1.0f, 0.0f, 0.0f};
+			if (k % 16 == 8) { d = Vector3f{0.0f, -1.0f, 0.0f}; o.y() = hi; }      // starts ON the box's face
+			const float startt = k % 16 == 8 ? 0.0f : uni(0.0f, 0.02f);
+			const MarchResult r = march_statements(o, d, startt, cone, box, bf.data());
+			for (float v : {lo, hi, cone, o.x(), o.y(), o.z(), d.x(), d.y(), d.z(), startt}) out.push_back(fb(v));
+			out.push_back(r.numsteps);
+			uint32_t chk = 0;
+			for (float v : r.coords) chk += fb(v);
+			out.push_back(chk);
+			for (int q = 0; q < 14; ++q) out.push_back(q < (int)r.coords.size() ? fb(r.coords[q]) : 0u);                                 // the first two samples
+			for (int q = 0; q < 7; ++q) out.push_back(r.numsteps ? fb(r.coords[(size_t)(r.numsteps - 1) * 7 + q]) : 0u);               // the last one
+		}
+		arr_u("marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", out, true);
 	}
 	printf("}\n");
 	return 0;
