@@ -328,3 +328,22 @@ def check_bitfield(ctx):
             assert (set_bits, chk) == (int(row[10 + 2 * mip]), int(row[11 + 2 * mip])), ("mip", int(row[0]), mip, set_bits, int(row[10 + 2 * mip]))
     assert v[0][1:2].view(np.float32)[0] < 0.1 < v[1][1:2].view(np.float32)[0]  # both thresholds are exercised
     return 16
+
+
+def check_controller(make_context):
+    """The ray-batch controller: the two statements of Counters::update_after_training that set the next step's rays_per_batch (testbed_nerf.cu:3554-3555) against
+    rnb_train_step_finish (the piece of a step a data-parallel host calls with the summed counters), 256 (rays, target, measured) triples."""
+    v = np.array(load()["controller_rays_target_measured_nextrays"], dtype=np.uint32).reshape(-1, 4)
+    n = 0
+    for target in sorted(set(v[:, 1].tolist())):
+        c = make_context(target_batch_size=int(target), max_rays_per_batch=1 << 18, overlap=0)
+        try:
+            for rays, _, measured, want in v[v[:, 1] == target].tolist():
+                c.set_controller(10, rays, measured, 0)
+                st = c.train_step_finish((measured + 7, measured, 100, measured + 7), (1.0, 2.0, 3.0))
+                assert st.next_rays_per_batch == want and c.rays_per_batch == want, (rays, target, measured, st.next_rays_per_batch, want)
+                assert st.loss == np.float32(np.float32(1.0) * np.float32(measured) / np.float32(target))  # reduce_sum(loss) x measured / target (:3549)
+                n += 1
+        finally:
+            c.close()
+    return n

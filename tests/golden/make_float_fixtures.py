@@ -336,6 +336,14 @@ static MarchResult march_statements(const Vector3f ray_o, const Vector3f dir, co
 	storage.resize(7 * (size_t)numsteps);
 	return {numsteps, storage};
 }""")
+    # the ray-batch controller: the two statements of Counters::update_after_training that set the next step's rays_per_batch (testbed_nerf.cu:3554-3555), host code in the reference too
+    parts.append("namespace tcnn { " + statement("dependencies/neus2_tcnn/include/tiny-cuda-nn/common.h", "constexpr uint32_t batch_size_granularity = 128;") + """ }
+static uint32_t controller_statements(uint32_t rays_per_batch, const uint32_t target_batch_size, const uint32_t measured_batch_size) {
+	using tcnn::next_multiple;
+	""" + statement(tn, "rays_per_batch = (uint32_t)((float)rays_per_batch * (float)target_batch_size / (float)measured_batch_size);") + "\n\t"
+                 + statement(tn, "rays_per_batch = std::min(next_multiple(rays_per_batch, tcnn::batch_size_granularity), 1u << 18);") + """
+	return rays_per_batch;
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -771,7 +779,19 @@ int main() {
 			for (int q = 0; q < 14; ++q) out.push_back(q < (int)r.coords.size() ? fb(r.coords[q]) : 0u);                                 // the first two samples
 			for (int q = 0; q < 7; ++q) out.push_back(r.numsteps ? fb(r.coords[(size_t)(r.numsteps - 1) * 7 + q]) : 0u);               // the last one
 		}
-		arr_u("marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", out, true);
+		arr_u("marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", out);
+	}
+	{ // ---- the next step's rays_per_batch from this step's compacted sample count (testbed_nerf.cu:3554-3555)
+		std::vector<uint32_t> out;
+		for (int k = 0; k < 256; ++k) {
+			const uint32_t target = k % 5 == 4 ? (1u << 16) : (1u << 18);
+			const uint32_t rays = 128u * (1u + gen.next_uint() % (k % 2 ? 2048u : 128u));
+			uint32_t measured = 1u + gen.next_uint() % (k % 3 == 0 ? (1u << 14) : (1u << 19));
+			if (k < 4) measured = target;                       // on target: unchanged up to the granularity
+			if (k >= 4 && k < 8) measured = target / 2 + (uint32_t)k;
+			out.push_back(rays); out.push_back(target); out.push_back(measured); out.push_back(controller_statements(rays, target, measured));
+		}
+		arr_u("controller_rays_target_measured_nextrays", out, true);
 	}
 	printf("}\n");
 	return 0;

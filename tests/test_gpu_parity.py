@@ -132,6 +132,7 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
         assert float_fixture_cases.check_bitfield(c) == 16  # grid_to_bitfield / bitfield_max_pool's own bodies: mean, 8 mips
     finally:
         c.close()
+    assert float_fixture_cases.check_controller(lambda **cfg: rnb.Context(**cfg)) == 256  # the ray-batch controller's two statements
 
 
 def test_density_grid_update(pair):
