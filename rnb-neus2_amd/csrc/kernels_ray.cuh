@@ -2060,7 +2060,7 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[17] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10}, PRIM_OUT_WORDS[17] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23};
+constexpr uint32_t PRIM_IN_WORDS[18] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2}, PRIM_OUT_WORDS[18] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -2223,6 +2223,8 @@ __global__ void k_primitives(const int kind, const uint32_t* __restrict__ in, co
 		});
 		o[0] = n; o[1] = chk;
 		for (int q = 0; q < 7; ++q) o[16 + q] = last[q];
+	} else if (kind == RNB_PRIM_SDF_DENSITY) {
+		o[0] = (uint32_t)__builtin_bit_cast(uint16_t, sdf_to_density(__builtin_bit_cast(half_t, (uint16_t)a[0]), __builtin_bit_cast(half_t, (uint16_t)a[1])));
 	} else if (kind == RNB_PRIM_GRID) {
 		float pos; uint32_t cell;
 		pos_fract(f(a[5]), f(a[6]), &pos, &cell);

@@ -2139,7 +2139,7 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_MARCH_RAY) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_SDF_DENSITY) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
 	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
 	uint32_t *in = nullptr, *out = nullptr;

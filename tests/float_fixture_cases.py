@@ -145,6 +145,17 @@ def check(ctx, exact_exp):
     assert np.array_equal(out[:, 1:], mr[:, 11:]), "NerfCoordinates"
     assert mr[:, 10].max() > 400 and (mr[:, 10] == 0).any()
     n["march_ray"] = len(mr)
+    # ---- SDF -> the occupancy grid's density, every operation in half (two expf: a half ulp of the result on the GPU, exact on the CPU; exp(12) overflows half -> inf, nan)
+    sd = np.array(fx["sdfdensity_sdf16_variance16_density16"], dtype=np.uint32).reshape(-1, 3)
+    out = ctx.eval_primitives("SDF_DENSITY", sd[:, :2])
+    if exact_exp:
+        assert np.array_equal(out[:, 0], sd[:, 2]), "sdf_to_density"
+    else:
+        g, w = out[:, 0].astype(np.uint16).view(np.float16).astype(np.float64), sd[:, 2].astype(np.uint16).view(np.float16).astype(np.float64)
+        fin = np.isfinite(w)
+        assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isinf(g), np.isinf(w))
+        assert np.all(np.abs(g[fin] - w[fin]) <= 4e-3 * np.abs(w[fin]) + 1e-7) and np.mean(out[:, 0] == sd[:, 2]) > 0.9
+    n["sdf_density"] = len(sd)
     return n
 
 

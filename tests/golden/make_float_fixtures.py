@@ -344,6 +344,13 @@ static uint32_t controller_statements(uint32_t rays_per_batch, const uint32_t ta
                  + statement(tn, "rays_per_batch = std::min(next_multiple(rays_per_batch, tcnn::batch_size_granularity), 1u << 18);") + """
 	return rays_per_batch;
 }""")
+    # SDF -> the occupancy grid's density: sdf_to_density_variance_buffer's body behind its index lines (common_operation.cuh:311-328), half arithmetic throughout
+    # (-ffloat16-excess-precision=none: every half operation rounds, as CUDA's __half operators do)
+    s2d = block_ignoring_comments("include/neural-graphics-primitives/common_operation.cuh", "__global__ void sdf_to_density_variance_buffer(")
+    parts.append("""template <typename T>
+static void sdf_to_density_element(const uint32_t i, const T* variance_output, tcnn::MatrixView<T> sdf_network_output) {
+	""" + s2d[s2d.index("T sdf = sdf_network_output(0, i);"):s2d.rindex("}")] + """
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -791,7 +798,20 @@ int main() {
 			if (k >= 4 && k < 8) measured = target / 2 + (uint32_t)k;
 			out.push_back(rays); out.push_back(target); out.push_back(measured); out.push_back(controller_statements(rays, target, measured));
 		}
-		arr_u("controller_rays_target_measured_nextrays", out, true);
+		arr_u("controller_rays_target_measured_nextrays", out);
+	}
+	{ // ---- SDF -> density of the occupancy grid (common_operation.cuh:311-328): density = s sigmoid(sdf s) (1 - sigmoid(sdf s)), s = exp(10 variance), every operation in half
+		std::vector<uint32_t> out;
+		auto hb = [](__half h) { uint16_t u; memcpy(&u, &h, 2); return (uint32_t)u; };
+		for (int k = 0; k < 512; ++k) {
+			__half sdf = (__half)(uni(-1, 1) * (k % 4 == 0 ? 0.5f : (k % 4 == 1 ? 0.02f : 0.002f)));
+			if (k % 32 == 5) sdf = (__half)0.0f;
+			__half var = (__half)(k % 8 == 7 ? 1.2f : uni(0.05f, 0.8f));   // 1.2: s = exp(12) overflows half
+			__half io = sdf;
+			sdf_to_density_element<__half>(0, &var, tcnn::MatrixView<__half>(&io, 1, 1));
+			out.push_back(hb(sdf)); out.push_back(hb(var)); out.push_back(hb(io));
+		}
+		arr_u("sdfdensity_sdf16_variance16_density16", out, true);
 	}
 	printf("}\n");
 	return 0;
@@ -806,7 +826,7 @@ def main():
         src = os.path.join(d, "float_fixtures.cpp")
         open(src, "w").write(prog)
         exe = os.path.join(d, "float_fixtures")
-        subprocess.check_call([CXX, "-O1", "-std=c++17", "-ffp-contract=off", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
+        subprocess.check_call([CXX, "-O1", "-std=c++17", "-ffp-contract=off", "-Xclang", "-ffloat16-excess-precision=none", "-DEIGEN_DONT_VECTORIZE", "-w", "-I", os.path.join(REF, "dependencies", "eigen"), src, "-o", exe])
         text = subprocess.check_output([exe]).decode()
     data = json.loads(text)
     data = {"_source": "tests/golden/make_float_fixtures.py: floating-point fragments of /root/reference compiled for the host with clang++ (-ffp-contract=off, -DEIGEN_DONT_VECTORIZE as Eigen configures itself under a GPU compiler) in the build container "
