@@ -135,7 +135,7 @@ def check(ctx, exact_exp):
     out = ctx.eval_primitives("ENCODE", en[:, :263])
     assert np.array_equal(out[:, 0:8], en[:, 263:271]), "encode_level_core"
     assert np.array_equal(out[:, 8:16], en[:, 263:271]), "level_issue / level_consume"
-    assert np.count_nonzero(en[:, 263]) > 300 and len(set(en[:, 0].tolist())) == 5
+    assert np.count_nonzero(en[:, 263]) > 120 and len(set(en[:, 0].tolist())) == 5
     n["encode"] = len(en)
     # ---- a ray through the occupancy bitfield: the sampler's two march loops (its own lines, writing the reference's NerfCoordinate) -- how many samples, and all of them (a checksum
     # over every word, the first two and the last sample in full); IEEE arithmetic and integer logic only: bit for bit everywhere

@@ -692,7 +692,7 @@ int main() {
 		std::vector<uint32_t> out;
 		auto hb = [](__half h) { uint16_t u; memcpy(&u, &h, 2); return (uint32_t)u; };
 		const uint32_t shapes[8][2] = {{32, 3}, {216, 6}, {128, 5}, {64, 151}, {128, 971}, {256, 2049}, {256, 50}, {64, 4}}; // table entries, resolution: dense (27 -> 32, 216, 125 -> 128, 64) and hashed
-		for (int k = 0; k < 384; ++k) {
+		for (int k = 0; k < 160; ++k) {
 			const uint32_t size = shapes[k % 8][0], res = shapes[k % 8][1];
 			const float scale = (float)(res - 1);
 			__half table[257 * 2];
