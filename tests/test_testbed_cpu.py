@@ -44,6 +44,37 @@ def test_version_and_help(install):
         assert flag in r.stdout, flag
 
 
+def test_every_flag_of_the_references_command_line(install):
+    """tests/golden/cli_flags.json: the `args` declarations of the reference's main (src/main.cu:73-258), parsed from its text by make_cli_fixture.py -- 25 of them. `testbed -h`
+    lists every one in the reference's order with its short and long names, its placeholder and (the scene flag's wording aside) its help text; a value flag refuses to go
+    without its value, a plain flag refuses one; the only flag the reference does not have is --accumulate."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_flags.json")) as f:
+        flags = json.load(f)["flags"]
+    assert len(flags) == 25
+    text = run(install, "-h").stdout
+    pos = -1
+    for fl in flags:
+        if fl["kind"] == "ValueFlag":
+            head = ", ".join(["-%s[%s]" % (c, fl["placeholder"]) for c in fl["short"]] + ["--%s=[%s]" % (n, fl["placeholder"]) for n in fl["long"]])
+        else:
+            head = ", ".join(["-%s" % c for c in fl["short"]] + ["--%s" % n for n in fl["long"]])
+        at = text.find("      " + head + "\n")
+        assert at > pos, (head, at, pos)  # present, in the reference's order
+        pos = at
+        if fl["long"] != ["scene"]:  # (the reference's text lists dataset kinds of its other modes)
+            assert fl["help"] in text[at:at + 400], (head, fl["help"])
+    listed = [l.strip() for l in text.splitlines() if l.startswith("      -")]
+    assert len(listed) == 26 and listed[-1].startswith("--accumulate=")
+    for fl in flags:
+        name = "--" + fl["long"][0]
+        if fl["kind"] == "ValueFlag":
+            r = run(install, name)
+            assert r.returncode == 255 and "OPTIONS" in r.stderr, name  # missing value: the usage text, `return -1`
+        elif fl["kind"] == "Flag" and name != "--version":
+            r = run(install, name + "=1")
+            assert r.returncode == 255, name
+
+
 def test_parse_errors_exit_minus_one(install):
     for bad in (["--does-not-exist"], ["--maxiter"], ["--maxiter", "many"], ["--no-gui=1"], ["stray"]):
         r = run(install, *bad)
