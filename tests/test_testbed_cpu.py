@@ -410,6 +410,19 @@ def test_snapshot_carries_every_key_the_reference_loader_reads(trained):
     assert snap["local_rotation"] == one + z * 3 + one + z * 3 and snap["local_transition"] == z * 4   # nerf_network.h:1062-1080
     for block in ("encoding", "network", "optimizer"):                                        # reset_network reads the config blocks of the same file (whatever the run's config held)
         assert block in root, block
+    # tests/golden/snapshot_keys.json: every key path Testbed::save_snapshot and Trainer::serialize assign, parsed from their text (make_snapshot_fixture.py)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "snapshot_keys.json")) as f:
+        keys = json.load(f)
+    assert len(keys["written_by_save_snapshot"]) == 9 and len(keys["written_by_trainer_serialize"]) == 3
+    for path in keys["written_by_save_snapshot"] + keys["written_by_trainer_serialize"]:
+        if path == ["snapshot", "optimizer"]:
+            continue  # only with include_optimizer_state, which main.cu does not ask for (src/main.cu: save_snapshot(path, false))
+        if path == ["snapshot", "nerf", "dataset"]:
+            continue  # the reference's serialised NerfDataset (image paths, transforms): not read back when --scene is given; not written here
+        node = root
+        for k in path:
+            assert isinstance(node, dict) and k in node, path
+            node = node[k]
 
 
 def test_resume_from_a_reference_style_snapshot(install, trained, tmp_path):
