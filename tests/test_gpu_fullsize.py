@@ -809,11 +809,27 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             # the loss gradients row by row (the compaction is identical, so the rows pair up): a converged SDF has 1/s in the hundreds, so a network output that lands on the
             # neighbouring half moves that sample's dL/dsdf by tens of per cent -- a few such rows carry the whole deviation D, and a fine-level cell that one of them touches
             # inherits it (the trained state differs from run to run, and with it D: 1e-4 ... 2e-3)
-            n_c = int(cc[1])
-            dg = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[:n_c].astype(np.float64)
-            dc = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[:n_c].astype(np.float64)
+            # rows paired RAY BY RAY: the compaction COUNT can be identical while the T < 1e-4 cut of two rays moved in opposite directions, which shifts every row between them by one
+            # (one run in ten of the state-producing training ends in such a state: 93 k of 262 k rows 'differed' when the rows were paired by position)
+            kept = int(cc[2])
+            ng, nc = gpu.get("NUMSTEPS", kept * 2).reshape(-1, 2), cpu.get("NUMSTEPS", kept * 2).reshape(-1, 2)
+            out["rays_with_another_cut"] = int(np.count_nonzero(ng[:, 0] != nc[:, 0]))
+            assert out["rays_with_another_cut"] <= 4, out["rays_with_another_cut"]
+            both = np.minimum(ng[:, 0], nc[:, 0]).astype(np.int64)
+            within = np.arange(int(both.sum())) - np.repeat(np.cumsum(both) - both, both)
+            ig, ic = np.repeat(ng[:, 1].astype(np.int64), both) + within, np.repeat(nc[:, 1].astype(np.int64), both) + within
+            dg = gpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[ig].astype(np.float64)
+            dc = cpu.get("DLOSS_DOUT").astype(np.float32).reshape(-1, 16)[ic].astype(np.float64)
             D = float(np.linalg.norm(dg - dc) / np.linalg.norm(dc))
             out["dloss_dout_dev_norm_over_norm"] = D
+            row_dev = np.linalg.norm(dg - dc, axis=1)
+            worst = np.argsort(-row_dev)[:8]
+            out["dloss_dout_worst_rows"] = [{"row": int(w), "dev": float(row_dev[w]), "norm_all": float(np.linalg.norm(dc)), "hip": [float(x) for x in dg[w][:11]], "emulated": [float(x) for x in dc[w][:11]]} for w in worst]
+            out["dloss_dout_rows_off_by_10_percent"] = int(np.count_nonzero(row_dev > 0.1 * np.maximum(np.linalg.norm(dc, axis=1), 1e-6)))
+            _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(_root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(_root, "gpurun_out", "r05_reference_as_coded_%s_diag.json" % hip_mode), "w") as f:
+                json.dump(out, f, indent=1)
             assert D <= 5e-3, D
             lo, hi = blocks["hash_grid"]
             levels = [int(v) for v in cpu.grid_tables()[0]]
@@ -859,6 +875,10 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             pass
         if half:
             assert max(rel) <= 1e-4, rel  # the north star's tolerance, against the reference AS CODED
+            # A ray whose T < 1e-4 cut moved has one sample more on one side: its loss gradient is nothing (weight <= 1e-4), its Eikonal gradient is a whole sample's -- in the
+            # cells it touches, of a fine level's few hundred thousand live entries. One state in five of the state-producing training has two such rays (none in the others):
+            # the tables then differ by those samples' addends, ~ 3 sqrt(flips / samples) of a level's rms at the outside.
+            D = D + 0.75 * float(np.sqrt(out["rays_with_another_cut"] / max(1, int(cc[1]))))
             assert out["sdf_mlp"]["cosine"] >= 0.99999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 5e-3 + 2 * D, (out["sdf_mlp"], D)
             floor = out["hash_grid_order_floor"]
             # every addend its own half atomic: the whole table within the distance of two legal orders of the reference itself
