@@ -6,11 +6,13 @@
  * pointers everywhere. It follows the reference function by function; every
  * block cites the file:line it restates (paths relative to /root/reference).
  *
- * PARITY UNPINNED for the floating-point path: the reference has no CPU path, no
- * tests and no golden vectors for it and cannot be compiled in this image
- * (nvcuda::wmma, CUTLASS, cuRAND). PCG32 / Morton / index arithmetic are pinned by
- * known-answer vectors (tests/golden/). Documented deviations from the reference
- * (DESIGN.md §oracle):
+ * PARITY: the reference has no CPU path, no tests and no golden vectors for this path and cannot be compiled in this image as a whole
+ * (nvcuda::wmma, CUTLASS, cuRAND). What it is pinned by is the reference's OWN CODE compiled for the host piece by piece (tests/golden/README.md): its functions
+ * (tests/golden/int_fixtures.json) and, since round 5, the bodies of its kernels behind their index lines or as runs of their own lines (float_fixtures.json) -- sampler
+ * (pinhole ray, both march loops), kernel_grid, the loss kernel (per-ray targets, ray loss terms, one iteration of the backward loop), adam_step + EMA, the occupancy
+ * update's sample generation and bitfield kernels, sdf -> density, the ray-batch controller: bit for bit. PARITY UNPINNED for what that cannot reach: the two fully fused
+ * MLPs (wmma fragments, CUTLASS) and the addends of the grid backward kernels (their host-visible branch needs CUDA's atomicAdd), and for everything only a CUDA
+ * binary decides (FMA contraction, the device's libm). Documented deviations from the reference:
  *   D1 MLP dot products accumulate in fp32 and round to half once per neuron
  *      (reference: WMMA fp16 accumulators, fully_fused_mlp.cu:68,198).
  *   D2 hash-grid and weight gradients accumulate in fp32 and are rounded to half
