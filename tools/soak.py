@@ -27,4 +27,8 @@ ctx.device_free(lat)
 dt = time.perf_counter() - t0
 r = np.linalg.norm(verts.astype(np.float64) - 0.5, axis=1)
 print("mesh %d^3: %d vertices, %d triangles in %.1f ms; |v - centre| mean %.5f (sphere 0.25), rms deviation %.5f, max %.5f" % (res, len(verts), len(idx) // 3, 1e3 * dt, r.mean(), np.sqrt(np.mean((r - 0.25) ** 2)), np.abs(r - 0.25).max()), flush=True)
+off = np.abs(r - 0.25) > 0.005
+if off.any():
+    d = verts[off].astype(np.float64) - 0.5
+    print("   %d vertices further than 0.005 from the sphere: radius %.4f .. %.4f, mean direction %s, extent %s" % (int(off.sum()), r[off].min(), r[off].max(), np.round((d / np.linalg.norm(d, axis=1, keepdims=True)).mean(0), 3).tolist(), np.round(np.ptp(verts[off], axis=0), 4).tolist()), flush=True)
 ctx.close()
