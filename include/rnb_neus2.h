@@ -370,9 +370,10 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *                    (the sampler's two march loops, testbed_nerf.cu:1330-1380)
  *   RNB_PRIM_SDF_DENSITY in sdf, variance (half bit patterns)    out the occupancy grid's density s sigmoid(sdf s) (1 - sigmoid(sdf s)), s = exp(10 variance), half arithmetic throughout
  *                    (sdf_to_density_variance_buffer, common_operation.cuh:311-328)
+ *   RNB_PRIM_PREP_DUE in training step    out 1 if that step begins with an occupancy update, and the interval n_prep_to_skip it is due at (Testbed::train, src/testbed.cu:2805-2806)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15, RNB_PRIM_MARCH_RAY = 16, RNB_PRIM_SDF_DENSITY = 17 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15, RNB_PRIM_MARCH_RAY = 16, RNB_PRIM_SDF_DENSITY = 17, RNB_PRIM_PREP_DUE = 18 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

@@ -2139,8 +2139,12 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_SDF_DENSITY) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_PREP_DUE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
+	if (kind == RNB_PRIM_PREP_DUE) { // host logic (Testbed::train, src/testbed.cu:2805-2806): does training step in[i] begin with an occupancy update, and the interval it is due at
+		for (uint32_t i = 0; i < n_items; ++i) { out_host[2 * i] = prep_due(in_host[i]) ? 1u : 0u; out_host[2 * i + 1] = std::min(std::max(in_host[i] / 16u, 1u), 16u); }
+		return RNB_OK;
+	}
 	const size_t n_in = (size_t)n_items * PRIM_IN_WORDS[kind], n_out = (size_t)n_items * PRIM_OUT_WORDS[kind], n_bf = (size_t)GRID_CELLS / 8 * N_CASCADES;
 	uint32_t *in = nullptr, *out = nullptr;
 	uint8_t* bf = nullptr;

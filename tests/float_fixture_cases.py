@@ -156,6 +156,12 @@ def check(ctx, exact_exp):
         assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isinf(g), np.isinf(w))
         assert np.all(np.abs(g[fin] - w[fin]) <= 4e-3 * np.abs(w[fin]) + 1e-7) and np.mean(out[:, 0] == sd[:, 2]) > 0.9
     n["sdf_density"] = len(sd)
+    # ---- which training steps begin with an occupancy update (host logic on both sides)
+    pd = np.array(fx["prep_step_due_skip"], dtype=np.uint32).reshape(-1, 3)
+    out = ctx.eval_primitives("PREP_DUE", pd[:, :1])
+    assert np.array_equal(out, pd[:, 1:3]), "occupancy-update schedule"
+    assert pd[:32, 1].all() and pd[pd[:, 0] == 1008][0, 1] == 1 and pd[pd[:, 0] == 1000][0, 1] == 0
+    n["prep_due"] = len(pd)
     return n
 
 

@@ -351,6 +351,20 @@ static uint32_t controller_statements(uint32_t rays_per_batch, const uint32_t ta
 static void sdf_to_density_element(const uint32_t i, const T* variance_output, tcnn::MatrixView<T> sdf_network_output) {
 	""" + s2d[s2d.index("T sdf = sdf_network_output(0, i);"):s2d.rindex("}")] + """
 }""")
+    # which steps begin with an occupancy update: the two lines of Testbed::train (src/testbed.cu:2805-2806) that decide it
+    tb = open(os.path.join(REF, "src", "testbed.cu")).read()
+    skip_stmt = "uint32_t n_prep_to_skip = (m_testbed_mode == ETestbedMode::Nerf) ? tcnn::clamp(m_canonical_training_step / 16u, 1u, 16u) : 1u;"
+    due_cond = "m_canonical_training_step % n_prep_to_skip == 0"
+    assert skip_stmt in tb and ("if (" + due_cond + ") {") in tb
+    modes = enum_names("include/neural-graphics-primitives/common.h", "enum class ETestbedMode")
+    assert modes[0] == "Nerf"
+    parts.append("enum class ETestbedMode : int { " + ", ".join(modes) + """ };
+static void prep_statements(const uint32_t m_canonical_training_step, uint32_t* skip_out, uint32_t* due_out) {
+	const ETestbedMode m_testbed_mode = ETestbedMode::Nerf;
+	""" + skip_stmt + """
+	*skip_out = n_prep_to_skip;
+	*due_out = (""" + due_cond + """) ? 1u : 0u;
+}""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -811,7 +825,13 @@ int main() {
 			sdf_to_density_element<__half>(0, &var, tcnn::MatrixView<__half>(&io, 1, 1));
 			out.push_back(hb(sdf)); out.push_back(hb(var)); out.push_back(hb(io));
 		}
-		arr_u("sdfdensity_sdf16_variance16_density16", out, true);
+		arr_u("sdfdensity_sdf16_variance16_density16", out);
+	}
+	{ // ---- which training steps begin with an occupancy update (src/testbed.cu:2805-2806): every step up to 31, then every 2nd, 3rd, ... 16th
+		std::vector<uint32_t> out;
+		for (uint32_t step = 0; step < 700; ++step) { uint32_t skip, due; prep_statements(step, &skip, &due); out.push_back(step); out.push_back(due); out.push_back(skip); }
+		for (uint32_t step : {1000u, 1008u, 4095u, 4096u, 65535u, 65536u, 1000000u, 4294967280u, 4294967295u}) { uint32_t skip, due; prep_statements(step, &skip, &due); out.push_back(step); out.push_back(due); out.push_back(skip); }
+		arr_u("prep_step_due_skip", out, true);
 	}
 	printf("}\n");
 	return 0;

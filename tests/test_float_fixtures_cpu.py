@@ -4,7 +4,7 @@ albedo, the L1 / L2 ray loss, image / pixel choice of a ray) against the outputs
 library in tests/test_gpu_parity.py."""
 from tests import float_fixture_cases, oracle_lib
 
-COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512, "read_rgba": 256, "camera_ray": 192, "ray_targets": 192, "loss_sample": 384, "ray_loss": 192, "encode": 160, "march_ray": 192, "sdf_density": 512}
+COUNTS = {"activation": 256, "warp": 192, "loss": 128, "pixel": 256, "grid": 512, "read_rgba": 256, "camera_ray": 192, "ray_targets": 192, "loss_sample": 384, "ray_loss": 192, "encode": 160, "march_ray": 192, "sdf_density": 512, "prep_due": 709}
 
 
 def test_oracle_float_primitives_match_the_reference_fragments():
@@ -61,4 +61,4 @@ def test_float_fixture_is_what_its_generator_says():
                        "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow",
                        "adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16",
                        "encode_size_res_scale_xyz_table257_f0_f1_dydx6", "gridsamples_call_slot_idx_pos3", "bitfield_pattern_mean_table8_then_setbits_checksum_per_mip",
-                       "marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", "controller_rays_target_measured_nextrays", "sdfdensity_sdf16_variance16_density16"}
+                       "marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", "controller_rays_target_measured_nextrays", "sdfdensity_sdf16_variance16_density16", "prep_step_due_skip"}
