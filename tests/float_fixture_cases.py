@@ -364,3 +364,32 @@ def check_controller(make_context):
         finally:
             c.close()
     return n
+
+
+def check_lr_decay(make_context):
+    """The learning-rate factor the k-th optimizer step runs with: the head of ExponentialDecayOptimizer::step (exponential_decay.h:61-72) against the library -- after
+    rnb_set_optimizer_step(k), one optimizer step on a fresh MLP weight (w = 0, moments 0, first step) with a unit gradient moves it by exactly learning_rate x factor(k)
+    (Adam's first step is lr x sign(g); the L2 term vanishes at w = 0): the base.json schedule at its events and a dense one."""
+    v = np.array(load()["lrdecay_start_interval_base_step_factor"], dtype=np.uint32).reshape(-1, 5)
+    n = 0
+    for start, interval in sorted({(int(r[0]), int(r[1])) for r in v}):
+        rows = v[(v[:, 0] == start) & (v[:, 1] == interval)]
+        base = float(rows[0, 2:3].view(np.float32)[0])
+        c = make_context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10, n_levels=2, lr_decay_start=start, lr_decay_interval=interval, lr_decay_base=base)
+        try:
+            c.init_params()
+            lr = float(np.float32(c.cfg.learning_rate))
+            npar = c.n_params
+            for r in rows:
+                k, want = int(r[3]), float(r[4:5].view(np.float32)[0])
+                c.set_params(np.zeros(npar, np.float32))
+                c.set_optimizer_step(k)
+                g = np.zeros(npar, np.float32); g[5] = 128.0  # the accumulators hold loss-scaled sums: gradient 1
+                c.put("GRADS_FP32", g)
+                c.optimizer_step()
+                dw = -float(c.get("PARAMS_FP32")[5])
+                assert abs(dw - lr * want) <= 2e-6 * lr * want, (start, interval, k, dw / lr, want)
+                n += 1
+        finally:
+            c.close()
+    return n

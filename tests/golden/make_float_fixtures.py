@@ -365,6 +365,17 @@ static void prep_statements(const uint32_t m_canonical_training_step, uint32_t* 
 	*skip_out = n_prep_to_skip;
 	*due_out = (""" + due_cond + """) ? 1u : 0u;
 }""")
+    # the learning-rate schedule: the two if-blocks at the head of ExponentialDecayOptimizer::step (optimizers/exponential_decay.h:61-72), in a struct with the members they use;
+    # step() is the nested optimizer's count of steps taken so far
+    dec_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/exponential_decay.h"
+    dec_step = fragment(dec_h, "void step(cudaStream_t stream, float loss_scale, float* weights_full_precision, T* weights, const T* gradients) override {")
+    parts.append("""struct DecaySchedule {
+	float m_learning_rate_factor; uint32_t m_decay_start, m_decay_interval, m_decay_end; float m_decay_base; uint32_t steps_taken;
+	uint32_t step() const { return steps_taken; }
+	void before_nested_step() {
+		""" + _block(dec_step, dec_step.index("if (step() == 0) {")) + "\n\t\t" + _block(dec_step, dec_step.index("if (step() >= m_decay_start")) + """
+	}
+};""")
     # the optimizer: one element of tcnn's adam_step (optimizers/adam.h:52-202: the kernel's body behind its two index lines, `i` bound as an argument), the half-precision EMA
     # step (ema.h:63-78, its one arithmetic line) with the two debias statements of EmaOptimizer::step (ema.h:115-116)
     adam_h = "dependencies/neus2_tcnn/include/tiny-cuda-nn/optimizers/adam.h"
@@ -394,6 +405,7 @@ static void ema_step_element(const uint32_t i, const float m_ema_decay, const ui
     assert base["otype"] == "Ema" and base["nested"]["otype"] == "ExponentialDecay" and adam_cfg["otype"] == "Adam"
     opt = {k: repr(float(adam_cfg[k])) + "f" for k in ("learning_rate", "beta1", "beta2", "epsilon", "l2_reg")}
     opt["ema_decay"] = repr(float(base["decay"])) + "f"
+    dec = {"decay_start": str(int(base["nested"]["decay_start"])), "decay_interval": str(int(base["nested"]["decay_interval"])), "decay_base": repr(float(base["nested"]["decay_base"])) + "f"}
     parts.append(r"""
 static uint32_t fb(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static float bf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -831,7 +843,23 @@ int main() {
 		std::vector<uint32_t> out;
 		for (uint32_t step = 0; step < 700; ++step) { uint32_t skip, due; prep_statements(step, &skip, &due); out.push_back(step); out.push_back(due); out.push_back(skip); }
 		for (uint32_t step : {1000u, 1008u, 4095u, 4096u, 65535u, 65536u, 1000000u, 4294967280u, 4294967295u}) { uint32_t skip, due; prep_statements(step, &skip, &due); out.push_back(step); out.push_back(due); out.push_back(skip); }
-		arr_u("prep_step_due_skip", out, true);
+		arr_u("prep_step_due_skip", out);
+	}
+	{ // ---- the learning-rate factor the k-th optimizer step runs with (exponential_decay.h:61-72), configs/nerf/base.json's schedule and a dense one
+		std::vector<uint32_t> out;
+		const uint32_t cfgs[2][2] = {{""" + dec["decay_start"] + r"""u, """ + dec["decay_interval"] + r"""u}, {3u, 2u}};
+		const float bases[2] = {""" + dec["decay_base"] + r""", 0.5f};
+		for (int c = 0; c < 2; ++c) {
+			DecaySchedule d{1.0f, cfgs[c][0], cfgs[c][1], 10000000u, bases[c], 0};
+			const uint32_t last = c == 0 ? 60001u : 40u;
+			for (uint32_t k = 0; k <= last; ++k) {
+				d.steps_taken = k;
+				d.before_nested_step();
+				const bool record = c == 1 || k < 3 || (k % 10000u) <= 1u || (k % 10000u) == 9999u;
+				if (record) { out.push_back(cfgs[c][0]); out.push_back(cfgs[c][1]); out.push_back(fb(bases[c])); out.push_back(k); out.push_back(fb(d.m_learning_rate_factor)); }
+			}
+		}
+		arr_u("lrdecay_start_interval_base_step_factor", out, true);
 	}
 	printf("}\n");
 	return 0;

@@ -49,6 +49,10 @@ def test_oracle_ray_batch_controller_matches_the_reference_statements():
     assert float_fixture_cases.check_controller(lambda **cfg: oracle_lib.context(**cfg)) == 256
 
 
+def test_oracle_learning_rate_schedule_matches_the_reference():
+    assert float_fixture_cases.check_lr_decay(lambda **cfg: oracle_lib.context(**cfg)) == 62
+
+
 def test_float_fixture_is_what_its_generator_says():
     fx = float_fixture_cases.load()
     assert "make_float_fixtures.py" in fx["_source"] and "-ffp-contract=off" in fx["_source"]
@@ -61,4 +65,4 @@ def test_float_fixture_is_what_its_generator_says():
                        "rayloss_L2_rgbplus_bce_maskweight_nrays_target4_ray4_albedoalpha_normalalpha_weightsum_loss_grad4_ws_gws_lossrow_maskrow",
                        "adam_globals8_then_ismatrix_step_optstep_w_w16_g16_m_v_ema16_neww_neww16_newm_newv_newstep_newema16",
                        "encode_size_res_scale_xyz_table257_f0_f1_dydx6", "gridsamples_call_slot_idx_pos3", "bitfield_pattern_mean_table8_then_setbits_checksum_per_mip",
-                       "marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", "controller_rays_target_measured_nextrays", "sdfdensity_sdf16_variance16_density16", "prep_step_due_skip"}
+                       "marchray_lo_hi_cone_o3_d3_startt_numsteps_checksum_first14_last7", "controller_rays_target_measured_nextrays", "sdfdensity_sdf16_variance16_density16", "prep_step_due_skip", "lrdecay_start_interval_base_step_factor"}

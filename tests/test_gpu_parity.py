@@ -133,6 +133,7 @@ def test_device_float_primitives_match_the_reference_fragments(pair):
     finally:
         c.close()
     assert float_fixture_cases.check_controller(lambda **cfg: rnb.Context(**cfg)) == 256  # the ray-batch controller's two statements
+    assert float_fixture_cases.check_lr_decay(lambda **cfg: rnb.Context(**cfg)) == 62  # ExponentialDecayOptimizer::step's head
 
 
 def test_density_grid_update(pair):
