@@ -742,16 +742,21 @@ constexpr size_t LDS_FBS_FULL = (size_t)(SWF_END + WAVES_PER_WG * FBS_FULL_WAVE_
 // Column order of the 32-wide input tiles: the 28 hash features first (a level's pair is one aligned 4-byte LDS access),
 // then x y z, then the pad -- the input index is a summation index of W0 . in, the weight images follow the same order.
 __host__ __device__ constexpr int fbs_logical(int p) { return p < 28 ? 3 + p : (p < 31 ? p - 28 : 31); }
+// The half mode's order of the INPUT tiles (and of W0's columns): features 0..12 | x y z | features 13..27 | pad, so that slots 0..15 are the reference's
+// columns 0..15 = its first 16-wide k-step and slots 16..31 its second: lane (r16, hq) reads slots 4 hq .. 4 hq + 3 of either half as the operand of a
+// K = 16 MFMA -- no masked operands (mlp.cuh). A level's pair is two 2-byte LDS stores there. W0^T's rows (the order the input GRADIENTS leave in) stay in tile order.
+__host__ __device__ constexpr int fbs_logical_h(int p) { return p < 13 ? 3 + p : (p < 16 ? p - 13 : p); }
+__host__ __device__ constexpr int fbs_feature_slot_h(int q) { return q < 13 ? q : q + 3; }
 
-__device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
-	for (int i = tid; i < 64 * 32; i += nthreads) { const int o = i >> 5, p = i & 31; w[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + fbs_logical(p)]; }
+__device__ inline void load_weights_fbs(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads, const bool half_order = false) {
+	for (int i = tid; i < 64 * 32; i += nthreads) { const int o = i >> 5, p = i & 31; w[SW_S0 + o * S32 + p] = net.sdf_w0[o * 32 + (half_order ? fbs_logical_h(p) : fbs_logical(p))]; }
 	for (int i = tid; i < 32 * 64; i += nthreads) { const int q = i >> 6, p = i & 63; w[SW_S0T + q * S64 + p] = net.sdf_w0[chain_logical(p) * 32 + fbs_logical(q)]; }
 	for (int i = tid; i < 64; i += nthreads) { w[SW_W1 + i] = net.sdf_w1[chain_logical(i)]; w[SW_W1N + i] = net.sdf_w1[i]; }
 	for (int i = SW_END + tid; i < SW_END_PADDED; i += nthreads) w[i] = (half_t)0.f;
 	// (row padding of the images is never read)
 }
-__device__ inline void load_weights_fbs_full(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads) {
-	load_weights_fbs(w, net, tid, nthreads);
+__device__ inline void load_weights_fbs_full(half_t* __restrict__ w, const NetW& net, const int tid, const int nthreads, const bool half_order = false) {
+	load_weights_fbs(w, net, tid, nthreads, half_order);
 	for (int i = tid; i < 64 * 32; i += nthreads) { const int u = i >> 5, o = i & 31; w[SW_W1T + u * S32 + o] = o < 16 ? net.sdf_w1[o * 64 + u] : (half_t)0.f; }
 }
 
@@ -760,10 +765,10 @@ __device__ inline void load_weights_rgb(half_t* __restrict__ w, const NetW& net,
 // gridDim.x workgroups per image (round 4: 16, one element per thread and array; one workgroup per image walked ~50 dependent 2-byte loads per thread, 15 us
 // alone and 70-90 us beside the scatter, at the end of the side stream that the next step's network evaluation waits for).
 constexpr uint32_t WIMG_WGS = 16;
-__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train, half_t* __restrict__ img_rgb) {
+__global__ __launch_bounds__(WG) void k_prepare_weight_images(const NetW net, half_t* __restrict__ img_fwd, half_t* __restrict__ img_fbs, half_t* __restrict__ img_train, half_t* __restrict__ img_rgb, const int half_order) {
 	const int tid = blockIdx.x * WG + threadIdx.x, nthreads = gridDim.x * WG;
 	if (blockIdx.y == 0) load_weights_chained(img_fwd, net, tid, nthreads);
-	else if (blockIdx.y == 1) load_weights_fbs_full(img_fbs, net, tid, nthreads);
+	else if (blockIdx.y == 1) load_weights_fbs_full(img_fbs, net, tid, nthreads, half_order != 0); // (accumulate = half: k_fwd_bwd_sdf*_h's input order)
 	else if (blockIdx.y == 2) load_weights<true>(img_train, net, tid, nthreads);
 	else load_weights_rgb(img_rgb, net, tid, nthreads);
 }
@@ -799,8 +804,8 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_live = min(G.n_levels, G.valid_level + 1u); // levels [0, n_live) are encoded, the others are zeros (grid.h:192-210)
 	if (a.wimg) copy_weight_image(wts, a.wimg, W_END, threadIdx.x, WG);
-	else if (FULL) load_weights_fbs_full(wts, net, threadIdx.x, WG);
-	else load_weights_fbs(wts, net, threadIdx.x, WG);
+	else if (FULL) load_weights_fbs_full(wts, net, threadIdx.x, WG, EMU);
+	else load_weights_fbs(wts, net, threadIdx.x, WG, EMU);
 	__syncthreads();
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	constexpr int WAVE_HALFS = FULL ? FBS_FULL_WAVE_HALFS : FBS_WAVE_HALFS;
@@ -870,14 +875,26 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 			for (int d = 0; d < 3; ++d) { r0 += d0[d] * dn[d]; r1 += d1[d] * dn[d]; }
 			const half_t e0 = f2h(r0), e1 = f2h(r1);
-			Xrow[level] = pack_h2(f0, f1);
-			Drow[level] = pack_h2(e0, e1);
+			if (EMU) { // fbs_feature_slot_h
+				const uint32_t q0 = 2u * level, q1 = q0 + 1u, p0 = q0 < 13u ? q0 : q0 + 3u, p1 = q1 < 13u ? q1 : q1 + 3u;
+				X[lane * S32 + p0] = f0; X[lane * S32 + p1] = f1;
+				D[lane * S32 + p0] = e0; D[lane * S32 + p1] = e1;
+			} else {
+				Xrow[level] = pack_h2(f0, f1);
+				Drow[level] = pack_h2(e0, e1);
+			}
 		}
 		{ // x y z (fill_positions_view_with_fixed_offset: half arithmetic, common_operation.cuh:187-199) | pad ; dn | pad
 			const half_t px = f2h(c[0]) - (half_t)0.5f, py = f2h(c[1]) - (half_t)0.5f, pz = f2h(c[2]) - (half_t)0.5f;
-			Xrow[14] = pack_h2(px, py); Xrow[15] = pack_h2(pz, (half_t)0.f);
 			const half_t n0 = f2h(dn[0]), n1 = f2h(dn[1]), n2 = f2h(dn[2]);
-			Drow[14] = pack_h2(n0, n1); Drow[15] = pack_h2(n2, (half_t)0.f);
+			if (EMU) {
+				half_t* xr = X + lane * S32; half_t* dr = D + lane * S32;
+				xr[13] = px; xr[14] = py; xr[15] = pz; xr[31] = (half_t)0.f;
+				dr[13] = n0; dr[14] = n1; dr[15] = n2; dr[31] = (half_t)0.f;
+			} else {
+				Xrow[14] = pack_h2(px, py); Xrow[15] = pack_h2(pz, (half_t)0.f);
+				Drow[14] = pack_h2(n0, n1); Drow[15] = pack_h2(n2, (half_t)0.f);
+			}
 		}
 		Z[lane] = dout[3];
 		var_sum += h2f(dout[7]); // variance gradient
@@ -938,8 +955,8 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
 				const h8 wbn = *reinterpret_cast<const h8*>(wts + SW_S0 + (16 * nt + r16) * S32 + 8 * hq);
-				h8 wbn_lo = wbn, wbn_hi = wbn;
-				if (EMU) split_ksteps<EMU_FBS>(wbn, hq, wbn_lo, wbn_hi);
+				// EMU: the two k-steps as K = 16 operands (slots 4 hq .. + 3 of either half of the row, fbs_logical_h)
+				const h4 wbn0 = *reinterpret_cast<const h4*>(wts + SW_S0 + (16 * nt + r16) * S32 + 4 * hq), wbn1 = *reinterpret_cast<const h4*>(wts + SW_S0 + (16 * nt + r16) * S32 + 16 + 4 * hq);
 				const half_t w1h = wts[SW_W1N + 16 * nt + r16];
 				const float w1f = h2f(w1h);
 				h8 wb1t;
@@ -950,8 +967,15 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
 						const int mt = 2 * ks + h;
-						const f4 z = EMU ? mfma_emul16_split(ain[mt], wbn_lo, wbn_hi, zero4) : __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
-						const f4 fr = EMU ? mfma_emul16_split(add[mt], wbn_lo, wbn_hi, zero4) : __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
+						f4 z, fr;
+						if (EMU) {
+							const half_t* xr = X + (16 * mt + r16) * S32 + 4 * hq; const half_t* dr = D + (16 * mt + r16) * S32 + 4 * hq;
+							z = mfma_emul16_k16(*reinterpret_cast<const h4*>(xr), *reinterpret_cast<const h4*>(xr + 16), wbn0, wbn1, zero4);
+							fr = mfma_emul16_k16(*reinterpret_cast<const h4*>(dr), *reinterpret_cast<const h4*>(dr + 16), wbn0, wbn1, zero4);
+						} else {
+							z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ain[mt], wbn, zero4, 0, 0, 0);
+							fr = __builtin_amdgcn_mfma_f32_16x16x32_f16(add[mt], wbn, zero4, 0, 0, 0);
+						}
 						f4 dzt = zero4;
 						if (FULL) dzt = __builtin_amdgcn_mfma_f32_16x16x32_f16(fso[mt], wb1t, zero4, 0, 0, 0); // (W1^T dso)^T: lane = hidden unit, registers = samples
 #pragma unroll
@@ -982,10 +1006,28 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 		// z1 = relu(W0 in), kept as next-layer fragments; its relu' mask in fragment order
 		h8 bz[4][2];
 		{
-			f4 acc[4][4];
-			zero_acc<4>(acc);
-			mfma_layer<4, 1, EMU ? EMU_FBS : EMU_OFF>(wts + SW_S0, S32, X, S32, acc, lane);
-			chain_pack<true>(acc, bz);
+			if (EMU) { // the reference's two k-steps as K = 16 MFMAs on the two halves of the rows (fbs_logical_h)
+				h4 b0[4], b1[4];
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) { const half_t* xr = X + (16 * nt + r16) * S32 + 4 * hq; b0[nt] = *reinterpret_cast<const h4*>(xr); b1[nt] = *reinterpret_cast<const h4*>(xr + 16); }
+#pragma unroll
+				for (int ks = 0; ks < 2; ++ks) {
+					f4 acc2[2][4];
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const half_t* wr = wts + SW_S0 + (16 * (2 * ks + h) + r16) * S32 + 4 * hq;
+						const h4 wa0 = *reinterpret_cast<const h4*>(wr), wa1 = *reinterpret_cast<const h4*>(wr + 16);
+#pragma unroll
+						for (int nt = 0; nt < 4; ++nt) acc2[h][nt] = mfma_emul16_k16(wa0, wa1, b0[nt], b1[nt], f4{0.f, 0.f, 0.f, 0.f});
+					}
+					chain_pack_ks<true>(acc2, bz, ks);
+				}
+			} else {
+				f4 acc[4][4];
+				zero_acc<4>(acc);
+				mfma_layer<4, 1, EMU_OFF>(wts + SW_S0, S32, X, S32, acc, lane);
+				chain_pack<true>(acc, bz);
+			}
 		}
 		half_t d3[4];
 #pragma unroll
@@ -1058,7 +1100,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 			for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-				for (int r = 0; r < 4; ++r) red[wave * N + (16 * mo + 4 * hq + r) * 32 + fbs_logical(16 * ni + r16)] = pass ? acc_w0b[mo][ni][r] : acc_w0[mo][ni][r];
+				for (int r = 0; r < 4; ++r) red[wave * N + (16 * mo + 4 * hq + r) * 32 + (EMU ? fbs_logical_h(16 * ni + r16) : fbs_logical(16 * ni + r16))] = pass ? acc_w0b[mo][ni][r] : acc_w0[mo][ni][r];
 		__syncthreads();
 		float* dst = (pass ? a.dw_w0b : a.dw_w0) + (size_t)blockIdx.x * N;
 		for (int q = threadIdx.x; q < N; q += WG) dst[q] = ((red[q] + red[N + q]) + red[2 * N + q]) + red[3 * N + q];

@@ -90,8 +90,21 @@ __device__ __forceinline__ f4 mfma_emul16_split(const h8 a, const h8 lo, const h
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, hi, acc, 0, 0, 0));
 	return acc;
 }
+// One 32-wide product as the reference's two k-steps. EMU_CHAINED: elements j < 4 of every lane ARE a 16-wide MFMA's operand (v_mfma_f32_16x16x16_f16: lane
+// (r16, hq) supplies k = 4 hq + j), so each k-step is one K = 16 instruction on half of the registers -- no masked copies. The other orders mask the
+// operand the caller shares between several MFMAs (split_ksteps, once).
+__device__ __forceinline__ f4 mfma_emul16_k16(const h4 a0, const h4 a1, const h4 b0, const h4 b1, f4 acc) {
+	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc, 0, 0, 0));
+	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc, 0, 0, 0));
+	return acc;
+}
 template <int ORD>
 __device__ __forceinline__ f4 mfma_emul16(const h8 a, const h8 b, f4 acc, const int hq) {
+	if (ORD == EMU_CHAINED) {
+		const h4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+		const h4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+		return mfma_emul16_k16(a0, a1, b0, b1, acc);
+	}
 	h8 lo, hi;
 	split_ksteps<ORD>(b, hq, lo, hi);
 	return mfma_emul16_split(a, lo, hi, acc);
@@ -111,8 +124,12 @@ __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const i
 #pragma unroll
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
+			h8 a_lo = a, a_hi = a; // (the weight operand is the one shared by the four sample tiles: masked once; a slot's product is zero whichever factor is)
+			if (EMU == EMU_NATURAL || EMU == EMU_FBS) split_ksteps<EMU>(a, hq, a_lo, a_hi);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<EMU>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt)
+				acc[mt][nt] = EMU == EMU_OFF ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0)
+				            : EMU == EMU_CHAINED ? mfma_emul16<EMU_CHAINED>(a, b[nt][ks], acc[mt][nt], hq) : round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b[nt][ks], round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b[nt][ks], acc[mt][nt], 0, 0, 0)), 0, 0, 0));
 		}
 	}
 }
@@ -211,8 +228,12 @@ __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, co
 #pragma unroll
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
+			h8 a_lo = a, a_hi = a; // (the weight operand is the one shared by the four sample tiles: masked once; a slot's product is zero whichever factor is)
+			if (EMU == EMU_NATURAL || EMU == EMU_FBS) split_ksteps<EMU>(a, hq, a_lo, a_hi);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = EMU ? mfma_emul16<EMU>(a, b[nt][ks], acc[mt][nt], hq) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
+			for (int nt = 0; nt < 4; ++nt)
+				acc[mt][nt] = EMU == EMU_OFF ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0)
+				            : EMU == EMU_CHAINED ? mfma_emul16<EMU_CHAINED>(a, b[nt][ks], acc[mt][nt], hq) : round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b[nt][ks], round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b[nt][ks], acc[mt][nt], 0, 0, 0)), 0, 0, 0));
 		}
 	}
 }
@@ -231,6 +252,20 @@ __device__ __forceinline__ void chain_pack(const f4 (&acc)[4][4], h8 (&b)[4][2])
 				b[nt][ks][j] = p[0];
 				b[nt][ks][j + 1] = p[1];
 			}
+}
+
+// The same for one K-step of the next layer: acc2[h] = the D fragments of hidden-unit tiles 2 ks + h.
+template <bool RELU>
+__device__ __forceinline__ void chain_pack_ks(const f4 (&acc2)[2][4], h8 (&b)[4][2], const int ks) {
+#pragma unroll
+	for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+		for (int j = 0; j < 8; j += 2) {
+			h2 p = {f2h(acc2[j >> 2][nt][j & 3]), f2h(acc2[j >> 2][nt][(j & 3) + 1])};
+			if (RELU) p = __builtin_elementwise_max(p, h2{(half_t)0.f, (half_t)0.f});
+			b[nt][ks][j] = p[0];
+			b[nt][ks][j + 1] = p[1];
+		}
 }
 
 // Also writes the fragments feature-major to global memory: dst[feature][n_total] at sample column s0 + ...

@@ -1103,7 +1103,7 @@ static int optimizer_finish(rnb_ctx* c, hipStream_t s, bool images_done = false)
 	c->opt.begun = false;
 	c->opt.early_done = false;
 	c->sc.valid = false;
-	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
+	if (!images_done) hipLaunchKernelGGL(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, s, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p, c->half_acc() ? 1 : 0);
 	c->wimg_valid = true;
 	c->prof.mark(s, P_ADAM);
 	c->prof.units[P_ADAM] += (double)c->n_params;
@@ -1179,7 +1179,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
-			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p);
+			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p, c->half_acc() ? 1 : 0);
 			images_done = true;
 			adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			// the join with the side stream: on the next step's march stream if that march is queued after this call (launch_premarch), else here
