@@ -55,13 +55,14 @@ __device__ inline void load_weights(half_t* __restrict__ w, const NetW& net, int
 // Half accumulation (the product mode rnb_config::accumulate = RNB_ACCUM_HALF): the reference's tensor-core path accumulates in HALF -- wmma 16x16x16
 // fragments of __half (fully_fused_mlp.cu:59-68, 198) -- where the default mode accumulates in fp32 (deviation D1). The matrix cores of
 // gfx950 have no half accumulator, so the model of the CPU checker (oracle/rnb_oracle.cpp dot_h) is followed instead: products exact, the 16 products of one
-// LOGICAL k-step (the reference's k index 16 q .. 16 q + 15) summed in fp32, the running accumulator rounded to half after every k-step. One 32-wide MFMA
-// covers TWO logical k-steps: it is issued twice, each time with the other step's operand elements zeroed, and the accumulator is rounded in between.
-// Which elements of a lane's 8-element operand belong to the first of the two steps depends on the operand's K order (k = 8 hq + j is the physical slot):
-//   EMU_NATURAL  tile read from LDS in the reference's column order                                  first step = lanes hq < 2
-//   EMU_CHAINED  chained fragments, k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3) (below)     first step = elements j < 4
-//   EMU_FBS      k_fwd_bwd_sdf's 32-wide input tiles, 28 hash features | x y z | pad (fbs_logical)  first step = reference columns 0..15 = slots 0..12, 28..30
-constexpr int EMU_OFF = 0, EMU_NATURAL = 1, EMU_CHAINED = 2, EMU_FBS = 3;
+// LOGICAL k-step (the reference's k index 16 q .. 16 q + 15) summed in fp32, the running accumulator rounded to half after every k-step. One k-step is one
+// v_mfma_f32_16x16x16_f16 (lane (r16, hq) supplies k = 4 hq + j, j < 4) wherever the operands' K order allows it:
+//   EMU_CHAINED  chained fragments, k <-> feature 16 (2 ks + (j >> 2)) + 4 hq + (j & 3) (below): elements j < 4 of a lane's 8 ARE the first k-step's operand, j >= 4 the second's
+//   EMU_NATURAL  tiles in LDS in the reference's column order: the two halves of a 32-wide row are the two k-steps, read as two 8-byte operands (mfma_layer);
+//                the same order in REGISTERS (k = 8 hq + j: the colour MLP's input rows in k_rgb_fwd_bwd) takes a 32-wide MFMA twice, each time with the other
+//                step's lanes (hq >= 2 / hq < 2) of the weight operand zeroed, the accumulator rounded in between (split_ksteps)
+//   k_fwd_bwd_sdf's input tiles are written in an order whose halves are the k-steps (kernels_net.cuh, fbs_logical_h) and read like EMU_NATURAL.
+constexpr int EMU_OFF = 0, EMU_NATURAL = 1, EMU_CHAINED = 2;
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f4 round_acc_half(f4 a) { // pairs: v_cvt_pk_f16_f32 (gfx950) + two unpacking converts = 3 instructions per 2 elements instead of 4
 	const h2 lo = __builtin_convertvector((f2v{a[0], a[1]}), h2), hi = __builtin_convertvector((f2v{a[2], a[3]}), h2);
@@ -78,11 +79,6 @@ __device__ __forceinline__ void split_ksteps(const h8 b, const int hq, h8& lo, h
 	else if (ORD == EMU_CHAINED) {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) { lo[j] = b[j]; hi[4 + j] = b[4 + j]; }
-	} else { // EMU_FBS: slots 8 hq + j with fbs_logical(slot) < 16: hq 0: all; hq 1: j <= 4; hq 2: none; hq 3: j = 4, 5, 6
-		const u4 m = hq == 0 ? u4{~0u, ~0u, ~0u, ~0u} : hq == 1 ? u4{~0u, ~0u, 0xffffu, 0u} : hq == 2 ? u4{0u, 0u, 0u, 0u} : u4{0u, 0u, ~0u, 0xffffu};
-		const u4 raw = __builtin_bit_cast(u4, b);
-		lo = __builtin_bit_cast(h8, raw & m);
-		hi = __builtin_bit_cast(h8, raw & ~m);
 	}
 }
 __device__ __forceinline__ f4 mfma_emul16_split(const h8 a, const h8 lo, const h8 hi, f4 acc) {
@@ -90,9 +86,7 @@ __device__ __forceinline__ f4 mfma_emul16_split(const h8 a, const h8 lo, const h
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a, hi, acc, 0, 0, 0));
 	return acc;
 }
-// One 32-wide product as the reference's two k-steps. EMU_CHAINED: elements j < 4 of every lane ARE a 16-wide MFMA's operand (v_mfma_f32_16x16x16_f16: lane
-// (r16, hq) supplies k = 4 hq + j), so each k-step is one K = 16 instruction on half of the registers -- no masked copies. The other orders mask the
-// operand the caller shares between several MFMAs (split_ksteps, once).
+// One 32-wide product as the reference's two k-steps: two K = 16 MFMAs, the accumulator rounded to half behind each.
 __device__ __forceinline__ f4 mfma_emul16_k16(const h4 a0, const h4 a1, const h4 b0, const h4 b1, f4 acc) {
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc, 0, 0, 0));
 	acc = round_acc_half(__builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc, 0, 0, 0));
@@ -114,6 +108,27 @@ __device__ __forceinline__ f4 mfma_emul16(const h8 a, const h8 b, f4 acc, const 
 template <int M_TILES, int K_STEPS, int EMU = EMU_OFF>
 __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const int w_stride, const half_t* __restrict__ X, const int x_stride, f4 (&acc)[M_TILES][4], const int lane) {
 	const int r16 = lane & 15, hq = lane >> 4;
+	static_assert(EMU == EMU_OFF || EMU == EMU_NATURAL, "operands in LDS: the reference's column order");
+	if (EMU == EMU_NATURAL) { // columns 32 ks .. + 15 and + 16 .. + 31 are the two k-steps: lane (r16, hq) reads slots 4 hq .. + 3 of either half as a K = 16 operand (no masks)
+		h4 b0[4][K_STEPS], b1[4][K_STEPS];
+#pragma unroll
+		for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+			for (int ks = 0; ks < K_STEPS; ++ks) {
+				const half_t* xr = X + (16 * nt + r16) * x_stride + 32 * ks + 4 * hq;
+				b0[nt][ks] = *reinterpret_cast<const h4*>(xr); b1[nt][ks] = *reinterpret_cast<const h4*>(xr + 16);
+			}
+#pragma unroll
+		for (int mt = 0; mt < M_TILES; ++mt)
+#pragma unroll
+			for (int ks = 0; ks < K_STEPS; ++ks) {
+				const half_t* wr = W + (16 * mt + r16) * w_stride + 32 * ks + 4 * hq;
+				const h4 a0 = *reinterpret_cast<const h4*>(wr), a1 = *reinterpret_cast<const h4*>(wr + 16);
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_emul16_k16(a0, a1, b0[nt][ks], b1[nt][ks], acc[mt][nt]);
+			}
+		return;
+	}
 	h8 b[4][K_STEPS];
 #pragma unroll
 	for (int nt = 0; nt < 4; ++nt)
@@ -124,12 +139,8 @@ __device__ __forceinline__ void mfma_layer(const half_t* __restrict__ W, const i
 #pragma unroll
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
-			h8 a_lo = a, a_hi = a; // (the weight operand is the one shared by the four sample tiles: masked once; a slot's product is zero whichever factor is)
-			if (EMU == EMU_NATURAL || EMU == EMU_FBS) split_ksteps<EMU>(a, hq, a_lo, a_hi);
 #pragma unroll
-			for (int nt = 0; nt < 4; ++nt)
-				acc[mt][nt] = EMU == EMU_OFF ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0)
-				            : EMU == EMU_CHAINED ? mfma_emul16<EMU_CHAINED>(a, b[nt][ks], acc[mt][nt], hq) : round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b[nt][ks], round_acc_half(__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b[nt][ks], acc[mt][nt], 0, 0, 0)), 0, 0, 0));
+			for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0);
 		}
 	}
 }
@@ -229,7 +240,7 @@ __device__ __forceinline__ void mfma_layer_regs(const half_t* __restrict__ W, co
 		for (int ks = 0; ks < K_STEPS; ++ks) {
 			const h8 a = *reinterpret_cast<const h8*>(W + (16 * mt + r16) * w_stride + 32 * ks + 8 * hq);
 			h8 a_lo = a, a_hi = a; // (the weight operand is the one shared by the four sample tiles: masked once; a slot's product is zero whichever factor is)
-			if (EMU == EMU_NATURAL || EMU == EMU_FBS) split_ksteps<EMU>(a, hq, a_lo, a_hi);
+			if (EMU == EMU_NATURAL) split_ksteps<EMU>(a, hq, a_lo, a_hi);
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt)
 				acc[mt][nt] = EMU == EMU_OFF ? __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[nt][ks], acc[mt][nt], 0, 0, 0)

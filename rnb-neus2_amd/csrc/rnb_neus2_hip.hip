@@ -219,6 +219,9 @@ struct rnb_ctx {
 		bool scatter_plain = false; // RNB_SCATTER_PLAIN=1 (A/B, tests): no LDS-privatised and no run-length scatter -- every corner of every level is its own L2 atomic, as in the reference; with
 		                            // accumulate = RNB_ACCUM_HALF every one of a corner's four addends is (k_grid_scatter_quad_h_per_addend), which reproduces the reference's sequential half sums
 		                            // on the coarse levels too
+		bool scatter_c_early = false; // RNB_SCATTER_C_EARLY=1: group C (LDS-privatised coarse levels, no global atomics to speak of) + its optimizer chunk on the optimizer's stream beside group A
+		                              // instead of last on the caller's stream. Measured again in round 5 (round 2: 42 -> 158 us): the kernel stretches 40 -> 167 us beside the atomic kernels and the march
+		                              // (which keep their times) and holds the optimizer's chunks back: 0.5846 -> 0.6404 ms/step at step 1000, 0.6217 -> 0.6753 at 6000 (profiles/r05_ab_scatter_c_early.txt). Off.
 		int scatter_rl_staged = -1; // RNB_SCATTER_RL_STAGED=0|1: the run-length scatter loads its operands from global memory inside the walk (rounds 2-4) / stages them in LDS (round 5). Alone the two take
 		                            // the same time (112 / 101 / 112 us staged vs 112 / 97 / 111 direct at steps 1000 / 2000 / 6000: the walk is NOT a chain of load -> atomic-acknowledge round trips,
 		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
@@ -262,7 +265,7 @@ struct rnb_ctx {
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_march_rest = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
 	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
 	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0; } sc;
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true, c_early = false; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0; } sc;
 	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
 	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
@@ -847,7 +850,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const bool half = c->half_acc();
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grad_ptr(0), 0, c->n_params * c->grad_elem(), s));
 	c->grads_clean = false;
-	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true;
+	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true; c->sc.c_early = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.B_global = B * c->cfg.world_size; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	const bool split = c->rgb_split(); // albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full instead of the generic kernel and its weight-gradient GEMMs
@@ -992,6 +995,11 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// 1200, 18.5 k: 0.6435 / 0.6594 / 0.6394; 1400, 24 k: 0.6304 / 0.6324 / 0.6388; 1800, 41 k: 0.6132 / 0.6142 / 0.6161; 6000, 94 k: 0.6452 / 0.6482 / 0.6470
 		// (profiles/r04_sweep_scatter_order.txt): the fine levels first and in one launch while the batch is few long rays (the regime of the 16-lanes-per-ray march).
 		c->sc.order = c->sc.dp ? 0 : c->knobs.scatter_order >= 0 ? c->knobs.scatter_order : ((c->cur_n_rays < c->knobs.march_narrow_from && !split) ? 2 : 0); // (albedo mode, step 1000: 0.763 with A-B-C vs 0.755 with B-A1-A2-C: its march is held behind the training kernels)
+		c->sc.c_early = !c->sc.dp && c->knobs.scatter_c_early && e_c != 0;
+		if (c->sc.c_early) { // C beside the first atomic group: LDS + VALU work next to wavefronts that wait for the memory side
+			HIP_TRY(hipStreamWaitEvent(c->s_adam, c->ev_fb, 0));
+			launch_c(c->s_adam, c->ev_sc[2]);
+		}
 		if (c->sc.order == 0) { // B, A1, A2 (, C)
 			launch_b(s, c->ev_sc[0]);
 			launch_a(s, c->ev_sc[1], l_fine, a_mid);
@@ -1005,7 +1013,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 			launch_b(s, c->ev_sc[0]);
 		}
 		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
-		if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
+		if (c->sc.c_early) HIP_TRY(hipStreamWaitEvent(s, c->ev_sc[2], 0)); // (every gradient is final when `s` is: rnb_gradient_part_wait, stage calls)
+		else if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
 		if (c->sc.dp || join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
 		c->sc.dw_joined = c->sc.dp || join_dw; // the training step leaves the join to the optimizer, which continues on the side stream (optimizer_step)
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
@@ -1150,6 +1159,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 		// The update is independent per parameter, so each scatter group's levels are stepped as soon as that group is done,
 		// on the side stream, beside the scatter of the next group; only the last half of group A is left for the end.
 		hipStream_t sa = c->s_adam;
+		if (c->sc.c_early) adam_launch(c, sa, c->off_grid, c->sc.split[1]); // group C's levels right behind their scatter on this stream
 		if (c->sc.order == 0) {
 			HIP_TRY(hipStreamWaitEvent(sa, c->ev_sc[0], 0));
 			adam_launch(c, sa, c->sc.split[1], c->sc.split[0]);  // group B's levels, beside the scatter of group A
@@ -1171,7 +1181,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			adam_launch(c, sa, c->sc.split[1], c->sc.split[0], c->ev_adam);
 		}
 		if (c->sc.dw_joined) {
-			adam_launch(c, s, 0, c->sc.split[1]);                // MLPs + group C's levels (contiguous), variance; s has joined the side stream
+			adam_launch(c, s, 0, c->sc.c_early ? c->off_grid : c->sc.split[1]); // MLPs + group C's levels (contiguous), variance; s has joined the side stream
 			adam_launch(c, s, c->off_var, c->n_params);
 		} else {
 			// behind the dW GEMMs on their stream: the MLPs' and the variance's parameters, then the LDS weight images of the next
@@ -1181,7 +1191,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			adam_launch(c, sd, c->off_var, c->n_params);
 			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p, c->half_acc() ? 1 : 0);
 			images_done = true;
-			adam_launch(c, s, c->off_grid, c->sc.split[1]);
+			if (!c->sc.c_early) adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			// the join with the side stream: on the next step's march stream if that march is queued after this call (launch_premarch), else here
 			if (c->knobs.defer_tail && !c->pre.valid && !prep_due(c->cur_step + 1)) c->tail_pending = true;
 			else HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
@@ -1433,6 +1443,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
+		if (const char* e = getenv("RNB_SCATTER_C_EARLY")) k.scatter_c_early = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
 	}
 	plan_scatter_groups(c);
