@@ -219,6 +219,7 @@ struct rnb_ctx {
 		bool scatter_plain = false; // RNB_SCATTER_PLAIN=1 (A/B, tests): no LDS-privatised and no run-length scatter -- every corner of every level is its own L2 atomic, as in the reference; with
 		                            // accumulate = RNB_ACCUM_HALF every one of a corner's four addends is (k_grid_scatter_quad_h_per_addend), which reproduces the reference's sequential half sums
 		                            // on the coarse levels too
+		int dbg_scatter_lo = -1, dbg_scatter_hi = -1; // RNB_DEBUG_SCATTER_LEVELS=lo,hi (measurement aid, WRONG gradients): while the per-kernel profiler is on, the atomic scatter kernels only walk levels [lo, hi)
 		bool scatter_c_early = false; // RNB_SCATTER_C_EARLY=1: group C (LDS-privatised coarse levels, no global atomics to speak of) + its optimizer chunk on the optimizer's stream beside group A
 		                              // instead of last on the caller's stream. Measured again in round 5 (round 2: 42 -> 158 us): the kernel stretches 40 -> 167 us beside the atomic kernels and the march
 		                              // (which keep their times) and holds the optimizer's chunks back: 0.5846 -> 0.6404 ms/step at step 1000, 0.6217 -> 0.6753 at 6000 (profiles/r05_ab_scatter_c_early.txt). Off.
@@ -940,7 +941,9 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = half ? nullptr : c->grads.p + c->off_grid;
 	sa.grid_grad16 = half ? reinterpret_cast<uint32_t*>(c->grads16.p + c->off_grid) : nullptr; // (off_grid is even: half2 entries are 4-byte aligned)
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
+	const bool dbg_levels = c->prof.on && c->knobs.dbg_scatter_lo >= 0;
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
+		if (dbg_levels) { l0 = std::max(l0, (uint32_t)c->knobs.dbg_scatter_lo); l1 = std::max(l0, std::min(l1, (uint32_t)c->knobs.dbg_scatter_hi)); }
 		const uint32_t n_vb = (B * 4 + 255) / 256, cap = scatter_cap ? std::max(1u, (uint32_t)c->n_cus * scatter_cap / std::max(1u, l1 - l0)) : n_vb;
 		if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EV(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (l1 > l0 && half) LAUNCH_EV(k_grid_scatter_quad_h, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
@@ -948,9 +951,11 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
+		uint32_t e_c = sg.e_c, l_fine = sg.l_fine; // (shadow the group's bounds: the measurement aid narrows them)
+		if (dbg_levels) { e_c = std::max(e_c, (uint32_t)c->knobs.dbg_scatter_lo); l_fine = std::min(l_fine, (uint32_t)c->knobs.dbg_scatter_hi); }
 		if (l_fine <= e_c) { if (done) (void)hipEventRecord(done, st); return; }
 		ScatterRlPlan plan;
-		plan.n = l_fine - e_c; plan.k_log2 = sg.k_log2;
+		plan.n = l_fine - e_c; plan.k_log2 = sg.k_log2 >> (4 * (e_c - sg.e_c));
 		uint32_t wg = 0;
 		for (uint32_t q = 0; q < plan.n; ++q) { plan.wg_start[q] = wg; wg += (((B + sg.Ks[e_c + q] - 1) / sg.Ks[e_c + q]) * 4 + 255) / 256; }
 		plan.wg_start[plan.n] = wg;
@@ -1099,6 +1104,8 @@ static void plan_scatter_groups(rnb_ctx* c) {
 	}
 	for (l = 0; l < L; ++l) if (l == g.e_c && (size_t)c->grid.offsets[l + 1] * 8 <= 150 * 1024) g.e_c = l + 1; // the coarsest levels whose fp32 gradient tables fit in LDS together
 	g.l_fine = g.e_c;
+	// (round 5: every atomic level through ONE run-length launch, K = 1 on the fine levels -- 225.8 vs 114.8 + 124.2 us at step 1000, 164.4 vs 94.2 + 74.8 at 2000: the launch boundary and
+	// nothing else; the coarse levels' latency-bound walks already overlap inside group B, the groups are bound by their atomic requests. profiles/r05_scatter_per_level.txt)
 	for (l = g.e_c; l < L && g.Ks[l] > 1 && l - g.e_c < 16; ++l) {
 		g.k_log2 |= (uint64_t)ilog2(g.Ks[l]) << (4 * (l - g.e_c));
 		g.l_fine = l + 1;
@@ -1443,6 +1450,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
+		if (const char* e = getenv("RNB_DEBUG_SCATTER_LEVELS")) { int lo = -1, hi = -1; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo) { k.dbg_scatter_lo = lo; k.dbg_scatter_hi = hi; } }
 		if (const char* e = getenv("RNB_SCATTER_C_EARLY")) k.scatter_c_early = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
 	}
