@@ -579,7 +579,12 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 		// the binades used, rnb_neus2_hip.hip lattice_is_linear). Then t_{k+m} = t_k + m d EXACTLY (m d and the sum are exact: multiples of the
 		// ulp below 2^e), and "the first position at or beyond a target" is a division plus one exact comparison instead of a scan over 16
 		// running sums. A round whose 17 positions straddle a binade boundary takes the running sums (below), as does the multi-cascade march.
-		float T[MG + 1];
+		// (the running sums of the slow path are formed again wherever they are compared, not kept: as an array they were 65 wave-uniform values of the one-wavefront-per-ray
+		// instance, i.e. SGPRs, 211 of which the compiler kept in VGPR lanes -- the kind of spill the side-stream hazard of round 1 was last seen with, rnb_neus2_hip.hip launch_premarch)
+		// (one wavefront per ray: rolled loops -- unrolled, the three loops' sums are common subexpressions again and come back as that array)
+		constexpr int SLOW_UNROLL = (MG == 64 || SC) ? 1 : MG; // (single-cascade scenes take these loops only where a round straddles a binade boundary; the multi-cascade march takes them every round)
+		auto step_from = [&](const float t) { return t + (SC ? MIN_CONE_STEPSIZE : calc_dt(t, cone)); };
+		float t_end = t_cur;
 		float my_t = t_cur;
 		float dlt = 0.f, inv_dlt = 0.f;
 		bool fast = false;
@@ -593,15 +598,16 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 		}
 		if (fast) {
 			my_t = t_cur + (float)g * dlt;
-			T[MG] = t_cur + (float)MG * dlt;
+			t_end = t_cur + (float)MG * dlt;
 			inv_dlt = __builtin_amdgcn_rcpf(dlt); // an estimate is enough: the candidate it yields is checked exactly
 		} else {
-			T[0] = t_cur;
-#pragma unroll
+			float run = t_cur; // T_0; T_{m+1} = T_m + dt(T_m)
+#pragma unroll SLOW_UNROLL
 			for (int m = 0; m < MG; ++m) {
-				T[m + 1] = T[m] + (SC ? MIN_CONE_STEPSIZE : calc_dt(T[m], cone));
-				if (m + 1 == g) my_t = T[m + 1];
+				run = step_from(run);
+				if (m + 1 == g) my_t = run;
 			}
+			t_end = run;
 		}
 		// my position
 		const Vec3 pos = o + my_t * dir;
@@ -620,10 +626,12 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 					int m0 = (int)floorf(fminf((t_target - t_cur) * inv_dlt, 64.f));
 					m0 += (t_cur + (float)m0 * dlt < t_target) ? 1 : 0;
 					nxt = (uint32_t)min(max(m0, g + 1), MG);
-				} else {
-#pragma unroll
-					for (int m = MG - 1; m >= 1; --m) {
-						if (m > g && T[m] >= t_target) nxt = (uint32_t)m;
+				} else { // the same by the running sums: the first m in (g, MG) with T_m >= t_target
+					float run = t_cur;
+#pragma unroll SLOW_UNROLL
+					for (int m = 1; m < MG; ++m) {
+						run = step_from(run);
+						if (nxt == (uint32_t)MG && m > g && run >= t_target) nxt = (uint32_t)m;
 					}
 				}
 			}
@@ -643,8 +651,12 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 					cur = min(max(m0, 0), MG);
 				} else {
 					cur = MG;
-#pragma unroll
-					for (int m = MG - 1; m >= 0; --m) if (T[m] >= pending_target) cur = m;
+					float run = t_cur;
+#pragma unroll SLOW_UNROLL
+					for (int m = 0; m < MG; ++m) {
+						if (cur == MG && run >= pending_target) cur = m;
+						run = step_from(run);
+					}
 				}
 				if (cur < MG) have_pending = false;
 			}
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 		const float tgt = __shfl(t_target, gb + (pend_src < 0 ? 0 : pend_src), 64);
 		if (pend_src >= 0) pending_target = tgt;
 		if ((vis >> g) & 1ull) tt[j0 + __popcll(vis & ((1ull << g) - 1ull))] = my_t;
-		t_cur = T[MG];
+		t_cur = t_end;
 	}
 	if (ray_exists && g == 0) {
 		float* st = a.setup + (size_t)i * 8;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Registers, scratch and LDS of every kernel of the shipped library (the code object's metadata notes), and the packed-fp32 guard:
-#   tools/kernel_resources.sh [pattern]        lines "kernel vgpr sgpr scratch lds" (pattern: grep on the kernel name)
+#   tools/kernel_resources.sh [pattern]        lines "kernel vgpr sgpr scratch vgpr_spill sgpr_spill lds" (sgpr_spill: scalar registers kept in VGPR lanes) (pattern: grep on the kernel name)
 #   tools/kernel_resources.sh --check-no-pk-f32  exit 1 if the gfx950 code contains a v_pk_{mul,add,fma}_f32 instruction (rnb-neus2_amd/build.py)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,6 +20,6 @@ if [ "$1" = "--check-no-pk-f32" ]; then
 fi
 $LLVM/llvm-readelf --notes "$TMP/dev.co" | awk -v pat="${1:-.}" '
   /\.name:/ {name=$2}
-  /\.vgpr_count:/ {v=$2} /\.sgpr_count:/ {s=$2} /\.private_segment_fixed_size:/ {p=$2} /\.group_segment_fixed_size:/ {g=$2} /\.agpr_count:/ {a=$2}
-  /\.vgpr_spill_count:/ {sp=$2}
-  /\.wavefront_size:/ { if (name ~ pat) printf "%-70s vgpr %3s agpr %3s sgpr %3s scratch %5s spill %4s lds %6s\n", name, v, a, s, p, sp, g }'
+  /\.vgpr_count:/ {v=$2} /\.sgpr_count:/ {s=$2} /\.private_segment_fixed_size:/ {p=$2} /\.group_segment_fixed_size:/ {g=$2}
+  /\.vgpr_spill_count:/ {sp=$2} /\.sgpr_spill_count:/ {ssp=$2}
+  /\.wavefront_size:/ { if (name ~ pat) printf "%-70s vgpr %3s sgpr %3s scratch %5s vgpr_spill %4s sgpr_spill %4s lds %6s\n", name, v, s, p, sp, ssp, g }'
