@@ -1,6 +1,7 @@
 #!/bin/bash
 # Registers, scratch and LDS of every kernel of the shipped library (the code object's metadata notes), and the packed-fp32 guard:
 #   tools/kernel_resources.sh [pattern]        lines "kernel vgpr sgpr scratch vgpr_spill sgpr_spill lds" (sgpr_spill: scalar registers kept in VGPR lanes) (pattern: grep on the kernel name)
+#   tools/kernel_resources.sh --check-march-no-sgpr-spill  exit 1 if k_march_count_wide<16|64, single cascade> keeps scalar registers in VGPR lanes
 #   tools/kernel_resources.sh --check-no-pk-f32  exit 1 if the gfx950 code contains a v_pk_{mul,add,fma}_f32 instruction (rnb-neus2_amd/build.py)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -16,6 +17,13 @@ if [ "$1" = "--check-no-pk-f32" ]; then
   n=$($LLVM/llvm-objdump -d --mcpu=gfx950 "$TMP/dev.co" | grep -c -E 'v_pk_(mul|add|fma)_f32' || true)
   echo "v_pk_*_f32 instructions in librnb_neus2_hip.so: $n"
   [ "$n" = "0" ]
+  exit $?
+fi
+if [ "$1" = "--check-march-no-sgpr-spill" ]; then
+  # the single-cascade march kernels that run on the side stream beside the backward pass keep no scalar register in VGPR lanes (the other half of round 1's hazard)
+  bad=$($LLVM/llvm-readelf --notes "$TMP/dev.co" | awk '/\.name:/ {name=$2} /\.sgpr_spill_count:/ {ssp=$2} /\.wavefront_size:/ { if (name ~ /k_march_count_wideILi(16|64)ELb1E/ && ssp + 0 > 0) print name, ssp }')
+  echo "single-cascade k_march_count_wide instances with SGPR spills: ${bad:-none}"
+  [ -z "$bad" ]
   exit $?
 fi
 $LLVM/llvm-readelf --notes "$TMP/dev.co" | awk -v pat="${1:-.}" '
