@@ -27,9 +27,11 @@ for f in glob.glob("/tmp/pkb/rnb-neus2_amd/csrc/*"):
 print("kernels per group:", count)
 PY
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Xclang -target-feature -Xclang -packed-fp32-ops"
+# a group name with the suffix +W0 adds -mllvm -amdgpu-waitcnt-forcezero=1 (an s_waitcnt 0 in front of every instruction: does a missing wait explain it?)
 for g in ${@:-NONE RAY LOSS OCC FWD FBS DW SC ADAM MISC}; do
-  def=""; [ $g != NONE ] && def="-DPK_$g=__attribute__((target(\"packed-fp32-ops\")))"
-  hipcc $FLAGS "$def" -o /tmp/lib_$g.so /tmp/pkb/rnb-neus2_amd/csrc/rnb_neus2_hip.hip 2>/tmp/pkb/build_$g.log || { echo "$g: build failed"; grep -v "not a recognized" /tmp/pkb/build_$g.log | head -5; continue; } 
+  gg=${g%+W0}; extra=""; [ "$gg" != "$g" ] && extra="-mllvm -amdgpu-waitcnt-forcezero=1"
+  def=""; [ $gg != NONE ] && def="-DPK_$gg=__attribute__((target(\"packed-fp32-ops\")))"
+  hipcc $FLAGS $extra "$def" -o /tmp/lib_$g.so /tmp/pkb/rnb-neus2_amd/csrc/rnb_neus2_hip.hip 2>/tmp/pkb/build_$g.log || { echo "$g: build failed"; grep -v "not a recognized" /tmp/pkb/build_$g.log | head -5; continue; } 
   cp /tmp/lib_$g.so $L
   n=$(tools/kernel_resources.sh --check-no-pk-f32 2>/dev/null | grep -o "[0-9]*$")
   timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k "overlapped_backward_equals_serial or overlapped_march" > /tmp/pkb/test_$g.log 2>&1
