@@ -38,5 +38,6 @@ for g in ${@:-NONE RAY LOSS OCC FWD FBS DW SC ADAM MISC}; do
   r=$(grep -E "passed|failed" /tmp/pkb/test_$g.log | tail -1)
   f=$(grep "^FAILED" /tmp/pkb/test_$g.log | sed 's/.*:://' | cut -d' ' -f1 | tr '\n' ' ')
   echo "packed fp32 in $g only: $n v_pk_*_f32 | $r | failed: ${f:-none}" | tee -a $O/result.txt
+  [ -n "$PK_DIFF" ] && timeout 900 python tools/packed_fp32_diff.py $PK_DIFF > $O/diff_$g.txt 2>&1
 done
 cp /tmp/lib_shipped.so $L
