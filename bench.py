@@ -297,7 +297,7 @@ def main(argv=None, engine=None):
     setup_s = scene_s + time.time() - t0
     for _ in range(args.burn_in + args.warmup):
         trainer.step()
-    elapsed, rays, samples, samples_before, _, last = timed_run(trainer, args.steps)
+    elapsed, rays, samples, samples_before, timed_ms, last = timed_run(trainer, args.steps)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu_state = state_of(ctx, last) if want_cpu and args.cpu_baseline_steps > 0 else None  # the regime `value` was measured in
 
@@ -503,6 +503,8 @@ def main(argv=None, engine=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            # host time of each timed step on rank 0 (K <= 64): one step in 16 begins with an occupancy update (~1.1 ms); anything else that stands out is the host
+            "timed_steps_ms": [round(x, 3) for x in timed_ms] if args.steps <= 64 else None,
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
