@@ -1,7 +1,7 @@
 """The `testbed` command line (rnb-neus2_amd/host/testbed_main.cpp, mirror of the reference's src/main.cu) on CPU:
 the same source is built here against the oracle library (`-include oracle/orc_prefix.h`), so the flag parser, the scene
 loader, the training loop, the snapshot writer/reader and the mesh export are exercised end to end without a GPU.
-The GPU build of the same file is covered by tests/test_gpu_parity.py::test_testbed_cli_gpu."""
+The GPU build of the same file is covered by tests/test_gpu_cli.py::test_testbed_cli_gpu."""
 import json
 import os
 import subprocess
@@ -474,7 +474,7 @@ def reference_style_config():
 def test_the_references_own_config_file_parses_and_is_kept_whole(install, tmp_path):
     """`--config <the reference's base.json>`: keys this path never reads (loss, globalmove, dir_encoding's Composite, predict_global_movement, anneal_end,
     optimize_*_params ...) must parse cleanly, give the rnb_config the shipped configs/nerf/base.json gives, and travel whole in the snapshot (m_network_config,
-    src/testbed.cu:3282-3313). Training with it runs on the GPU (tests/test_gpu_parity.py: the full network is minutes per step on the CPU checker)."""
+    src/testbed.cu:3282-3313). Training with it runs on the GPU (tests/test_gpu_cli.py: the full network is minutes per step on the CPU checker)."""
     cfg = reference_style_config()
     assert set(cfg) == {"loss", "optimizer", "encoding", "network", "dir_encoding", "rgb_network", "hyperparams", "globalmove"}
     assert cfg["dir_encoding"]["nested"][0]["otype"] == "SphericalHarmonics" and cfg["hyperparams"]["anneal_end"] == 0

@@ -2,7 +2,7 @@
 checker, the collectives through the host-staged test transport (dist_transport.hpp, RNB_DP_TRANSPORT=staged) -- reduce-scatter / shard apply / all-gather over
 three gradient blocks with non-zero chunk offsets, the step-vector all-reduce, the sharded occupancy update's max exchange, sync_parameters() before rank 0 writes.
 Pinned three ways: sharded == all-reduce + replicated optimizer bit for bit; both == the same protocol stated in Python on two checker contexts (numpy sums);
-a rank that fails takes the job down with a non-zero exit code. The GPU twin (two HIP processes sharing the one GPU) is tests/test_gpu_parity.py."""
+a rank that fails takes the job down with a non-zero exit code. The GPU twin (two HIP processes sharing the one GPU) is tests/test_gpu_cli.py."""
 import json
 import os
 import shutil
