@@ -31,8 +31,9 @@ extern "C" {
 /* 2 (round 4): RNB_BUF_PARAMS_FP32 / ADAM_M / ADAM_V / ADAM_STEPS became staging views (see rnb_buffer); buffer ids 25, 26 and
  * rnb_bitfield_changed were added after 1 without a bump -- a binary built against 1 must not link silently.
  * 3 (round 4): rnb_shard_layout fills up to RNB_MAX_SHARD_PARTS = 3 blocks (2: two) -- a caller's array must have room for them.
- * 4 (round 5): rnb_config::accumulate (taken from `reserved`; 0 keeps the behaviour of ABI 3) and RNB_BUF_GRADS_FP16. */
-#define RNB_ABI_VERSION 4
+ * 4 (round 5): rnb_config::accumulate (taken from `reserved`; 0 keeps the behaviour of ABI 3) and RNB_BUF_GRADS_FP16.
+ * 5 (round 6): rnb_config::deterministic (taken from `reserved`; 0 keeps the behaviour of ABI 4). */
+#define RNB_ABI_VERSION 5
 
 typedef enum rnb_status {
 	RNB_OK = 0,
@@ -108,8 +109,20 @@ typedef struct rnb_config {
 	                                     half where the reference stores half. RNB_ACCUM_HALF (1): the reference's arithmetic as coded -- the MLPs' dot products round their
 	                                     accumulator to half after every 16-wide k-step (WMMA half fragments, fully_fused_mlp.cu:59-68, 198), the hash-grid gradients are summed
 	                                     by atomicAdd(__half2) into a half gradient vector (grid.h:410-430, trainer.h:78-84: RNB_BUF_GRADS_FP16 replaces RNB_BUF_GRADS_FP32).
-	                                     Fixed at rnb_create. */
-	uint32_t reserved[5];
+	                                     Fixed at rnb_create. Two stated departures from the reference's code in this mode: the weight-gradient GEMMs keep fp32
+	                                     accumulators in the kernel's own tiling and round to half once (the reference: CUTLASS split-K slices of 4096 samples with half
+	                                     accumulators, cutlass_matmul.h:83, 315-322), and the default scatter sums a cell run / a workgroup's slice in fp32 before its one packed
+	                                     half atomic (RNB_SCATTER_PLAIN=1 issues the reference's own sequence: every addend its own atomicAdd(__half2)). */
+	uint32_t deterministic;           /* 0 (default): the hash-grid gradients are summed by floating-point atomics, as in the reference (grid.h:410-430) -- the sum depends on the order
+	                                     the hardware retires them in, so two runs from one state differ in the last bits and a training run is not reproducible (neither is the
+	                                     reference's: src/testbed_nerf.cu:1352, 1557-1561). 1: every addend -- rounded to half first exactly as the reference rounds it (grid.h:415-416),
+	                                     hence a multiple of 2^-24 -- is added as a 64-bit FIXED-POINT INTEGER (scale 2^24; integer atomics commute, the sum is exact and independent
+	                                     of any order), and the sum is narrowed ONCE into the gradient vector of the accumulate mode (fp32 accumulators, or half). Every other stage
+	                                     is order-independent already (prefix-sum slots, fixed-order weight-gradient and loss sums, atomicMax splat), so with it a training run is
+	                                     bit-reproducible: same state in, same bits out, on any schedule (overlap on or off) and -- the sums being exact -- for any split of the
+	                                     batch over workgroups. Works with both accumulate modes and with the data-parallel entry points (the gradient vector they describe is
+	                                     complete, narrowed, at the same points). Fixed at rnb_create. */
+	uint32_t reserved[4];
 } rnb_config;
 typedef enum rnb_accumulate { RNB_ACCUM_FP32 = 0, RNB_ACCUM_HALF = 1 } rnb_accumulate;
 

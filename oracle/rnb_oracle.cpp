@@ -431,6 +431,13 @@ static inline void atomic_add(float* p, float v) {
 #pragma omp atomic
 	*p += v;
 }
+// rnb_config::deterministic (include/rnb_neus2.h): a half-valued addend (grid.h:415-416) as a 64-bit fixed-point integer at scale 2^24 -- exact; integer sums commute
+static inline void atomic_add_fixed(int64_t* p, float half_valued) {
+	const int64_t v = (int64_t)(half_valued * 16777216.0f);
+#pragma omp atomic
+	*p += v;
+}
+static inline float fixed24_to_float(int64_t v) { return (float)v * 5.9604644775390625e-08f; }
 
 // One sample's operands of the weight-gradient GEMMs and of the grid scatter, kept when the accumulation itself is emulated in
 // a second pass (orc_ctx_s::emul_*).
@@ -482,7 +489,7 @@ static inline void scatter_level(const orc_ctx_s* c, uint32_t level, const float
 
 // NerfNetwork::backward_impl (nerf_network.h:257-452) for one compacted sample. With `ops` the accumulations (weight-gradient
 // outer products, grid scatter) are left to the caller's second pass and only their operands are recorded.
-void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, const half_t dout[16], uint32_t batch_size, float* grid_grad, MlpGrads& mg, SampleOps* ops = nullptr) {
+void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, const half_t dout[16], uint32_t batch_size, float* grid_grad, MlpGrads& mg, SampleOps* ops = nullptr, int64_t* grid_fixed = nullptr) {
 	float* dW_sdf0 = mg.g1.data();
 	float* dW_sdf1 = dW_sdf0 + 64 * 32;
 	float* dW_rgb0 = mg.g1.data() + RNB_N_SDF_MLP_PARAMS;
@@ -544,7 +551,10 @@ void backward_sample(const orc_ctx_s* c, const NetParams& np, const FwdCtx& k, c
 			float* gg = grid_grad + (uint64_t)c->offsets[level] * 2;
 			const float g1[2] = {h2f(dsin[3 + level * 2]), h2f(dsin[3 + level * 2 + 1])};
 			const float g2[2] = {h2f(k.dsdf_din[3 + level * 2]), h2f(k.dsdf_din[3 + level * 2 + 1])};
-			scatter_level(c, level, k.x, g1, g2, dn, [&](uint32_t q, float v) { atomic_add(&gg[q], v); });
+			if (grid_fixed) {
+				int64_t* gf = grid_fixed + (uint64_t)c->offsets[level] * 2;
+				scatter_level(c, level, k.x, g1, g2, dn, [&](uint32_t q, float v) { atomic_add_fixed(&gf[q], v); });
+			} else scatter_level(c, level, k.x, g1, g2, dn, [&](uint32_t q, float v) { atomic_add(&gg[q], v); });
 		}
 	}
 
@@ -1375,6 +1385,17 @@ static void emulated_accumulate(orc_ctx_s* c, const std::vector<SampleOps>& ops)
 		if ((uint32_t)level > c->valid_level) continue;
 		float* gg = g + c->off_grid + (uint64_t)c->offsets[level] * 2;
 		const size_t n = (size_t)(c->offsets[level + 1] - c->offsets[level]) * 2;
+		if (c->cfg.deterministic) { // exact integer sums, narrowed once (whatever the accumulate mode: the order of the half atomics no longer exists)
+			std::vector<int64_t> gf(n, 0);
+			for (uint32_t s = 0; s < B; ++s) {
+				const SampleOps& o = ops[s];
+				const float g1[2] = {h2f(o.dsin[3 + level * 2]), h2f(o.dsin[3 + level * 2 + 1])};
+				const float g2[2] = {h2f(o.dsdf_din[3 + level * 2]), h2f(o.dsdf_din[3 + level * 2 + 1])};
+				scatter_level(c, level, o.x, g1, g2, o.dn, [&](uint32_t q, float v) { gf[q] += (int64_t)(v * 16777216.0f); });
+			}
+			for (size_t q = 0; q < n; ++q) gg[q] = fixed24_to_float(gf[q]);
+			continue;
+		}
 		std::vector<half_t> gh(c->emul_half_atomics ? n : 0, 0);
 		std::vector<uint32_t> order;
 		if (c->emul_half_atomics && c->atomic_order_seed) {
@@ -1406,6 +1427,7 @@ void forward_backward(orc_ctx_s* c) {
 #endif
 	std::vector<MlpGrads> partial(n_threads);
 	const bool emulate = c->emul_fp16_acc || c->emul_half_atomics;
+	std::vector<int64_t> fixed((c->cfg.deterministic && !emulate) ? c->n_params - c->off_grid : 0, 0); // rnb_config::deterministic: the hash-grid sums as integers
 	std::vector<SampleOps> ops(emulate ? B : 0);
 #pragma omp parallel
 	{
@@ -1420,11 +1442,12 @@ void forward_backward(orc_ctx_s* c) {
 			half_t out[16];
 			forward_sample(c, np, &c->coords_compacted[(size_t)i * 7], out, &k);
 			// batch_size of the Eikonal term = the samples of the whole step (nerf_network.h:359-365): all ranks' batches
-			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B * c->cfg.world_size, grid_grad, mg, emulate ? &ops[i] : nullptr);
+			backward_sample(c, np, k, &c->dloss_dout[(size_t)i * 16], B * c->cfg.world_size, grid_grad, mg, emulate ? &ops[i] : nullptr, fixed.empty() ? nullptr : fixed.data());
 		}
 	}
 	double var = 0.0;
 	for (int t = 0; t < n_threads; ++t) var += partial[t].var;
+	if (!fixed.empty()) for (uint64_t q = 0; q < c->off_var - c->off_grid; ++q) grid_grad[q] = fixed24_to_float(fixed[q]); // the one rounding (k_fixed_narrow)
 	if (emulate) {
 		emulated_accumulate(c, ops);
 	} else {
@@ -1625,6 +1648,7 @@ int rnb_create(const rnb_config* cfg, orc_ctx_s** out) {
 	c->valid_level = compute_valid_level(c->cfg, 0);
 	build_light_dirs(c);
 	if (cfg->accumulate > RNB_ACCUM_HALF) { delete c; return fail(RNB_ERR_INVALID, "accumulate must be RNB_ACCUM_FP32 or RNB_ACCUM_HALF"); }
+	if (cfg->deterministic > 1) { delete c; return fail(RNB_ERR_INVALID, "deterministic must be 0 or 1"); }
 	// rnb_config::accumulate = RNB_ACCUM_HALF: the model of the reference as coded, both parts; the two environment variables switch the parts on one by one (tools/oracle_deviation_report.py)
 	c->emul_fp16_acc = cfg->accumulate == RNB_ACCUM_HALF || (getenv("ORC_EMULATE_FP16_ACCUM") != nullptr && atoi(getenv("ORC_EMULATE_FP16_ACCUM")) != 0);
 	c->emul_half_atomics = cfg->accumulate == RNB_ACCUM_HALF || (getenv("ORC_EMULATE_HALF_ATOMICS") != nullptr && atoi(getenv("ORC_EMULATE_HALF_ATOMICS")) != 0);
@@ -1640,7 +1664,7 @@ int rnb_update_config(orc_ctx_s* c, const rnb_config* cfg) {
 	rnb_config& dst = c->cfg;
 	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
 	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
-	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate)
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate || cfg->deterministic != dst.deterministic)
 		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
 	dst = *cfg;
 	build_light_dirs(c);

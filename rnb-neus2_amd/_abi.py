@@ -6,7 +6,7 @@ the identical signatures under its own prefix.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # status codes (rnb_status)
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NO_SAMPLES = 0, -1, -2, -3, -4
@@ -59,7 +59,8 @@ class Config(C.Structure):
         ("only_sdf_training", C.c_uint32),
         ("overlap", C.c_uint32),
         ("accumulate", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("deterministic", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 

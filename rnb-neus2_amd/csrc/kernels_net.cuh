@@ -1580,7 +1580,15 @@ struct ScatterArgs {
 	uint32_t B;
 	float* grid_grad;    // GRADS_FP32 + off_grid
 	uint32_t* grid_grad16; // rnb_config::accumulate = RNB_ACCUM_HALF: GRADS_FP16 + off_grid, one half2 per table entry (the reference's gradient vector, trainer.h:78-84)
+	unsigned long long* grid_fixed; // rnb_config::deterministic: [n_grid_params] 64-bit fixed-point accumulators (scale 2^24), narrowed into the gradient vector by k_fixed_narrow
 };
+
+// rnb_config::deterministic. An addend of the scatter is a half value (grid.h:415-416: the reference narrows every addend to half before its atomicAdd), i.e. an integer
+// multiple of 2^-24 below 2^16 in magnitude: times 2^24 it is an integer below 2^40, exact in fp32 and in a 64-bit integer. Integer additions commute, so a sum of such
+// addends is EXACT and the same bits whatever order atomics retire in (a table entry overflows after 2^23 addends of the largest half; a batch holds 2^21 corners).
+enum { SCATTER_FP32 = 0, SCATTER_HALF = 1, SCATTER_FIXED = 2 };
+__device__ __forceinline__ long long fixed24(const float half_valued) { return (long long)(half_valued * 16777216.0f); }
+__device__ __forceinline__ void atomic_add_fixed(unsigned long long* __restrict__ p, const long long v) { (void)atomicAdd(p, (unsigned long long)v); }
 
 // atomicAdd(__half2) of grid.h:416 / 476-494: one packed L2 atomic carries both features of a table entry (global_atomic_pk_add_f16, no return value)
 __device__ __forceinline__ void atomic_add_h2(uint32_t* __restrict__ entry, const float v0, const float v1) {
@@ -1636,6 +1644,13 @@ __device__ __forceinline__ void corner_addends(const float g1, const float g2, c
 		}
 		out[1 + gd] = rh(g2 * (c[gd] ? w2 : -w2));
 	}
+}
+
+// rnb_config::deterministic: the same four half-valued addends as integers
+__device__ __forceinline__ long long corner_addend_fixed(const float g1, const float g2, const float scale, const float (&dn)[3], const float (&pos)[3], const uint32_t (&c)[3]) {
+	float t[4];
+	corner_addends(g1, g2, scale, dn, pos, c, t);
+	return (fixed24(t[0]) + fixed24(t[1])) + (fixed24(t[2]) + fixed24(t[3]));
 }
 
 // Coarsest dense levels (table <= 13 824 entries): every ray of the batch lands in the same few hundred surface cells, so
@@ -2025,6 +2040,197 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_h(const GridMeta G
 // RNB_SCATTER_RL_STAGED=0 (A/B): the walk with its operands loaded from global memory four samples ahead (rounds 2-4)
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false>(G, a, level0, plan); }
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<true>(G, a, level0, plan); }
+
+// ---------------------------------------------------------------------------------------------
+// rnb_config::deterministic: the three scatter mechanisms above on 64-bit fixed-point accumulators (ScatterArgs::grid_fixed; fixed24 / corner_addend_fixed). The same
+// samples meet the same table entries through the same walks; what changes is the arithmetic of a sum -- every half-valued addend enters as an integer, registers, LDS
+// tables (ds_add_u64) and global accumulators (global_atomic_add_x2) hold integers, and nothing is rounded before k_fixed_narrow: the result does not depend on K, on the
+// workgroup slicing, on which kernel a level goes through or on the order anything retires in.
+// ---------------------------------------------------------------------------------------------
+// coarse levels: one FEATURE per workgroup (blockIdx.y), so that a level's private table of 8-byte sums takes the LDS the fp32 form takes for both features; the four
+// lanes of a quad are (dx, dy), each keeps its two dz corners.
+__global__ __launch_bounds__(512) void k_grid_scatter_lds_fixed(const GridMeta G, const ScatterLdsArgs p) {
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	unsigned long long* tab = reinterpret_cast<unsigned long long*>(smem_raw);
+	const ScatterArgs& a = p.a;
+	const uint32_t NL = min(p.n_levels, G.valid_level + 1u);
+	if (NL == 0) return;
+	const uint32_t n_tab = G.offsets[NL]; // entries (one feature)
+	for (uint32_t q = threadIdx.x; q < n_tab; q += blockDim.x) tab[q] = 0ull;
+	__syncthreads();
+	constexpr uint32_t K = 16, C = 4;
+	const uint32_t f = blockIdx.y;
+	const uint32_t wg_begin = blockIdx.x * p.samples_per_wg;
+	const uint32_t wg_end = min(wg_begin + p.samples_per_wg, a.B);
+	const uint32_t quad = threadIdx.x >> 2, n_quads = blockDim.x >> 2;
+	const uint32_t dx = (threadIdx.x >> 1) & 1u, dy = threadIdx.x & 1u;
+#pragma unroll 1
+	for (uint32_t level = 0; level < NL; ++level) {
+		unsigned long long* lt = tab + G.offsets[level];
+		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+		const float scale = G.scale[level];
+		const uint32_t res = G.resolution[level];
+		const uint2* g12 = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+#pragma unroll 1
+		for (uint32_t s0 = wg_begin + quad * K; s0 < wg_end; s0 += n_quads * K) {
+			const uint32_t s_end = min(s0 + K, wg_end);
+			long long acc[2] = {0, 0};
+			uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+			auto flush = [&]() {
+#pragma unroll
+				for (uint32_t dz = 0; dz < 2; ++dz) {
+					if (acc[dz] != 0) {
+						(void)atomicAdd(lt + grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + dy, cur[2] + dz), (unsigned long long)acc[dz]);
+						acc[dz] = 0;
+					}
+				}
+			};
+#pragma unroll 1
+			for (uint32_t sc = s0; sc < s_end; sc += C) {
+				ScatterSample sm[C];
+				uint2 q12[C];
+#pragma unroll
+				for (uint32_t j = 0; j < C; ++j) { const uint32_t s = min(sc + j, s_end - 1); sm[j] = load_srec(a.srec, s); q12[j] = g12[s]; }
+#pragma unroll
+				for (uint32_t j = 0; j < C; ++j) {
+					if (sc + j >= s_end) break;
+					float pos[3];
+					uint32_t pg[3];
+					pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
+					pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
+					pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
+					if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+						if (cur[0] != 0xffffffffu) flush();
+						cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+					}
+					const float g1 = h2f(unpack_h2(q12[j].x)[f]);
+					const float g2 = h2f(unpack_h2(q12[j].y)[f]);
+#pragma unroll
+					for (uint32_t dz = 0; dz < 2; ++dz) {
+						const uint32_t c[3] = {dx, dy, dz};
+						acc[dz] += corner_addend_fixed(g1, g2, scale, sm[j].dn, pos, c);
+					}
+				}
+			}
+			flush();
+		}
+	}
+	__syncthreads();
+	for (uint32_t e = threadIdx.x; e < n_tab; e += blockDim.x) {
+		const unsigned long long v = tab[e];
+		if (v != 0ull) (void)atomicAdd(a.grid_fixed + (size_t)e * 2 + f, v);
+	}
+}
+
+// fine levels: one integer atomic per corner; lanes (dx, feature) as in k_grid_scatter_quad -- a quad's four 8-byte addends of one (dy, dz) fall on 32 contiguous bytes
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_fixed(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) {
+	const uint32_t level = blockIdx.y + level0;
+	if (level > G.valid_level) return;
+	unsigned long long* gg = a.grid_fixed + (size_t)G.offsets[level] * 2;
+	const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+	const float scale = G.scale[level];
+	const uint32_t res = G.resolution[level];
+#pragma unroll 1
+	for (uint32_t vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+		const uint32_t t = vb * blockDim.x + threadIdx.x;
+		const uint32_t s = t >> 2;
+		if (s >= a.B) continue;
+		const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+		const ScatterSample sm = load_srec(a.srec, s);
+		float pos[3];
+		uint32_t pg[3];
+		pos_fract(sm.x, scale, &pos[0], &pg[0]);
+		pos_fract(sm.y, scale, &pos[1], &pg[1]);
+		pos_fract(sm.z, scale, &pos[2], &pg[2]);
+		const uint2 q12 = reinterpret_cast<const uint2*>(a.g12)[(size_t)level * a.B + s];
+		const float g1 = h2f(unpack_h2(q12.x)[f]);
+		const float g2 = h2f(unpack_h2(q12.y)[f]);
+#pragma unroll
+		for (uint32_t yz = 0; yz < 4; ++yz) {
+			const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+			const long long add = corner_addend_fixed(g1, g2, scale, sm.dn, pos, c);
+			if (add != 0) atomic_add_fixed(gg + (size_t)grid_entry(hashmap_size, res, pg[0] + c[0], pg[1] + c[1], pg[2] + c[2]) * 2 + f, add);
+		}
+	}
+}
+
+// middle levels: the run-length walk of grid_scatter_quad_rl_body (operands loaded four samples ahead), integer run sums
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_fixed(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) {
+#pragma unroll 1
+	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) {
+		uint32_t li = 0;
+#pragma unroll 1
+		for (uint32_t q = 1; q < plan.n; ++q) if (vb >= plan.wg_start[q]) li = q;
+		const uint32_t level = level0 + li;
+		const uint32_t K = 1u << ((plan.k_log2 >> (4 * li)) & 15u);
+		if (level > G.valid_level) continue;
+		const uint32_t t = (vb - plan.wg_start[li]) * blockDim.x + threadIdx.x;
+		const uint32_t s0 = (t >> 2) * K;
+		if (s0 >= a.B) continue;
+		const uint32_t dx = (t >> 1) & 1u, f = t & 1u;
+		unsigned long long* gg = a.grid_fixed + (size_t)G.offsets[level] * 2;
+		const uint32_t hashmap_size = G.offsets[level + 1] - G.offsets[level];
+		const float scale = G.scale[level];
+		const uint32_t res = G.resolution[level];
+		long long acc[4] = {0, 0, 0, 0};
+		uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+		auto flush = [&]() {
+#pragma unroll
+			for (uint32_t yz = 0; yz < 4; ++yz) {
+				if (acc[yz] != 0) {
+					atomic_add_fixed(gg + (size_t)grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1)) * 2 + f, acc[yz]);
+					acc[yz] = 0;
+				}
+			}
+		};
+		const uint32_t s_end = min(s0 + K, a.B);
+		const uint2* g12l = reinterpret_cast<const uint2*>(a.g12) + (size_t)level * a.B;
+		constexpr uint32_t C = 4;
+#pragma unroll 1
+		for (uint32_t sc = s0; sc < s_end; sc += C) {
+			ScatterSample sm[C];
+			uint2 q12[C];
+#pragma unroll
+			for (uint32_t j = 0; j < C; ++j) { const uint32_t s = min(sc + j, s_end - 1); sm[j] = load_srec(a.srec, s); q12[j] = g12l[s]; }
+#pragma unroll
+			for (uint32_t j = 0; j < C; ++j) {
+				if (sc + j >= s_end) break;
+				float pos[3];
+				uint32_t pg[3];
+				pos_fract(sm[j].x, scale, &pos[0], &pg[0]);
+				pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
+				pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
+				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+					if (cur[0] != 0xffffffffu) flush();
+					cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+				}
+				const float g1 = h2f(unpack_h2(q12[j].x)[f]);
+				const float g2 = h2f(unpack_h2(q12[j].y)[f]);
+#pragma unroll
+				for (uint32_t yz = 0; yz < 4; ++yz) {
+					const uint32_t c[3] = {dx, yz & 1u, yz >> 1};
+					acc[yz] += corner_addend_fixed(g1, g2, scale, sm[j].dn, pos, c);
+				}
+			}
+		}
+		flush();
+	}
+}
+
+// The one rounding of the deterministic mode: exact integer sum -> the gradient vector of the accumulate mode (fp32 accumulator, or half), entries [lo, hi) of the grid's
+// parameters; the accumulators are left clear for the next step. An entry nothing was added to is neither written (the optimizer left the vector clear) nor cleared.
+__device__ __forceinline__ float fixed24_to_float(const long long v) { return (float)v * 5.9604644775390625e-08f; } // (float)int64: round to nearest even; x 2^-24: exact
+__global__ __launch_bounds__(256) void k_fixed_narrow(unsigned long long* __restrict__ fixed, float* __restrict__ grads, half_t* __restrict__ grads16, const uint64_t lo, const uint64_t hi) {
+	// two entries (both features of a table entry) per thread: lo and hi are even
+	for (uint64_t i = lo + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < hi; i += (uint64_t)gridDim.x * blockDim.x * 2) {
+		const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(fixed + i);
+		if (v.x == 0ull && v.y == 0ull) continue;
+		*reinterpret_cast<ulonglong2*>(fixed + i) = ulonglong2{0ull, 0ull};
+		const float g0 = fixed24_to_float((long long)v.x), g1 = fixed24_to_float((long long)v.y);
+		if (grads16) { grads16[i] = f2h(g0); grads16[i + 1] = f2h(g1); }
+		else { grads[i] = g0; grads[i + 1] = g1; }
+	}
+}
 
 // ---------------------------------------------------------------------------------------------
 // K12: Adam (adam.h:52-202) + EMA (ema.h:63-78), one pass; consumes and clears the gradient accumulators.

@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
+#include <stdexcept>
 #include <random>
 #include <string>
 #include <vector>
@@ -120,6 +122,8 @@ struct rnb_ctx {
 	DevBuf<half_t> params_fp16, params_ema;
 	DevBuf<half_t> grads16; // cfg.accumulate = RNB_ACCUM_HALF: the half gradient vector (RNB_BUF_GRADS_FP16) instead of the fp32 accumulators `grads`
 	bool half_acc() const { return cfg.accumulate == RNB_ACCUM_HALF; }
+	DevBuf<unsigned long long> grads_fixed; // cfg.deterministic: [n_grid_params] 64-bit fixed-point sums of the hash-grid scatter (scale 2^24), narrowed into grads / grads16 by k_fixed_narrow
+	bool fixed_acc() const { return cfg.deterministic != 0; }
 	size_t grad_elem() const { return half_acc() ? sizeof(half_t) : sizeof(float); }
 	char* grad_ptr(uint64_t i) const { return half_acc() ? reinterpret_cast<char*>(grads16.p + i) : reinterpret_cast<char*>(grads.p + i); }
 	DevBuf<uint32_t> adam_steps;
@@ -940,12 +944,26 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	ScatterArgs sa;
 	sa.g12 = T.g12; sa.srec = T.srec; sa.B = B; sa.grid_grad = half ? nullptr : c->grads.p + c->off_grid;
 	sa.grid_grad16 = half ? reinterpret_cast<uint32_t*>(c->grads16.p + c->off_grid) : nullptr; // (off_grid is even: half2 entries are 4-byte aligned)
+	// cfg.deterministic: the scatter kernels add 64-bit fixed-point integers into grads_fixed, and k_fixed_narrow -- behind each group, on its stream, in front of the
+	// group's event -- rounds the group's exact sums once into the gradient vector: everything downstream (optimizer chunks, data-parallel blocks, stage calls) finds the
+	// vector it finds in the other modes, at the same points
+	const bool fixed = c->fixed_acc();
+	sa.grid_fixed = fixed ? c->grads_fixed.p : nullptr;
+	auto narrow = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1)
+		const uint64_t lo = (uint64_t)c->grid.offsets[l0] * 2, hi = (uint64_t)c->grid.offsets[l1] * 2;
+		if (hi <= lo) { if (done) (void)hipEventRecord(done, st); return; }
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((hi - lo) / 2 + 255) / 256);
+		LAUNCH_EV(k_fixed_narrow, dim3(blocks), dim3(256), 0, st, done, c->grads_fixed.p, half ? nullptr : c->grads.p + c->off_grid, half ? c->grads16.p + c->off_grid : nullptr, lo, hi);
+	};
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
 	const bool dbg_levels = c->prof.on && c->knobs.dbg_scatter_lo >= 0;
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
 		if (dbg_levels) { l0 = std::max(l0, (uint32_t)c->knobs.dbg_scatter_lo); l1 = std::max(l0, std::min(l1, (uint32_t)c->knobs.dbg_scatter_hi)); }
 		const uint32_t n_vb = (B * 4 + 255) / 256, cap = scatter_cap ? std::max(1u, (uint32_t)c->n_cus * scatter_cap / std::max(1u, l1 - l0)) : n_vb;
-		if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EV(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
+		if (l1 > l0 && fixed) {
+			hipLaunchKernelGGL(k_grid_scatter_quad_fixed, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, c->meta(), sa, l0, n_vb);
+			narrow(st, done, l0, l1);
+		} else if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EV(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (l1 > l0 && half) LAUNCH_EV(k_grid_scatter_quad_h, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
 		else if (done) (void)hipEventRecord(done, st);
@@ -961,7 +979,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		plan.wg_start[plan.n] = wg;
 		const uint32_t cap_rl = scatter_cap ? (uint32_t)c->n_cus * scatter_cap : wg;
 		const bool staged = c->knobs.scatter_rl_staged >= 0 ? c->knobs.scatter_rl_staged != 0 : (c->cur_n_rays != 0 && c->cur_n_rays < c->knobs.march_narrow_from);
-		if (!staged) {
+		if (fixed) {
+			hipLaunchKernelGGL(k_grid_scatter_quad_rl_fixed, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, c->meta(), sa, e_c, plan);
+			narrow(st, done, e_c, l_fine);
+		} else if (!staged) {
 			if (half) LAUNCH_EV(k_grid_scatter_quad_rl_direct_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 			else LAUNCH_EV(k_grid_scatter_quad_rl_direct, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
 		} else if (half) LAUNCH_EV(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, c->meta(), sa, e_c, plan);
@@ -973,7 +994,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		const uint32_t wg_cap = 128; // workgroups of the LDS scatter (measured optimum: half the CUs, each zeroing / flushing its private table once)
 		const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 		la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
-		if (half) LAUNCH_EV(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
+		if (fixed) {
+			hipLaunchKernelGGL(k_grid_scatter_lds_fixed, dim3(n_wg, 2), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, c->meta(), la);
+			narrow(st, done, 0, e_c);
+		} else if (half) LAUNCH_EV(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
 		else LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
 	};
 
@@ -1234,7 +1258,7 @@ static int update_config_common(rnb_config& dst, const rnb_config* cfg) {
 	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
 	if (cfg->n_levels != dst.n_levels || cfg->log2_hashmap_size != dst.log2_hashmap_size || cfg->base_resolution != dst.base_resolution ||
 	    cfg->per_level_scale != dst.per_level_scale || cfg->target_batch_size != dst.target_batch_size || cfg->max_rays_per_batch != dst.max_rays_per_batch ||
-	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate)
+	    cfg->aabb_scale != dst.aabb_scale || cfg->seed != dst.seed || cfg->world_size != dst.world_size || cfg->rank != dst.rank || cfg->accumulate != dst.accumulate || cfg->deterministic != dst.deterministic)
 		return fail(RNB_ERR_INVALID, "rnb_update_config: geometry fields differ from the context's");
 	dst = *cfg;
 	return RNB_OK;
@@ -1245,11 +1269,17 @@ static int update_config_common(rnb_config& dst, const rnb_config* cfg) {
 
 // =====================================================================================================
 extern "C" {
+// No exception crosses the C boundary: a std::bad_alloc of a host-side container, or anything else thrown below an entry point, becomes a
+// status code and a message for rnb_last_error() -- across ctypes / a C caller it would be std::terminate and SIGABRT.
+#define RNB_GUARD                                                                                                   \
+	catch (const std::bad_alloc&) { return fail(RNB_ERR_NOMEM, "out of host memory (std::bad_alloc)"); }                \
+	catch (const std::exception& e_) { return fail(RNB_ERR_INVALID, std::string("exception: ") + e_.what()); }          \
+	catch (...) { return fail(RNB_ERR_INVALID, "unknown exception"); }
 
 const char* rnb_last_error(void) { return g_err.c_str(); }
 uint32_t rnb_abi_version(void) { return RNB_ABI_VERSION; }
 
-int rnb_default_config(rnb_config* cfg) {
+int rnb_default_config(rnb_config* cfg) try {
 	if (!cfg) return fail(RNB_ERR_INVALID, "cfg is null");
 	std::memset(cfg, 0, sizeof(*cfg));
 	cfg->abi_version = RNB_ABI_VERSION;
@@ -1268,11 +1298,11 @@ int rnb_default_config(rnb_config* cfg) {
 	cfg->world_size = 1; cfg->rank = 0;
 	cfg->overlap = 1;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_destroy(rnb_ctx* c) {
+int rnb_destroy(rnb_ctx* c) try {
 	if (!c) return RNB_OK;
-	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->grads16.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
+	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->grads16.free(); c->grads_fixed.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_grid_tmp_alt.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
 	c->gs_sorted_pos.free(); c->gs_sorted_idx.free(); c->gs_stage_pos.free(); c->gs_stage_idx.free(); c->gs_hist.free(); c->gs_range.free(); c->gs_eval_pos.free(); c->gs_eval_idx.free();
@@ -1289,9 +1319,9 @@ int rnb_destroy(rnb_ctx* c) {
 	if (c->host_coarse) (void)hipHostFree(c->host_coarse);
 	delete c;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
+int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	if (!cfg || !out) return fail(RNB_ERR_INVALID, "null argument");
 	if (cfg->abi_version != RNB_ABI_VERSION) return fail(RNB_ERR_INVALID, "abi_version mismatch");
 	if (cfg->n_levels == 0 || cfg->n_levels > 14) return fail(RNB_ERR_INVALID, "n_levels must be in [1,14]");
@@ -1301,6 +1331,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	if (cfg->max_rays_per_batch == 0 || cfg->max_rays_per_batch > (1u << 18)) return fail(RNB_ERR_INVALID, "max_rays_per_batch must be in [1, 2^18]");
 	if (cfg->world_size == 0 || cfg->rank >= cfg->world_size) return fail(RNB_ERR_INVALID, "bad rank/world_size");
 	if (cfg->accumulate > RNB_ACCUM_HALF) return fail(RNB_ERR_INVALID, "accumulate must be RNB_ACCUM_FP32 or RNB_ACCUM_HALF");
+	if (cfg->deterministic > 1) return fail(RNB_ERR_INVALID, "deterministic must be 0 or 1");
 	if (cfg->accumulate == RNB_ACCUM_HALF && getenv("RNB_FWD_BWD_GENERIC")) return fail(RNB_ERR_INVALID, "RNB_FWD_BWD_GENERIC (the generic training kernel of rounds 1-3) has no half-accumulate form");
 	int dev = 0;
 	HIP_TRY(hipGetDevice(&dev));
@@ -1344,6 +1375,9 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
 	ALLOC(c->opt_rec, c->param_capacity * 4);
 	if (cfg->accumulate == RNB_ACCUM_HALF) ALLOC_P(c->grads16); else ALLOC_P(c->grads);
+	if (cfg->deterministic) {
+		if (c->grads_fixed.alloc_padded(c->n_grid_params, c->n_grid_params) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for the fixed-point gradient accumulators"); }
+	}
 	ALLOC_P(c->params_fp32); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_grid_tmp_alt, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
@@ -1417,6 +1451,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) {
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	// Testbed::reset_network (testbed.cu:2223-2237)
 	c->rng = Pcg32{cfg->seed};
 	c->density_grid_rng = Pcg32{c->rng.next_uint()};
@@ -1474,33 +1509,33 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	*out = c;
 	return RNB_OK;
 #undef HIP_TRY_C
-}
+} RNB_GUARD
 
-int rnb_update_config(rnb_ctx* c, const rnb_config* cfg) {
+int rnb_update_config(rnb_ctx* c, const rnb_config* cfg) try {
 	if (!c || !cfg) return fail(RNB_ERR_INVALID, "null argument");
 	discard_premarch(c);
 	int rc = update_config_common(c->cfg, cfg);
 	if (rc != RNB_OK) return rc;
 	build_light_dirs(c);
 	return RNB_OK;
-}
+} RNB_GUARD
 
 uint64_t rnb_n_params(const rnb_ctx* c) { return c ? c->n_params : 0; }
 
-int rnb_param_layout(const rnb_ctx* c, uint64_t offsets[5]) {
+int rnb_param_layout(const rnb_ctx* c, uint64_t offsets[5]) try {
 	if (!c || !offsets) return fail(RNB_ERR_INVALID, "null argument");
 	offsets[0] = c->off_sdf; offsets[1] = c->off_rgb; offsets[2] = c->off_grid; offsets[3] = c->off_var; offsets[4] = c->n_params;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_grid_tables(const rnb_ctx* c, uint32_t* offsets, uint32_t* resolution, float* scale) {
+int rnb_grid_tables(const rnb_ctx* c, uint32_t* offsets, uint32_t* resolution, float* scale) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	for (uint32_t i = 0; i <= c->cfg.n_levels; ++i) if (offsets) offsets[i] = c->grid.offsets[i];
 	for (uint32_t i = 0; i < c->cfg.n_levels; ++i) { if (resolution) resolution[i] = c->grid.resolution[i]; if (scale) scale[i] = c->grid.scale[i]; }
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
+int rnb_init_params(rnb_ctx* c, const float* sdf_w) try {
 	if (!c || !sdf_w) return fail(RNB_ERR_INVALID, "null argument");
 	discard_premarch(c);
 	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer (side streams)
@@ -1548,9 +1583,9 @@ int rnb_init_params(rnb_ctx* c, const float* sdf_w) {
 	if (rc != RNB_OK) return rc;
 	HIP_TRY(hipDeviceSynchronize());
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_set_params(rnb_ctx* c, const float* params) {
+int rnb_set_params(rnb_ctx* c, const float* params) try {
 	if (!c || !params) return fail(RNB_ERR_INVALID, "null argument");
 	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
 	HIP_TRY(hipMemcpy(c->params_fp32.p, params, c->params_fp32.bytes(), hipMemcpyHostToDevice));
@@ -1562,9 +1597,9 @@ int rnb_set_params(rnb_ctx* c, const float* params) {
 	if (rc != RNB_OK) return rc;
 	HIP_TRY(hipDeviceSynchronize());
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
+int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) try {
 	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
 #define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
 	const bool read_only = (id & RNB_BUF_READONLY) != 0;
@@ -1613,37 +1648,37 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) {
 		default: return fail(RNB_ERR_INVALID, "unknown buffer id");
 	}
 #undef BUF
-}
+} RNB_GUARD
 
-int rnb_params_changed(rnb_ctx* c) {
+int rnb_params_changed(rnb_ctx* c) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->wimg_valid = false;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_bitfield_changed(rnb_ctx* c) {
+int rnb_bitfield_changed(rnb_ctx* c) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c); // a batch generated ahead of time marched through the old bits
 	c->coarse_valid = false;
 	c->gs_pre.valid = false;
 	c->bitfield_foreign = true;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_device_malloc(rnb_ctx* c, uint64_t n_bytes, void** ptr) {
+int rnb_device_malloc(rnb_ctx* c, uint64_t n_bytes, void** ptr) try {
 	if (!c || !ptr) return fail(RNB_ERR_INVALID, "null argument");
 	*ptr = nullptr;
 	if (n_bytes == 0) return RNB_OK;
 	if (hipMalloc(ptr, n_bytes) != hipSuccess) return fail(RNB_ERR_NOMEM, "hipMalloc failed");
 	return RNB_OK;
-}
-int rnb_device_free(rnb_ctx* c, void* ptr) {
+} RNB_GUARD
+int rnb_device_free(rnb_ctx* c, void* ptr) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (ptr) HIP_TRY(hipFree(ptr));
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kind) {
+int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kind) try {
 	if (!dst || !src) return fail(RNB_ERR_INVALID, "null argument");
 	if (c && kind != RNB_D2H) { // a write into the occupancy grid: the next update's samples, prepared from the old grid, are generated afresh
 		const char *d = static_cast<const char*>(dst), *g = reinterpret_cast<const char*>(c->density_grid.p);
@@ -1655,9 +1690,9 @@ int rnb_memcpy(rnb_ctx* c, void* dst, const void* src, uint64_t n_bytes, int kin
 	if (c) { const int rc = check_scan_errors(c); if (rc != RNB_OK) return rc; } // stage API: the scans of rnb_generate_training_samples / rnb_compute_loss are read through here
 	HIP_TRY(hipMemcpy(dst, src, n_bytes, k));
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const uint16_t* const* normals, const uint16_t* const* albedos) {
+int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const uint16_t* const* normals, const uint16_t* const* albedos) try {
 	if (!c || !views || !normals || !albedos || n_views == 0) return fail(RNB_ERR_INVALID, "bad dataset");
 	discard_premarch(c);
 	size_t total = 0;
@@ -1685,62 +1720,62 @@ int rnb_set_dataset(rnb_ctx* c, uint32_t n_views, const rnb_view* views, const u
 	HIP_TRY(hipMemcpy(c->views.p, vd.data(), sizeof(ViewDev) * n_views, hipMemcpyHostToDevice));
 	c->n_views = n_views;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_set_training_step(rnb_ctx* c, uint32_t step) {
+int rnb_set_training_step(rnb_ctx* c, uint32_t step) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	c->training_step = step;
 	c->valid_level = compute_valid_level(c->cfg, (int)step);
 	return RNB_OK;
-}
+} RNB_GUARD
 uint32_t rnb_valid_level(const rnb_ctx* c) { return c ? c->valid_level : 0; }
 
-int rnb_update_density_grid(rnb_ctx* c, void* stream) {
+int rnb_update_density_grid(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	const int rc = training_prep(c, as_stream(stream));
 	if (rc != RNB_OK) return rc;
 	return pregenerate_grid_samples(c, as_stream(stream));
-}
-int rnb_set_grid_exchange(rnb_ctx* c, rnb_grid_exchange_fn fn, void* user) {
+} RNB_GUARD
+int rnb_set_grid_exchange(rnb_ctx* c, rnb_grid_exchange_fn fn, void* user) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->grid_exchange = fn; c->grid_exchange_user = user;
 	return RNB_OK;
-}
-int rnb_update_density_grid_begin(rnb_ctx* c, void* stream) {
+} RNB_GUARD
+int rnb_update_density_grid_begin(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	return training_prep_front(c, as_stream(stream), c->cfg.world_size > 1);
-}
-int rnb_update_density_grid_end(rnb_ctx* c, void* stream) {
+} RNB_GUARD
+int rnb_update_density_grid_end(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	const int rc = update_density_grid_back(c, as_stream(stream));
 	if (rc != RNB_OK) return rc;
 	return pregenerate_grid_samples(c, as_stream(stream));
-}
-int rnb_update_density_bitfield(rnb_ctx* c, void* stream) {
+} RNB_GUARD
+int rnb_update_density_bitfield(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	c->gs_pre.valid = false; // called after the grid was written from outside
 	return update_bitfield(c, as_stream(stream));
-}
+} RNB_GUARD
 
-int rnb_sdf(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) {
+int rnb_sdf(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) try {
 	if (!c || (!xyz && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
 	return launch_point_query(c, as_stream(stream), xyz, n, reinterpret_cast<half_t*>(out), nullptr, nullptr, 0, inference != 0);
-}
-int rnb_density(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) {
+} RNB_GUARD
+int rnb_density(rnb_ctx* c, void* stream, const float* xyz, uint32_t n, uint16_t* out, int inference) try {
 	if (!c || (!xyz && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
 	return launch_point_query(c, as_stream(stream), xyz, n, reinterpret_cast<half_t*>(out), nullptr, nullptr, 1, inference != 0);
-}
-int rnb_forward_infer(rnb_ctx* c, void* stream, const float* coords, uint32_t n, uint16_t* out, int inference) {
+} RNB_GUARD
+int rnb_forward_infer(rnb_ctx* c, void* stream, const float* coords, uint32_t n, uint16_t* out, int inference) try {
 	if (!c || (!coords && n) || (!out && n)) return fail(RNB_ERR_INVALID, "null argument");
 	return launch_forward(c, as_stream(stream), coords, nullptr, n, reinterpret_cast<half_t*>(out), inference != 0);
-}
+} RNB_GUARD
 
 // ---- mesh extraction (src/testbed_nerf.cu:4218-4269, src/marching_cubes.cu:276-430, 794-822) ----
-int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float lattice_min, float lattice_max, float* out, int inference) {
+int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float lattice_min, float lattice_max, float* out, int inference) try {
 	if (!c || !res || !out) return fail(RNB_ERR_INVALID, "null argument");
 	if (!res[0] || !res[1] || !res[2]) return fail(RNB_ERR_INVALID, "empty lattice");
 	hipStream_t s = as_stream(stream);
@@ -1767,7 +1802,7 @@ int rnb_sdf_lattice(rnb_ctx* c, void* stream, const uint32_t res[3], float latti
 	if (rc != RNB_OK) return rc;
 	if (e != hipSuccess) return fail(RNB_ERR_DEVICE, std::string("rnb_sdf_lattice: ") + hipGetErrorString(e));
 	return RNB_OK;
-}
+} RNB_GUARD
 
 namespace {
 // elements of block-sum scratch scan_exclusive needs for n counts: sum over the levels of ceil(n / 1024^k)
@@ -1802,7 +1837,7 @@ int scan_exclusive(uint32_t* data, uint64_t n, hipStream_t s, uint32_t* total_ou
 } // namespace
 
 int rnb_marching_cubes(rnb_ctx* c, void* stream, const float* density, const uint32_t res[3], const float aabb_min[3], const float aabb_max[3], float thresh,
-                       float** verts_out, uint32_t** indices_out, uint32_t* n_verts, uint32_t* n_indices) {
+                       float** verts_out, uint32_t** indices_out, uint32_t* n_verts, uint32_t* n_indices) try {
 	if (!c || !density || !res || !aabb_min || !aabb_max || !verts_out || !indices_out || !n_verts || !n_indices) return fail(RNB_ERR_INVALID, "null argument");
 	*verts_out = nullptr; *indices_out = nullptr; *n_verts = 0; *n_indices = 0;
 	const uint64_t res3 = (uint64_t)res[0] * res[1] * res[2];
@@ -1846,9 +1881,9 @@ int rnb_marching_cubes(rnb_ctx* c, void* stream, const float* density, const uin
 	if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return cleanup(fail(RNB_ERR_DEVICE, "rnb_marching_cubes: kernel failure"));
 	*verts_out = verts; *indices_out = indices; *n_verts = nv; *n_indices = ni;
 	return cleanup(RNB_OK);
-}
+} RNB_GUARD
 
-int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) {
+int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total, uint32_t max_samples) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	discard_premarch(c);
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
@@ -1856,26 +1891,26 @@ int rnb_generate_training_samples(rnb_ctx* c, void* stream, uint32_t n_rays, uin
 	if (max_samples > c->cfg.target_batch_size * 16) return fail(RNB_ERR_INVALID, "max_samples exceeds 16*target_batch_size");
 	c->cin_flow = false; // stage calls never use the rows a (failed) training step may have left behind
 	return generate_training_samples(c, as_stream(stream), n_rays, n_rays_total, max_samples);
-}
+} RNB_GUARD
 
-int rnb_compute_loss(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total) {
+int rnb_compute_loss(rnb_ctx* c, void* stream, uint32_t n_rays, uint32_t n_rays_total) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	if (n_rays == 0 || n_rays > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "n_rays out of range");
 	c->cin_flow = false;
 	return compute_loss(c, as_stream(stream), n_rays, n_rays_total);
-}
+} RNB_GUARD
 
-int rnb_forward_backward(rnb_ctx* c, void* stream) {
+int rnb_forward_backward(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->cin_flow = false; // the stage pass evaluates the compacted batch itself for the colour MLP's input rows
 	return forward_backward(c, as_stream(stream));
-}
+} RNB_GUARD
 
-int rnb_optimizer_step(rnb_ctx* c, void* stream) {
+int rnb_optimizer_step(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	return optimizer_step(c, as_stream(stream));
-}
+} RNB_GUARD
 
 // Drops samples generated ahead of time for a step whose inputs have since changed (controller, flags, bitfield ...).
 static void discard_premarch(rnb_ctx* c) {
@@ -2027,7 +2062,7 @@ static int launch_premarch(rnb_ctx* c) {
 	return RNB_OK;
 }
 
-int rnb_train_step_begin(rnb_ctx* c, void* stream) {
+int rnb_train_step_begin(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (c->n_views == 0) return fail(RNB_ERR_INVALID, "no dataset");
 	hipStream_t s = as_stream(stream);
@@ -2040,19 +2075,19 @@ int rnb_train_step_begin(rnb_ctx* c, void* stream) {
 	rc = launch_reduce_losses(c, s);
 	if (rc != RNB_OK) return rc;
 	return step_back(c, s);
-}
+} RNB_GUARD
 
-int rnb_train_step_apply(rnb_ctx* c, void* stream) {
+int rnb_train_step_apply(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	hipStream_t s = as_stream(stream);
 	int rc = optimizer_step(c, s);
 	if (rc != RNB_OK) return rc;
 	++c->training_step;
 	return RNB_OK;
-}
+} RNB_GUARD
 
 // Counters + loss sums of the step started by the last rnb_train_step_begin. May be called before or after _apply.
-int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], double loss_sums_out[3]) {
+int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], double loss_sums_out[3]) try {
 	if (!c || !counters_out || !loss_sums_out) return fail(RNB_ERR_INVALID, "null argument");
 	if (c->poll_loss()) { const int rc = wait_loss_readback(c, as_stream(stream)); if (rc != RNB_OK) return rc; } // the backward pass / optimizer may still be running
 	else if (c->overlap()) HIP_TRY(hipEventSynchronize(c->ev_loss));
@@ -2064,10 +2099,10 @@ int rnb_train_step_local(rnb_ctx* c, void* stream, uint64_t counters_out[4], dou
 	for (int k = 0; k < 3; ++k) loss_sums_out[k] = c->host_rb->sums[k];
 	c->local_measured_before = counters[0];
 	return RNB_OK;
-}
+} RNB_GUARD
 
 // Counters::update_after_training (testbed_nerf.cu:3532-3558) on counters summed over the data-parallel ranks.
-int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double sums[3], rnb_step_stats* stats) {
+int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double sums[3], rnb_step_stats* stats) try {
 	if (!c || !counters || !sums) return fail(RNB_ERR_INVALID, "null argument");
 	const uint64_t Bg = (uint64_t)c->cfg.target_batch_size * c->cfg.world_size;
 	const uint32_t n_rays = c->cur_n_rays;
@@ -2104,9 +2139,9 @@ int rnb_train_step_finish(rnb_ctx* c, const uint64_t counters[4], const double s
 	c->rays_per_batch = next_rays;
 	if (rc != RNB_OK) return rc;
 	return launch_premarch(c);
-}
+} RNB_GUARD
 
-int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) try {
 	if (c && c->overlap()) {
 		// Overlapped schedule: the ray controller and the next step's march FIRST, the moment the loss readback arrives, the optimizer's launches behind them (they are not
 		// due before the first scatter group has finished, ~0.2 ms later). Measured (round 4, 200-step slices): optimizer first 0.6081 / 0.5953 / 0.6319 ms/step at steps
@@ -2126,37 +2161,37 @@ int rnb_train_step_end(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
 	rc = rnb_train_step_local(c, stream, counters, sums);
 	if (rc != RNB_OK) return rc;
 	return rnb_train_step_finish(c, counters, sums, stats);
-}
+} RNB_GUARD
 
-int rnb_train_step(rnb_ctx* c, void* stream, rnb_step_stats* stats) {
+int rnb_train_step(rnb_ctx* c, void* stream, rnb_step_stats* stats) try {
 	// With cfg.overlap the host only waits for the loss pass (rnb_train_step_local), so the call returns once the step's
 	// statistics are known and the next step's march has been queued beside the backward pass; the optimizer may still be
 	// running. Without it (or while profiling) every wait is a full stream synchronisation, as in the reference.
 	int rc = rnb_train_step_begin(c, stream);
 	if (rc != RNB_OK) return rc;
 	return rnb_train_step_end(c, stream, stats);
-}
+} RNB_GUARD
 
-int rnb_profile_enable(rnb_ctx* c, int on) {
+int rnb_profile_enable(rnb_ctx* c, int on) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	c->prof.on = on != 0;
 	c->prof.reset();
 	return RNB_OK;
-}
+} RNB_GUARD
 int rnb_profile_count(const rnb_ctx*) { return P_COUNT; }
-int rnb_profile_get(const rnb_ctx* c, int idx, const char** name, double* total_ms, uint64_t* launches, double* units) {
+int rnb_profile_get(const rnb_ctx* c, int idx, const char** name, double* total_ms, uint64_t* launches, double* units) try {
 	if (!c || idx < 0 || idx >= P_COUNT) return fail(RNB_ERR_INVALID, "bad profile index");
 	if (name) *name = PROF_NAMES[idx];
 	if (total_ms) *total_ms = c->prof.total_ms[idx];
 	if (launches) *launches = c->prof.launches[idx];
 	if (units) *units = c->prof.units[idx];
 	return RNB_OK;
-}
+} RNB_GUARD
 
 uint32_t rnb_training_step(const rnb_ctx* c) { return c ? c->training_step : 0; }
 uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0; }
 
-int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) {
+int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) try {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
 	if (kind < 0 || kind > RNB_PRIM_PREP_DUE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
@@ -2193,9 +2228,9 @@ int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t 
 	if (out) (void)hipFree(out);
 	if (bf) (void)hipFree(bf);
 	return rc;
-}
+} RNB_GUARD
 
-int rnb_set_optimizer_step(rnb_ctx* c, uint32_t step) {
+int rnb_set_optimizer_step(rnb_ctx* c, uint32_t step) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	HIP_TRY(hipDeviceSynchronize()); // a pipelined step may still be running its optimizer
 	c->opt.begun = false;
@@ -2203,9 +2238,9 @@ int rnb_set_optimizer_step(rnb_ctx* c, uint32_t step) {
 	c->lr_factor = 1.0f;
 	for (uint64_t s0 = c->cfg.lr_decay_start; s0 < step && s0 <= 10000000u; s0 += std::max(1u, c->cfg.lr_decay_interval)) c->lr_factor *= c->cfg.lr_decay_base; // exponential_decay.h:61-72, one factor per event
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) {
+int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_batch, uint32_t measured_before, uint32_t n_rays_total) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (rays_per_batch == 0 || rays_per_batch > c->cfg.max_rays_per_batch) return fail(RNB_ERR_INVALID, "rays_per_batch out of range");
 	discard_premarch(c);
@@ -2215,9 +2250,9 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 	c->measured_batch_size_before_compaction = measured_before;
 	c->n_rays_total = n_rays_total;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
+int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) try {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
 	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A1, A2: everything in front of A's levels is final first (ev_sc[0]), then A1 (ev_sc[1])
@@ -2235,37 +2270,37 @@ int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) {
 		ranges[0][0] = 0; ranges[0][1] = c->n_params; *n_parts = 1;
 	}
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_train_step_apply_early(rnb_ctx* c, void* stream) {
+int rnb_train_step_apply_early(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	return optimizer_step_early(c, as_stream(stream));
-}
+} RNB_GUARD
 
-int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity) {
+int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity) try {
 	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
 	c->sc.exchanged = true;
 	c->sc.sharded = true;
 	shard_layout(c, parts, n_parts);
 	*capacity = c->param_capacity;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_train_step_apply_shard(rnb_ctx* c, uint32_t part, void* stream) {
+int rnb_train_step_apply_shard(rnb_ctx* c, uint32_t part, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	return optimizer_step_shard(c, part, as_stream(stream));
-}
+} RNB_GUARD
 
-int rnb_train_step_apply_done(rnb_ctx* c, void* stream) {
+int rnb_train_step_apply_done(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	if (!c->opt.begun) return fail(RNB_ERR_INVALID, "rnb_train_step_apply_done without rnb_train_step_apply_shard");
 	int rc = optimizer_finish(c, as_stream(stream));
 	if (rc != RNB_OK) return rc;
 	++c->training_step;
 	return RNB_OK;
-}
+} RNB_GUARD
 
-int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
+int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
 	// blocks 0 (and, in the data-parallel order, 1 = the first half of the fine levels) of the overlapped schedule have their own events; everything is final at the
 	// end of the backward pass
@@ -2283,6 +2318,6 @@ int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) {
 	HIP_TRY(hipStreamWaitEvent(as_stream(stream), early ? c->ev_sc[0] : mid ? c->ev_sc[1] : c->ev_all, 0));
 	if (early && c->sc.dp) HIP_TRY(hipStreamWaitEvent(as_stream(stream), c->ev_dw, 0)); // block 0 holds the MLPs' gradients (side stream)
 	return RNB_OK;
-}
+} RNB_GUARD
 
 } // extern "C"

@@ -82,6 +82,7 @@ const std::vector<FlagSpec> FLAGS = {
 	{{"mask-weight"}, true, "MASK_WEIGHT", "Mask weight."},
 	{{"fractional-training"}, true, "FRACTIONAL_TRAINING", "Step for fractional training"},
 	{{"accumulate"}, true, "ACCUMULATE", "fp32 (default) or half: width of the accumulators (half = the reference's arithmetic as coded). Not a flag of the reference."},
+	{{"deterministic"}, false, "", "Sum the hash-grid gradients as fixed-point integers: a bit-reproducible training run. Not a flag of the reference."},
 };
 
 struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -666,6 +667,7 @@ struct Testbed {
 		hp.set("batch_size", mpk::Value::uint((uint64_t)cfg.target_batch_size * ((dist.world > 1 && !dist.weak) ? dist.world : 1))); // the job's batch, not this rank's share
 		hp.set("mask_loss_weight", mpk::Value::real(cfg.mask_loss_weight)); hp.set("ek_loss_weight", mpk::Value::real(cfg.ek_loss_weight));
 		hp.set("accumulate", mpk::Value::str(cfg.accumulate == RNB_ACCUM_HALF ? "half" : "fp32")); // (this build's key: a resumed run continues in the mode the snapshot was trained in)
+		hp.set("deterministic", mpk::Value::boolean(cfg.deterministic != 0));
 		mpk::Value& net = obj("network");
 		if (!net.find("otype")) net.set("otype", mpk::Value::str("FullyFusedMLP"));
 		net.set("sdf_bias", mpk::Value::real(cfg.sdf_bias));
@@ -818,6 +820,7 @@ int main(int argc, char** argv) {
 			tb.cfg.accumulate = m == "half" ? RNB_ACCUM_HALF : RNB_ACCUM_FP32;
 			tb.accumulate_from_flag = true;
 		}
+		if (args.has("deterministic")) tb.cfg.deterministic = 1; // (not a flag of the reference, whose runs are not reproducible: include/rnb_neus2.h rnb_config::deterministic)
 		tb.dist.init();
 		struct AbortGuard { bool done = false; ~AbortGuard() { if (!done && !g_abort_file.empty()) if (std::FILE* f = std::fopen(g_abort_file.c_str(), "wb")) std::fclose(f); } } abort_guard; // any exit but the regular one
 		const bool lead = tb.dist.rank == 0; // meshes, snapshots and progress lines come from rank 0 only

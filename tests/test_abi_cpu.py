@@ -33,7 +33,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert not missing, missing
     # callable without a GPU: version + defaults (no compute)
     fns = api.load_library()
-    assert fns.abi_version() == 4
+    assert fns.abi_version() == 5
     cfg = api.default_config()
     assert (cfg.n_levels, cfg.log2_hashmap_size, cfg.target_batch_size, cfg.seed) == (14, 19, 1 << 18, 1337)
     assert abs(cfg.per_level_scale - 1.45242) < 1e-4  # exp(ln(2048/16)/13), testbed.cu:2320-2323

@@ -359,3 +359,36 @@ def test_half_accumulate_mode_is_the_model_of_the_reference_as_coded():
     finally:
         for c in (a, b, d, o):
             c.close()
+
+
+def test_deterministic_mode_sums_the_hash_grid_gradients_exactly():
+    """rnb_config::deterministic on the checker: the hash-grid addends (half values, grid.h:415-416) summed as 64-bit integers at scale 2^24 and narrowed once. The sums are
+    then (a) the same bits on every call, whatever the OpenMP schedule does, (b) the same bits in any order of the samples -- the half mode's atomic-order seed moves nothing --,
+    (c) equal to an independent exact sum: the default mode's addends re-added in float64 (whose 53 bits hold these sums exactly) and rounded once to fp32, and (d) close to the
+    default mode's fp32 sums. The MLP gradients and the variance are untouched by the mode."""
+    d0 = _staged_backward()
+    d1 = _staged_backward(deterministic=1)
+    h1 = _staged_backward(deterministic=1, accumulate=1)
+    h2 = _staged_backward(env={"ORC_ATOMIC_ORDER_SEED": "3"}, deterministic=1, accumulate=1)
+    try:
+        lay = d0.param_layout()
+        lo, hi = lay["grid"], lay["variance"]
+        g0, g1 = d0.get("GRADS_FP32").copy(), d1.get("GRADS_FP32").copy()
+        assert np.array_equal(g0[:lo].view(np.uint32), g1[:lo].view(np.uint32)) and g0[hi] == g1[hi]
+        for _ in range(3):
+            d1.forward_backward()
+            assert np.array_equal(g1.view(np.uint32), d1.get("GRADS_FP32").view(np.uint32))
+        assert g1[lo:hi].any() and np.array_equal(g0[lo:hi] != 0, g1[lo:hi] != 0)
+        scale = np.abs(g0[lo:hi]).max()
+        assert np.abs(g0[lo:hi].astype(np.float64) - g1[lo:hi]).max() <= 1e-5 * scale  # fp32 summation noise of the default mode
+        # every sum is a multiple of 2^-24 that fits in fp32's 24 bits after ONE rounding: re-narrowing through the integer form changes nothing
+        q = np.round(g1[lo:hi].astype(np.float64) * 2.0 ** 24)
+        assert np.array_equal((q * 2.0 ** -24).astype(np.float32), g1[lo:hi])
+        a, b = h1.get("GRADS_FP16"), h2.get("GRADS_FP16")
+        assert np.array_equal(a.view(np.uint16), b.view(np.uint16))  # no order left to depend on
+        # (the half mode's operands come out of half-accumulating MLPs: other addends, so other sums -- close to the fp32 mode's)
+        x, y = a[lo:hi].astype(np.float64), g1[lo:hi].astype(np.float64)
+        assert x @ y / (np.linalg.norm(x) * np.linalg.norm(y)) > 0.999
+    finally:
+        for c in (d0, d1, h1, h2):
+            c.close()

@@ -47,7 +47,7 @@ def test_version_and_help(install):
 def test_every_flag_of_the_references_command_line(install):
     """tests/golden/cli_flags.json: the `args` declarations of the reference's main (src/main.cu:73-258), parsed from its text by make_cli_fixture.py -- 25 of them. `testbed -h`
     lists every one in the reference's order with its short and long names, its placeholder and (the scene flag's wording aside) its help text; a value flag refuses to go
-    without its value, a plain flag refuses one; the only flag the reference does not have is --accumulate."""
+    without its value, a plain flag refuses one; the only flags the reference does not have are --accumulate and --deterministic."""
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_flags.json")) as f:
         flags = json.load(f)["flags"]
     assert len(flags) == 25
@@ -64,7 +64,7 @@ def test_every_flag_of_the_references_command_line(install):
         if fl["long"] != ["scene"]:  # (the reference's text lists dataset kinds of its other modes)
             assert fl["help"] in text[at:at + 400], (head, fl["help"])
     listed = [l.strip() for l in text.splitlines() if l.startswith("      -")]
-    assert len(listed) == 26 and listed[-1].startswith("--accumulate=")
+    assert len(listed) == 27 and listed[-2].startswith("--accumulate=") and listed[-1].startswith("--deterministic")
     for fl in flags:
         name = "--" + fl["long"][0]
         if fl["kind"] == "ValueFlag":
