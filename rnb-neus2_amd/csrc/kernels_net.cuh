@@ -1838,6 +1838,28 @@ __device__ __forceinline__ void grid_scatter_quad_h_body(const GridMeta& G, cons
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) { grid_scatter_quad_h_body<false>(G, a, level0, n_vblocks); }
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_h_per_addend(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) { grid_scatter_quad_h_body<true>(G, a, level0, n_vblocks); }
 
+// Round 6: FACE SHARING in the run-length walks (fp32 accumulate mode). A quad keeps the four (dy, dz) corner sums of its (dx, feature) while the cell does not change; when the
+// ray steps into the cell BEHIND A y- OR z-FACE (one coordinate by +-1, the usual transition on the levels whose cells are wider than a march step), the two corners on that face
+// belong to both cells: their sums stay in registers (moved to the other side of the pair), only the two corners left behind are flushed -- two atomic requests per cell
+// instead of four. (An x-step shares the x-pair, which travels in ONE request already: nothing to save, it flushes all four like any other transition.) Same addends per table
+// entry; a different grouping of the fp32 partial sums, as with any run length.
+template <typename Flush2>
+__device__ __forceinline__ bool share_face(float (&acc)[4], const uint32_t (&cur)[3], const uint32_t (&pg)[3], Flush2&& flush_pair) {
+	const int dy = (int)(pg[1] - cur[1]), dz = (int)(pg[2] - cur[2]);
+	if (pg[0] != cur[0]) return false;
+	if (dz == 0 && (dy == 1 || dy == -1)) {
+		if (dy == 1) { flush_pair(0, 2); acc[0] = acc[1]; acc[2] = acc[3]; acc[1] = 0.f; acc[3] = 0.f; }
+		else { flush_pair(1, 3); acc[1] = acc[0]; acc[3] = acc[2]; acc[0] = 0.f; acc[2] = 0.f; }
+		return true;
+	}
+	if (dy == 0 && (dz == 1 || dz == -1)) {
+		if (dz == 1) { flush_pair(0, 1); acc[0] = acc[2]; acc[1] = acc[3]; acc[2] = 0.f; acc[3] = 0.f; }
+		else { flush_pair(2, 3); acc[2] = acc[0]; acc[3] = acc[1]; acc[0] = 0.f; acc[1] = 0.f; }
+		return true;
+	}
+	return false;
+}
+
 // Middle levels (cell a few march steps wide): the quad layout above, but each quad walks K consecutive samples of the
 // ray-ordered batch and keeps the four (dy, dz) corner sums of its (dx, feature) in registers while the cell does not
 // change. Same-address lanes of one atomic instruction are serialised by the memory system (one request each), so merging
@@ -1847,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_h_per_addend(const Gr
 struct ScatterRlPlan { uint32_t n; uint32_t wg_start[17]; uint64_t k_log2; };
 
 // HALF (rnb_config::accumulate = RNB_ACCUM_HALF): lanes (dx, dy), registers (dz, feature), packed half atomics (see k_grid_scatter_quad_h); a run is still summed in fp32.
-template <bool HALF>
+template <bool HALF, bool SHARE = false>
 __device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
 #pragma unroll 1
 	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) { // virtual workgroups (see k_grid_scatter_quad)
@@ -1907,7 +1929,18 @@ __device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, con
 				pos_fract(sm[j].y, scale, &pos[1], &pg[1]);
 				pos_fract(sm[j].z, scale, &pos[2], &pg[2]);
 				if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-					if (cur[0] != 0xffffffffu) flush();
+					if (cur[0] != 0xffffffffu) {
+						bool shared = false;
+						if (SHARE && !HALF) shared = share_face(acc, cur, pg, [&](const uint32_t y0, const uint32_t y1) {
+							const uint32_t two[2] = {y0, y1};
+#pragma unroll
+							for (int q = 0; q < 2; ++q) {
+								const uint32_t yz = two[q];
+								if (acc[yz] != 0.f) atomicAdd(gg + (size_t)grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1)) * 2 + f, acc[yz]);
+							}
+						});
+						if (!shared) flush();
+					}
 					cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
 				}
 				if (HALF) {
@@ -1941,7 +1974,7 @@ __device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, con
 // wavefront read consecutive 32-byte records at every step of the walk (no bank conflicts; the four lanes of a quad read the same address: a broadcast).
 constexpr uint32_t RL_MAX_K = 16;
 constexpr size_t LDS_SCATTER_RL = (size_t)RL_MAX_K * 64 * 32; // 16 B {x y z dn0} + 8 B {dn1 dn2} + 8 B g12 per sample
-template <bool HALF>
+template <bool HALF, bool SHARE = false>
 __device__ __forceinline__ void grid_scatter_quad_rl_staged_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	f4* sA = reinterpret_cast<f4*>(smem_raw);                                  // [K * 64] x y z dn0
@@ -2011,7 +2044,18 @@ __device__ __forceinline__ void grid_scatter_quad_rl_staged_body(const GridMeta&
 			pos_fract(r0[1], scale, &pos[1], &pg[1]);
 			pos_fract(r0[2], scale, &pos[2], &pg[2]);
 			if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-				if (cur[0] != 0xffffffffu) flush();
+				if (cur[0] != 0xffffffffu) {
+					bool shared = false;
+					if (SHARE && !HALF) shared = share_face(acc, cur, pg, [&](const uint32_t y0, const uint32_t y1) {
+						const uint32_t two[2] = {y0, y1};
+#pragma unroll
+						for (int q = 0; q < 2; ++q) {
+							const uint32_t yz = two[q];
+							if (acc[yz] != 0.f) atomicAdd(gg + (size_t)grid_entry(hashmap_size, res, cur[0] + dx, cur[1] + (yz & 1u), cur[2] + (yz >> 1)) * 2 + f, acc[yz]);
+						}
+					});
+					if (!shared) flush();
+				}
 				cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
 			}
 			if (HALF) {
@@ -2040,6 +2084,9 @@ __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_h(const GridMeta G
 // RNB_SCATTER_RL_STAGED=0 (A/B): the walk with its operands loaded from global memory four samples ahead (rounds 2-4)
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false>(G, a, level0, plan); }
 __global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct_h(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<true>(G, a, level0, plan); }
+// face sharing (round 6, RNB_SCATTER_SHARE)
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_share(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_staged_body<false, true>(G, a, level0, plan); }
+__global__ __launch_bounds__(256) void k_grid_scatter_quad_rl_direct_share(const GridMeta G, const ScatterArgs a, const uint32_t level0, const ScatterRlPlan plan) { grid_scatter_quad_rl_body<false, true>(G, a, level0, plan); }
 
 // ---------------------------------------------------------------------------------------------
 // rnb_config::deterministic: the three scatter mechanisms above on 64-bit fixed-point accumulators (ScatterArgs::grid_fixed; fixed24 / corner_addend_fixed). The same

@@ -61,6 +61,8 @@ uint32_t next_multiple_u32(uint32_t v, uint32_t m) { return ((v + m - 1) / m) * 
 // into the queue, which costs the stream ~6 us between two kernels (measured); binding the event to the kernel's own
 // completion signal costs nothing, and the step's critical stream records 4-5 events.
 #define LAUNCH_EV(kernel, grid, block, lds, stream, ev, ...) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev, 0, __VA_ARGS__)
+// the same with the launch flags spelled out (hipExtAnyOrderLaunch: the packet carries no barrier bit -- it may start while the kernel in front of it on the stream still runs)
+#define LAUNCH_EVF(kernel, grid, block, lds, stream, ev, flags, ...) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev, flags, __VA_ARGS__)
 
 uint32_t compute_valid_level(const rnb_config& cfg, int training_step) { // grid.h:1430-1437
 	if (training_step <= 0) return cfg.n_levels;
@@ -232,6 +234,9 @@ struct rnb_ctx {
 		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
 		                            // few long rays: 0.6078 -> 0.5971 ms/step at step 1000, 0.5900 -> 0.5929 at 2000, 0.6334 -> 0.6360 at 6000 (profiles/r05_ab_scatter_rl_staged.txt).
 		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
+		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
+		int scatter_kmin = 0, scatter_rl_upto = 0; // RNB_SCATTER_KMIN, RNB_SCATTER_RL_UPTO (A/B, plan_scatter_groups)
+		bool scatter_anyorder = true;  // RNB_SCATTER_ANYORDER=1 (A/B): the scatter groups behind the first one are launched with hipExtAnyOrderLaunch -- they touch other levels, so a group may start in the tail of the one in front of it
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
@@ -957,15 +962,19 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	};
 	// `done` (if any) fires when the group's last kernel has completed; a group without kernels records it the plain way
 	const bool dbg_levels = c->prof.on && c->knobs.dbg_scatter_lo >= 0;
+	// RNB_SCATTER_ANYORDER: every scatter launch behind the step's first one may start before the kernel in front of it has drained (other levels: no dependency); the first one keeps
+	// its barrier (it needs k_fwd_bwd's operands), and so does everything behind the scatter
+	bool sc_first = true;
+	auto sc_flags = [&]() -> uint32_t { const bool any = c->knobs.scatter_anyorder && side_streams && !sc_first; sc_first = false; return any ? (uint32_t)hipExtAnyOrderLaunch : 0u; };
 	auto launch_a = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1) of the group
 		if (dbg_levels) { l0 = std::max(l0, (uint32_t)c->knobs.dbg_scatter_lo); l1 = std::max(l0, std::min(l1, (uint32_t)c->knobs.dbg_scatter_hi)); }
 		const uint32_t n_vb = (B * 4 + 255) / 256, cap = scatter_cap ? std::max(1u, (uint32_t)c->n_cus * scatter_cap / std::max(1u, l1 - l0)) : n_vb;
 		if (l1 > l0 && fixed) {
-			hipLaunchKernelGGL(k_grid_scatter_quad_fixed, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, c->meta(), sa, l0, n_vb);
+			LAUNCH_EVF(k_grid_scatter_quad_fixed, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, nullptr, sc_flags(), c->meta(), sa, l0, n_vb);
 			narrow(st, done, l0, l1);
-		} else if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EV(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
-		else if (l1 > l0 && half) LAUNCH_EV(k_grid_scatter_quad_h, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
-		else if (l1 > l0) LAUNCH_EV(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, c->meta(), sa, l0, n_vb);
+		} else if (l1 > l0 && half && c->knobs.scatter_plain) LAUNCH_EVF(k_grid_scatter_quad_h_per_addend, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, l0, n_vb);
+		else if (l1 > l0 && half) LAUNCH_EVF(k_grid_scatter_quad_h, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, l0, n_vb);
+		else if (l1 > l0) LAUNCH_EVF(k_grid_scatter_quad, dim3(std::min(n_vb, cap), l1 - l0), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, l0, n_vb);
 		else if (done) (void)hipEventRecord(done, st);
 	};
 	auto launch_b = [&](hipStream_t st, hipEvent_t done) { // one launch for all these levels, each with the workgroups its run length needs
@@ -980,13 +989,15 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		const uint32_t cap_rl = scatter_cap ? (uint32_t)c->n_cus * scatter_cap : wg;
 		const bool staged = c->knobs.scatter_rl_staged >= 0 ? c->knobs.scatter_rl_staged != 0 : (c->cur_n_rays != 0 && c->cur_n_rays < c->knobs.march_narrow_from);
 		if (fixed) {
-			hipLaunchKernelGGL(k_grid_scatter_quad_rl_fixed, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, c->meta(), sa, e_c, plan);
+			LAUNCH_EVF(k_grid_scatter_quad_rl_fixed, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, nullptr, sc_flags(), c->meta(), sa, e_c, plan);
 			narrow(st, done, e_c, l_fine);
 		} else if (!staged) {
-			if (half) LAUNCH_EV(k_grid_scatter_quad_rl_direct_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
-			else LAUNCH_EV(k_grid_scatter_quad_rl_direct, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, c->meta(), sa, e_c, plan);
-		} else if (half) LAUNCH_EV(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, c->meta(), sa, e_c, plan);
-		else LAUNCH_EV(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, c->meta(), sa, e_c, plan);
+			if (half) LAUNCH_EVF(k_grid_scatter_quad_rl_direct_h, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, e_c, plan);
+			else if (c->knobs.scatter_share) LAUNCH_EVF(k_grid_scatter_quad_rl_direct_share, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, e_c, plan);
+			else LAUNCH_EVF(k_grid_scatter_quad_rl_direct, dim3(std::min(wg, cap_rl)), dim3(256), 0, st, done, sc_flags(), c->meta(), sa, e_c, plan);
+		} else if (half) LAUNCH_EVF(k_grid_scatter_quad_rl_h, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, sc_flags(), c->meta(), sa, e_c, plan);
+		else if (c->knobs.scatter_share) LAUNCH_EVF(k_grid_scatter_quad_rl_share, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, sc_flags(), c->meta(), sa, e_c, plan);
+		else LAUNCH_EVF(k_grid_scatter_quad_rl, dim3(std::min(wg, cap_rl)), dim3(256), LDS_SCATTER_RL, st, done, sc_flags(), c->meta(), sa, e_c, plan);
 	};
 	auto launch_c = [&](hipStream_t st, hipEvent_t done) {
 		if (!e_c) { if (done) (void)hipEventRecord(done, st); return; }
@@ -995,10 +1006,10 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		const uint32_t n_wg = std::max(1u, std::min<uint32_t>(wg_cap, (B + 1023) / 1024));
 		la.samples_per_wg = ((B + n_wg - 1) / n_wg + 3) / 4 * 4;
 		if (fixed) {
-			hipLaunchKernelGGL(k_grid_scatter_lds_fixed, dim3(n_wg, 2), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, c->meta(), la);
+			LAUNCH_EVF(k_grid_scatter_lds_fixed, dim3(n_wg, 2), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, nullptr, sc_flags(), c->meta(), la);
 			narrow(st, done, 0, e_c);
-		} else if (half) LAUNCH_EV(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
-		else LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, c->meta(), la);
+		} else if (half) LAUNCH_EVF(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, sc_flags(), c->meta(), la);
+		else LAUNCH_EVF(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c] * 8, st, done, sc_flags(), c->meta(), la);
 	};
 
 	if (!side_streams) {
@@ -1119,6 +1130,9 @@ static void plan_scatter_groups(rnb_ctx* c) {
 		for (l = 0; l < L; ++l) {
 			const float run = 590.f / (float)c->grid.resolution[l]; // compacted samples of a ray that share a cell of this level
 			g.Ks[l] = run >= 5.f ? 16 : run >= 2.5f ? 8 : run >= 1.2f ? 4 : 1; // below ~1 sample per cell the plain quad kernel is faster (measured)
+			// A/B (round 6, face sharing): RNB_SCATTER_KMIN = the shortest walk of a run-length level; RNB_SCATTER_RL_UPTO = levels below it walk (at least 4 samples) even where a cell holds < 1.2 samples
+			if (c->knobs.scatter_rl_upto > 0 && l < (uint32_t)c->knobs.scatter_rl_upto && g.Ks[l] == 1) g.Ks[l] = 4;
+			if (c->knobs.scatter_kmin > 0 && g.Ks[l] > 1) g.Ks[l] = std::max<uint32_t>(g.Ks[l], (uint32_t)c->knobs.scatter_kmin);
 		}
 	}
 	if (c->knobs.scatter_plain) { // RNB_SCATTER_PLAIN=1: every level through the plain kernel, one atomic per corner and sample -- the reference's own scatter structure (grid.h:366-495)
@@ -1346,6 +1360,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 		if (e_ != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
 	} while (0)
 	c->cfg = *cfg;
+	if (const char* e = getenv("RNB_DETERMINISTIC")) c->cfg.deterministic = atoi(e) != 0 ? 1u : 0u; // measurement aid (tools/ab_interleaved.sh): the mode without touching the caller
 	c->n_cus = prop.multiProcessorCount;
 	build_grid_tables(c);
 	c->off_sdf = 0;
@@ -1375,7 +1390,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
 	ALLOC(c->opt_rec, c->param_capacity * 4);
 	if (cfg->accumulate == RNB_ACCUM_HALF) ALLOC_P(c->grads16); else ALLOC_P(c->grads);
-	if (cfg->deterministic) {
+	if (c->cfg.deterministic) {
 		if (c->grads_fixed.alloc_padded(c->n_grid_params, c->n_grid_params) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for the fixed-point gradient accumulators"); }
 	}
 	ALLOC_P(c->params_fp32); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
@@ -1488,6 +1503,10 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_DEBUG_SCATTER_LEVELS")) { int lo = -1, hi = -1; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo) { k.dbg_scatter_lo = lo; k.dbg_scatter_hi = hi; } }
 		if (const char* e = getenv("RNB_SCATTER_C_EARLY")) k.scatter_c_early = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
+		if (const char* e = getenv("RNB_SCATTER_ANYORDER")) k.scatter_anyorder = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_SHARE")) k.scatter_share = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
+		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}
 	plan_scatter_groups(c);
 	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));

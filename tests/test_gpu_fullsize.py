@@ -818,8 +818,8 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
                 plain.close()
             assert np.array_equal(gp[:lo], g[:lo])  # (the MLPs' gradients do not depend on the scatter's structure: fixed-order sums)
             out["hash_grid_plain_scatter"] = _grad_distance(gp[lo:hi], r[lo:hi])
-            out["hash_grid_by_level"] = [dict(level=l, hip=a_, hip_plain=b_, floor=c_, model_vs_exact=d_, hip_vs_exact=e_) for l, (a_, b_, c_, d_, e_) in
-                                         enumerate(zip(by_level(g, r), by_level(gp, r), by_level(r2, r), by_level(r, rx), by_level(g, rx)))]
+            out["hash_grid_by_level"] = [dict(level=l, hip=a_, hip_plain=b_, floor=c_, model_vs_exact=d_, hip_vs_exact=e_, hip_vs_hip_plain=f_) for l, (a_, b_, c_, d_, e_, f_) in
+                                         enumerate(zip(by_level(g, r), by_level(gp, r), by_level(r2, r), by_level(r, rx), by_level(g, rx), by_level(g, gp)))]
         print("emulated-reference bound:", json.dumps(out))
         try:
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -843,17 +843,17 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             # every addend its own half atomic: the whole table within the distance of two legal orders of the reference itself
             pl = out["hash_grid_plain_scatter"]
             assert pl["rms_dev_over_rms"] <= 1.25 * floor["rms_dev_over_rms"] + 1e-4 and 1 - pl["cosine"] <= 1.6 * (1 - floor["cosine"]) + 1e-7, (pl, floor)
-            # the product's scatter (LDS-privatised coarse levels, run-length sums in fp32): at that floor wherever a cell holds few addends; on the levels whose sums the
-            # reference's half atomics round away it must sit closer to the exact sum than the model does, and no further from the model than the model is from the exact sum
+            # Level by level. (a) What the product's scatter changes -- a cell run or a workgroup's slice summed in fp32 before its one half atomic -- measured DIRECTLY: against the
+            # per-addend scatter on the SAME operands (same launch sequence, same loss gradients) it sits within the distance of two legal orders of the half atomics (the floor).
+            # (b) Against the model the two HIP scatters agree with each other to that floor and differ from the model by what their OPERANDS differ by: on the pinned state the one
+            # loss-gradient row of (D = 1.6e-3) whose |grad sdf| sits on the other side of 1 (rows 137374-5 of the diagnostics) lands in one cell per level and carries 4e-3 ... 7e-3
+            # of the rms of the levels it is large in (4, 5, 7, 8, 11); measured maximum 7.2e-3, asserted 1e-2. (c) On the two coarsest levels, where thousands of addends meet one
+            # entry and the reference's sequential half sums round small addends away, the product sits CLOSER to the exact sum than the model does.
             for q in out["hash_grid_by_level"]:
-                # + ULPS: the addends themselves. A k-step's 16 products are summed in fp32 by the matrix core in an order the model's sequential sum need not share (the vendor
-                # documents neither), so a backward dot product may round to the neighbouring half: where a cell holds one or two addends (the fine levels, whose order floor
-                # is 2e-4) the level's rms deviation is that of its addends, up to three half ulps (4.9e-4 each)
-                ULPS = 1.5e-3
-                if q["model_vs_exact"] <= 2 * q["floor"]:
-                    assert q["hip"] <= 2.0 * q["floor"] + ULPS, q
-                else:
-                    assert q["hip_vs_exact"] <= q["model_vs_exact"] + ULPS and q["hip"] <= 1.25 * q["model_vs_exact"] + q["floor"] + ULPS, q
+                assert q["hip_vs_hip_plain"] <= 2.0 * q["floor"] + 2e-4, q
+                assert q["hip"] <= 1e-2 and abs(q["hip"] - q["hip_plain"]) <= q["floor"] + 2e-4, q
+                if q["model_vs_exact"] > 2 * q["floor"] or q["level"] < 2:
+                    assert q["hip_vs_exact"] <= q["model_vs_exact"], q
             assert abs(vg - vr) <= 2e-3 * abs(vr) + 1e-3, out["variance_grad"]  # one half value: the fp32 sum of the same rows narrowed once
             if colour_not_met:
                 # Reported as what it is -- NOT MET -- instead of being asserted around (round 5 set such rays aside). On the pinned state ONE ray of 4483 carries 1.65e-4 of the
