@@ -247,6 +247,28 @@ class Context:
         self._check(self.f.eval_primitives(self._h, k, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out
 
+    # -- a training state as data (what a snapshot holds, src/testbed.cu:3333-3390, plus the optimizer's moments) ---------------------------
+    def training_state(self, last_stats=None):
+        """Everything a fresh context needs to continue this run: master weights, Adam moments and per-parameter step counts, EMA weights, the number of optimizer
+        steps taken (= the learning-rate schedule's position), the occupancy grid and the ray controller. `last_stats`: the rnb_step_stats of the last step
+        (its un-compacted sample count feeds the controller). The ray generator's position is not part of it (nor of the reference's snapshot)."""
+        return dict(params=self.get("PARAMS_FP32").copy(), adam_m=self.get("ADAM_M").copy(), adam_v=self.get("ADAM_V").copy(), adam_steps=self.get("ADAM_STEPS").copy(),
+                    ema=self.get("PARAMS_EMA").copy(), grid=self.get("DENSITY_GRID").copy(), step=self.training_step, rays=self.rays_per_batch,
+                    before=int(last_stats.measured_batch_size_before_compaction) if last_stats is not None else 0)
+
+    def load_training_state(self, state):
+        """The inverse: set_params resets the optimizer (trainer.h:263-275), then the moments, step counts and EMA weights are put back, the schedule's position,
+        the occupancy grid (and its bitfield) and the controller. Works across accumulate / deterministic modes: the state is mode-independent data."""
+        self.set_params(state["params"])
+        self.put("ADAM_M", state["adam_m"])
+        self.put("ADAM_V", state["adam_v"])
+        self.put("ADAM_STEPS", state["adam_steps"])
+        self.put("PARAMS_EMA", state["ema"])
+        self.set_optimizer_step(state["step"])
+        self.put("DENSITY_GRID", state["grid"])
+        self.update_density_bitfield()
+        self.set_controller(state["step"], state["rays"], state["before"], 0)
+
     def set_optimizer_step(self, step):
         """Optimizer steps taken so far (adam.h:486-495, exponential_decay.h:143-147): step counter + learning-rate factor."""
         self._check(self.f.set_optimizer_step(self._h, int(step)))

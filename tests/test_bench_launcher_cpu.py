@@ -10,7 +10,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--views", "4", "--res", "48", "--focal", "84", "--batch-log2", "12", "--burn-in", "0", "--warmup", "1", "--steps", "2", "--other-leg-steps", "1",
+SMALL = ["--views", "4", "--res", "48", "--focal", "84", "--batch-log2", "12", "--burn-in", "2", "--warmup", "1", "--steps", "2", "--other-leg-steps", "1",
          "--window-end", "0", "--late-step", "0", "--profile-steps", "0", "--no-cpu-baseline"]
 
 
@@ -40,6 +40,11 @@ def test_bench_gpus_2_spawns_its_own_ranks(strong):
     assert other["samples_per_step_per_gpu"] == ((1 << 12) if strong else (1 << 11))
     assert rec["config"]["parallelism"] == "dp2" and "launcher test" in rec["config"]["engine"]
     assert rec["config"]["rays_per_step_per_gpu"] > 0 and other["rays_per_step_per_gpu"] > 0
+    # the untimed burn-in ran in a deterministic context (both ranks, through the trainer's collectives) and was handed over as data; its hash is in the record
+    b = rec["config"]["burn_in"]
+    assert b["mode"] == "deterministic" and b["steps"] == 2 and b["state_step"] == 2 and len(b["state_sha256"]) == 64
+    again = _run(["--gpus", "2"] + (["--strong"] if strong else []))
+    assert again["config"]["burn_in"]["state_sha256"] == b["state_sha256"]  # the same bytes on every run
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
