@@ -290,15 +290,13 @@ def main(argv=None, engine=None):
 
     burn_states = {}
 
-    def burn_in(ctx, trainer, strong, n_steps):
-        """The untimed steps in front of the warm-up. --burn-in-mode deterministic: trained ONCE per (leg shape) in a context with rnb_config::deterministic = 1 and handed over as data
-        (api.Context.training_state / load_training_state: weights, Adam state, EMA, occupancy grid, controller) -- every run of this script then times the same steps from the same state."""
-        if n_steps <= 0:
+    def burn_state(strong, n_steps):
+        """--burn-in-mode deterministic: the state after the untimed steps, trained ONCE per leg shape in a context with rnb_config::deterministic = 1 -- created, trained and CLOSED before the
+        leg's own context exists -- and kept as data (api.Context.training_state: weights, Adam state, EMA, occupancy grid, controller): every run of this script times the same steps from the same bytes.
+        (Two contexts alive at once share the process's four hardware queues: a context created after another one was closed beside a live one lost its side-stream overlap, 0.27 -> 0.40 ms/step
+        for the fixed-cost leg -- measured this round; hence strictly one context at a time.)"""
+        if n_steps <= 0 or args.burn_in_mode != "deterministic":
             return None
-        if args.burn_in_mode != "deterministic":
-            for _ in range(n_steps):
-                trainer.step()
-            return {"steps": n_steps, "mode": "same"}
         key = (bool(strong), n_steps)
         if key not in burn_states:
             dctx, dtr = open_leg(strong, deterministic=1)
@@ -310,9 +308,19 @@ def main(argv=None, engine=None):
             engine.sync()
             burn_states[key] = dctx.training_state(st)
             dctx.close()
-        state = burn_states[key]
+            del dtr, dctx
+        return burn_states[key]
+
+    def open_leg_burnt_in(strong, n_steps, **mode):
+        """A leg's context at the end of the burn-in: (context, trainer, record)."""
+        state = burn_state(strong, n_steps)
+        ctx, trainer = open_leg(strong, **mode)
+        if state is None:
+            for _ in range(max(0, n_steps)):
+                trainer.step()
+            return ctx, trainer, ({"steps": n_steps, "mode": "same"} if n_steps > 0 else None)
         ctx.load_training_state(state)
-        return {"steps": n_steps, "mode": "deterministic", "state_step": int(state["step"]), "state_rays_per_batch": int(state["rays"]), "state_sha256": state_sha256(state)}
+        return ctx, trainer, {"steps": n_steps, "mode": "deterministic", "state_step": int(state["step"]), "state_rays_per_batch": int(state["rays"]), "state_sha256": state_sha256(state)}
 
     def timed_run(trainer, n_steps):
         """n_steps training steps between two barriers: (wall seconds (max over ranks), rays, compacted samples, samples before compaction, per-step host ms, last stats)."""
@@ -335,9 +343,8 @@ def main(argv=None, engine=None):
 
     # ---- the leg `value` is taken from ----
     t0 = time.time()
-    ctx, trainer = open_leg(args.strong)
+    ctx, trainer, burn_info = open_leg_burnt_in(args.strong, args.burn_in)
     setup_s = scene_s + time.time() - t0
-    burn_info = burn_in(ctx, trainer, args.strong, args.burn_in)
     for _ in range(args.warmup):
         trainer.step()
     elapsed, rays, samples, samples_before, timed_ms, last = timed_run(trainer, args.steps)
@@ -388,8 +395,7 @@ def main(argv=None, engine=None):
     # ---- several ranks: the other scaling mode, same job ----
     other = None
     if world > 1 and args.other_leg_steps > 0:
-        ctx2, trainer2 = open_leg(not args.strong)
-        burn_in(ctx2, trainer2, not args.strong, args.burn_in)
+        ctx2, trainer2, _ = open_leg_burnt_in(not args.strong, args.burn_in)
         for _ in range(args.warmup):
             trainer2.step()
         o_el, o_rays, o_smp, _, _, o_last = timed_run(trainer2, args.other_leg_steps)
@@ -435,11 +441,7 @@ def main(argv=None, engine=None):
     parity = None
     if world == 1 and rank == 0 and args.parity_mode_steps > 0 and not args.strong and accumulate == 0 and engine.name == "hip":
         sizes = dict(target_batch_size=B, max_rays_per_batch=min(1 << 18, B), initial_rays_per_batch=min(1 << 12, B)) if B != (1 << 18) else {}
-        pctx = engine.context(world_size=1, rank=0, accumulate=1, **flags, **sizes)
-        pctx.init_params()
-        pctx.set_dataset(*scene)
-        ptr = engine.trainer(pctx)
-        burn_in(pctx, ptr, False, args.burn_in)  # the SAME pinned state (a state is mode-independent data)
+        pctx, ptr, _ = open_leg_burnt_in(False, args.burn_in, accumulate=1)  # the SAME pinned state (a state is mode-independent data)
         for _ in range(args.warmup):
             ptr.step()
         p_el, p_rays, _, _, _, p_last = timed_run(ptr, args.steps)          # the driver's K steps
@@ -466,8 +468,7 @@ def main(argv=None, engine=None):
     # ---- one GPU: the same steps from the same state with rnb_config::deterministic (the mode the parity tests and the burn-in run in) ----
     det_leg = None
     if world == 1 and rank == 0 and args.parity_mode_steps > 0 and not args.strong and not deterministic and engine.name == "hip":
-        dctx, dtr = open_leg(False, deterministic=1)
-        burn_in(dctx, dtr, False, args.burn_in)
+        dctx, dtr, _ = open_leg_burnt_in(False, args.burn_in, deterministic=1)
         for _ in range(args.warmup):
             dtr.step()
         d_el, d_rays, _, _, _, d_last = timed_run(dtr, args.steps)
