@@ -185,93 +185,93 @@ def test_config2_shape_normals_only_10000_steps_gpu(tmp_path):
     print("10000 steps + 512^3 mesh: %.1f s wall, final loss %.2e" % (elapsed, losses[-1]))
 
 
+def _run_testbed(tmp_path, name, scene_data, extra_cmd=(), env_extra=None, launcher=None, maxiter=400):
+    """One `build/testbed` run (optionally through tools/launch_testbed.sh) on a fresh copy of the scene: (snapshot dict, printed losses, stdout)."""
+    import os
+    import subprocess
+    import msgpack
+    from rnb_neus2_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "testbed")
+    views, normals, albedos = scene_data
+    scene = str(tmp_path / name)
+    synthetic.write_scene(scene, views, normals, albedos, scale=2.0, offset=(0.5, 0.5, 0.5))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [exe, "--scene", scene + "/", "--maxiter", str(maxiter), "--no-gui", "--mask-weight", "1.0", "--no-albedo", "--save-snapshot", "--save-mesh", "--resolution", "128"] + list(extra_cmd)
+    if launcher:
+        cmd = [os.path.join(root, "tools", "launch_testbed.sh")] + list(launcher) + cmd
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
+    its = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
+    assert [l.split()[0] for l in its] == ["iteration=%d" % k for k in range(100, maxiter, 100)]
+    with open(os.path.join(scene, "output", "snapshot_%d.msgpack" % maxiter), "rb") as f:
+        snap = msgpack.unpackb(f.read(), raw=False)
+    v = np.array([[float(x) for x in l.split()[1:4]] for l in open(os.path.join(scene, "output", "mesh_%d.obj" % maxiter)) if l.startswith("v ")])
+    rad = np.linalg.norm(v, axis=1)
+    assert abs(np.median(rad) - 0.125) < 0.005 and rad.std() < 0.008, (name, np.median(rad), rad.std())
+    return snap, [float(l.split("loss=")[1]) for l in its], r.stdout
+
+
+def _same_training(a, b):
+    """Two runs are ONE trajectory: every printed loss, the weights, the occupancy grid and the optimizer's position in the snapshots, byte for byte."""
+    assert a[1] == b[1], (a[1], b[1])
+    for key in ("params_binary", "density_grid_binary"):
+        assert a[0]["snapshot"][key] == b[0]["snapshot"][key], key
+    assert a[0]["snapshot"]["training_step"] == b[0]["snapshot"]["training_step"]
+
+
 def test_testbed_cli_over_rccl_single_rank(tmp_path):
-    """build/testbed's one-process-per-GPU mode (struct Dist in host/testbed_main.cpp, tools/launch_testbed.sh): with a world of 1
-    and RNB_DP_FORCE_COLLECTIVES the step runs through the RCCL calls of the multi-GPU path -- all-reduce of the 7 counters on
-    the library's device block, gradient blocks in completion order with the early block and its optimizer chunk on their own
-    stream -- and must train like the plain command line (same rays, same first-step loss, the same converged sphere)."""
-    import os
-    import subprocess
-    import msgpack
+    """build/testbed's one-process-per-GPU mode (struct Dist in host/testbed_main.cpp, tools/launch_testbed.sh): with a world of 1 and RNB_DP_FORCE_COLLECTIVES the step runs
+    through the RCCL calls of the multi-GPU path -- all-reduce of the 7 counters on the library's device block, gradient blocks in completion order with the early block and its
+    optimizer chunk on their own stream, the sharded optimizer's reduce-scatter / all-gather -- and, with `--deterministic`, must BE the plain command line's training: a collective
+    over one rank is the identity and the gradient sums are exact, so the two snapshots agree byte for byte (rounds 3-5 compared two trajectories within 15 %). The default mode
+    (floating-point atomics) is run through the same path once and must train the same sphere."""
     from rnb_neus2_amd import synthetic
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "testbed")
-    views, normals, albedos = synthetic.make_scene(12, 200, 350.0)
-    snaps = {}
-    for mode in ("plain", "rccl"):
-        scene = str(tmp_path / mode)
-        synthetic.write_scene(scene, views, normals, albedos, scale=2.0, offset=(0.5, 0.5, 0.5))
-        env = dict(os.environ)
-        cmd = [exe, "--scene", scene + "/", "--maxiter", "400", "--no-gui", "--mask-weight", "1.0", "--no-albedo", "--save-snapshot", "--save-mesh", "--resolution", "128"]
-        if mode == "rccl":
-            env["RNB_DP_FORCE_COLLECTIVES"] = "1"
-            cmd = [os.path.join(root, "tools", "launch_testbed.sh"), "1"] + cmd
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
-        its = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
-        assert [l.split()[0] for l in its] == ["iteration=%d" % k for k in range(100, 400, 100)]
-        with open(os.path.join(scene, "output", "snapshot_400.msgpack"), "rb") as f:
-            snaps[mode] = (msgpack.unpackb(f.read(), raw=False), [float(l.split("loss=")[1]) for l in its])
-        v = np.array([[float(x) for x in l.split()[1:4]] for l in open(os.path.join(scene, "output", "mesh_400.obj")) if l.startswith("v ")])
-        rad = np.linalg.norm(v, axis=1)
-        assert abs(np.median(rad) - 0.125) < 0.005 and rad.std() < 0.008, (mode, np.median(rad), rad.std())
-    a, b = snaps["plain"], snaps["rccl"]
-    assert a[0]["snapshot"]["training_step"] == b[0]["snapshot"]["training_step"] == 400
-    assert a[0]["hyperparams"]["batch_size"] == b[0]["hyperparams"]["batch_size"]
-    for x, y in zip(a[1], b[1]):  # same training up to the order of the fp32 atomics
-        assert abs(x - y) <= 0.15 * max(x, y), (a[1], b[1])
+    data = synthetic.make_scene(12, 200, 350.0)
+    plain = _run_testbed(tmp_path, "plain", data, ["--deterministic"])
+    rccl = _run_testbed(tmp_path, "rccl", data, ["--deterministic"], {"RNB_DP_FORCE_COLLECTIVES": "1"}, launcher=["1"])
+    assert "rccl_ranks: 1" in rccl[2] or "ranks: 1" in rccl[2]
+    _same_training(plain, rccl)
+    allred = _run_testbed(tmp_path, "rccl_allreduce", data, ["--deterministic"], {"RNB_DP_FORCE_COLLECTIVES": "1", "RNB_DP_SHARDED": "0"}, launcher=["1"])
+    _same_training(plain, allred)
+    dflt = _run_testbed(tmp_path, "rccl_default_mode", data, [], {"RNB_DP_FORCE_COLLECTIVES": "1"}, launcher=["1"])
+    assert dflt[0]["snapshot"]["training_step"] == 400 and dflt[1][-1] < 2 * plain[1][-1] + 1e-3
 
 
-@pytest.mark.parametrize("variant", ["sharded", "allreduce", "half_sharded"])
-def test_testbed_cli_two_ranks_on_one_gpu(tmp_path, variant):
-    """TWO `build/testbed` processes as ranks 0 / 1 of one job on the one GPU (struct Dist with a world of 2: non-zero chunk offsets of the sharded optimizer,
-    three gradient blocks with the first two exchanged on the early stream beside the scatter, the sharded occupancy update's max exchange, sync_parameters()
-    before rank 0 writes). RCCL refuses two ranks on one device, so the collectives go through the host-staged test transport (RNB_DP_TRANSPORT=staged,
-    host/dist_transport.hpp) -- the same Dist code, the same library calls, the same streams. The job must train the plain command line's sphere (strong
-    scaling: the job's step is the single-GPU step) and report the job's batch in its snapshot. half_sharded: --accumulate half, the ranks exchange
-    RNB_BUF_GRADS_FP16 in half. (The CPU twin, bit-exact against the protocol stated in Python: tests/test_testbed_multirank_cpu.py.)"""
-    import os
-    import subprocess
-    import msgpack
+@pytest.mark.parametrize("accumulate", ["fp32", "half"])
+def test_testbed_cli_two_ranks_on_one_gpu(tmp_path, accumulate):
+    """TWO `build/testbed` processes as ranks 0 / 1 of one job on the one GPU (struct Dist with a world of 2: non-zero chunk offsets of the sharded optimizer, three gradient blocks
+    with the first two exchanged on the early stream beside the scatter, the sharded occupancy update's max exchange, sync_parameters() before rank 0 writes). RCCL refuses two ranks
+    on one device, so the collectives go through the host-staged test transport (RNB_DP_TRANSPORT=staged, host/dist_transport.hpp) -- the same Dist code, the same library calls,
+    the same streams. With `--deterministic`: the job with the SHARDED optimizer and the job with all-reduce + replicated optimizer are one trajectory, byte for byte (a two-rank
+    sum commutes; the hash-grid sums are exact) -- the first bit-exact statement about the product's multi-rank path on the GPU; and the job trains the plain command line's sphere
+    (strong scaling: the job's step is the single-GPU step; each rank pads its own half of the batch, so job and single process are two trajectories -- reproducible ones now).
+    half: --accumulate half, the ranks exchange RNB_BUF_GRADS_FP16 in half. (The CPU twin, against the protocol stated in Python: tests/test_testbed_multirank_cpu.py.)"""
     from rnb_neus2_amd import synthetic
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "testbed")
-    views, normals, albedos = synthetic.make_scene(12, 200, 350.0)
-    runs = {}
-    for mode in ("plain", "job"):
-        scene = str(tmp_path / mode)
-        synthetic.write_scene(scene, views, normals, albedos, scale=2.0, offset=(0.5, 0.5, 0.5))
-        env = dict(os.environ)
-        cmd = [exe, "--scene", scene + "/", "--maxiter", "400", "--no-gui", "--mask-weight", "1.0", "--no-albedo", "--save-snapshot", "--save-mesh", "--resolution", "128"]
-        if variant == "half_sharded":
-            cmd += ["--accumulate", "half"]
-        if mode == "job":
-            env.update(RNB_DP_TRANSPORT="staged", RNB_DP_STAGE_DIR=str(tmp_path / "stage"), RNB_LOCAL_RANK="0")
-            if variant == "allreduce":
-                env["RNB_DP_SHARDED"] = "0"
-            # both ranks on device 0: the launcher exports RNB_LOCAL_RANK = rank, overridden per process here
-            cmd = [os.path.join(root, "tools", "launch_testbed.sh"), "2", "env", "RNB_LOCAL_RANK=0"] + cmd
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-        assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
-        if mode == "job":
-            assert ("staged_ranks: 2 (%s)" % ("all-reduce, replicated optimizer" if variant == "allreduce" else "sharded optimizer")) in r.stdout
-            assert r.stdout.count("Saving Snapshot !") == 1
-        its = [l for l in r.stdout.splitlines() if l.startswith("iteration=")]
-        assert [l.split()[0] for l in its] == ["iteration=%d" % k for k in range(100, 400, 100)]
-        with open(os.path.join(scene, "output", "snapshot_400.msgpack"), "rb") as f:
-            runs[mode] = (msgpack.unpackb(f.read(), raw=False), [float(l.split("loss=")[1]) for l in its])
-        v = np.array([[float(x) for x in l.split()[1:4]] for l in open(os.path.join(scene, "output", "mesh_400.obj")) if l.startswith("v ")])
-        rad = np.linalg.norm(v, axis=1)
-        assert abs(np.median(rad) - 0.125) < 0.005 and rad.std() < 0.008, (mode, np.median(rad), rad.std())
-    a, b = runs["plain"], runs["job"]
+    data = synthetic.make_scene(12, 200, 350.0)
+    mode = ["--deterministic"] + (["--accumulate", "half"] if accumulate == "half" else [])
+    plain = _run_testbed(tmp_path, "plain", data, mode)
+    jobs = {}
+    for variant in ("sharded", "allreduce"):
+        env = dict(RNB_DP_TRANSPORT="staged", RNB_DP_STAGE_DIR=str(tmp_path / ("stage_" + variant)), RNB_LOCAL_RANK="0")
+        if variant == "allreduce":
+            env["RNB_DP_SHARDED"] = "0"
+        # both ranks on device 0: the launcher exports RNB_LOCAL_RANK = rank, overridden per process here
+        jobs[variant] = _run_testbed(tmp_path, "job_" + variant, data, mode, env, launcher=["2", "env", "RNB_LOCAL_RANK=0"])
+        out = jobs[variant][2]
+        assert ("staged_ranks: 2 (%s)" % ("all-reduce, replicated optimizer" if variant == "allreduce" else "sharded optimizer")) in out
+        assert out.count("Saving Snapshot !") == 1
+    _same_training(jobs["sharded"], jobs["allreduce"])
+    a, b = plain, jobs["sharded"]
     assert a[0]["snapshot"]["training_step"] == b[0]["snapshot"]["training_step"] == 400
     assert a[0]["hyperparams"]["batch_size"] == b[0]["hyperparams"]["batch_size"]  # the job's batch, not a rank's share
-    for x, y in zip(a[1], b[1]):  # the same training up to the order of the atomics and each rank padding its own half of the batch: two trajectories, whose
-        assert abs(x - y) <= 0.3 * max(x, y), (a[1], b[1])  # printed losses are single steps (+-30 % from step to step once the batches differ); bit-for-bit: the CPU twin
+    assert a[0]["hyperparams"]["deterministic"] is True and b[0]["hyperparams"]["deterministic"] is True
+    for x, y in zip(a[1], b[1]):  # two trajectories (each rank pads its own half batch): printed losses are single steps, +-30 % from step to step once the batches differ
+        assert abs(x - y) <= 0.3 * max(x, y), (a[1], b[1])
     ea, eb = (np.frombuffer(q[0]["snapshot"]["params_binary"], np.float16).astype(np.float64) for q in (a, b))
     n_mlp = 3072 + 8192
-    # rank 0 wrote WHOLE weights: without sync_parameters() the other rank's chunks of the EMA weights would still hold their initial zeros. The two runs are two
-    # trajectories of a chaotic training (order of the atomics, each rank padding its own half batch): same live hash-grid entries, MLPs that point the same way
+    # rank 0 wrote WHOLE weights: without sync_parameters() the other rank's chunks of the EMA weights would still hold their initial zeros
     cos = float(ea[:n_mlp] @ eb[:n_mlp] / (np.linalg.norm(ea[:n_mlp]) * np.linalg.norm(eb[:n_mlp])))
     assert cos > 0.9, cos
     live_a, live_b = np.count_nonzero(ea[n_mlp:]), np.count_nonzero(eb[n_mlp:])
@@ -279,7 +279,7 @@ def test_testbed_cli_two_ranks_on_one_gpu(tmp_path, variant):
     for lo, hi in ((0, n_mlp // 2), (n_mlp // 2, n_mlp)):  # ... in both halves of every block
         assert np.count_nonzero(eb[lo:hi]) >= 0.9 * np.count_nonzero(ea[lo:hi])
     ga, gb = (np.frombuffer(q[0]["snapshot"]["density_grid_binary"], np.float16).astype(np.float32) for q in (a, b))
-    occ_a, occ_b = ga > 0.01, gb > 0.01  # (two trajectories: the shells agree in size, not cell by cell; the sharded update is checked bit for bit by the CPU twin)
+    occ_a, occ_b = ga > 0.01, gb > 0.01
     assert 0.7 * occ_a.sum() <= occ_b.sum() <= 1.3 * occ_a.sum() and np.mean(occ_a & occ_b) >= 0.5 * np.mean(occ_a), (occ_a.sum(), occ_b.sum())
 
 

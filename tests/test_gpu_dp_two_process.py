@@ -10,7 +10,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KW = dict(target_batch_size=1 << 14, max_rays_per_batch=1 << 14, initial_rays_per_batch=1024, apply_no_albedo=1)
+# rnb_config::deterministic: the hash-grid sums are exact integers and a two-rank sum a + b commutes, so the sharded and the replicated optimizer must agree BIT FOR BIT on every step
+# (rounds 2-5 compared two chaotic trajectories with tolerances)
+KW = dict(target_batch_size=1 << 14, max_rays_per_batch=1 << 14, initial_rays_per_batch=1024, apply_no_albedo=1, deterministic=1)
 
 
 class _GlooDeviceShardCollectives:
@@ -71,7 +73,7 @@ def _worker(rank, world, port, q):
         for i in range(40):
             a, b = tr_sh.step(), tr_rep.step()
             out["steps"].append((a.as_dict(), b.as_dict()))
-            if i == 0:  # same rays, same losses; the updates differ by the order of the fp32 atomics only
+            if i == 0:  # same rays, same losses, the same update
                 torch.cuda.synchronize()
                 out["first_w16_absdiff"] = float(np.abs(sh.get("PARAMS_FP16").astype(np.float32) - rep.get("PARAMS_FP16").astype(np.float32)).max())
         torch.cuda.synchronize()
@@ -125,16 +127,14 @@ def test_two_processes_share_the_gpu():
     for r in res:
         assert r["grads_clear"] and 0.45 < r["own_fraction"] < 0.55
         assert r["foreign_steps_before_sync"] == 0       # the other rank's chunks were never stepped here
-        assert r["first_w16_absdiff"] <= 4e-3            # one step: atomic order (a sum that rounds to +-tiny moves a weight by lr either way)
-        a, b = r["steps"][0]
-        for k in ("training_step", "rays_per_batch", "next_rays_per_batch", "measured_batch_size", "loss", "mask_loss", "ek_loss"):
-            assert a[k] == b[k], k
-        a, b = r["steps"][-1]
-        assert a["training_step"] == b["training_step"] == 40
-        assert abs(a["loss"] - b["loss"]) <= 0.25 * abs(b["loss"])
+        assert r["first_w16_absdiff"] == 0.0
+        for a, b in r["steps"]:  # sharded == replicated on every step, every statistic
+            for k in ("training_step", "rays_per_batch", "next_rays_per_batch", "measured_batch_size", "measured_batch_size_before_compaction", "n_rays_kept", "loss", "mask_loss", "ek_loss"):
+                assert a[k] == b[k], k
+        assert r["steps"][-1][0]["training_step"] == 40
     for (a0, _), (a1, _) in zip(r0["steps"], r1["steps"]):  # the ranks agree on every controller decision
         for k in ("training_step", "rays_per_batch", "next_rays_per_batch", "measured_batch_size", "loss"):
             assert a0[k] == a1[k], k
-    # training went somewhere and the two optimizers stayed together
-    d = np.abs(r0["w16"].astype(np.float32) - r0["w16_rep"].astype(np.float32))
-    assert np.mean(d > 1e-2) < 1e-3, float(np.mean(d > 1e-2))
+    # training went somewhere and the two optimizers are ONE trajectory
+    assert np.array_equal(r0["w16"].view(np.uint16), r0["w16_rep"].view(np.uint16))
+    assert r0["steps"][-1][0]["loss"] < r0["steps"][0][0]["loss"]
