@@ -263,6 +263,7 @@ struct Dist {
 	hipEvent_t ev_early = nullptr;
 #endif
 	double host7[7] = {0, 0, 0, 0, 0, 0, 0};
+	double* host7_pinned = nullptr; // RCCL transport: the step vector's readback, pinned (an async copy on s_vec; the staged transport's synchronous helper is for the tests)
 	bool synced = true; // no sharded update since the last sync_parameters()
 	static int env_int(const char* a, const char* b, int def) {
 		const char* v = std::getenv(a);
@@ -298,9 +299,14 @@ struct Dist {
 #endif
 		if (want_staged) {
 			const char* dir = std::getenv("RNB_DP_STAGE_DIR");
-			staged = new dist::StagedTransport(dir ? dir : "", world, rank, dist::MemOps{&Dist::mem_to_host, &Dist::mem_from_host});
+			if (!dir || !*dir) throw std::runtime_error("staged transport: RNB_DP_STAGE_DIR is not set");
+			// every job in a directory of its own (tools/launch_testbed.sh exports a fresh RNB_DP_JOB_ID per launch): a directory reused after a crashed or killed run still
+			// holds that run's last files and its `abort` marker, which the next job would fold into its sums or stop at
+			std::string job_dir = dir;
+			if (const char* job = std::getenv("RNB_DP_JOB_ID")) { ::mkdir(dir, 0777); job_dir += std::string("/job_") + job; }
+			staged = new dist::StagedTransport(job_dir, world, rank, dist::MemOps{&Dist::mem_to_host, &Dist::mem_from_host});
 			tr.reset(staged);
-			g_abort_file = std::string(dir) + "/abort";
+			g_abort_file = job_dir + "/abort";
 		} else {
 #ifdef RNB_WITH_RCCL
 			tr.reset(new RcclTransport(world, rank, std::getenv("RNB_RCCL_ID_FILE")));
@@ -314,6 +320,7 @@ struct Dist {
 		if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess ||
 		    hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess) throw std::runtime_error("stream creation failed");
 		s_main = a; s_early = b; s_vec = c;
+		if (!want_staged && hipHostMalloc((void**)&host7_pinned, 7 * sizeof(double), hipHostMallocDefault) != hipSuccess) throw std::runtime_error("hipHostMalloc failed");
 #endif
 	}
 	// sizes of ONE rank (dp.strong_scaling_sizes of the Python side)
@@ -379,6 +386,12 @@ struct Dist {
 		if (rc != RNB_OK) return rc;
 		char* vec = buffer(ctx, RNB_BUF_STEP_VECTOR);
 		tr->all_reduce(vec, 7, dist::F64, dist::SUM, CH_VEC, s_vec);
+#ifdef RNB_WITH_HIP
+		if (host7_pinned) { // product path: asynchronous on the channel's own stream into pinned memory (a pageable hipMemcpy goes through the null stream and waits for every blocking stream of the process)
+			if (hipMemcpyAsync(host7_pinned, vec, 7 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s_vec) != hipSuccess || hipStreamSynchronize((hipStream_t)s_vec) != hipSuccess) throw std::runtime_error("step vector readback failed");
+			std::memcpy(host7, host7_pinned, sizeof(host7));
+		} else
+#endif
 		mem_to_host(host7, vec, 7 * sizeof(double), s_vec);
 		for (int k = 0; k < 4; ++k) cnt[k] = (uint64_t)std::llround(host7[k]);
 		for (int k = 0; k < 3; ++k) sums[k] = host7[4 + k];

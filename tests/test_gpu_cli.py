@@ -285,34 +285,16 @@ def test_testbed_cli_two_ranks_on_one_gpu(tmp_path, accumulate):
 
 def test_testbed_trains_with_the_references_own_config_file(tmp_path):
     """`build/testbed --config <a file of the shape of the reference's configs/nerf/base.json>` (every key and value of it, rebuilt from
-    tests/golden/reference_config_keys.json) on the HIP library: parses, trains, and -- the keys this path does not read aside -- is the shipped base.json: the
-    same rays, the same compacted batch, the same first loss, the same sphere."""
+    tests/golden/reference_config_keys.json) on the HIP library: parses, trains, and -- the keys this path does not read aside -- IS the shipped base.json: with
+    `--deterministic` the two runs are one trajectory, every printed loss and the snapshot's weights and occupancy grid byte for byte (round 5: within 15 %)."""
     import json
-    import os
-    import subprocess
-    import msgpack
     from rnb_neus2_amd import synthetic
     from tests.test_testbed_cpu import reference_style_config
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "build", "testbed")
     cfg_path = tmp_path / "reference_base.json"
     cfg_path.write_text(json.dumps(reference_style_config(), indent=4))
-    views, normals, albedos = synthetic.make_scene(12, 200, 350.0)
-    out = {}
-    for name, extra in (("reference", ["--config", str(cfg_path)]), ("shipped", [])):
-        scene = str(tmp_path / name)
-        synthetic.write_scene(scene, views, normals, albedos, scale=2.0, offset=(0.5, 0.5, 0.5))
-        r = subprocess.run([exe, "--scene", scene + "/", "--maxiter", "300", "--no-gui", "--mask-weight", "1.0", "--no-albedo", "--save-mesh", "--resolution", "128", "--save-snapshot"] + extra,
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr + r.stdout
-        its = [float(l.split("loss=")[1]) for l in r.stdout.splitlines() if l.startswith("iteration=")]
-        with open(os.path.join(scene, "output", "snapshot_300.msgpack"), "rb") as f:
-            out[name] = (msgpack.unpackb(f.read(), raw=False), its)
-        v = np.array([[float(x) for x in l.split()[1:4]] for l in open(os.path.join(scene, "output", "mesh_300.obj")) if l.startswith("v ")])
-        rad = np.linalg.norm(v, axis=1)
-        assert abs(np.median(rad) - 0.125) < 0.006 and rad.std() < 0.01, (name, np.median(rad), rad.std())
-    a, b = out["reference"], out["shipped"]
+    data = synthetic.make_scene(12, 200, 350.0)
+    a = _run_testbed(tmp_path, "reference", data, ["--deterministic", "--config", str(cfg_path)], maxiter=300)
+    b = _run_testbed(tmp_path, "shipped", data, ["--deterministic"], maxiter=300)
     assert a[0]["snapshot"]["n_params"] == b[0]["snapshot"]["n_params"] == 10559396
     assert a[0]["globalmove"]["optimizer"]["nested"]["nested"]["learning_rate"] == 0.005 and a[0]["loss"]["otype"] == "Huber"
-    for x, y in zip(a[1], b[1]):
-        assert abs(x - y) <= 0.15 * max(x, y), (a[1], b[1])
+    _same_training(a, b)

@@ -204,25 +204,30 @@ def test_two_round_network_evaluation_is_exact(scene, trained):
         one.close()
 
 
-def test_overlapped_schedule_matches_serial_order(scene, trained):
-    """cfg.overlap only moves kernels onto side streams; the first step from a common state is identical down to the
-    per-ray losses, and later steps differ by the order of fp32 gradient atomics only."""
+@pytest.mark.parametrize("deterministic", [1, 0])
+def test_overlapped_schedule_matches_serial_order(scene, trained, deterministic):
+    """cfg.overlap only moves kernels onto side streams. deterministic = 1 (rnb_config::deterministic): the overlapped and the strictly serial schedule are ONE
+    trajectory -- 21 steps, every statistic, and the whole state at the end byte for byte. deterministic = 0 (floating-point atomics): the first step from a common state is
+    identical down to the losses and differs in the update by the order of the atomics only (the chaotic continuation is not compared: round 5 did, within 25 %)."""
     _, state = trained
-    ser = _clone(scene, state, overlap=0)
-    ovl = _clone(scene, state, overlap=1)
+    ser = _clone(scene, state, overlap=0, deterministic=deterministic)
+    ovl = _clone(scene, state, overlap=1, deterministic=deterministic)
     try:
         a, b = ser.train_step(), ovl.train_step()
-        for f in ("rays_per_batch", "measured_batch_size", "measured_batch_size_before_compaction", "n_rays_kept", "next_rays_per_batch", "training_step"):
+        fields = ("rays_per_batch", "measured_batch_size", "measured_batch_size_before_compaction", "n_rays_kept", "next_rays_per_batch", "training_step", "loss", "ek_loss", "mask_loss")
+        for f in fields:
             assert getattr(a, f) == getattr(b, f), f
-        assert a.loss == b.loss and a.ek_loss == b.ek_loss and a.mask_loss == b.mask_loss
         pa, pb = ser.get("PARAMS_FP32"), ovl.get("PARAMS_FP32")
-        d = np.abs(pa - pb)  # same update up to atomic summation order (a sum that rounds to +-tiny moves a parameter by lr either way)
-        assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5 and np.mean(pa != pb) < 0.2
-        for _ in range(20):
+        if not deterministic:
+            d = np.abs(pa - pb)  # same update up to atomic summation order (a sum that rounds to +-tiny moves a parameter by lr either way)
+            assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5 and np.mean(pa != pb) < 0.2
+            return
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+        for i in range(20):
             a, b = ser.train_step(), ovl.train_step()
-        assert a.training_step == b.training_step
-        assert abs(a.rays_per_batch - b.rays_per_batch) <= max(256, 0.02 * a.rays_per_batch)  # the controller rounds to multiples of 128
-        assert abs(a.loss - b.loss) <= 0.25 * max(a.loss, b.loss)
+            for f in fields:
+                assert getattr(a, f) == getattr(b, f), (i, f)
+        assert _state_digest(_state_of(ser, a)) == _state_digest(_state_of(ovl, b))
     finally:
         ser.close()
         ovl.close()
@@ -232,8 +237,8 @@ def test_data_parallel_hooks_single_rank(scene, trained):
     """The entry points a data-parallel caller uses (gradient blocks in completion order, device-side wait, optimizer on the
     early block, the step vector) driven by hand on one rank: same update as the plain sequence."""
     _, state = trained
-    plain = _clone(scene, state, overlap=1)
-    hooks = _clone(scene, state, overlap=1)
+    plain = _clone(scene, state, overlap=1, deterministic=1)  # (exact sums: the two call sequences must give the same bytes)
+    hooks = _clone(scene, state, overlap=1, deterministic=1)
     try:
         plain.train_step_begin()
         c0, s0 = plain.train_step_local()
@@ -255,8 +260,7 @@ def test_data_parallel_hooks_single_rank(scene, trained):
         hooks.train_step_apply()
         assert np.array_equal(c0, c1) and st0.loss == st1.loss and st0.next_rays_per_batch == st1.next_rays_per_batch
         pa, pb = plain.get("PARAMS_FP32"), hooks.get("PARAMS_FP32")
-        d = np.abs(pa - pb)  # same update up to the order of the fp32 atomics (a sum that rounds to +-tiny moves a parameter by lr either way)
-        assert d.max() <= 2.5e-3 and np.mean(d > 2e-5) < 1e-5, (float(d.max()), int((d > 2e-5).sum()))
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
         assert np.array_equal(plain.get("ADAM_STEPS"), hooks.get("ADAM_STEPS"))
         assert plain.training_step == hooks.training_step
         for _ in range(3):  # and the sequence keeps working

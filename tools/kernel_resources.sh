@@ -6,15 +6,24 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SO=$ROOT/rnb-neus2_amd/librnb_neus2_hip.so
-LLVM=/opt/rocm/lib/llvm/bin
+# the ROCm installation: ROCM_PATH, else where hipcc lives, else /opt/rocm (as rnb-neus2_amd/build.py resolves it)
+ROCM=${ROCM_PATH:-}
+if [ -z "$ROCM" ] && command -v hipcc >/dev/null 2>&1; then ROCM=$(dirname "$(dirname "$(readlink -f "$(command -v hipcc)")")"); fi
+[ -d "$ROCM/lib/llvm/bin" ] || ROCM=/opt/rocm
+LLVM=$ROCM/lib/llvm/bin
+ARCH=${RNB_OFFLOAD_ARCH:-gfx950}
+if [ ! -x "$LLVM/clang-offload-bundler" ] || [ ! -x "$LLVM/llvm-objdump" ]; then
+  echo "kernel_resources.sh: no clang-offload-bundler / llvm-objdump under $LLVM -- the code-object guards are SKIPPED (the library itself was built by hipcc)" >&2
+  exit 0
+fi
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
-$LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=<($LLVM/llvm-objcopy --dump-section .hip_fatbin=/dev/stdout "$SO") --output="$TMP/dev.co" --unbundle 2>/dev/null || {
+$LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--$ARCH --input=<($LLVM/llvm-objcopy --dump-section .hip_fatbin=/dev/stdout "$SO") --output="$TMP/dev.co" --unbundle 2>/dev/null || {
   $LLVM/llvm-objcopy --dump-section .hip_fatbin="$TMP/fat.bin" "$SO"
-  $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input="$TMP/fat.bin" --output="$TMP/dev.co" --unbundle
+  $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--$ARCH --input="$TMP/fat.bin" --output="$TMP/dev.co" --unbundle
 }
 if [ "$1" = "--check-no-pk-f32" ]; then
-  n=$($LLVM/llvm-objdump -d --mcpu=gfx950 "$TMP/dev.co" | grep -c -E 'v_pk_(mul|add|fma)_f32' || true)
+  n=$($LLVM/llvm-objdump -d --mcpu=$ARCH "$TMP/dev.co" | grep -c -E 'v_pk_(mul|add|fma)_f32' || true)
   echo "v_pk_*_f32 instructions in librnb_neus2_hip.so: $n"
   [ "$n" = "0" ]
   exit $?

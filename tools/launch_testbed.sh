@@ -8,6 +8,7 @@
 N=$1; shift
 ID=$(mktemp -u /tmp/rnb_rccl_id.XXXXXX)
 export HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+export RNB_DP_JOB_ID=${RNB_DP_JOB_ID:-$$.$(date +%s%N)}  # the staged test transport works in <RNB_DP_STAGE_DIR>/job_<id>: nothing a crashed earlier job left behind is ever read
 pids=()
 for ((r = 0; r < N; r++)); do
   RNB_WORLD_SIZE=$N RNB_RANK=$r RNB_LOCAL_RANK=$r RNB_RCCL_ID_FILE=$ID "$@" &
