@@ -176,6 +176,11 @@ __global__ void k_mean_final(const double* __restrict__ partial, const uint32_t 
 // set, are the reference's bit for bit.
 constexpr uint32_t COARSE_WORDS = GRID_CELLS / 64 / 32;
 constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup: 8 KB + 32 KB
+// Round 6: behind the image, COARSE_WORDS more words: the coarse bits DILATED by one block in every direction (a block's bit is set if it or any of its 26 neighbours is non-empty).
+// A point within 1/32 of a non-empty block (in every coordinate) reads a set bit there: k_march_count_skip samples a ray every 1/32 of its length against these words to find,
+// conservatively, the stretches of the ray that can hold samples at all.
+constexpr uint32_t COARSE_DIL_OFF = 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS;
+constexpr uint32_t COARSE_BUF_WORDS = COARSE_DIL_OFF + COARSE_WORDS;
 template <uint32_t NW = 16>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
 // One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
@@ -191,6 +196,18 @@ __device__ __forceinline__ void coarse_bitfield_body(const uint8_t* __restrict__
 	const uint32_t before = block_exclusive_scan(__popc(bits), lane, wave, wsum, total);
 	out[w] = bits;
 	out[COARSE_WORDS + w] = before;
+	__syncthreads(); // (every word of `out[0 .. COARSE_WORDS)` is written: a word is one x-row of blocks, w = y | z << 5)
+	{
+		const int y = (int)(w & 31u), z = (int)(w >> 5);
+		uint32_t acc = 0;
+		for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+			const int y2 = y + dy, z2 = z + dz;
+			if (y2 < 0 || y2 > 31 || z2 < 0 || z2 > 31) continue;
+			const uint32_t v = out[(uint32_t)y2 | ((uint32_t)z2 << 5)];
+			acc |= v | (v << 1) | (v >> 1);
+		}
+		out[COARSE_DIL_OFF + w] = acc;
+	}
 	uint2* blocks = reinterpret_cast<uint2*>(out + 2 * COARSE_WORDS);
 	uint32_t r = before;
 	for (uint32_t k = 0; k < 32; ++k) {
@@ -447,6 +464,7 @@ struct MarchArgs {
 	float* ray_const;   // [n_rays kept][RAY_CONST_FLOATS]
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
+	unsigned long long* stats; // RNB_MARCH_STATS=1 (measurement aid, k_march_count_skip): [0] wavefronts, [1] loop iterations, [2] rays, [3] rays that skipped, [4] start-overs, [5] rounds spent looking for a re-entry cell, [6] rays ended early
 };
 
 // SC: one cascade and no cone (aabb_scale 1, every RNb scene): dt is the constant step and every position inside the box is in
@@ -685,6 +703,266 @@ __global__ __launch_bounds__(WGS) void k_march_count_wide(const MarchArgs a) {
 		if (pend_src >= 0) pending_target = tgt;
 		if ((vis >> g) & 1ull) tt[j0 + __popcll(vis & ((1ull << g) - 1ull))] = my_t;
 		t_cur = t_end;
+	}
+	if (ray_exists && g == 0) {
+		float* st = a.setup + (size_t)i * 8;
+		st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
+		a.d_unnorm[(size_t)i * 3 + 0] = du.x; a.d_unnorm[(size_t)i * 3 + 1] = du.y; a.d_unnorm[(size_t)i * 3 + 2] = du.z;
+		a.steps[i] = j;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: k_march_count_wide<16, true> that SKIPS the stretches of a ray that cannot hold a sample -- the same sample set and the same t, bit for bit.
+//
+// What a ray costs above is its ~45 rounds of 16 march positions from the box entry to the box exit, of which 4-5 find occupied cells: the reference's march visits every
+// fine voxel on the way (its jump from an empty position lands on the first lattice position at or behind that voxel's exit, computed in fp32 FROM the position it jumped from),
+// and a bit-exact replay has to know, at the first occupied cell, which lattice position the chain arrives on. Two facts make the empty stretches skippable all the same:
+//  (1) WHERE: a set bit of the DILATED coarse occupancy (COARSE_DIL_OFF) at the 64 points startt + i / 32 of the ray marks, conservatively, every stretch
+//      [startt + (i - 1/2) / 32, startt + (i + 1/2) / 32) in which a position can be occupied (a point of the ray inside a non-empty 4^3 block is within 1/64 of a sample point,
+//      which then lies in that block or a neighbour). Rounds whose stretch -- and the one behind it -- has no set bit emit nothing; behind the last set bit the ray is over.
+//  (2) RE-ENTRY: let A be a cell ALL of whose lattice positions a .. b are in one round, with position b + 1 in another cell, and let every one of a .. b, taken as the visited
+//      position, jump to b + 1 (each lane computes exactly that jump for its own position: `nxt`). Then the reference's chain visits b + 1, whatever it did before: its last
+//      visited position v < b + 1 is either in A (and jumps to b + 1 by its own vote) or in a cell in front of A, whose exit is at or before position a up to an fp32 rounding
+//      of ~1e-6 of a march step -- it lands on a or a + 1, inside A (or on b + 1 itself if A is that one position). So behind a skip the kernel evaluates rounds WITHOUT replaying
+//      them until it finds such a cell (cells hold at most 9 positions: almost always the first round), and continues the exact replay from b + 1 with no pending jump.
+// A ray that finds no such cell before its next stretch of interest starts over from its box entry without skipping (measured: none in 10^6 rays; the path is tested by forcing it).
+// The lattice position behind n skipped steps is exact: inside a binade t + m d is exact (one fma: a multiple of the binade's ulp below the binade's end), across a binade
+// boundary the step is the reference's own addition.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lattice_advance(float t, int n) { // t_{k+n} of t_{k+1} = fl(t_k + MIN_CONE_STEPSIZE); t in [0.25, 8), MarchArgs::lattice_ok
+	while (n > 0) {
+		int e;
+		(void)frexpf(t, &e);
+		const float base = scalbnf(0.5f, e), hi = scalbnf(1.0f, e);
+		const float d = (base + MIN_CONE_STEPSIZE) - base;
+		int m = (int)floorf((hi - t) / d); // steps that stay below the binade's end: the largest m with t + m d < hi
+		m = max(m - 1, 0);
+		while (__builtin_fmaf((float)(m + 1), d, t) < hi) ++m;
+		if (n <= m) return __builtin_fmaf((float)n, d, t);
+		t = __builtin_fmaf((float)m, d, t);
+		n -= m;
+		t = t + MIN_CONE_STEPSIZE; // the step across the boundary: the reference's own addition
+		n -= 1;
+	}
+	return t;
+}
+
+template <int WGS = 256>
+__global__ __launch_bounds__(WGS) void k_march_count_skip(const MarchArgs a) {
+	constexpr int MG = 16;
+	constexpr bool SC = true;
+	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+	load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x);
+	uint32_t* dil = coarse_lds + 2 * COARSE_WORDS + 2 * a.n_blocks_lds;
+	for (uint32_t q = threadIdx.x; q < COARSE_WORDS; q += blockDim.x) dil[q] = a.coarse[COARSE_DIL_OFF + q];
+	__syncthreads();
+	constexpr uint64_t GM = (1ull << MG) - 1ull;
+	const uint32_t i = blockIdx.x * (WGS / MG) + (threadIdx.x / MG);
+	const int lane = threadIdx.x & 63;
+	const int g = lane & (MG - 1);
+	const int gb = lane & ~(MG - 1);
+	const bool ray_exists = i < a.n_rays;
+	Vec3 o = {0, 0, 0}, dir = {0, 0, 1}, du = {0, 0, 1}, idir = {0, 0, 1};
+	float t_cur = 0.f, startt = 0.f, alive = 0.f, t_exit = 0.f;
+	bool term = true;
+	if (ray_exists) {
+		const uint32_t gi = a.ray_offset + i;
+		const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+		const ViewDev m = a.views[img];
+		Pcg32 rng = a.rng;
+		rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+		float xy[2];
+		random_image_pos(rng, m.width, m.height, a.snap != 0, xy);
+		bool dead = false;
+		if (red_is_nonpositive(xy, m, m.normal)) {
+			if (rng.next_float() >= 0.9) dead = true; // testbed_nerf.cu:1264
+		}
+		if (!dead) {
+			(void)rng.next_float(); // motionblur_time
+			camera_ray(m, xy, o, du, dir);
+			idir = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+			float tmin, tmax;
+			ray_intersect(a.A, o, dir, &tmin, &tmax);
+			tmin = fmaxf(tmin, 0.0f);
+			startt = tmin;
+			startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
+			t_cur = startt;
+			t_exit = tmax;
+			alive = 1.f;
+			term = false;
+		}
+	}
+	// (1) the ray's stretches of interest: bit i = the dilated coarse occupancy at startt + i / 32 (the point clamped into the box: a sample point just outside the box still
+	// answers for the positions just inside it)
+	uint64_t interest = 0;
+	bool skipping = a.lattice_ok != 0;
+	{
+#pragma unroll
+		for (int it = 0; it < 4; ++it) {
+			const int k = g + 16 * it;
+			const float ts = startt + (float)k * (1.0f / 32.0f);
+			bool hit = false;
+			if (!term && ts <= t_exit + (1.5f / 32.0f)) {
+				const Vec3 p = o + ts * dir;
+				const int bx = min(max((int)(p.x * 32.0f), 0), 31), by = min(max((int)(p.y * 32.0f), 0), 31), bz = min(max((int)(p.z * 32.0f), 0), 31);
+				hit = (dil[(uint32_t)by | ((uint32_t)bz << 5)] >> bx) & 1u;
+			}
+			const unsigned long long w = __ballot(hit);
+			interest |= (((uint64_t)w >> gb) & GM) << (16 * it);
+		}
+		// a ray longer than 63 / 32 (the box diagonal is 55.4 / 32) cannot happen; if the last sample point is still inside the box, do not skip at all
+		if (!term && startt + (63.0f / 32.0f) < t_exit) skipping = false;
+	}
+	uint32_t j = 0;
+	bool have_pending = false;
+	float pending_target = 0.f;
+	bool anchoring = false;      // behind a skip: rounds are evaluated but not replayed until a cell with unanimous votes is found
+	float anchor_deadline = 0.f; // ... which has to happen before the round that starts here
+	const bool force_restart = (a.lattice_ok & 2u) != 0u; // RNB_MARCH_SKIP=2 (tests): no cell is ever accepted, every skipping ray takes the start-over path
+	float* tt = a.ray_t + (size_t)(ray_exists ? i : 0) * RNB_MAX_STEPS;
+	float bin_lo = 1.f, bin_hi = 0.f, dlt = 0.f, d2 = 0.f, inv_dlt = 0.f, inv_d2 = 0.f; // the binade of t_cur and its lattice steps (formed again when t_cur leaves it)
+	uint32_t st_iters = 0, st_skips = 0, st_restarts = 0, st_anchor_rounds = 0, st_early = 0;
+	while (__any(!term)) {
+		++st_iters;
+		// ---- skip / end decision (group-uniform: every lane of a ray holds the same state) ----
+		if (!term && skipping && !anchoring && t_cur >= 0.25f) {
+			const int i_first = max((int)floorf((t_cur - startt) * 32.0f) - 1, 0);
+			const uint64_t ahead = i_first < 64 ? (interest >> i_first) : 0ull;
+			if ((ahead & 0xFull) == 0ull) { // this round's stretch and the two behind it: nothing
+				if (ahead == 0ull) { term = true; st_early = 1; } // nothing ever again: the reference marches on to the box exit and emits nothing
+				else {
+					const int nb = i_first + __builtin_ctzll(ahead);
+					const float t_int = startt + ((float)nb - 0.5f) * (1.0f / 32.0f);
+					const int n = (int)floorf((t_int - 52.0f * MIN_CONE_STEPSIZE - t_cur) * (1.0f / MIN_CONE_STEPSIZE)) - 2;
+					if (n >= 32) {
+						t_cur = lattice_advance(t_cur, n);
+						anchoring = true;
+						++st_skips;
+						have_pending = false;
+						anchor_deadline = t_int - 17.0f * MIN_CONE_STEPSIZE;
+					}
+				}
+			}
+		}
+		if (!term && anchoring && t_cur > anchor_deadline) { // no unanimous cell in the window: this ray again, from its box entry, every round
+			anchoring = false; skipping = false; t_cur = startt; j = 0; have_pending = false;
+			++st_restarts;
+		}
+		if (!term && anchoring) ++st_anchor_rounds;
+		// ---- the round's 16 positions: the lattice in closed form, ACROSS a binade boundary too (k_march_count_wide takes 16-step running sums there, wave-wide; with the
+		// rays of a wavefront no longer in step that would be up to eight such rounds per wavefront). Positions 0 .. mb lie below the binade's end: t_cur + m d, exact; position
+		// mb + 1 is the reference's own addition across the boundary, tx = fl(T_mb + C); the positions behind it are tx + (m - mb - 1) d2 with the next binade's d2, exact.
+		if (!(t_cur >= bin_lo && t_cur < bin_hi)) {
+			int eb;
+			(void)frexpf(t_cur, &eb);
+			bin_lo = scalbnf(0.5f, eb); bin_hi = scalbnf(1.0f, eb);
+			dlt = (bin_lo + MIN_CONE_STEPSIZE) - bin_lo; d2 = (bin_hi + MIN_CONE_STEPSIZE) - bin_hi;
+			inv_dlt = __builtin_amdgcn_rcpf(dlt); inv_d2 = __builtin_amdgcn_rcpf(d2); // estimates: every candidate they yield is checked exactly
+		}
+		int mb = MG + 1; // the last position below bin_hi (MG + 1: all 17 of them)
+		if (!(t_cur + (float)MG * dlt < bin_hi)) {
+			mb = (int)floorf((bin_hi - t_cur) * inv_dlt);
+			mb = max(mb - 1, 0);
+			while (mb < MG && __builtin_fmaf((float)(mb + 1), dlt, t_cur) < bin_hi) ++mb;
+		}
+		const float tx = __builtin_fmaf((float)min(mb, MG), dlt, t_cur) + MIN_CONE_STEPSIZE;
+		auto lattice = [&](const int m) { return m <= mb ? __builtin_fmaf((float)m, dlt, t_cur) : __builtin_fmaf((float)(m - mb - 1), d2, tx); };
+		// the smallest m in [lo, MG) with lattice(m) >= target, else MG
+		auto first_at_or_after = [&](const float target, const int lo) {
+			int m = (int)floorf(fminf(fmaxf((target - t_cur) * inv_dlt, -2.f), 64.f));
+			m += (__builtin_fmaf((float)m, dlt, t_cur) < target) ? 1 : 0;
+			m = max(m, lo);
+			if (m > mb) {
+				int q = (int)floorf(fminf(fmaxf((target - tx) * inv_d2, -2.f), 64.f));
+				q += (__builtin_fmaf((float)q, d2, tx) < target) ? 1 : 0;
+				m = max(mb + 1 + max(q, 0), lo);
+			}
+			return min(m, MG);
+		};
+		const float my_t = lattice(g);
+		const float t_end = lattice(MG);
+		const Vec3 pos = o + my_t * dir;
+		const bool inside = !term && aabb_contains(a.A, pos);
+		bool occ = false;
+		float t_target = 0.f;
+		uint32_t nxt = MG;
+		if (inside) {
+			occ = occupied_mip0(pos, a.bitfield, coarse_lds, a.n_blocks_lds);
+			if (!occ) {
+				t_target = my_t + distance_to_next_voxel(pos, dir, idir, GRIDSIZE);
+				nxt = (uint32_t)first_at_or_after(t_target, g + 1);
+			}
+		}
+		const unsigned long long occ_w = __ballot(occ), in_w = __ballot(inside);
+		const uint64_t occ16 = ((uint64_t)occ_w >> gb) & GM, in16 = ((uint64_t)in_w >> gb) & GM;
+		// ---- (2) behind a skip: the first cell of this round with all its positions in the round, all empty, all voting for the position behind it ----
+		int start_cur = 0;
+		bool replay = !term && !anchoring;
+		if (__any(!term && anchoring)) { // (wave-uniform: most rounds have no ray looking for its way back in)
+			// the cell of the position (cascaded_grid_idx_at's integer coordinates, as occupied_mip0 forms them)
+			const int cx = min(max((int)(pos.x * GRIDSIZE), 0), (int)GRIDSIZE - 1), cy = min(max((int)(pos.y * GRIDSIZE), 0), (int)GRIDSIZE - 1), cz = min(max((int)(pos.z * GRIDSIZE), 0), (int)GRIDSIZE - 1);
+			const uint32_t cell = (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)cz << 14);
+			const uint32_t prev = (uint32_t)__shfl((int)cell, gb + max(g - 1, 0), 64);
+			const bool bnd = g > 0 && cell != prev; // a cell begins at this position (position 0: unknown, the cell may have begun in the round before)
+			const unsigned long long bnd_w = __ballot(bnd);
+			const uint32_t bnd16 = (uint32_t)(((uint64_t)bnd_w >> gb) & GM);
+			// my cell's first position a (the highest boundary at or below me) and the position behind its last one, u (the lowest boundary above me)
+			const uint32_t below = bnd16 & ((2u << g) - 1u), above = bnd16 & ~((2u << g) - 1u);
+			const int u = above ? __builtin_ctz(above) : MG;
+			const bool complete = below != 0u && u < MG;
+			const bool vote_ok = complete && inside && !occ && nxt == (uint32_t)u && ((in16 >> u) & 1ull);
+			const unsigned long long ok_w = __ballot(vote_ok);
+			const uint32_t ok16 = (uint32_t)(((uint64_t)ok_w >> gb) & GM);
+			if (!term && anchoring) {
+				// walk the round's cells in order (at most 15 boundaries): the first one whose positions all voted for the position behind it
+				uint32_t rest = bnd16;
+				while (rest) {
+					const int a0 = __builtin_ctz(rest);
+					rest &= rest - 1u;
+					if (!rest) break; // the last cell of the round has no end in it
+					const int u0 = __builtin_ctz(rest);
+					const uint32_t cellmask = ((1u << u0) - 1u) & ~((1u << a0) - 1u);
+					if (!force_restart && (ok16 & cellmask) == cellmask) { start_cur = u0; anchoring = false; replay = true; break; }
+				}
+			}
+		}
+		// ---- replay of the sequential visit order over this round's outcomes (as k_march_count_wide; start_cur: the position the chain is known to arrive on) ----
+		uint64_t vis = 0;
+		const uint32_t j0 = j;
+		int pend_src = -1;
+		if (replay) {
+			int cur = start_cur;
+			if (have_pending) {
+				cur = first_at_or_after(pending_target, 0);
+				if (cur < MG) have_pending = false;
+			}
+			while (cur < MG) {
+				if (!((in16 >> cur) & 1ull)) { term = true; break; }
+				if ((occ16 >> cur) & 1ull) {
+					const uint64_t run_mask = (occ16 & in16) >> cur;
+					int run = __builtin_ctzll(~run_mask);
+					run = min(run, MG - cur);
+					const int allowed = min(run, (int)(RNB_MAX_STEPS - j));
+					vis |= ((1ull << allowed) - 1ull) << cur;
+					j += (uint32_t)allowed;
+					cur += allowed;
+					if (j >= RNB_MAX_STEPS) { term = true; break; }
+				} else {
+					const int nx = (int)__shfl(nxt, gb + cur, 64);
+					if (nx >= MG) { have_pending = true; pend_src = cur; }
+					cur = nx;
+				}
+			}
+		}
+		const float tgt = __shfl(t_target, gb + (pend_src < 0 ? 0 : pend_src), 64);
+		if (pend_src >= 0) pending_target = tgt;
+		if ((vis >> g) & 1ull) tt[j0 + __popcll(vis & ((1ull << g) - 1ull))] = my_t;
+		t_cur = t_end;
+	}
+	if (a.stats) {
+		if (lane == 0) { atomicAdd(a.stats + 0, 1ull); atomicAdd(a.stats + 1, (unsigned long long)st_iters); }
+		if (ray_exists && g == 0) { atomicAdd(a.stats + 2, 1ull); atomicAdd(a.stats + 3, (unsigned long long)(st_skips != 0)); atomicAdd(a.stats + 4, (unsigned long long)st_restarts); atomicAdd(a.stats + 5, (unsigned long long)st_anchor_rounds); atomicAdd(a.stats + 6, (unsigned long long)st_early); }
 	}
 	if (ray_exists && g == 0) {
 		float* st = a.setup + (size_t)i * 8;

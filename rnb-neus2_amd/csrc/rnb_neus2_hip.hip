@@ -143,6 +143,7 @@ struct rnb_ctx {
 	bool bitfield_foreign = false; // a caller may have written the bitfield: levels >= 1 are not known to be zero outside the pooled supports (update_bitfield takes the zero-filling kernels once)
 	DevBuf<double> mean_partial, loss_sums;
 	DevBuf<uint8_t> bitfield;
+	DevBuf<unsigned long long> march_stats; // RNB_MARCH_STATS=1: k_march_count_skip's counters, printed by rnb_destroy
 	DevBuf<uint32_t> coarse_bits, coarse_count; // k_coarse_bitfield: cascade 0's occupancy in the form the march kernels keep in LDS; its number of non-empty blocks
 	bool coarse_valid = false;
 	uint32_t* host_coarse = nullptr; // mapped host memory: k_coarse_bitfield's block count as last written by the device (0xffffffff: never)
@@ -234,6 +235,7 @@ struct rnb_ctx {
 		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
 		                            // few long rays: 0.6078 -> 0.5971 ms/step at step 1000, 0.5900 -> 0.5929 at 2000, 0.6334 -> 0.6360 at 6000 (profiles/r05_ab_scatter_rl_staged.txt).
 		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
+		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
 		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
 		int scatter_kmin = 0, scatter_rl_upto = 0; // RNB_SCATTER_KMIN, RNB_SCATTER_RL_UPTO (A/B, plan_scatter_groups)
 		bool scatter_anyorder = true;  // RNB_SCATTER_ANYORDER=1 (A/B): the scatter groups behind the first one are launched with hipExtAnyOrderLaunch -- they touch other levels, so a group may start in the tail of the one in front of it
@@ -705,6 +707,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	for (int k = 0; k < 9; ++k) a.light_dirs[k] = c->light_dirs[k];
 	a.ray_const = c->ray_const.p;
 	a.part = 0;
+	a.stats = c->march_stats.p;
 	return a;
 }
 
@@ -728,7 +731,12 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		hipLaunchKernelGGL((k_march_count_wide<64, true, 256>), dim3((n_rays + 3) / 4), dim3(256), march_lds, s, a);
 	} else {
 		const dim3 grid((n_rays + 15) / 16); // 16 lanes per ray (8: 0.19 ms alone but a slower step; 32: 0.32 ms, measured in round 1)
-		if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), march_lds, s, a);
+		if (sc && c->knobs.march_skip && a.lattice_ok) {
+			// round 6: the same rounds, minus the stretches of the ray that cannot hold a sample (kernels_ray.cuh: k_march_count_skip); bit-identical sample set and t
+			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u;
+			hipLaunchKernelGGL((k_march_count_skip<256>), grid, dim3(256), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			a.lattice_ok &= 1u;
+		} else if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), march_lds, s, a);
 		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
 	}
 	c->prof.mark(s, P_MARCH_COUNT);
@@ -1316,6 +1324,14 @@ int rnb_default_config(rnb_config* cfg) try {
 
 int rnb_destroy(rnb_ctx* c) try {
 	if (!c) return RNB_OK;
+	if (c->march_stats.p) { // RNB_MARCH_STATS=1
+		unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		(void)hipDeviceSynchronize();
+		if (hipMemcpy(h, c->march_stats.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0])
+			fprintf(stderr, "k_march_count_skip: %llu wavefronts, %.2f loop iterations each; %llu rays: %.3f skipped at least once, %.3f ended early, %.5f start-overs per ray, %.3f rounds per ray looking for a re-entry cell\n",
+			        h[0], (double)h[1] / h[0], h[2], (double)h[3] / h[2], (double)h[6] / h[2], (double)h[4] / h[2], (double)h[5] / h[2]);
+		c->march_stats.free();
+	}
 	c->opt_rec.free(); c->params_fp32.free(); c->grads.free(); c->grads16.free(); c->grads_fixed.free(); c->adam_m.free(); c->adam_v.free(); c->params_fp16.free(); c->params_ema.free(); c->adam_steps.free(); c->adam_lr_table.free();
 	c->density_grid.free(); c->density_grid_tmp.free(); c->density_grid_tmp_alt.free(); c->density_mean.free(); c->mean_partial.free(); c->loss_sums.free(); c->bitfield.free(); c->coarse_bits.free(); c->coarse_count.free();
 	c->grid_sample_pos.free(); c->grid_sample_idx.free(); c->views.free(); c->pixels.free();
@@ -1387,6 +1403,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	do {                                                                                                               \
 		if ((buf).alloc_padded(c->n_params, c->param_capacity) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed for " #buf); } \
 	} while (0)
+	if (getenv("RNB_MARCH_STATS")) { if (c->march_stats.alloc_padded(8, 8) != hipSuccess) { rnb_destroy(c); return fail(RNB_ERR_NOMEM, "hipMalloc failed"); } }
 	ALLOC(c->adam_lr_table, ADAM_LR_TABLE_N);
 	ALLOC(c->opt_rec, c->param_capacity * 4);
 	if (cfg->accumulate == RNB_ACCUM_HALF) ALLOC_P(c->grads16); else ALLOC_P(c->grads);
@@ -1396,7 +1413,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	ALLOC_P(c->params_fp32); ALLOC_P(c->adam_m); ALLOC_P(c->adam_v); ALLOC_P(c->params_fp16); ALLOC_P(c->params_ema); ALLOC_P(c->adam_steps);
 #undef ALLOC_P
 	ALLOC(c->density_grid, n_grid); ALLOC(c->density_grid_tmp, n_grid); ALLOC(c->density_grid_tmp_alt, n_grid); ALLOC(c->density_mean, 1); ALLOC(c->mean_partial, 1024); ALLOC(c->loss_sums, 16);
-	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS); ALLOC(c->coarse_count, 1);
+	ALLOC(c->bitfield, (size_t)GRID_CELLS / 8 * N_CASCADES); ALLOC(c->coarse_bits, COARSE_BUF_WORDS); ALLOC(c->coarse_count, 1);
 	ALLOC(c->grid_sample_pos, (size_t)n_grid * 3); ALLOC(c->grid_sample_idx, n_grid);
 	ALLOC(c->ray_indices, maxr); ALLOC(c->numsteps, (size_t)maxr * 2); ALLOC(c->counters, 4); ALLOC(c->rays, (size_t)maxr * 6);
 	ALLOC(c->coords, (size_t)B * 16 * 7); ALLOC(c->mlp_out, (size_t)B * 16 * 16); ALLOC(c->chain_rec, (size_t)B * 16 * CHAIN_REC_FLOATS); ALLOC(c->ray_grad, (size_t)maxr * 16); ALLOC(c->ray_of, B); ALLOC(c->slot_of, B); ALLOC(c->wg_partial, ((size_t)maxr + 15) / 16 * 3); ALLOC(c->dloss_dout, (size_t)B * 16); ALLOC(c->coords_compacted, (size_t)B * 7);
@@ -1464,6 +1481,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
 	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1505,6 +1523,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_RL_STAGED")) k.scatter_rl_staged = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_ANYORDER")) k.scatter_anyorder = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_SHARE")) k.scatter_share = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_SKIP")) k.march_skip = std::max(0, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}

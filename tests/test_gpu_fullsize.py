@@ -887,7 +887,7 @@ def early(scene):
     """The state at step 256: the batch is still a few thousand long rays, so the march is the one-wavefront-per-ray kernel (k_march_count_wide<64>, batches of <= 4096 rays:
     the first steps of every run and every rank of a strong-scaling job) -- a kernel whose ballot masks live in SGPRs the compiler spills through VGPR lanes."""
     import rnb_neus2_amd as rnb
-    ctx = rnb.Context(overlap=0, **KW)
+    ctx = rnb.Context(overlap=0, deterministic=1, **KW)  # (pinned like the other states of this file)
     ctx.init_params()
     ctx.set_dataset(*scene)
     st = None
@@ -896,6 +896,37 @@ def early(scene):
     state = _state_of(ctx, st)
     ctx.close()
     return state
+
+
+@pytest.mark.parametrize("regime", ["window", "early", "late"])
+def test_skipping_march_equals_the_full_march(scene, states, early, regime):
+    """k_march_count_skip (round 6: the 16-lanes-per-ray march minus the stretches of a ray that cannot hold a sample, re-entering the reference's visit chain through a cell whose
+    positions all jump to the same lattice position) against k_march_count_wide<16> marching every round from box entry to box exit (RNB_MARCH_SKIP=0), and against itself with
+    the start-over path forced for every skipping ray (RNB_MARCH_SKIP=2): counters, per-ray sample counts and slots, every coordinate word of every sample -- at the occupancy of
+    step 256 (a volume: few empty stretches), of the window (a shell) and of step 6000 (a thin shell), for batches of 512 ... 18 000 rays (the kernel's range) and three ray-generator
+    positions each."""
+    state = early if regime == "early" else states[regime]
+    ref = None
+    for mode in ("0", "1", "2"):
+        c = _clone(scene, state, env={"RNB_MARCH_SKIP": mode}, overlap=0)
+        try:
+            got = []
+            for n_rays, n_total in ((512, 0), (4096, 123456), (12416, 7), (18000, 40000 * 64)):
+                c.generate_training_samples(n_rays, n_total)
+                cnt = c.get("COUNTERS").copy()
+                kept = int(cnt[2])
+                ns = c.get("NUMSTEPS", 2 * kept).copy()
+                coords = c.get("COORDS", int(cnt[3]) * 7).copy()
+                assert kept > 0 and cnt[3] > 0
+                got.append((cnt, ns, c.get("RAY_INDICES", kept).copy(), coords.view(np.uint32)))
+        finally:
+            c.close()
+        if ref is None:
+            ref = got
+            continue
+        for (c0, n0, r0, x0), (c1, n1, r1, x1) in zip(ref, got):
+            assert np.array_equal(c0, c1) and np.array_equal(n0, n1) and np.array_equal(r0, r1), mode
+            assert np.array_equal(x0, x1), mode
 
 
 @pytest.mark.parametrize("regime", ["window", "early"])

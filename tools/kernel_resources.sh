@@ -30,7 +30,7 @@ if [ "$1" = "--check-no-pk-f32" ]; then
 fi
 if [ "$1" = "--check-march-no-sgpr-spill" ]; then
   # the single-cascade march kernels that run on the side stream beside the backward pass keep no scalar register in VGPR lanes (the other half of round 1's hazard)
-  bad=$($LLVM/llvm-readelf --notes "$TMP/dev.co" | awk '/\.name:/ {name=$2} /\.sgpr_spill_count:/ {ssp=$2} /\.wavefront_size:/ { if (name ~ /k_march_count_wideILi(16|64)ELb1E/ && ssp + 0 > 0) print name, ssp }')
+  bad=$($LLVM/llvm-readelf --notes "$TMP/dev.co" | awk '/\.name:/ {name=$2} /\.sgpr_spill_count:/ {ssp=$2} /\.wavefront_size:/ { if (name ~ /(k_march_count_wideILi(16|64)ELb1E|k_march_count_skip)/ && ssp + 0 > 0) print name, ssp }')
   echo "single-cascade k_march_count_wide instances with SGPR spills: ${bad:-none}"
   [ -z "$bad" ]
   exit $?
