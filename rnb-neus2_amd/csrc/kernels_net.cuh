@@ -133,9 +133,21 @@ __device__ __forceinline__ void copy_weight_image(half_t* __restrict__ dst, cons
 // and the 112 gathers of one sample hide behind those of the others. Results are those of k_forward_chained's sdf channel.
 constexpr int PQ2_WAVE_HALFS = TILE * S32 + TILE;
 constexpr size_t LDS_POINT2 = (size_t)(W_S0T + WAVES_PER_WG * PQ2_WAVE_HALFS) * sizeof(half_t);
+// -DRNB_POISON_LDS (tools/lds_poison_check.sh, never shipped): the MFMA kernels begin by filling their dynamic LDS with the half NaN pattern 0x7e00 (as fp32: 4.3e37). A kernel that
+// reads only what it has written computes what it computes without the fill; one that reads a tile, a padding column or a weight slot it never wrote shows NaNs or another result.
+__device__ __forceinline__ void poison_lds(char* smem_raw, const size_t bytes, const int tid, const int nthreads) {
+#ifdef RNB_POISON_LDS
+	uint32_t* w = reinterpret_cast<uint32_t*>(smem_raw);
+	for (uint32_t q = (uint32_t)tid; q < (uint32_t)(bytes / 4); q += (uint32_t)nthreads) w[q] = 0x7e007e00u;
+	__syncthreads();
+#else
+	(void)smem_raw; (void)bytes; (void)tid; (void)nthreads;
+#endif
+}
 
 template <bool EMU, int PIPE_DEPTH = 0>
 __device__ __forceinline__ void point_query_chained_body(const GridMeta& G, const NetW& net, const PointArgs& a, const half_t* __restrict__ wimg, char* smem_raw, LevelMeta* lm) {
+	poison_lds(smem_raw, LDS_POINT2, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
@@ -220,6 +232,7 @@ constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS)
 
 template <bool EMU, int PIPE_DEPTH = 0>
 __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const NetW& net, const FwdArgs& a, char* smem_raw, LevelMeta* lm) {
+	poison_lds(smem_raw, LDS_FWD2, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	fill_level_meta(lm, G, threadIdx.x);
 	const uint32_t n_levels = G.n_levels, valid_level = G.valid_level;
@@ -799,6 +812,7 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 // summation order is this kernel's tiling, not the reference's split-K slices (deviation D1').
 template <bool FULL, bool EMU = false>
 __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& net, const TrainArgs& a, char* smem_raw, LevelMeta* lm) {
+	poison_lds(smem_raw, FULL ? LDS_FBS_FULL : LDS_FBS, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	constexpr int W_END = FULL ? SWF_END : SW_END;
 	fill_level_meta(lm, G, threadIdx.x);
