@@ -35,10 +35,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_TRAFFIC, PMC_UNITS = "r05_pmc_traffic.json", "r05_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
-PMC_FALLBACK = {"r05_pmc_traffic.json": "r04_pmc_traffic.json", "r05_pmc_units.json": "r04_pmc_units.json"}
+PMC_TRAFFIC, PMC_UNITS = "r06_pmc_traffic.json", "r06_pmc_units.json"  # summaries of the separate rocprofv3 --pmc passes (tools/collect_pmc.sh)
+PMC_FALLBACK = {"r06_pmc_traffic.json": "r05_pmc_traffic.json", "r06_pmc_units.json": "r05_pmc_units.json"}
 # committed rocprofv3 summaries of this same command from which every `frac` of the record can be recomputed (profiles/README.md)
-PROFILE_FILES = {"kernel_trace_serial": "profiles/r05_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r05_steady_overlapped_step1000.json",
+PROFILE_FILES = {"kernel_trace_serial": "profiles/r06_steady_serial_step2000.json", "kernel_trace_overlapped": "profiles/r06_steady_overlapped_step1000.json",
                  "pmc_traffic": "profiles/" + PMC_TRAFFIC, "pmc_units": "profiles/" + PMC_UNITS, "counter_calibration": "profiles/r05_counter_calibration.json"}
 # What FETCH_SIZE means on gfx950, calibrated on this path's own access patterns (tools/probe_counters.hip -> profiles/r05_counter_calibration.json): the counter is the L2's
 # memory-side read REQUESTS x 64 B. A scattered 8-byte gather is one 64-byte request (p_gather8_far: 64.0 B counted per gather = the bytes moved: x1); a coalesced stream is
