@@ -980,6 +980,139 @@ __global__ __launch_bounds__(WGS) void k_march_count_skip(const MarchArgs a) {
 	}
 }
 
+// The same two facts for the ONE-THREAD-PER-RAY march (k_march_count<true>, batches from 18 432 rays on: the window's second half and the late regime, where a ray holds ~20 marched
+// samples and ~220 visited empty voxels). A thread walks the reference's loop itself, so its chain state is always exact; when the stretch in front of it is clear for at least 32 steps
+// (and safely inside the box) it jumps to 52 steps in front of the next stretch of interest and looks, position by position, for the re-entry cell: a cell whose FIRST lattice position
+// it has seen (a cell change behind the jump target), all of whose positions are empty and jump to the position behind the cell's last one. If it finds none within 48 positions it has
+// changed nothing: it goes on from where it stood, every voxel, and does not try again on this ray.
+template <typename F>
+__device__ __forceinline__ uint32_t march_skip_narrow(const MarchArgs& a, const uint32_t* __restrict__ coarse_lds, const uint32_t* __restrict__ dil, const Vec3& o, const Vec3& dir,
+                                                      const float startt, const float t_exit, unsigned long long* __restrict__ stats, F&& emit) {
+	const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	// bit i: the dilated coarse occupancy at startt + i / 32 (see k_march_count_skip)
+	uint64_t interest = 0;
+	bool skipping = a.lattice_ok != 0 && !(startt + (63.0f / 32.0f) < t_exit);
+	if (skipping) {
+		const int n_pts = min(64, (int)((t_exit - startt) * 32.0f) + 3);
+#pragma unroll 1
+		for (int k = 0; k < n_pts; ++k) {
+			const Vec3 p = o + (startt + (float)k * (1.0f / 32.0f)) * dir;
+			const int bx = min(max((int)(p.x * 32.0f), 0), 31), by = min(max((int)(p.y * 32.0f), 0), 31), bz = min(max((int)(p.z * 32.0f), 0), 31);
+			interest |= (uint64_t)((dil[(uint32_t)by | ((uint32_t)bz << 5)] >> bx) & 1u) << k;
+		}
+	}
+	const bool force_fail = (a.lattice_ok & 2u) != 0u; // RNB_MARCH_SKIP=2 (tests): no re-entry cell is ever accepted
+	const float mlo = a.A.mn + 1e-4f, mhi = a.A.mx - 1e-4f;
+	auto safely_inside = [&](const Vec3& p) { return p.x > mlo && p.x < mhi && p.y > mlo && p.y < mhi && p.z > mlo && p.z < mhi; };
+	auto cell_of = [&](const Vec3& p) {
+		const int cx = min(max((int)(p.x * GRIDSIZE), 0), (int)GRIDSIZE - 1), cy = min(max((int)(p.y * GRIDSIZE), 0), (int)GRIDSIZE - 1), cz = min(max((int)(p.z * GRIDSIZE), 0), (int)GRIDSIZE - 1);
+		return (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)cz << 14);
+	};
+	uint32_t j = 0, n_skips = 0, n_fail = 0, n_early = 0;
+	float t = startt;
+	Vec3 pos;
+	while (aabb_contains(a.A, pos = o + t * dir) && j < RNB_MAX_STEPS) {
+		if (skipping && t >= 0.25f) {
+			const int i_first = max((int)floorf((t - startt) * 32.0f) - 1, 0);
+			const uint64_t ahead = i_first < 64 ? (interest >> i_first) : 0ull;
+			if ((ahead & 0xFull) == 0ull) {
+				if (ahead == 0ull) { n_early = 1; break; } // nothing ever again: the reference marches on (or ends at a position outside the box) and emits nothing
+				const int nb = i_first + __builtin_ctzll(ahead);
+				const float t_int = startt + ((float)nb - 0.5f) * (1.0f / 32.0f);
+				const int n = (int)floorf((t_int - 52.0f * MIN_CONE_STEPSIZE - t) * (1.0f / MIN_CONE_STEPSIZE)) - 2;
+				if (n >= 32 && safely_inside(pos)) {
+					float tq = lattice_advance(t, n);
+					Vec3 pq = o + tq * dir;
+					if (safely_inside(pq)) {
+						// the re-entry cell: positions tq, tq + dt, ... (the reference's own additions); `first` = the first position of the cell being examined (-1: its first position was not seen)
+						uint32_t prev_cell = cell_of(pq);
+						float cell_first = -1.f, t_prev = tq;
+						bool cell_ok = false;     // every position of the examined cell so far is inside, empty ...
+						float max_target = 0.f;   // ... and the latest of their jump targets (all must land on the position behind the cell: t_last < target <= t_next for every one of them)
+						float min_target = 3.0e38f;
+						bool found = false;
+#pragma unroll 1
+						for (int k = 1; k < 48; ++k) {
+							// votes of position t_prev (in the examined cell, if one is open)
+							if (cell_first >= 0.f) {
+								const bool in = aabb_contains(a.A, pq);
+								const bool occ = in && occupied_mip0(pq, a.bitfield, coarse_lds, a.n_blocks_lds);
+								const float target = t_prev + distance_to_next_voxel(pq, dir, idir, GRIDSIZE);
+								cell_ok = cell_ok && in && !occ;
+								max_target = fmaxf(max_target, target); min_target = fminf(min_target, target);
+							}
+							const float t_next = t_prev + MIN_CONE_STEPSIZE;
+							const Vec3 p_next = o + t_next * dir;
+							const uint32_t c_next = cell_of(p_next);
+							if (c_next != prev_cell) {
+								// t_prev was the cell's last position, t_next is the position behind it: every vote must satisfy t_prev < target <= t_next
+								if (cell_first >= 0.f && cell_ok && min_target > t_prev && max_target <= t_next && aabb_contains(a.A, p_next) && !force_fail) { tq = t_next; found = true; break; }
+								cell_first = t_next; cell_ok = true; max_target = 0.f; min_target = 3.0e38f; // the next cell starts here: its first position is seen
+								prev_cell = c_next;
+							}
+							t_prev = t_next; pq = p_next;
+							if (t_prev > t_int - 17.0f * MIN_CONE_STEPSIZE) break;
+						}
+						if (found) { t = tq; ++n_skips; continue; } // t is a position the reference's chain visits: go on from it
+						skipping = false; ++n_fail;                 // nothing was changed: every voxel from here on
+					}
+				}
+			}
+		}
+		if (occupied_mip0(pos, a.bitfield, coarse_lds, a.n_blocks_lds)) {
+			emit(j, pos, MIN_CONE_STEPSIZE, t);
+			++j;
+			t += MIN_CONE_STEPSIZE;
+		} else {
+			const float t_target = t + distance_to_next_voxel(pos, dir, idir, GRIDSIZE);
+			do { t += MIN_CONE_STEPSIZE; } while (t < t_target);
+		}
+	}
+	if (stats) { atomicAdd(stats + 2, 1ull); atomicAdd(stats + 3, (unsigned long long)(n_skips != 0)); atomicAdd(stats + 4, (unsigned long long)n_fail); atomicAdd(stats + 6, (unsigned long long)n_early); }
+	return j;
+}
+
+__global__ __launch_bounds__(128) void k_march_count_skip_narrow(const MarchArgs a) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+	load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x);
+	uint32_t* dil = coarse_lds + 2 * COARSE_WORDS + 2 * a.n_blocks_lds;
+	for (uint32_t q = threadIdx.x; q < COARSE_WORDS; q += blockDim.x) dil[q] = a.coarse[COARSE_DIL_OFF + q];
+	__syncthreads();
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays) return;
+	const uint32_t gi = a.ray_offset + i;
+	const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+	const ViewDev m = a.views[img];
+	Pcg32 rng = a.rng;
+	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+	float xy[2];
+	random_image_pos(rng, m.width, m.height, a.snap != 0, xy);
+	uint32_t steps = 0;
+	float alive = 0.f;
+	Vec3 o = {0, 0, 0}, dir = {0, 0, 1}, du = {0, 0, 1};
+	float startt = 0.f;
+	bool dead = false;
+	if (red_is_nonpositive(xy, m, m.normal)) {
+		if (rng.next_float() >= 0.9) dead = true; // testbed_nerf.cu:1264, short-circuit draw
+	}
+	if (!dead) {
+		(void)rng.next_float(); // motionblur_time, testbed_nerf.cu:1270
+		camera_ray(m, xy, o, du, dir);
+		float tmin, tmax;
+		ray_intersect(a.A, o, dir, &tmin, &tmax);
+		tmin = fmaxf(tmin, 0.0f);
+		startt = tmin;
+		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
+		alive = 1.f;
+		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
+		steps = march_skip_narrow(a, coarse_lds, dil, o, dir, startt, tmax, a.stats, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
+	}
+	float* st = a.setup + (size_t)i * 8;
+	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
+	a.d_unnorm[(size_t)i * 3 + 0] = du.x; a.d_unnorm[(size_t)i * 3 + 1] = du.y; a.d_unnorm[(size_t)i * 3 + 2] = du.z;
+	a.steps[i] = steps;
+}
+
 // Single-workgroup exclusive scans over the rays (n <= 2^18): base = scan(steps); survivors = base + steps <= max_samples;
 // slot = scan(survivor). counters[0] = sum(steps) (numsteps_counter), [2] = #survivors (ray_counter), [3] = samples written.
 // Exclusive prefix sums over the rays, tile by tile (1024 coalesced elements per tile, wave shuffles + one LDS hop):

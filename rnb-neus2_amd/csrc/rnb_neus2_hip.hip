@@ -235,6 +235,9 @@ struct rnb_ctx {
 		                            // which is what the staging removes); in the step the staged form's 40 registers and 32 KB of LDS leave the march beside it more of the CU while the batch is
 		                            // few long rays: 0.6078 -> 0.5971 ms/step at step 1000, 0.5900 -> 0.5929 at 2000, 0.6334 -> 0.6360 at 6000 (profiles/r05_ab_scatter_rl_staged.txt).
 		                            // Default: staged below march_narrow_from rays per step (the regime of the A-B-C scatter order), direct from there on
+		bool march_skip_narrow = false; // RNB_MARCH_SKIP_NARROW=1: the same skipping in the one-thread-per-ray march of the large batches. Bit-identical (tests, 6100 lockstep steps) and SLOWER: k_march_count 192 -> 221 us
+		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
+		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
 		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
 		int scatter_kmin = 0, scatter_rl_upto = 0; // RNB_SCATTER_KMIN, RNB_SCATTER_RL_UPTO (A/B, plan_scatter_groups)
@@ -723,7 +726,11 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	const bool sc = c->aabb.cone_angle == 0.f && c->aabb.max_cascade == 0; // one cascade, constant step: the specialised instances
 	const size_t march_lds = sc ? (size_t)(2 * COARSE_WORDS + 2 * a.n_blocks_lds) * sizeof(uint32_t) : 0;
 	if (c->knobs.march_narrow || n_rays >= c->knobs.march_narrow_from) {
-		if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
+		if (sc && c->knobs.march_skip && c->knobs.march_skip_narrow && a.lattice_ok) { // RNB_MARCH_SKIP_NARROW=1 (dropped, kept as an A/B knob): the thread-per-ray march minus the stretches that cannot hold a sample (kernels_ray.cuh: march_skip_narrow)
+			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u;
+			hipLaunchKernelGGL(k_march_count_skip_narrow, dim3(blocks), dim3(128), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			a.lattice_ok &= 1u;
+		} else if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
 	} else if (sc && n_rays <= c->knobs.march_wave_per_ray_below) {
 		// a batch so small that 16 lanes per ray leave most SIMDs without a wavefront (a rank of a strong-scaling job: 1.8 k rays = 0.4 wavefronts per SIMD): the kernel
@@ -1482,6 +1489,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
 	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1524,6 +1532,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_ANYORDER")) k.scatter_anyorder = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_SHARE")) k.scatter_share = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_SKIP")) k.march_skip = std::max(0, std::min(2, atoi(e)));
+		if (const char* e = getenv("RNB_MARCH_SKIP_NARROW")) k.march_skip_narrow = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}

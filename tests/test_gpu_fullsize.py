@@ -903,15 +903,15 @@ def test_skipping_march_equals_the_full_march(scene, states, early, regime):
     """k_march_count_skip (round 6: the 16-lanes-per-ray march minus the stretches of a ray that cannot hold a sample, re-entering the reference's visit chain through a cell whose
     positions all jump to the same lattice position) against k_march_count_wide<16> marching every round from box entry to box exit (RNB_MARCH_SKIP=0), and against itself with
     the start-over path forced for every skipping ray (RNB_MARCH_SKIP=2): counters, per-ray sample counts and slots, every coordinate word of every sample -- at the occupancy of
-    step 256 (a volume: few empty stretches), of the window (a shell) and of step 6000 (a thin shell), for batches of 512 ... 18 000 rays (the kernel's range) and three ray-generator
-    positions each."""
+    step 256 (a volume: few empty stretches), of the window (a shell) and of step 6000 (a thin shell), for batches of 512 ... 92 672 rays (both skipping kernels: 16 lanes per ray
+    below 18 432 rays, one thread per ray from there on)."""
     state = early if regime == "early" else states[regime]
     ref = None
     for mode in ("0", "1", "2"):
-        c = _clone(scene, state, env={"RNB_MARCH_SKIP": mode}, overlap=0)
+        c = _clone(scene, state, env={"RNB_MARCH_SKIP": mode, "RNB_MARCH_SKIP_NARROW": "1"}, overlap=0)  # (the thread-per-ray form of the skipping is not the default -- slower -- but stays tested)
         try:
             got = []
-            for n_rays, n_total in ((512, 0), (4096, 123456), (12416, 7), (18000, 40000 * 64)):
+            for n_rays, n_total in ((512, 0), (4096, 123456), (12416, 7), (18000, 40000 * 64), (40000, 99), (92672, 3)):  # (<= 4096: one wavefront per ray; < 18 432: k_march_count_skip; from there on: k_march_count_skip_narrow)
                 c.generate_training_samples(n_rays, n_total)
                 cnt = c.get("COUNTERS").copy()
                 kept = int(cnt[2])
