@@ -1595,7 +1595,13 @@ struct ScatterArgs {
 	float* grid_grad;    // GRADS_FP32 + off_grid
 	uint32_t* grid_grad16; // rnb_config::accumulate = RNB_ACCUM_HALF: GRADS_FP16 + off_grid, one half2 per table entry (the reference's gradient vector, trainer.h:78-84)
 	unsigned long long* grid_fixed; // rnb_config::deterministic: [n_grid_params] 64-bit fixed-point accumulators (scale 2^24), narrowed into the gradient vector by k_fixed_narrow
+	uint32_t prio;                  // RNB_SCATTER_PRIO (A/B, round 6): the scatter's wavefronts raise their issue priority (s_setprio) above the side streams' kernels that share their SIMDs
 };
+__device__ __forceinline__ void scatter_prio(const uint32_t prio) {
+	if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+	else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+	else if (prio >= 3u) __builtin_amdgcn_s_setprio(3);
+}
 
 // rnb_config::deterministic. An addend of the scatter is a half value (grid.h:415-416: the reference narrows every addend to half before its atomicAdd), i.e. an integer
 // multiple of 2^-24 below 2^16 in magnitude: times 2^24 it is an integer below 2^40, exact in fp32 and in a 64-bit integer. Integer additions commute, so a sum of such
@@ -1682,6 +1688,7 @@ struct ScatterLdsArgs { ScatterArgs a; uint32_t n_levels; uint32_t samples_per_w
 // LDS layout: level l's table at float offset 2 * G.offsets[l]. The per-sample loads of a walk are issued four samples ahead.
 template <bool HALF>
 __device__ __forceinline__ void grid_scatter_lds_body(const GridMeta& G, const ScatterLdsArgs& p) {
+	scatter_prio(p.a.prio);
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	float* tab = reinterpret_cast<float*>(smem_raw);
 	const ScatterArgs& a = p.a;
@@ -1772,6 +1779,7 @@ __global__ __launch_bounds__(512) void k_grid_scatter_lds_h(const GridMeta G, co
 // wavefront only takes a slot from the kernels of the side streams (march, optimizer chunks), which were starved beside the scatter
 // (k_march_write 48 -> 186 us beside the one-shot grid of 65 k wavefronts, profiles/r03_*).
 __global__ __launch_bounds__(256) void k_grid_scatter_quad(const GridMeta G, const ScatterArgs a, const uint32_t level0, const uint32_t n_vblocks) {
+	scatter_prio(a.prio);
 	const uint32_t level = blockIdx.y + level0;
 	if (level > G.valid_level) return;
 	float* gg = a.grid_grad + (size_t)G.offsets[level] * 2;
@@ -1885,6 +1893,7 @@ struct ScatterRlPlan { uint32_t n; uint32_t wg_start[17]; uint64_t k_log2; };
 // HALF (rnb_config::accumulate = RNB_ACCUM_HALF): lanes (dx, dy), registers (dz, feature), packed half atomics (see k_grid_scatter_quad_h); a run is still summed in fp32.
 template <bool HALF, bool SHARE = false>
 __device__ __forceinline__ void grid_scatter_quad_rl_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
+	scatter_prio(a.prio);
 #pragma unroll 1
 	for (uint32_t vb = blockIdx.x; vb < plan.wg_start[plan.n]; vb += gridDim.x) { // virtual workgroups (see k_grid_scatter_quad)
 		uint32_t li = 0;
@@ -1990,6 +1999,7 @@ constexpr uint32_t RL_MAX_K = 16;
 constexpr size_t LDS_SCATTER_RL = (size_t)RL_MAX_K * 64 * 32; // 16 B {x y z dn0} + 8 B {dn1 dn2} + 8 B g12 per sample
 template <bool HALF, bool SHARE = false>
 __device__ __forceinline__ void grid_scatter_quad_rl_staged_body(const GridMeta& G, const ScatterArgs& a, const uint32_t level0, const ScatterRlPlan& plan) {
+	scatter_prio(a.prio);
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	f4* sA = reinterpret_cast<f4*>(smem_raw);                                  // [K * 64] x y z dn0
 	float2* sB = reinterpret_cast<float2*>(smem_raw + (size_t)RL_MAX_K * 64 * 16); // [K * 64] dn1 dn2

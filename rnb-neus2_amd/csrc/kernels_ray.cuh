@@ -464,6 +464,7 @@ struct MarchArgs {
 	float* ray_const;   // [n_rays kept][RAY_CONST_FLOATS]
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
+	uint32_t prio;             // RNB_MARCH_PRIO (A/B): s_setprio of the march kernels' wavefronts
 	unsigned long long* stats; // RNB_MARCH_STATS=1 (measurement aid, k_march_count_skip): [0] wavefronts, [1] loop iterations, [2] rays, [3] rays that skipped, [4] start-overs, [5] rounds spent looking for a re-entry cell, [6] rays ended early
 };
 
@@ -496,6 +497,7 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 
 template <bool SC>
 __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
+	if (a.prio == 1u) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2u) __builtin_amdgcn_s_setprio(2); else if (a.prio >= 3u) __builtin_amdgcn_s_setprio(3);
 	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
 	if (SC) { load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x); __syncthreads(); }
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -750,6 +752,7 @@ __device__ __forceinline__ float lattice_advance(float t, int n) { // t_{k+n} of
 
 template <int WGS = 256>
 __global__ __launch_bounds__(WGS) void k_march_count_skip(const MarchArgs a) {
+	if (a.prio == 1u) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2u) __builtin_amdgcn_s_setprio(2); else if (a.prio >= 3u) __builtin_amdgcn_s_setprio(3);
 	constexpr int MG = 16;
 	constexpr bool SC = true;
 	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];

@@ -239,6 +239,8 @@ struct rnb_ctx {
 		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
 		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
+		int march_prio = 0; // RNB_MARCH_PRIO=0..3 (A/B): s_setprio of k_march_count / k_march_count_skip
+		int scatter_prio = 0; // RNB_SCATTER_PRIO=0..3 (A/B): s_setprio of the scatter kernels' wavefronts
 		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
 		int scatter_kmin = 0, scatter_rl_upto = 0; // RNB_SCATTER_KMIN, RNB_SCATTER_RL_UPTO (A/B, plan_scatter_groups)
 		bool scatter_anyorder = true;  // RNB_SCATTER_ANYORDER=1 (A/B): the scatter groups behind the first one are launched with hipExtAnyOrderLaunch -- they touch other levels, so a group may start in the tail of the one in front of it
@@ -711,6 +713,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.ray_const = c->ray_const.p;
 	a.part = 0;
 	a.stats = c->march_stats.p;
+	a.prio = (uint32_t)c->knobs.march_prio;
 	return a;
 }
 
@@ -969,6 +972,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	// vector it finds in the other modes, at the same points
 	const bool fixed = c->fixed_acc();
 	sa.grid_fixed = fixed ? c->grads_fixed.p : nullptr;
+	sa.prio = side_streams ? (uint32_t)c->knobs.scatter_prio : 0u;
 	auto narrow = [&](hipStream_t st, hipEvent_t done, uint32_t l0, uint32_t l1) { // levels [l0, l1)
 		const uint64_t lo = (uint64_t)c->grid.offsets[l0] * 2, hi = (uint64_t)c->grid.offsets[l1] * 2;
 		if (hi <= lo) { if (done) (void)hipEventRecord(done, st); return; }
@@ -1533,6 +1537,8 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_SHARE")) k.scatter_share = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_SKIP")) k.march_skip = std::max(0, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_MARCH_SKIP_NARROW")) k.march_skip_narrow = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_PRIO")) k.scatter_prio = std::max(0, std::min(3, atoi(e)));
+		if (const char* e = getenv("RNB_MARCH_PRIO")) k.march_prio = std::max(0, std::min(3, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}
