@@ -180,7 +180,10 @@ constexpr uint32_t COARSE_MAX_BLOCKS = 4096; // LDS budget of a march workgroup:
 // A point within 1/32 of a non-empty block (in every coordinate) reads a set bit there: k_march_count_skip samples a ray every 1/32 of its length against these words to find,
 // conservatively, the stretches of the ray that can hold samples at all.
 constexpr uint32_t COARSE_DIL_OFF = 2 * COARSE_WORDS + 2 * COARSE_MAX_BLOCKS;
-constexpr uint32_t COARSE_BUF_WORDS = COARSE_DIL_OFF + COARSE_WORDS;
+// ... and 8 words: the bounding box of the non-empty blocks in block coordinates {x0 y0 z0 x1 y1 z1} (inclusive; x0 > x1: the grid is empty). A ray is over once it has left that
+// box (dilated by one block): no position behind it can be occupied. The thread-per-ray march of the large batches stops there instead of walking on to the scene box's exit.
+constexpr uint32_t COARSE_BBOX_OFF = COARSE_DIL_OFF + COARSE_WORDS;
+constexpr uint32_t COARSE_BUF_WORDS = COARSE_BBOX_OFF + 8;
 template <uint32_t NW = 16>
 __device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, const uint32_t lane, const uint32_t wave, uint32_t* __restrict__ wsum, uint32_t& total);
 // One workgroup of 1024 threads (= COARSE_WORDS): out = coarse | rank | blocks (uint2 each) ; *n_blocks = number of non-empty blocks.
@@ -196,7 +199,13 @@ __device__ __forceinline__ void coarse_bitfield_body(const uint8_t* __restrict__
 	const uint32_t before = block_exclusive_scan(__popc(bits), lane, wave, wsum, total);
 	out[w] = bits;
 	out[COARSE_WORDS + w] = before;
+	if (w < 8) out[COARSE_BBOX_OFF + w] = w < 3 ? 31u : 0u;
 	__syncthreads(); // (every word of `out[0 .. COARSE_WORDS)` is written: a word is one x-row of blocks, w = y | z << 5)
+	if (bits) {
+		atomicMin(out + COARSE_BBOX_OFF + 0, (uint32_t)__builtin_ctz(bits)); atomicMax(out + COARSE_BBOX_OFF + 3, 31u - (uint32_t)__builtin_clz(bits));
+		atomicMin(out + COARSE_BBOX_OFF + 1, w & 31u); atomicMax(out + COARSE_BBOX_OFF + 4, w & 31u);
+		atomicMin(out + COARSE_BBOX_OFF + 2, w >> 5); atomicMax(out + COARSE_BBOX_OFF + 5, w >> 5);
+	}
 	{
 		const int y = (int)(w & 31u), z = (int)(w >> 5);
 		uint32_t acc = 0;
@@ -465,6 +474,7 @@ struct MarchArgs {
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
 	uint32_t prio;             // RNB_MARCH_PRIO (A/B): s_setprio of the march kernels' wavefronts
+	uint32_t use_bbox;         // RNB_MARCH_BBOX (round 6, default 1): the thread-per-ray march ends where the ray leaves the bounding box of the non-empty blocks
 	unsigned long long* stats; // RNB_MARCH_STATS=1 (measurement aid, k_march_count_skip): [0] wavefronts, [1] loop iterations, [2] rays, [3] rays that skipped, [4] start-overs, [5] rounds spent looking for a re-entry cell, [6] rays ended early
 };
 
@@ -472,12 +482,12 @@ struct MarchArgs {
 // mip 0 (mip_from_pos clamps to max_cascade = 0, mip_from_dt returns it because dt * 2 * GRIDSIZE < 1), so the per-position
 // frexp / scalbn / variable-resolution arithmetic folds into constants. Same values, fewer dependent instructions per voxel.
 template <bool SC, typename F>
-__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds, const uint32_t n_blocks_lds, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit) {
+__device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __restrict__ bitfield, const uint32_t* __restrict__ coarse_lds, const uint32_t n_blocks_lds, const Vec3& o, const Vec3& dir, const float startt, const uint32_t max_steps, F&& emit, const float t_stop = 3.0e38f) {
 	const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
 	uint32_t j = 0;
 	float t = startt;
 	Vec3 pos;
-	while (aabb_contains(A, pos = o + t * dir) && j < max_steps) {
+	while (aabb_contains(A, pos = o + t * dir) && j < max_steps && t <= t_stop) { // (t_stop: behind it no position can be occupied -- the reference walks on and emits nothing)
 		const float dt = SC ? MIN_CONE_STEPSIZE : calc_dt(t, A.cone_angle);
 		const uint32_t mip = SC ? 0u : (uint32_t)mip_from_dt(dt, pos);
 		if (SC ? occupied_mip0(pos, bitfield, coarse_lds, n_blocks_lds) : density_grid_occupied_at(pos, bitfield, mip)) {
@@ -527,7 +537,25 @@ __global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
 		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
 		alive = 1.f;
 		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
-		steps = march<SC>(a.A, a.bitfield, coarse_lds, a.n_blocks_lds, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; });
+		float t_stop = 3.0e38f;
+		bool can_hit = true;
+		if (SC && a.use_bbox) { // round 6: where the ray leaves the (dilated) bounding box of the non-empty blocks it is over; a ray that misses the box has no sample
+			const uint32_t* bb = a.coarse + COARSE_BBOX_OFF;
+			const float lo[3] = {((float)bb[0] - 1.0f) * (1.0f / 32.0f), ((float)bb[1] - 1.0f) * (1.0f / 32.0f), ((float)bb[2] - 1.0f) * (1.0f / 32.0f)};
+			const float hi[3] = {((float)bb[3] + 2.0f) * (1.0f / 32.0f), ((float)bb[4] + 2.0f) * (1.0f / 32.0f), ((float)bb[5] + 2.0f) * (1.0f / 32.0f)};
+			const float oo[3] = {o.x, o.y, o.z}, dd[3] = {dir.x, dir.y, dir.z};
+			float t0 = -3.0e38f, t1 = 3.0e38f;
+			can_hit = bb[0] <= bb[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (fabsf(dd[d]) < 1e-12f) { if (oo[d] < lo[d] || oo[d] > hi[d]) can_hit = false; continue; }
+				const float ta = (lo[d] - oo[d]) / dd[d], tb = (hi[d] - oo[d]) / dd[d];
+				t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+			}
+			if (t0 > t1) can_hit = false;
+			t_stop = t1 + 4.0f * MIN_CONE_STEPSIZE; // (the box is already a block = 18 steps wider than the non-empty blocks on every side)
+		}
+		if (can_hit) steps = march<SC>(a.A, a.bitfield, coarse_lds, a.n_blocks_lds, o, dir, startt, RNB_MAX_STEPS, [&](uint32_t j, const Vec3&, float, float t) { tt[j] = t; }, t_stop);
 	}
 	float* st = a.setup + (size_t)i * 8;
 	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;

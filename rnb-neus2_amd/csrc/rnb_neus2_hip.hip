@@ -239,6 +239,7 @@ struct rnb_ctx {
 		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
 		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
+		bool march_bbox = true; // RNB_MARCH_BBOX=0: the thread-per-ray march walks on to the scene box's exit (rounds 1-5)
 		int march_prio = 0; // RNB_MARCH_PRIO=0..3 (A/B): s_setprio of k_march_count / k_march_count_skip
 		int scatter_prio = 0; // RNB_SCATTER_PRIO=0..3 (A/B): s_setprio of the scatter kernels' wavefronts
 		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
@@ -714,6 +715,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.part = 0;
 	a.stats = c->march_stats.p;
 	a.prio = (uint32_t)c->knobs.march_prio;
+	a.use_bbox = c->knobs.march_bbox ? 1u : 0u;
 	return a;
 }
 
@@ -1539,6 +1541,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_SKIP_NARROW")) k.march_skip_narrow = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_PRIO")) k.scatter_prio = std::max(0, std::min(3, atoi(e)));
 		if (const char* e = getenv("RNB_MARCH_PRIO")) k.march_prio = std::max(0, std::min(3, atoi(e)));
+		if (const char* e = getenv("RNB_MARCH_BBOX")) k.march_bbox = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}

@@ -40,7 +40,9 @@ _GPU_ORDER = ["test_gpu_parity.py", "test_gpu_half_mode.py", "test_gpu_mesh.py",
               "test_gpu_rccl.py", "test_gpu_dp_two_process.py"]
 _progress = {"passed": 0, "failed": 0}
 _CHILD_ENV = "RNB_GPU_CHILD_RESULTS"
-_CHILD_WALL_LIMIT_S = 2400
+_CHILD_WALL_LIMIT_S = 900        # one module's child process
+_SUITE_BUDGET_S = float(os.environ.get("RNB_GPU_SUITE_BUDGET_S", "1100"))  # the whole GPU tier (the driver ends the run at 1200 s): a hang must not take the summary line with it
+_suite_t0 = [None]
 
 
 def _is_gpu_run(config):
@@ -124,6 +126,20 @@ def _run_module_in_children(session, items):
     pending = [it.nodeid for it in items]
     restarts = 0
     while pending:
+        if _suite_t0[0] is None:
+            _suite_t0[0] = time.time()
+        budget_left = _SUITE_BUDGET_S - (time.time() - _suite_t0[0])
+        if budget_left < 1.0:  # report what is left as not run, so that the session still ends with its summary line and the tests that passed
+            for nid in pending:
+                _progress["replaying"] = True
+                try:
+                    _replay(by_id[nid], [{"outcome": "failed", "longrepr": "not run: the GPU tier's time budget (%d s, RNB_GPU_SUITE_BUDGET_S) was used up" % _SUITE_BUDGET_S, "when": "setup", "sections": [], "duration": 0.0}])
+                finally:
+                    _progress["replaying"] = False
+                if session.shouldfail or session.shouldstop:
+                    return False
+            return True
+        wall_limit = min(_CHILD_WALL_LIMIT_S, budget_left)
         fd, path = tempfile.mkstemp(prefix="rnb_gpu_child_", suffix=".jsonl")
         os.close(fd)
         env = dict(os.environ)
@@ -143,7 +159,7 @@ def _run_module_in_children(session, items):
         timed_out = False
         while proc.poll() is None:
             time.sleep(0.2)
-            if time.time() - t0 > _CHILD_WALL_LIMIT_S:
+            if time.time() - t0 > wall_limit:
                 timed_out = True
                 try:
                     os.killpg(proc.pid, signal.SIGKILL)
@@ -227,7 +243,7 @@ def _run_module_in_children(session, items):
         else:
             how = "exit code %s" % rc
         if timed_out:
-            how = "killed after the %d s wall limit of one module's child process" % _CHILD_WALL_LIMIT_S
+            how = "killed after %d s (the wall limit of one module's child process / what was left of the GPU tier's time budget)" % wall_limit
         partial = per_test.get(culprit, [])
         phase = "setup" if not any(r["when"] == "setup" for r in partial) else ("call" if not any(r["when"] == "call" for r in partial) else "teardown")
         text = ("the python process running this test ended by %s during its %s phase (a native abort: HIP runtime / GPU memory fault / std::terminate; "

@@ -907,8 +907,14 @@ def test_skipping_march_equals_the_full_march(scene, states, early, regime):
     below 18 432 rays, one thread per ray from there on)."""
     state = early if regime == "early" else states[regime]
     ref = None
-    for mode in ("0", "1", "2"):
-        c = _clone(scene, state, env={"RNB_MARCH_SKIP": mode, "RNB_MARCH_SKIP_NARROW": "1"}, overlap=0)  # (the thread-per-ray form of the skipping is not the default -- slower -- but stays tested)
+    for mode in ("0", "1", "2", "bbox"):
+        # "0": every voxel from box entry to box exit in both march forms (rounds 1-5: the comparator); "1": both skipping kernels (the thread-per-ray one is not the default -- slower -- but tested);
+        # "2": the same with every skipping ray forced through its fall-back path; "bbox": the shipped defaults (k_march_count_skip below 18 432 rays, above them k_march_count<true> ending
+        # where the ray leaves the bounding box of the non-empty blocks)
+        env = {"RNB_MARCH_SKIP": mode, "RNB_MARCH_SKIP_NARROW": "1", "RNB_MARCH_BBOX": "0" if mode == "0" else "1"}
+        if mode == "bbox":  # the shipped defaults: k_march_count_skip below 18 432 rays, k_march_count<true> ending at the occupied region's bounding box above
+            env = {}
+        c = _clone(scene, state, env=env, overlap=0)
         try:
             got = []
             for n_rays, n_total in ((512, 0), (4096, 123456), (12416, 7), (18000, 40000 * 64), (40000, 99), (92672, 3)):  # (<= 4096: one wavefront per ray; < 18 432: k_march_count_skip; from there on: k_march_count_skip_narrow)

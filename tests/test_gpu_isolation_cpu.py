@@ -76,3 +76,33 @@ def test_x_stops_at_the_abort_and_names_it(tmp_path):
     assert "1 passed" in out and "1 failed" in out, out
     assert "test_aborts" in out and "SIGABRT" in out
     assert "test_after_the_abort" not in out.split("child process ended by")[-1].split("FAILURES")[0]
+
+
+MOD_HANG = '''
+import time, pytest
+pytestmark = pytest.mark.gpu
+
+def test_passes_first():
+    pass
+
+def test_hangs():
+    time.sleep(600)
+'''
+
+
+def test_a_hang_is_cut_by_the_time_budget_and_the_summary_still_prints(tmp_path):
+    """The driver ends the GPU tier at 1200 s; the runner's own budget (RNB_GPU_SUITE_BUDGET_S, 1100 s by default; 6 s here) ends a hanging module first, reports the hanging test
+    and what was left as failed / not run, and prints the summary with the tests that passed."""
+    t = tmp_path / "tests"
+    t.mkdir()
+    shutil.copy(os.path.join(HERE, "conftest.py"), t / "conftest.py")
+    (t / "__init__.py").write_text("")
+    (t / "test_gpu_aaa.py").write_text(MOD_HANG)
+    (t / "test_gpu_bbb.py").write_text(MOD_B)
+    env = dict(os.environ, RNB_GPU_SUITE_BUDGET_S="6")
+    env.pop("RNB_GPU_CHILD_RESULTS", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    out = r.stdout + r.stderr
+    assert r.returncode == 1, out
+    assert "1 passed" in out and "1 failed" in out and "2 errors" in out, out  # the hanging test failed (killed), the module behind it was not run, the first test's pass stands
+    assert "test_hangs" in out and "killed after" in out and "time budget" in out

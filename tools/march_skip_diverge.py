@@ -13,11 +13,13 @@ KW = dict(apply_no_albedo=1, mask_loss_weight=1.0, overlap=0, deterministic=1)
 ctx = []
 for mode in ("0", "1"):
     os.environ["RNB_MARCH_SKIP"] = mode
+    os.environ["RNB_MARCH_BBOX"] = mode
     c = rnb.Context(**KW)
     c.init_params()
     c.set_dataset(*scene)
     ctx.append(c)
 os.environ.pop("RNB_MARCH_SKIP")
+os.environ.pop("RNB_MARCH_BBOX")
 max_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1100
 for step in range(max_steps):
     a, b = ctx[0].train_step(), ctx[1].train_step()
