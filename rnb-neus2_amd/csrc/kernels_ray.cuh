@@ -474,7 +474,7 @@ struct MarchArgs {
 	// outputs
 	uint32_t* ray_indices; float* rays; uint32_t* numsteps; float* coords; uint32_t* counters;
 	uint32_t prio;             // RNB_MARCH_PRIO (A/B): s_setprio of the march kernels' wavefronts
-	uint32_t use_bbox;         // RNB_MARCH_BBOX (round 6, default 1): the thread-per-ray march ends where the ray leaves the bounding box of the non-empty blocks
+	uint32_t use_bbox;         // RNB_MARCH_BBOX (round 6): 0 off; 1 (default): the thread-per-ray march ends where the ray leaves the bounding box of the non-empty blocks; 2: + one jump to that box's entry (k_march_count_bbox)
 	unsigned long long* stats; // RNB_MARCH_STATS=1 (measurement aid, k_march_count_skip): [0] wavefronts, [1] loop iterations, [2] rays, [3] rays that skipped, [4] start-overs, [5] rounds spent looking for a re-entry cell, [6] rays ended early
 };
 
@@ -1016,6 +1016,43 @@ __global__ __launch_bounds__(WGS) void k_march_count_skip(const MarchArgs a) {
 // (and safely inside the box) it jumps to 52 steps in front of the next stretch of interest and looks, position by position, for the re-entry cell: a cell whose FIRST lattice position
 // it has seen (a cell change behind the jump target), all of whose positions are empty and jump to the position behind the cell's last one. If it finds none within 48 positions it has
 // changed nothing: it goes on from where it stood, every voxel, and does not try again on this ray.
+// The re-entry cell behind a jump to lattice position tq (thread-per-ray forms): walks positions tq, tq + dt, ... (the reference's own additions) until it has seen a cell from its
+// FIRST position to its last, all of them inside the box, empty, and jumping to the position behind the cell's last one; that position (a position the reference's chain visits,
+// see k_march_count_skip) is returned in t_found. false: none before t_limit (nothing has been changed; the caller walks on from where it stood).
+__device__ __forceinline__ bool find_reentry(const MarchArgs& a, const uint32_t* __restrict__ coarse_lds, const Vec3& o, const Vec3& dir, const Vec3& idir, float tq, const float t_limit, float& t_found) {
+	auto cell_of = [&](const Vec3& p) {
+		const int cx = min(max((int)(p.x * GRIDSIZE), 0), (int)GRIDSIZE - 1), cy = min(max((int)(p.y * GRIDSIZE), 0), (int)GRIDSIZE - 1), cz = min(max((int)(p.z * GRIDSIZE), 0), (int)GRIDSIZE - 1);
+		return (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)cz << 14);
+	};
+	const bool force_fail = (a.lattice_ok & 2u) != 0u; // RNB_MARCH_SKIP=2 (tests): no re-entry cell is ever accepted
+	Vec3 pq = o + tq * dir;
+	uint32_t prev_cell = cell_of(pq);
+	float cell_first = -1.f, t_prev = tq; // cell_first < 0: the first position of the cell being examined was not seen
+	bool cell_ok = false;                 // every position of the examined cell so far is inside and empty ...
+	float max_target = 0.f, min_target = 3.0e38f; // ... and their jump targets: all must land on the position behind the cell (t_last < target <= t_next for every one of them)
+#pragma unroll 1
+	for (int k = 1; k < 48; ++k) {
+		if (cell_first >= 0.f) { // the vote of position t_prev
+			const bool in = aabb_contains(a.A, pq);
+			const bool occ = in && occupied_mip0(pq, a.bitfield, coarse_lds, a.n_blocks_lds);
+			const float target = t_prev + distance_to_next_voxel(pq, dir, idir, GRIDSIZE);
+			cell_ok = cell_ok && in && !occ;
+			max_target = fmaxf(max_target, target); min_target = fminf(min_target, target);
+		}
+		const float t_next = t_prev + MIN_CONE_STEPSIZE;
+		const Vec3 p_next = o + t_next * dir;
+		const uint32_t c_next = cell_of(p_next);
+		if (c_next != prev_cell) {
+			if (cell_first >= 0.f && cell_ok && min_target > t_prev && max_target <= t_next && aabb_contains(a.A, p_next) && !force_fail) { t_found = t_next; return true; }
+			cell_first = t_next; cell_ok = true; max_target = 0.f; min_target = 3.0e38f; // the next cell starts here: its first position is seen
+			prev_cell = c_next;
+		}
+		t_prev = t_next; pq = p_next;
+		if (t_prev > t_limit) break;
+	}
+	return false;
+}
+
 template <typename F>
 __device__ __forceinline__ uint32_t march_skip_narrow(const MarchArgs& a, const uint32_t* __restrict__ coarse_lds, const uint32_t* __restrict__ dil, const Vec3& o, const Vec3& dir,
                                                       const float startt, const float t_exit, unsigned long long* __restrict__ stats, F&& emit) {
@@ -1032,13 +1069,8 @@ __device__ __forceinline__ uint32_t march_skip_narrow(const MarchArgs& a, const 
 			interest |= (uint64_t)((dil[(uint32_t)by | ((uint32_t)bz << 5)] >> bx) & 1u) << k;
 		}
 	}
-	const bool force_fail = (a.lattice_ok & 2u) != 0u; // RNB_MARCH_SKIP=2 (tests): no re-entry cell is ever accepted
 	const float mlo = a.A.mn + 1e-4f, mhi = a.A.mx - 1e-4f;
 	auto safely_inside = [&](const Vec3& p) { return p.x > mlo && p.x < mhi && p.y > mlo && p.y < mhi && p.z > mlo && p.z < mhi; };
-	auto cell_of = [&](const Vec3& p) {
-		const int cx = min(max((int)(p.x * GRIDSIZE), 0), (int)GRIDSIZE - 1), cy = min(max((int)(p.y * GRIDSIZE), 0), (int)GRIDSIZE - 1), cz = min(max((int)(p.z * GRIDSIZE), 0), (int)GRIDSIZE - 1);
-		return (uint32_t)cx | ((uint32_t)cy << 7) | ((uint32_t)cz << 14);
-	};
 	uint32_t j = 0, n_skips = 0, n_fail = 0, n_early = 0;
 	float t = startt;
 	Vec3 pos;
@@ -1055,35 +1087,9 @@ __device__ __forceinline__ uint32_t march_skip_narrow(const MarchArgs& a, const 
 					float tq = lattice_advance(t, n);
 					Vec3 pq = o + tq * dir;
 					if (safely_inside(pq)) {
-						// the re-entry cell: positions tq, tq + dt, ... (the reference's own additions); `first` = the first position of the cell being examined (-1: its first position was not seen)
-						uint32_t prev_cell = cell_of(pq);
-						float cell_first = -1.f, t_prev = tq;
-						bool cell_ok = false;     // every position of the examined cell so far is inside, empty ...
-						float max_target = 0.f;   // ... and the latest of their jump targets (all must land on the position behind the cell: t_last < target <= t_next for every one of them)
-						float min_target = 3.0e38f;
-						bool found = false;
-#pragma unroll 1
-						for (int k = 1; k < 48; ++k) {
-							// votes of position t_prev (in the examined cell, if one is open)
-							if (cell_first >= 0.f) {
-								const bool in = aabb_contains(a.A, pq);
-								const bool occ = in && occupied_mip0(pq, a.bitfield, coarse_lds, a.n_blocks_lds);
-								const float target = t_prev + distance_to_next_voxel(pq, dir, idir, GRIDSIZE);
-								cell_ok = cell_ok && in && !occ;
-								max_target = fmaxf(max_target, target); min_target = fminf(min_target, target);
-							}
-							const float t_next = t_prev + MIN_CONE_STEPSIZE;
-							const Vec3 p_next = o + t_next * dir;
-							const uint32_t c_next = cell_of(p_next);
-							if (c_next != prev_cell) {
-								// t_prev was the cell's last position, t_next is the position behind it: every vote must satisfy t_prev < target <= t_next
-								if (cell_first >= 0.f && cell_ok && min_target > t_prev && max_target <= t_next && aabb_contains(a.A, p_next) && !force_fail) { tq = t_next; found = true; break; }
-								cell_first = t_next; cell_ok = true; max_target = 0.f; min_target = 3.0e38f; // the next cell starts here: its first position is seen
-								prev_cell = c_next;
-							}
-							t_prev = t_next; pq = p_next;
-							if (t_prev > t_int - 17.0f * MIN_CONE_STEPSIZE) break;
-						}
+						float t_re = 0.f;
+						const bool found = find_reentry(a, coarse_lds, o, dir, idir, tq, t_int - 17.0f * MIN_CONE_STEPSIZE, t_re);
+						if (found) tq = t_re;
 						if (found) { t = tq; ++n_skips; continue; } // t is a position the reference's chain visits: go on from it
 						skipping = false; ++n_fail;                 // nothing was changed: every voxel from here on
 					}
@@ -1101,6 +1107,94 @@ __device__ __forceinline__ uint32_t march_skip_narrow(const MarchArgs& a, const 
 	}
 	if (stats) { atomicAdd(stats + 2, 1ull); atomicAdd(stats + 3, (unsigned long long)(n_skips != 0)); atomicAdd(stats + 4, (unsigned long long)n_fail); atomicAdd(stats + 6, (unsigned long long)n_early); }
 	return j;
+}
+
+// Round 6, RNB_MARCH_BBOX=2 (measured, NOT the default: the jump costs what it saves): the thread-per-ray march of the single-cascade scenes (batches from 18 432 rays on): k_march_count<true>'s walk, with the ray cut to the part that can hold a sample by
+// the BOUNDING BOX of the non-empty 4^3 blocks (COARSE_BBOX_OFF, dilated by a block): a ray that misses the box has no sample; a ray is over where it leaves the box; and ONE jump -- from
+// the first position that lies safely inside the scene box to 52 steps in front of the occupied box's entry, re-entering the reference's visit chain through find_reentry (a ray
+// that finds no re-entry cell has changed nothing and walks every voxel). Unlike the per-ray stretch scan of march_skip_narrow every lane of a wavefront does the same thing at the same
+// time: first position, jump, re-entry search, walk -- which is what a wavefront of 64 independent rays needs to gain anything. Sample set and t: the reference's, bit for bit.
+__global__ __launch_bounds__(128) void k_march_count_bbox(const MarchArgs a) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+	load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x);
+	__syncthreads();
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= a.n_rays) return;
+	const uint32_t gi = a.ray_offset + i;
+	const uint32_t img = image_idx(gi, a.n_rays_global, a.n_rays_total, a.n_images);
+	const ViewDev m = a.views[img];
+	Pcg32 rng = a.rng;
+	rng.advance((int64_t)gi * N_MAX_RANDOM_SAMPLES_PER_RAY);
+	float xy[2];
+	random_image_pos(rng, m.width, m.height, a.snap != 0, xy);
+	uint32_t j = 0;
+	float alive = 0.f;
+	Vec3 o = {0, 0, 0}, dir = {0, 0, 1}, du = {0, 0, 1};
+	float startt = 0.f;
+	bool dead = false;
+	if (red_is_nonpositive(xy, m, m.normal)) {
+		if (rng.next_float() >= 0.9) dead = true; // testbed_nerf.cu:1264, short-circuit draw
+	}
+	if (!dead) {
+		(void)rng.next_float(); // motionblur_time, testbed_nerf.cu:1270
+		camera_ray(m, xy, o, du, dir);
+		float tmin, tmax;
+		ray_intersect(a.A, o, dir, &tmin, &tmax);
+		tmin = fmaxf(tmin, 0.0f);
+		startt = tmin;
+		startt += calc_dt(startt, a.A.cone_angle) * rng.next_float();
+		alive = 1.f;
+		float* tt = a.ray_t + (size_t)i * RNB_MAX_STEPS;
+		// the ray against the dilated bounding box of the non-empty blocks: [t_in, t_out]
+		const uint32_t* bb = a.coarse + COARSE_BBOX_OFF;
+		const float lo[3] = {((float)bb[0] - 1.0f) * (1.0f / 32.0f), ((float)bb[1] - 1.0f) * (1.0f / 32.0f), ((float)bb[2] - 1.0f) * (1.0f / 32.0f)};
+		const float hi[3] = {((float)bb[3] + 2.0f) * (1.0f / 32.0f), ((float)bb[4] + 2.0f) * (1.0f / 32.0f), ((float)bb[5] + 2.0f) * (1.0f / 32.0f)};
+		const float oo[3] = {o.x, o.y, o.z}, dd[3] = {dir.x, dir.y, dir.z};
+		float t_in = -3.0e38f, t_out = 3.0e38f;
+		bool can_hit = bb[0] <= bb[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			if (fabsf(dd[d]) < 1e-12f) { if (oo[d] < lo[d] || oo[d] > hi[d]) can_hit = false; continue; }
+			const float ta = (lo[d] - oo[d]) / dd[d], tb = (hi[d] - oo[d]) / dd[d];
+			t_in = fmaxf(t_in, fminf(ta, tb)); t_out = fminf(t_out, fmaxf(ta, tb));
+		}
+		if (t_in > t_out) can_hit = false;
+		if (can_hit) {
+			const float t_stop = t_out + 4.0f * MIN_CONE_STEPSIZE;
+			const Vec3 idir = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+			const float mlo = a.A.mn + 1e-4f, mhi = a.A.mx - 1e-4f;
+			auto safely_inside = [&](const Vec3& p) { return p.x > mlo && p.x < mhi && p.y > mlo && p.y < mhi && p.z > mlo && p.z < mhi; };
+			bool may_jump = (a.lattice_ok & 1u) != 0u && a.use_bbox >= 2u;
+			uint32_t jumped = 0, failed = 0;
+			float t = startt;
+			Vec3 pos;
+			while (aabb_contains(a.A, pos = o + t * dir) && j < RNB_MAX_STEPS && t <= t_stop) {
+				if (may_jump && t >= 0.25f && safely_inside(pos)) { // (the ray's first position lies ON the entry face: it is always visited the reference's way)
+					may_jump = false; // one attempt per ray
+					const int n = (int)floorf((t_in - 52.0f * MIN_CONE_STEPSIZE - t) * (1.0f / MIN_CONE_STEPSIZE)) - 2;
+					if (n >= 32) {
+						const float tq = lattice_advance(t, n);
+						float t_re = 0.f;
+						if (safely_inside(o + tq * dir) && find_reentry(a, coarse_lds, o, dir, idir, tq, t_in - 17.0f * MIN_CONE_STEPSIZE, t_re)) { t = t_re; jumped = 1; continue; }
+						failed = 1;
+					}
+				}
+				if (occupied_mip0(pos, a.bitfield, coarse_lds, a.n_blocks_lds)) {
+					tt[j] = t;
+					++j;
+					t += MIN_CONE_STEPSIZE;
+				} else {
+					const float t_target = t + distance_to_next_voxel(pos, dir, idir, GRIDSIZE);
+					do { t += MIN_CONE_STEPSIZE; } while (t < t_target);
+				}
+			}
+			if (a.stats) { atomicAdd(a.stats + 2, 1ull); atomicAdd(a.stats + 3, (unsigned long long)jumped); atomicAdd(a.stats + 4, (unsigned long long)failed); }
+		}
+	}
+	float* st = a.setup + (size_t)i * 8;
+	st[0] = o.x; st[1] = o.y; st[2] = o.z; st[3] = dir.x; st[4] = dir.y; st[5] = dir.z; st[6] = startt; st[7] = alive;
+	a.d_unnorm[(size_t)i * 3 + 0] = du.x; a.d_unnorm[(size_t)i * 3 + 1] = du.y; a.d_unnorm[(size_t)i * 3 + 2] = du.z;
+	a.steps[i] = j;
 }
 
 __global__ __launch_bounds__(128) void k_march_count_skip_narrow(const MarchArgs a) {

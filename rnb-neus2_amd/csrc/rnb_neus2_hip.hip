@@ -239,7 +239,9 @@ struct rnb_ctx {
 		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
 		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
-		bool march_bbox = true; // RNB_MARCH_BBOX=0: the thread-per-ray march walks on to the scene box's exit (rounds 1-5)
+		int march_bbox = 1; // RNB_MARCH_BBOX=0: the thread-per-ray march walks from the scene box's entry to its exit (rounds 1-5); 1 (round 6, default): it ends where the ray leaves the occupied region's bounding
+		                    // box: window 0.5609 -> 0.5531 ms/step, late 0.6152 -> 0.6086; 2: + one jump to that box's entry (k_march_count_bbox): bit-identical, but the jump and its re-entry search cost what they save
+		                    // (0.5624 / 0.6165; profiles/r06_ab_march_bbox.txt) -- kept as a knob
 		int march_prio = 0; // RNB_MARCH_PRIO=0..3 (A/B): s_setprio of k_march_count / k_march_count_skip
 		int scatter_prio = 0; // RNB_SCATTER_PRIO=0..3 (A/B): s_setprio of the scatter kernels' wavefronts
 		bool scatter_share = true;  // RNB_SCATTER_SHARE=1 (A/B, round 6): face sharing in the run-length scatter (kernels_net.cuh: share_face)
@@ -715,7 +717,7 @@ MarchArgs march_args(rnb_ctx* c, uint32_t n_rays, uint32_t n_rays_total, uint32_
 	a.part = 0;
 	a.stats = c->march_stats.p;
 	a.prio = (uint32_t)c->knobs.march_prio;
-	a.use_bbox = c->knobs.march_bbox ? 1u : 0u;
+	a.use_bbox = (uint32_t)c->knobs.march_bbox;
 	return a;
 }
 
@@ -734,6 +736,10 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		if (sc && c->knobs.march_skip && c->knobs.march_skip_narrow && a.lattice_ok) { // RNB_MARCH_SKIP_NARROW=1 (dropped, kept as an A/B knob): the thread-per-ray march minus the stretches that cannot hold a sample (kernels_ray.cuh: march_skip_narrow)
 			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u;
 			hipLaunchKernelGGL(k_march_count_skip_narrow, dim3(blocks), dim3(128), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			a.lattice_ok &= 1u;
+		} else if (sc && c->knobs.march_bbox >= 2 && a.lattice_ok) {
+			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u; // (tests: no re-entry cell is accepted -- every ray walks every voxel up to the occupied box's exit)
+			hipLaunchKernelGGL(k_march_count_bbox, dim3(blocks), dim3(128), march_lds, s, a);
 			a.lattice_ok &= 1u;
 		} else if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
@@ -1496,6 +1502,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_bbox), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 	}
 HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_fixed), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1541,7 +1548,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_MARCH_SKIP_NARROW")) k.march_skip_narrow = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_PRIO")) k.scatter_prio = std::max(0, std::min(3, atoi(e)));
 		if (const char* e = getenv("RNB_MARCH_PRIO")) k.march_prio = std::max(0, std::min(3, atoi(e)));
-		if (const char* e = getenv("RNB_MARCH_BBOX")) k.march_bbox = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_BBOX")) k.march_bbox = std::max(0, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}

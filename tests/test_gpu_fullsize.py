@@ -907,13 +907,16 @@ def test_skipping_march_equals_the_full_march(scene, states, early, regime):
     below 18 432 rays, one thread per ray from there on)."""
     state = early if regime == "early" else states[regime]
     ref = None
-    for mode in ("0", "1", "2", "bbox"):
+    for mode in ("0", "1", "2", "bbox", "bbox2", "bbox2j"):
         # "0": every voxel from box entry to box exit in both march forms (rounds 1-5: the comparator); "1": both skipping kernels (the thread-per-ray one is not the default -- slower -- but tested);
-        # "2": the same with every skipping ray forced through its fall-back path; "bbox": the shipped defaults (k_march_count_skip below 18 432 rays, above them k_march_count<true> ending
-        # where the ray leaves the bounding box of the non-empty blocks)
+        # "2": the same with every skipping ray forced through its fall-back path; "bbox" / "bbox2": the shipped defaults (below)
         env = {"RNB_MARCH_SKIP": mode, "RNB_MARCH_SKIP_NARROW": "1", "RNB_MARCH_BBOX": "0" if mode == "0" else "1"}
-        if mode == "bbox":  # the shipped defaults: k_march_count_skip below 18 432 rays, k_march_count<true> ending at the occupied region's bounding box above
+        if mode == "bbox":  # the shipped defaults: k_march_count_skip below 18 432 rays; above them k_march_count<true> ending where the ray leaves the occupied region's bounding box
             env = {}
+        if mode == "bbox2":  # RNB_MARCH_BBOX=2 (not the default): + one jump to that box's entry, with every re-entry search forced to fail; "bbox2j": the jump taken
+            env = {"RNB_MARCH_SKIP": "2", "RNB_MARCH_BBOX": "2"}
+        if mode == "bbox2j":
+            env = {"RNB_MARCH_BBOX": "2"}
         c = _clone(scene, state, env=env, overlap=0)
         try:
             got = []
