@@ -239,6 +239,7 @@ struct rnb_ctx {
 		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
 		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
+		bool dw_late = false; // RNB_DW_LATE=1 (A/B)
 		int march_bbox = 1; // RNB_MARCH_BBOX=0: the thread-per-ray march walks from the scene box's entry to its exit (rounds 1-5); 1 (round 6, default): it ends where the ray leaves the occupied region's bounding
 		                    // box: window 0.5609 -> 0.5531 ms/step, late 0.6152 -> 0.6086; 2: + one jump to that box's entry (k_march_count_bbox): bit-identical, but the jump and its re-entry search cost what they save
 		                    // (0.5624 / 0.6165; profiles/r06_ab_march_bbox.txt) -- kept as a knob
@@ -1052,8 +1053,9 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// after C is the MLPs' and the coarse levels' parameters.
 		hipStream_t sd = c->s_dw;
 		HIP_TRY(hipStreamWaitEvent(sd, c->ev_fb, 0));
-		launch_dw(sd, c->ev_dw);
 		c->sc.dp = c->dp_order();
+		const bool dw_late = c->knobs.dw_late && !c->sc.dp && !split; // RNB_DW_LATE=1 (A/B): k_dw_finish behind the first scatter group instead of beside it
+		if (!dw_late) launch_dw(sd, c->ev_dw);
 		const uint32_t a_mid = l_fine + (L - l_fine + 1) / 2;
 		// Data parallel: C, B, then A, so that the parameters in front of A's levels (MLPs, C, B: one contiguous block) are final at
 		// ev_sc[0] + ev_dw and their exchange runs beside the scatter of A; A's levels + variance are the second block.
@@ -1069,14 +1071,17 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		}
 		if (c->sc.order == 0) { // B, A1, A2 (, C)
 			launch_b(s, c->ev_sc[0]);
+			if (dw_late) { HIP_TRY(hipStreamWaitEvent(sd, c->ev_sc[0], 0)); launch_dw(sd, c->ev_dw); }
 			launch_a(s, c->ev_sc[1], l_fine, a_mid);
 			launch_a(s, c->ev_sc[3], a_mid, L);
 		} else if (c->sc.order == 1) { // A1, A2, B, C: the fine levels' atomics before any optimizer chunk shares the memory side with them
 			launch_a(s, c->ev_sc[1], l_fine, a_mid);
+			if (dw_late) { HIP_TRY(hipStreamWaitEvent(sd, c->ev_sc[1], 0)); launch_dw(sd, c->ev_dw); }
 			launch_a(s, c->ev_sc[3], a_mid, L);
 			launch_b(s, c->ev_sc[0]);
 		} else { // A (one launch), B, C
 			launch_a(s, c->ev_sc[1], l_fine, L);
+			if (dw_late) { HIP_TRY(hipStreamWaitEvent(sd, c->ev_sc[1], 0)); launch_dw(sd, c->ev_dw); }
 			launch_b(s, c->ev_sc[0]);
 		}
 		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
@@ -1549,6 +1554,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_PRIO")) k.scatter_prio = std::max(0, std::min(3, atoi(e)));
 		if (const char* e = getenv("RNB_MARCH_PRIO")) k.march_prio = std::max(0, std::min(3, atoi(e)));
 		if (const char* e = getenv("RNB_MARCH_BBOX")) k.march_bbox = std::max(0, std::min(2, atoi(e)));
+		if (const char* e = getenv("RNB_DW_LATE")) k.dw_late = atoi(e) != 0;
 		if (const char* e = getenv("RNB_SCATTER_KMIN")) k.scatter_kmin = std::max(0, std::min(16, atoi(e)));
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}
