@@ -101,7 +101,8 @@ def parse(argv=None):
                     "(the reference's arithmetic as coded: half k-step accumulators, packed half atomics into a half gradient vector)")
     ap.add_argument("--parity-mode-steps", type=int, default=400, help="single-GPU fp32 runs: a second context in the OTHER accumulate mode (half), trained to the same step and timed over the driver's K steps "
                     "and over this many more (`parity_mode` in the record); 0 = skip")
-    ap.add_argument("--burn-in-mode", choices=["deterministic", "same"], default="deterministic", help="how the untimed burn-in steps are trained. deterministic (default): in a second context with "
+    ap.add_argument("--burn-in-mode", choices=["deterministic", "same"], default=None, help="how the untimed burn-in steps are trained (default: deterministic on one GPU, same on several -- the multi-rank form "
+                    "is covered on two CPU ranks and has never run on several GPUs, and a scaling record must not depend on it). deterministic: in a second context with "
                     "rnb_config::deterministic = 1 (hash-grid gradients summed as fixed-point integers), whose state -- the SAME bytes on every run, `burn_in.state_sha256` -- is then loaded into the context "
                     "that is timed; the timed context always runs the mode of --accumulate / --deterministic. same: in the timed context itself (rounds 1-5: the non-reproducible training reached the "
                     "timed steps in one of several states, 0.592 or 0.616 ms/step)")
@@ -263,6 +264,8 @@ def main(argv=None, engine=None):
     flags = dict(apply_no_albedo=0 if args.albedo else 1, mask_loss_weight=1.0)  # stage 1 of run_two_stage: --mask-weight 1.0 --no-albedo (rnb_neus2/pipeline.py:63-74)
     accumulate = 1 if args.accumulate == "half" else 0
     deterministic = 1 if args.deterministic else 0
+    if args.burn_in_mode is None:
+        args.burn_in_mode = "deterministic" if world == 1 else "same"
 
     def state_of(ctx, st):
         return dict(params=ctx.get("PARAMS_FP32").copy(), grid=ctx.get("DENSITY_GRID").copy(), step=ctx.training_step, rays=ctx.rays_per_batch,

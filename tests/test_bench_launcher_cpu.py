@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--views", "4", "--res", "48", "--focal", "84", "--batch-log2", "12", "--burn-in", "2", "--warmup", "1", "--steps", "2", "--other-leg-steps", "1",
-         "--window-end", "0", "--late-step", "0", "--profile-steps", "0", "--no-cpu-baseline"]
+         "--window-end", "0", "--late-step", "0", "--profile-steps", "0", "--no-cpu-baseline", "--burn-in-mode", "deterministic"]
 
 
 def _run(extra):
