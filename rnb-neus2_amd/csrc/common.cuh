@@ -281,6 +281,10 @@ __device__ __forceinline__ void encode_level_lm(const LevelMeta* __restrict__ lm
 // level_issue computes the eight table indices WITHOUT branches (the uniform conditions become selects) and issues the eight loads; level_consume recomputes the
 // interpolation weights (a few VALU instructions) and reduces the eight values: the same expressions on the same operands as encode_level_core, hence the same bits.
 // A caller issues DEPTH levels ahead of the one it consumes (vmcnt counts in order: consuming level l waits until at most 8 (DEPTH - 1) loads are outstanding).
+// PAIR (round 6): the caller promises that `level` is a DENSE level (checked on the host: the kernels are instantiated for the number of leading dense levels of the configuration): the x-neighbour of a
+// corner is then the next table entry, and one 8-byte gather serves both x-corners -- four gathers per level instead of eight (the wrapped index of the neighbour differs from e0 + 1 only when e0 is the
+// table's last entry: that lane takes the table's first entry, read once through a wave-uniform address). The same eight values, hence the same bits.
+template <bool PAIR = false>
 __device__ __forceinline__ void level_issue(const LevelMeta* __restrict__ lm, const uint32_t* __restrict__ grid, const uint32_t level, const float x, const float y, const float z, uint32_t (&v)[8]) {
 	const uint4 raw = reinterpret_cast<const uint4*>(lm + level)[0], raw2 = reinterpret_cast<const uint4*>(lm + level)[1];
 	const uint32_t off = __builtin_amdgcn_readfirstlane(raw.x), hashmap_size = __builtin_amdgcn_readfirstlane(raw.y);
@@ -299,12 +303,18 @@ __device__ __forceinline__ void level_issue(const LevelMeta* __restrict__ lm, co
 	for (uint32_t yz = 0; yz < 4; ++yz) {
 		const uint32_t ty = (yz & 1u) ? ty1 : ty0, tz = (yz >> 1) ? tz1 : tz0;
 		const uint32_t d0 = pg[0] + ty + tz, h = ty ^ tz;
-		uint32_t e0 = dense ? d0 : (pg[0] ^ h), e1 = dense ? d0 + 1u : ((pg[0] + 1u) ^ h);
+		uint32_t e0 = (PAIR || dense) ? d0 : (pg[0] ^ h), e1 = (PAIR || dense) ? d0 + 1u : ((pg[0] + 1u) ^ h);
 		const uint32_t w0 = e0 >= hashmap_size ? e0 - hashmap_size : e0, w1 = e1 >= hashmap_size ? e1 - hashmap_size : e1;
 		e0 = pow2 ? (e0 & (hashmap_size - 1u)) : w0;
 		e1 = pow2 ? (e1 & (hashmap_size - 1u)) : w1;
-		v[yz * 2 + 0] = g[e0];
-		v[yz * 2 + 1] = g[e1];
+		if (PAIR) {
+			const U2 p = *reinterpret_cast<const U2*>(g + e0);
+			v[yz * 2 + 0] = p.x;
+			v[yz * 2 + 1] = e1 == e0 + 1u ? p.y : g[0];
+		} else {
+			v[yz * 2 + 0] = g[e0];
+			v[yz * 2 + 1] = g[e1];
+		}
 	}
 }
 template <bool GRAD>

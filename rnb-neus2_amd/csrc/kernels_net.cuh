@@ -56,7 +56,7 @@ __device__ __forceinline__ void encode_all_lm(const LevelMeta* __restrict__ lm, 
 
 // The same encode with the gathers of DEPTH levels in flight (common.cuh: level_issue / level_consume). Levels [0, n_live) are encoded, the others give zeros
 // (grid.h:192-210); n_live is wave-uniform. Fully unrolled: the in-flight values live in registers v[l % DEPTH].
-template <bool GRAD, int DEPTH>
+template <bool GRAD, int DEPTH, int ND = 0>
 __device__ __forceinline__ void encode_all_pipelined(const LevelMeta* __restrict__ lm, const uint32_t n_levels, const uint32_t valid_level, const uint32_t* __restrict__ grid,
                                                      const float x, const float y, const float z, half_t (&feat)[28], float (&dydx)[GRAD ? 28 : 1][3]) {
 	const uint32_t n_live = min(n_levels, valid_level + 1u);
@@ -65,14 +65,15 @@ __device__ __forceinline__ void encode_all_pipelined(const LevelMeta* __restrict
 	// level's table instead (its values are dropped below) -- only before training step 660, when fewer than 14 levels are live.
 	const uint32_t last = n_live ? n_live - 1u : 0u;
 #pragma unroll
-	for (uint32_t l = 0; l < (uint32_t)DEPTH; ++l) level_issue(lm, grid, min(l, last), x, y, z, v[l]);
+	// ND: the first ND levels are dense (host-checked): their x-pairs travel in one gather (level_issue<true>); a slot whose level is not live yet gathers from a level in FRONT of it, which is dense too
+	for (uint32_t l = 0; l < (uint32_t)DEPTH; ++l) { if (l < (uint32_t)ND) level_issue<true>(lm, grid, min(l, last), x, y, z, v[l]); else level_issue<false>(lm, grid, min(l, last), x, y, z, v[l]); }
 #pragma unroll
 	for (uint32_t level = 0; level < 14; ++level) {
 		half_t f0, f1;
 		float d0[3], d1[3];
 		const bool live = level < n_live;
 		level_consume<GRAD>(lm, min(level, last), x, y, z, v[level % DEPTH], f0, f1, d0, d1);
-		if (level + DEPTH < 14) level_issue(lm, grid, min(level + (uint32_t)DEPTH, last), x, y, z, v[level % DEPTH]);
+		if (level + DEPTH < 14) { if (level + DEPTH < (uint32_t)ND) level_issue<true>(lm, grid, min(level + (uint32_t)DEPTH, last), x, y, z, v[level % DEPTH]); else level_issue<false>(lm, grid, min(level + (uint32_t)DEPTH, last), x, y, z, v[level % DEPTH]); }
 		feat[level * 2 + 0] = live ? f0 : (half_t)0.f;
 		feat[level * 2 + 1] = live ? f1 : (half_t)0.f;
 		if (GRAD) {
@@ -145,7 +146,7 @@ __device__ __forceinline__ void poison_lds(char* smem_raw, const size_t bytes, c
 #endif
 }
 
-template <bool EMU, int PIPE_DEPTH = 0>
+template <bool EMU, int PIPE_DEPTH = 0, int ND = 0>
 __device__ __forceinline__ void point_query_chained_body(const GridMeta& G, const NetW& net, const PointArgs& a, const half_t* __restrict__ wimg, char* smem_raw, LevelMeta* lm) {
 	poison_lds(smem_raw, LDS_POINT2, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
@@ -175,7 +176,7 @@ __device__ __forceinline__ void point_query_chained_body(const GridMeta& G, cons
 		if (valid && a.splat_idx) cell = a.splat_idx[s];
 		half_t feat[28];
 		float dummy[1][3];
-		if (PIPE_DEPTH) encode_all_pipelined<false, PIPE_DEPTH ? PIPE_DEPTH : 1>(lm, n_levels, valid_level, net.grid, x, y, z, feat, dummy);
+		if (PIPE_DEPTH) encode_all_pipelined<false, PIPE_DEPTH ? PIPE_DEPTH : 1, ND>(lm, n_levels, valid_level, net.grid, x, y, z, feat, dummy);
 		else encode_all_lm<false>(lm, n_levels, valid_level, net.grid, x, y, z, feat, dummy);
 		write_sdf_in_row(X, lane, x, y, z, feat);
 		wave_lds_sync();
@@ -208,11 +209,11 @@ __global__ __launch_bounds__(WG, 4) void k_point_query_chained(const GridMeta G,
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	point_query_chained_body<false>(G, net, a, wimg, smem_raw, lm);
 }
-template <int DEPTH>
+template <int DEPTH, int ND = 0>
 __global__ __launch_bounds__(WG, 3) void k_point_query_chained_pipe(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
-	point_query_chained_body<false, DEPTH>(G, net, a, wimg, smem_raw, lm);
+	point_query_chained_body<false, DEPTH, ND>(G, net, a, wimg, smem_raw, lm);
 }
 // rnb_config::accumulate = RNB_ACCUM_HALF: the reference's half accumulators (mlp.cuh, mfma_emul16)
 __global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
@@ -220,17 +221,17 @@ __global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul(const GridMe
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	point_query_chained_body<true>(G, net, a, wimg, smem_raw, lm);
 }
-template <int DEPTH>
+template <int DEPTH, int ND = 0>
 __global__ __launch_bounds__(WG, 2) void k_point_query_chained_emul_pipe(const GridMeta G, const NetW net, const PointArgs a, const half_t* __restrict__ wimg) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
-	point_query_chained_body<true, DEPTH>(G, net, a, wimg, smem_raw, lm);
+	point_query_chained_body<true, DEPTH, ND>(G, net, a, wimg, smem_raw, lm);
 }
 
 constexpr int FWD2_WAVE_HALFS = TILE * S32 + TILE * 8 + TILE;
 constexpr size_t LDS_FWD2 = (size_t)(W_FWD_END + WAVES_PER_WG * FWD2_WAVE_HALFS) * sizeof(half_t);
 
-template <bool EMU, int PIPE_DEPTH = 0>
+template <bool EMU, int PIPE_DEPTH = 0, int ND = 0>
 __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const NetW& net, const FwdArgs& a, char* smem_raw, LevelMeta* lm) {
 	poison_lds(smem_raw, LDS_FWD2, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
@@ -261,7 +262,7 @@ __device__ __forceinline__ void forward_chained_body(const GridMeta& G, const Ne
 		}
 		half_t feat[28];
 		float dydx[28][3];
-		if (PIPE_DEPTH) encode_all_pipelined<true, PIPE_DEPTH ? PIPE_DEPTH : 1>(lm, n_levels, valid_level, net.grid, c[0], c[1], c[2], feat, dydx);
+		if (PIPE_DEPTH) encode_all_pipelined<true, PIPE_DEPTH ? PIPE_DEPTH : 1, ND>(lm, n_levels, valid_level, net.grid, c[0], c[1], c[2], feat, dydx);
 		else encode_all_lm<true>(lm, n_levels, valid_level, net.grid, c[0], c[1], c[2], feat, dydx);
 		write_sdf_in_row(X, lane, c[0], c[1], c[2], feat);
 		wave_lds_sync();
@@ -389,11 +390,11 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained(const GridMeta G, con
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	forward_chained_body<false>(G, net, a, smem_raw, lm);
 }
-template <int DEPTH>
+template <int DEPTH, int ND = 0>
 __global__ __launch_bounds__(WG, 2) void k_forward_chained_pipe(const GridMeta G, const NetW net, const FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
-	forward_chained_body<false, DEPTH>(G, net, a, smem_raw, lm);
+	forward_chained_body<false, DEPTH, ND>(G, net, a, smem_raw, lm);
 }
 // rnb_config::accumulate = RNB_ACCUM_HALF: the reference's half accumulators (mlp.cuh, mfma_emul16)
 __global__ __launch_bounds__(WG, 2) void k_forward_chained_emul(const GridMeta G, const NetW net, const FwdArgs a) {
@@ -401,11 +402,11 @@ __global__ __launch_bounds__(WG, 2) void k_forward_chained_emul(const GridMeta G
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	forward_chained_body<true>(G, net, a, smem_raw, lm);
 }
-template <int DEPTH>
+template <int DEPTH, int ND = 0>
 __global__ __launch_bounds__(WG, 2) void k_forward_chained_emul_pipe(const GridMeta G, const NetW net, const FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
-	forward_chained_body<true, DEPTH>(G, net, a, smem_raw, lm);
+	forward_chained_body<true, DEPTH, ND>(G, net, a, smem_raw, lm);
 }
 
 

@@ -116,6 +116,7 @@ struct rnb_ctx {
 	Profiler prof;
 	GridMeta grid;
 	uint64_t n_grid_params = 0, n_params = 0;
+	uint32_t n_dense_lead = 0; // build_grid_tables
 	uint64_t off_sdf = 0, off_rgb = 0, off_grid = 0, off_var = 0;
 	SceneAabb aabb;
 	int n_cus = 256;
@@ -251,6 +252,9 @@ struct rnb_ctx {
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		bool encode_pair = false; // RNB_ENCODE_PAIR=1 (A/B, round 6): when the configuration's first five levels are dense (the default's are: 16^3 ... 71^3), the depth-4 evaluation kernels gather their x-pairs with one 8-byte load
+		                          // (level_issue<true>): bit-identical, 18 % fewer gather instructions -- and SLOWER: 0.5538 vs 0.5500 ms/step over steps 1000-2000, 0.6092 vs 0.6058 at step 6000 (profiles/r06_ab_encode_pair.txt;
+		                          // a 4-byte-aligned 8-byte gather that straddles a 64-byte line costs a second pass, and the coarse levels were L2 hits to begin with). Off.
 		bool grid_presort = true; // RNB_GRID_PRESORT=0: occupancy updates evaluate their samples in the reference's order (no pregenerate_grid_samples)
 	} knobs;
 	DevBuf<RayLoss> ray_loss;
@@ -360,6 +364,12 @@ void build_grid_tables(rnb_ctx* c) { // grid.h:977-1012
 	}
 	for (uint32_t i = cfg.n_levels; i <= RNB_MAX_LEVELS; ++i) c->grid.offsets[i] = offset;
 	c->n_grid_params = (uint64_t)offset * 2;
+	c->n_dense_lead = 0; // the leading levels whose tables hold the whole lattice (fill_level_meta's rule): the pipelined encode gathers their x-pairs with one load (level_issue<true>)
+	for (uint32_t i = 0; i < cfg.n_levels; ++i) {
+		const uint64_t r = c->grid.resolution[i], size = c->grid.offsets[i + 1] - c->grid.offsets[i];
+		if (r * r * r > size) break;
+		c->n_dense_lead = i + 1;
+	}
 }
 
 void build_light_dirs(rnb_ctx* c) { // testbed_nerf.cu:1537-1554
@@ -469,6 +479,7 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
 	if (c->half_acc() && c->knobs.encode_depth) hipLaunchKernelGGL(k_point_query_chained_emul_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->half_acc()) hipLaunchKernelGGL(k_point_query_chained_emul, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
+	else if (c->knobs.encode_depth == 4 && c->knobs.encode_pair && c->n_dense_lead >= 5) hipLaunchKernelGGL((k_point_query_chained_pipe<4, 5>), dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_point_query_chained_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_point_query_chained_pipe<7>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
 	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_point_query_chained_pipe<2>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
@@ -644,6 +655,7 @@ int launch_forward(rnb_ctx* c, hipStream_t s, const float* coords, const uint32_
 	if (c->half_acc() && c->knobs.encode_depth) hipLaunchKernelGGL(k_forward_chained_emul_pipe<4>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->half_acc()) hipLaunchKernelGGL(k_forward_chained_emul, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 2) hipLaunchKernelGGL(k_forward_chained_pipe<2>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
+	else if (c->knobs.encode_depth == 4 && c->knobs.encode_pair && c->n_dense_lead >= 5) hipLaunchKernelGGL((k_forward_chained_pipe<4, 5>), dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 4) hipLaunchKernelGGL(k_forward_chained_pipe<4>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else if (c->knobs.encode_depth == 7) hipLaunchKernelGGL(k_forward_chained_pipe<7>, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
 	else hipLaunchKernelGGL(k_forward_chained, dim3(grid), dim3(WG), LDS_FWD2, s, c->meta(), c->net(inference), a);
@@ -1492,6 +1504,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_forward_chained_pipe<4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FWD2));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TRAIN));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
@@ -1543,6 +1556,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_ENCODE_PAIR")) k.encode_pair = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
 		if (const char* e = getenv("RNB_DEBUG_SCATTER_LEVELS")) { int lo = -1, hi = -1; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo) { k.dbg_scatter_lo = lo; k.dbg_scatter_hi = hi; } }
 		if (const char* e = getenv("RNB_SCATTER_C_EARLY")) k.scatter_c_early = atoi(e) != 0;
