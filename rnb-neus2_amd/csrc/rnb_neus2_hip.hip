@@ -1573,9 +1573,15 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_RL_UPTO")) k.scatter_rl_upto = std::max(0, std::min(14, atoi(e)));
 	}
 	plan_scatter_groups(c);
-	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_march, hipStreamNonBlocking));
-	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_dw, hipStreamNonBlocking));
-	HIP_TRY_C(hipStreamCreateWithFlags(&c->s_adam, hipStreamNonBlocking));
+	{ // RNB_STREAM_PRIO="march,dw,adam" (A/B): HIP stream priorities of the three side streams (0 = normal, -1 = high, 1 = low)
+		int pr[3] = {0, 0, 0};
+		if (const char* e = getenv("RNB_STREAM_PRIO")) sscanf(e, "%d,%d,%d", &pr[0], &pr[1], &pr[2]);
+		hipStream_t* st[3] = {&c->s_march, &c->s_dw, &c->s_adam};
+		for (int i = 0; i < 3; ++i) {
+			if (pr[i] == 0) HIP_TRY_C(hipStreamCreateWithFlags(st[i], hipStreamNonBlocking));
+			else HIP_TRY_C(hipStreamCreateWithPriority(st[i], hipStreamNonBlocking, pr[i]));
+		}
+	}
 	// ev_loss publishes the step's counters to the HOST (system-scope release). The others only order kernels on this device:
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them.
 	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
