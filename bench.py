@@ -459,9 +459,9 @@ def main(argv=None, engine=None):
         pctx.close()
         parity = {"what": "rnb_config::accumulate = RNB_ACCUM_HALF on the same workload, same steps from the same state: every MLP dot product rounds its accumulator to half after each 16-wide k-step "
                           "(fully_fused_mlp.cu:59-68), the hash-grid gradients go through global_atomic_pk_add_f16 into a half gradient vector (grid.h:410-430, trainer.h:78-84) that the "
-                          "optimizer reads at 2 bytes per parameter. Two stated departures from the reference's code in this mode: the weight-gradient GEMMs keep fp32 accumulators in the kernel's "
-                          "tiling and round to half once (reference: CUTLASS split-K slices with half accumulators), and the scatter sums a cell run / a workgroup's slice in fp32 before its one "
-                          "packed half atomic (RNB_SCATTER_PLAIN=1: every addend its own atomic). Against the reference-as-coded model on the pinned state: "
+                          "optimizer reads at 2 bytes per parameter, the weight-gradient GEMMs run in CUTLASS's split-K order (4096-sample slices, half accumulators per 16-sample k-step, "
+                          "cutlass_matmul.h:83, 315-322: k_dw_sliced, bit-identical to the model on the same operands). One stated departure from the reference's code in this mode: the scatter "
+                          "sums a cell run / a workgroup's slice in fp32 before its one packed half atomic (RNB_SCATTER_PLAIN=1: every addend its own atomic). Against the reference-as-coded model on the pinned state: "
                           "tests/test_gpu_fullsize.py::test_hip_against_the_reference_as_coded_emulation[half] (Eikonal / mask sums 4e-6 / 6e-9; colour sum 1.65e-4 -- one ray -- NOT within the 1e-4)",
                   "accumulate": "half", "first_step": int(p_last.training_step) - args.steps, "steps": args.steps, "ms_per_step": round(1e3 * p_el / args.steps, 4), "rays_per_s": round(p_rays / p_el, 1),
                   "next_steps": {"steps": args.parity_mode_steps, "ms_per_step": round(1e3 * q_el / args.parity_mode_steps, 4), "p50_ms_per_step": round(float(np.median(q_ms)), 4),

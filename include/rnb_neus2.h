@@ -109,10 +109,12 @@ typedef struct rnb_config {
 	                                     half where the reference stores half. RNB_ACCUM_HALF (1): the reference's arithmetic as coded -- the MLPs' dot products round their
 	                                     accumulator to half after every 16-wide k-step (WMMA half fragments, fully_fused_mlp.cu:59-68, 198), the hash-grid gradients are summed
 	                                     by atomicAdd(__half2) into a half gradient vector (grid.h:410-430, trainer.h:78-84: RNB_BUF_GRADS_FP16 replaces RNB_BUF_GRADS_FP32).
-	                                     Fixed at rnb_create. Two stated departures from the reference's code in this mode: the weight-gradient GEMMs keep fp32
-	                                     accumulators in the kernel's own tiling and round to half once (the reference: CUTLASS split-K slices of 4096 samples with half
-	                                     accumulators, cutlass_matmul.h:83, 315-322), and the default scatter sums a cell run / a workgroup's slice in fp32 before its one packed
-	                                     half atomic (RNB_SCATTER_PLAIN=1 issues the reference's own sequence: every addend its own atomicAdd(__half2)). */
+	                                     The weight-gradient GEMMs follow tcnn's CUTLASS split-K order (slices of 4096 samples, half accumulators rounded after every 16-sample
+	                                     k-step, the slices reduced in half: cutlass_matmul.h:83, 315-322; RNB_PRIM_DW_SLICED) with --no-albedo (apply_no_albedo = 1, the benchmarked
+	                                     configuration). Fixed at rnb_create. Stated departures from the reference's code in this mode: the default scatter sums a
+	                                     cell run / a workgroup's slice in fp32 before its one packed half atomic (RNB_SCATTER_PLAIN=1 issues the reference's own sequence: every
+	                                     addend its own atomicAdd(__half2)); with the colour MLP live (apply_no_albedo = 0) the weight gradients keep fp32 accumulators in the
+	                                     training kernels' own tiling and round to half once. */
 	uint32_t deterministic;           /* 0 (default): the hash-grid gradients are summed by floating-point atomics, as in the reference (grid.h:410-430) -- the sum depends on the order
 	                                     the hardware retires them in, so two runs from one state differ in the last bits and a training run is not reproducible (neither is the
 	                                     reference's: src/testbed_nerf.cu:1352, 1557-1561). 1: every addend -- rounded to half first exactly as the reference rounds it (grid.h:415-416),
@@ -384,9 +386,13 @@ int rnb_set_controller(rnb_ctx* ctx, uint32_t training_step, uint32_t rays_per_b
  *   RNB_PRIM_SDF_DENSITY in sdf, variance (half bit patterns)    out the occupancy grid's density s sigmoid(sdf s) (1 - sigmoid(sdf s)), s = exp(10 variance), half arithmetic throughout
  *                    (sdf_to_density_variance_buffer, common_operation.cuh:311-328)
  *   RNB_PRIM_PREP_DUE in training step    out 1 if that step begins with an occupancy update, and the interval n_prep_to_skip it is due at (Testbed::train, src/testbed.cu:2805-2806)
+ *   RNB_PRIM_DW_SLICED in 4 words (word 0: 1 = the Y operand is the constant 1 on row 0, rows 1..3 zero), then 8 rows of 8256 halves (two per word): Y rows 0..3, X rows 0..3
+ *                    out the 4 x 4 weight gradient dW[o][i] = sum_s Y[o][s] X[i][s] as accumulate = RNB_ACCUM_HALF forms it (float bit patterns of half values): slices of 4096 samples
+ *                    (here 4096 + 4096 + 64), a half accumulator per slice rounded after every 16-sample k-step, the slices' results added in half
+ *                    (tcnn cutlass_matmul.h:83, 315-322 as the oracle's emulated_dw models it; the library's own k_dw_sliced / k_dw_finish code)
  * Host pointers; syncs. */
 typedef enum rnb_primitive { RNB_PRIM_PCG32 = 0, RNB_PRIM_MORTON = 1, RNB_PRIM_SRGB = 2, RNB_PRIM_RAY_BOX = 3, RNB_PRIM_MARCH = 4,
-                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15, RNB_PRIM_MARCH_RAY = 16, RNB_PRIM_SDF_DENSITY = 17, RNB_PRIM_PREP_DUE = 18 } rnb_primitive;
+                             RNB_PRIM_ACTIVATION = 5, RNB_PRIM_WARP = 6, RNB_PRIM_LOSS = 7, RNB_PRIM_PIXEL = 8, RNB_PRIM_GRID = 9, RNB_PRIM_READ_RGBA = 10, RNB_PRIM_CAMERA_RAY = 11, RNB_PRIM_RAY_TARGETS = 12, RNB_PRIM_LOSS_SAMPLE = 13, RNB_PRIM_RAY_LOSS = 14, RNB_PRIM_ENCODE = 15, RNB_PRIM_MARCH_RAY = 16, RNB_PRIM_SDF_DENSITY = 17, RNB_PRIM_PREP_DUE = 18, RNB_PRIM_DW_SLICED = 19 } rnb_primitive;
 int rnb_eval_primitives(rnb_ctx* ctx, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host);
 
 /* Data parallel only: gradient blocks in the order they become final during the backward pass queued by

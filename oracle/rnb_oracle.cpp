@@ -2071,8 +2071,9 @@ uint32_t rnb_rays_per_batch(const orc_ctx_s* c) { return c ? c->rays_per_batch :
 // rnb_eval_primitives (include/rnb_neus2.h): the checker's own statements of the index primitives, item by item.
 int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_items, uint32_t* out) {
 	if (!c || (!in && n_items) || (!out && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_PREP_DUE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
-	static const uint32_t IN_W[19] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1}, OUT_W[19] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2};
+	if (kind < 0 || kind > RNB_PRIM_DW_SLICED) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	constexpr uint32_t DW_S = 8256; // RNB_PRIM_DW_SLICED: samples per GEMM
+	static const uint32_t IN_W[20] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1, 4 + 8 * DW_S / 2}, OUT_W[20] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2, 16};
 	auto f = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
 	auto u = [](float v) { uint32_t w; std::memcpy(&w, &v, 4); return w; };
 	std::vector<uint8_t> bf;
@@ -2220,6 +2221,16 @@ int rnb_eval_primitives(orc_ctx_s* c, int kind, const uint32_t* in, uint32_t n_i
 			const half_t d = sdf_to_density(sdf, var);
 			uint16_t d16; std::memcpy(&d16, &d, 2);
 			o[0] = d16;
+		} else if (kind == RNB_PRIM_DW_SLICED) { // the weight-gradient GEMM of the half mode: emulated_dw itself, on the caller's operands
+			const half_t* rows = reinterpret_cast<const half_t*>(a + 4);
+			const bool ones = (a[0] & 1u) != 0u;
+			for (uint32_t oo = 0; oo < 4; ++oo)
+				for (uint32_t ii = 0; ii < 4; ++ii) {
+					float v = 0.f;
+					if (!ones) v = emulated_dw(DW_S, true, [&](uint32_t s) { return h2f(rows[(size_t)oo * DW_S + s]); }, [&](uint32_t s) { return h2f(rows[(size_t)(4 + ii) * DW_S + s]); });
+					else if (oo == 0) v = emulated_dw(DW_S, true, [&](uint32_t) { return 1.0f; }, [&](uint32_t s) { return h2f(rows[(size_t)(4 + ii) * DW_S + s]); });
+					o[oo * 4 + ii] = u(v);
+				}
 		} else if (kind == RNB_PRIM_PREP_DUE) {
 			const uint32_t n_prep_to_skip = std::min(std::max(a[0] / 16u, 1u), 16u); // testbed.cu:2805, as the step driver below states it
 			o[0] = a[0] % n_prep_to_skip == 0 ? 1u : 0u; o[1] = n_prep_to_skip;

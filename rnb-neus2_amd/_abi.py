@@ -110,8 +110,8 @@ BUF_DTYPE = dict(
 ACCUM_FP32, ACCUM_HALF = 0, 1  # rnb_accumulate
 BUF_READONLY = 0x100  # RNB_BUF_READONLY
 GRID_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)  # rnb_grid_exchange_fn(user, grid_tmp, n_elements, stream)
-PRIM = dict(PCG32=0, MORTON=1, SRGB=2, RAY_BOX=3, MARCH=4, ACTIVATION=5, WARP=6, LOSS=7, PIXEL=8, GRID=9, READ_RGBA=10, CAMERA_RAY=11, RAY_TARGETS=12, LOSS_SAMPLE=13, RAY_LOSS=14, ENCODE=15, MARCH_RAY=16, SDF_DENSITY=17, PREP_DUE=18)  # rnb_primitive
-PRIM_IN_WORDS, PRIM_OUT_WORDS = (6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1), (4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2)
+PRIM = dict(PCG32=0, MORTON=1, SRGB=2, RAY_BOX=3, MARCH=4, ACTIVATION=5, WARP=6, LOSS=7, PIXEL=8, GRID=9, READ_RGBA=10, CAMERA_RAY=11, RAY_TARGETS=12, LOSS_SAMPLE=13, RAY_LOSS=14, ENCODE=15, MARCH_RAY=16, SDF_DENSITY=17, PREP_DUE=18, DW_SLICED=19)  # rnb_primitive
+PRIM_IN_WORDS, PRIM_OUT_WORDS = (6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1, 33028), (4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2, 16)
 H2D, D2H, D2D = 0, 1, 2
 
 _ctx = C.c_void_p

@@ -809,9 +809,11 @@ __device__ __forceinline__ void export_frags(const h8 (&b)[4][2], half_t* __rest
 //   dz = (W1^T dso) (.) relu'(z1)  as a K = 16 MFMA (both orientations) instead of one product per element, and
 //   dW1 += dso z1^T                as a 16 x 64 MFMA (dso^T by an identity MFMA) instead of row 0 on the VALU.
 // EMU (rnb_config::accumulate = RNB_ACCUM_HALF): every dot product over features rounds its accumulator to half after each of the reference's 16-wide k-steps (mlp.cuh);
-// products with K = 16 (W1^T dso, the identity transposes) are one k-step and need nothing. The weight gradients (K = samples) keep their fp32 accumulators: their
-// summation order is this kernel's tiling, not the reference's split-K slices (deviation D1').
-template <bool FULL, bool EMU = false>
+// products with K = 16 (W1^T dso, the identity transposes) are one k-step and need nothing. The weight gradients (K = samples): SLICED (below) hands their operands to k_dw_sliced,
+// which sums them in the reference's split-K order; without it (the albedo mode's FULL kernel, RNB_DW_SLICED=0) they keep fp32 accumulators in this kernel's tiling (deviation D1').
+// SLICED (half mode, round 6): the weight gradients are NOT accumulated here: the tile's GEMM operands leave feature-major (TrainScratch: dz, dz1, z1, front as the fragments they are formed in,
+// the two input tiles from LDS, dL/dsdf) for k_dw_sliced, which sums them in the reference's split-K order -- 642 B per sample of stores instead of 80 MFMAs per tile.
+template <bool FULL, bool EMU = false, bool SLICED = false>
 __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& net, const TrainArgs& a, char* smem_raw, LevelMeta* lm) {
 	poison_lds(smem_raw, FULL ? LDS_FBS_FULL : LDS_FBS, threadIdx.x, WG);
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
@@ -921,6 +923,15 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 			if (hq < 2) v = *reinterpret_cast<const h8*>(SO + (16 * nt + r16) * SO_STRIDE + 8 * hq);
 			return v;
 		};
+		if (SLICED) { // the two input tiles, feature-major in the reference's column order (one 128-byte row segment per store), and dso's row 0
+			static_assert(!SLICED || (EMU && !FULL), "the sliced weight gradients are built for the half mode's SDF-only kernel");
+#pragma unroll
+			for (uint32_t q = 0; q < 32; ++q) {
+				st32(T.sdfin, (uint32_t)fbs_logical_h(q) * B + s, X[lane * S32 + q]);
+				st32(T.ddin, (uint32_t)fbs_logical_h(q) * B + s, D[lane * S32 + q]);
+			}
+			st32(T.dso, s, dout[3]);
+		}
 		{ // ---- weight gradients of this tile (see the header) ----
 			h8 fso[4];
 			if (FULL) {
@@ -953,7 +964,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 			// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
 			h8 b_in[2][2], b_dd[2][2];
 #pragma unroll
-			for (int n2 = 0; n2 < 2; ++n2) {
+			for (int n2 = 0; n2 < (SLICED ? 0 : 2); ++n2) {
 				h8 idf;
 #pragma unroll
 				for (int j = 0; j < 8; ++j) idf[j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
@@ -976,7 +987,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 				const float w1f = h2f(w1h);
 				h8 wb1t;
 				if (FULL) wb1t = *reinterpret_cast<const h8*>(wts + SW_W1T + (16 * nt + r16) * S32 + 8 * hq);
-				h8 a_dz[2], a_dz1[2], b_z1[2];
+				h8 a_dz[2], a_dz1[2], b_z1[2], a_fr[2];
 #pragma unroll
 				for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -998,11 +1009,19 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 							const half_t zh = f2h(z[r]);
 							const bool on = zh > (half_t)0.f; // relu' tests the stored half activation (common_device.h:182 ff.)
 							const float d = h2f(d3v[mt][r]);
-							if (!FULL) acc_w1[nt] += on ? d * h2f(zh) : 0.f;
-							acc_w1b[nt] += on ? h2f(f2h(fr[r])) : 0.f;
+							if (!FULL && !SLICED) acc_w1[nt] += on ? d * h2f(zh) : 0.f;
+							if (!SLICED) acc_w1b[nt] += on ? h2f(f2h(fr[r])) : 0.f;
 							a_dz[ks][4 * h + r] = on ? (FULL ? f2h(dzt[r]) : f2h(w1f * d)) : (half_t)0.f;
 							a_dz1[ks][4 * h + r] = on ? w1h : (half_t)0.f;
-							if (FULL) b_z1[ks][4 * h + r] = on ? zh : (half_t)0.f;
+							if (FULL || SLICED) b_z1[ks][4 * h + r] = on ? zh : (half_t)0.f;
+							if (SLICED) a_fr[ks][4 * h + r] = on ? f2h(fr[r]) : (half_t)0.f;
+						}
+						if (SLICED) { // row = hidden unit 16 nt + r16, four consecutive samples 16 mt + 4 hq .. + 3 of the tile per lane
+							const uint32_t off = (16u * nt + r16) * B + tile * TILE + 16u * mt + 4u * hq;
+							st32(reinterpret_cast<h4*>(T.dz), off / 4u, h4{a_dz[ks][4 * h], a_dz[ks][4 * h + 1], a_dz[ks][4 * h + 2], a_dz[ks][4 * h + 3]});
+							st32(reinterpret_cast<h4*>(T.dz1), off / 4u, h4{a_dz1[ks][4 * h], a_dz1[ks][4 * h + 1], a_dz1[ks][4 * h + 2], a_dz1[ks][4 * h + 3]});
+							st32(reinterpret_cast<h4*>(T.z1), off / 4u, h4{b_z1[ks][4 * h], b_z1[ks][4 * h + 1], b_z1[ks][4 * h + 2], b_z1[ks][4 * h + 3]});
+							st32(reinterpret_cast<h4*>(T.front), off / 4u, h4{a_fr[ks][4 * h], a_fr[ks][4 * h + 1], a_fr[ks][4 * h + 2], a_fr[ks][4 * h + 3]});
 						}
 					}
 				if (FULL) {
@@ -1010,7 +1029,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 					for (int ks = 0; ks < 2; ++ks) acc_w1f[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_so[ks], b_z1[ks], acc_w1f[nt], 0, 0, 0);
 				}
 #pragma unroll
-				for (int ks = 0; ks < 2; ++ks)
+				for (int ks = 0; ks < (SLICED ? 0 : 2); ++ks)
 #pragma unroll
 					for (int ni = 0; ni < 2; ++ni) {
 						acc_w0[nt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_dz[ks], b_in[ni][ks], acc_w0[nt][ni], 0, 0, 0);
@@ -1105,6 +1124,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 	if (lane == 0) T.var_partial[blockIdx.x * WAVES_PER_WG + wave] = var_sum;
 	// The four wavefronts' weight gradients, summed in a fixed order, leave as ONE partial per workgroup in k_dw's layout. The per-wave
 	// tiles are dead: their LDS is the staging area. D layout: lane = input column 16 ni + r16 (tile order), register r = hidden unit 16 mo + 4 hq + r.
+	if (SLICED) return; // (k_dw_sliced forms the weight gradients from the exported operands)
 	float* red = reinterpret_cast<float*>(wts + W_END);
 	static_assert((size_t)WAVES_PER_WG * FBS_WAVE_HALFS * sizeof(half_t) >= (size_t)WAVES_PER_WG * 64 * 32 * sizeof(float), "staging area of the weight-gradient partials");
 	constexpr int N = 64 * 32;
@@ -1160,6 +1180,11 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_h(const GridMeta G, const
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fwd_bwd_sdf_body<false, true>(G, net, a, smem_raw, lm);
+}
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_hs(const GridMeta G, const NetW net, const TrainArgs a) { // half mode, weight-gradient operands exported for k_dw_sliced
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<false, true, true>(G, net, a, smem_raw, lm);
 }
 __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full_h(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1496,6 +1521,106 @@ __global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
 	}
 }
 
+// rnb_config::accumulate = RNB_ACCUM_HALF (round 6; removes deviation D1'): the weight-gradient GEMMs in the REFERENCE's summation order. tcnn computes them with CUTLASS split-K
+// (cutlass_matmul.h:83, 315-322: slices of 4096 samples, half accumulators, the slices' results reduced in half); the model of it is oracle/rnb_oracle.cpp emulated_dw: per output element
+// and slice, 256 dependent k-steps -- the 16 products of a k-step (exact in fp32) added one after the other in fp32, the half accumulator + that sum rounded to half -- and the slices' results
+// added in half in slice order. This kernel IS that statement: one thread per 4 output elements (o, i0 .. i0 + 3), the samples of its slice in order, the operands read from the feature-major
+// arrays the training kernel exported (TrainScratch; L1 serves a lane's 64-byte line for 32 samples). Plain VALU fp32 adds in the stated order: bit-identical to the model on the same operands
+// (RNB_PRIM_DW_SLICED); an MFMA would add a k-step's products in an order of its own (tools/probe_mfma_arith.hip). Every chain is 4096 samples long whatever the launch: ~70 us beside the scatter.
+// out[g][slice][n_out * n_in] floats holding half values; k_dw_finish (sliced) adds the slices in half.
+constexpr uint32_t DW_SLICE = 4096; // cutlass_matmul.h:83
+struct DwSlicedArgs {
+	const half_t* YT[7]; const half_t* XT[7]; float* out[7];
+	uint32_t n_out[7], n_out_live[7], n_in[7], ones[7]; // rows >= n_out_live are exact zeros (not computed: a zero operand row gives +0 at every step); ones: Y is the constant 1 (row 0)
+	uint32_t first_wg[8];                                // workgroups [first_wg[g], first_wg[g + 1]) work on GEMM g: n_slices x blocks(g)
+	uint32_t n, B, n_slices;
+};
+constexpr uint32_t DWS_CHUNK = 128, DWS_ROW = DWS_CHUNK + 8, DWS_MAX_ROWS = 80; // samples staged per step; halfs per staged row (+16 bytes: the 16-byte reads of different rows fall into different banks); Y rows + X rows of a workgroup
+__global__ __launch_bounds__(256) void k_dw_sliced(const DwSlicedArgs a) {
+	// The workgroup's operand rows travel through LDS in chunks of 128 samples, the next chunk's 16-byte pieces in flight (registers) while this one is summed: a lane that read its rows
+	// itself waited one L2 round trip per k-step -- 256 dependent round trips per slice, 0.5 ms beside the scatter (profiles/r06_half_mode_sliced.txt).
+	__shared__ __attribute__((aligned(16))) half_t stage[2][DWS_MAX_ROWS * DWS_ROW];
+	uint32_t g = 0;
+	while (g + 1 < a.n && blockIdx.x >= a.first_wg[g + 1]) ++g;
+	const uint32_t n_in = a.n_in[g], per_row = n_in / 4u, n_threads = a.n_out[g] * per_row, blocks = (n_threads + 255u) / 256u;
+	const uint32_t wl = blockIdx.x - a.first_wg[g], slice = wl / blocks, t0 = (wl - slice * blocks) * 256u, t = t0 + threadIdx.x;
+	const uint32_t o = t / per_row, i0 = 4u * (t - o * per_row), B = a.B, n_live = a.n_out_live[g];
+	const bool ones = a.ones[g] != 0u, live = t < n_threads && o < n_live;
+	const uint32_t o0 = t0 / per_row;                                                    // first output row of this workgroup
+	const uint32_t y_rows = (ones || o0 >= n_live) ? 0u : min(n_live - o0, (255u + per_row) / per_row); // staged Y rows: o0 .. o0 + y_rows - 1
+	const uint32_t rows = (o0 >= n_live) ? 0u : y_rows + n_in, pieces = rows * (DWS_CHUNK / 8u);          // (a workgroup without live rows stages nothing)
+	const uint32_t s_begin = slice * DW_SLICE, s_end = min(B, s_begin + DW_SLICE);
+	const half_t* YT = a.YT[g]; const half_t* XT = a.XT[g];
+	if (o0 >= n_live) { // a workgroup of rows that are exact zeros (wave-uniform: no barrier is left waiting)
+		if (t < n_threads) { float* dst = a.out[g] + (size_t)slice * (a.n_out[g] * n_in) + o * n_in + i0; dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f; dst[3] = 0.f; }
+		return;
+	}
+	h8 in_flight[(DWS_MAX_ROWS * (DWS_CHUNK / 8u) + 255u) / 256u] = {};
+	auto request = [&](const uint32_t s) {
+#pragma unroll
+		for (uint32_t k = 0; k < sizeof(in_flight) / sizeof(h8); ++k) {
+			const uint32_t idx = threadIdx.x + 256u * k, row = idx / (DWS_CHUNK / 8u), piece = idx % (DWS_CHUNK / 8u);
+			if (idx < pieces && s + 8u * piece < s_end) in_flight[k] = *reinterpret_cast<const h8*>((row < y_rows ? YT + (size_t)(o0 + row) * B : XT + (size_t)(row - y_rows) * B) + s + 8u * piece); // (nothing beyond the slice: a row's end may be the array's)
+		}
+	};
+	auto deposit = [&](half_t* buf) {
+#pragma unroll
+		for (uint32_t k = 0; k < sizeof(in_flight) / sizeof(h8); ++k) {
+			const uint32_t idx = threadIdx.x + 256u * k, row = idx / (DWS_CHUNK / 8u), piece = idx % (DWS_CHUNK / 8u);
+			if (idx < pieces) *reinterpret_cast<h8*>(buf + row * DWS_ROW + 8u * piece) = in_flight[k];
+		}
+	};
+	float acc[4] = {0.f, 0.f, 0.f, 0.f}; // half values
+	const h8 one8 = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+	const uint32_t ry = ones ? 0u : (o - o0) * DWS_ROW, rx = (y_rows + i0) * DWS_ROW;
+	request(s_begin);
+	deposit(stage[0]);
+	__syncthreads();
+	uint32_t cur = 0;
+	for (uint32_t s = s_begin; s < s_end; s += DWS_CHUNK) { // (B is a multiple of 64, a slice of 4096: chunks of 128 or one of 64 at the end -- whole k-steps)
+		const bool more = s + DWS_CHUNK < s_end;
+		if (more) request(s + DWS_CHUNK);
+		if (live) {
+			const half_t* buf = stage[cur];
+			const uint32_t n_k = min(DWS_CHUNK, s_end - s) / 16u;
+			for (uint32_t k = 0; k < n_k; ++k) {
+				float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const h8 yy = ones ? one8 : *reinterpret_cast<const h8*>(buf + ry + 16u * k + 8 * h);
+					h8 xx[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) xx[q] = *reinterpret_cast<const h8*>(buf + rx + q * DWS_ROW + 16u * k + 8 * h);
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+#pragma unroll
+						for (int q = 0; q < 4; ++q) part[q] = __builtin_fmaf((float)yy[j], (float)xx[q][j], part[q]); // v_fma_mix_f32: the product of two halfs is exact in fp32, so fused = multiplied and added
+				}
+#pragma unroll
+				for (int q = 0; q < 4; ++q) acc[q] = rh(acc[q] + part[q]);
+			}
+		}
+		if (more) deposit(stage[cur ^ 1u]);
+		__syncthreads();
+		cur ^= 1u;
+	}
+	if (t < n_threads) {
+		float* dst = a.out[g] + (size_t)slice * (a.n_out[g] * n_in) + o * n_in + i0;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) dst[q] = live ? acc[q] : 0.f;
+	}
+}
+// the slices' results added in half, in slice order (GemmSplitKParallel's reduction, cutlass_matmul.h:315-322; emulated_dw's `total`)
+__device__ __forceinline__ float dw_sum_sliced(const float* __restrict__ base, const uint32_t stride, const uint32_t idx, const uint32_t n_slices) {
+	float t = 0.f;
+	for (uint32_t p = 0; p < n_slices; ++p) t = rh(t + base[(size_t)p * stride + idx]);
+	return t;
+}
+__global__ void k_prim_dw_sliced_total(const float* __restrict__ slices, const uint32_t n, const uint32_t n_slices, float* __restrict__ out) { // RNB_PRIM_DW_SLICED
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = dw_sum_sliced(slices, n, i, n_slices);
+}
+
 // Offsets (floats) of the seven partial blocks inside one wave's slab are given by the host.
 struct DwFinishArgs {
 	const float* partial[7]; // rgb2[16x64], rgb1[64x64], rgb0c[64x32], sdf1[16x64], sdf0[64x32], sdf0_2nd[64x32], sdf1_2nd[16x64]
@@ -1506,6 +1631,7 @@ struct DwFinishArgs {
 	half_t* grads16;         // rnb_config::accumulate = RNB_ACCUM_HALF: GRADS_FP16 instead (the values below are half-rounded already: exact)
 	uint32_t off_sdf, off_rgb, off_var;
 	uint32_t skip_rgb;       // colour-MLP gradients are exactly zero (see TrainArgs::skip_rgb): their accumulators are clear already and no workgroup is launched for them
+	uint32_t sliced;         // the partials are k_dw_sliced's per-slice results (half values): added in half in slice order instead of in fp32
 };
 
 // DWF_PARAMS parameters per workgroup x DWF_SLICES slices of the partial list (fixed summation order -> deterministic). Mirrors the
@@ -1517,6 +1643,17 @@ struct DwFinishArgs {
 constexpr uint32_t DWF_SLICES = 16, DWF_PARAMS = 16, DWF_WG = DWF_PARAMS * DWF_SLICES;
 __device__ __forceinline__ float dw_sum(const float* __restrict__ base, const uint32_t stride, const uint32_t idx, const uint32_t n_partials, const uint32_t slice, float (*sh)[DWF_PARAMS], const uint32_t e) {
 	float s = 0.f;
+	if (n_partials & 0x80000000u) { // sliced: the slices' half results are fetched by the 16 slice-threads at once (64 at a time), then added in half in slice order by one of them
+		__shared__ float all[64][DWF_PARAMS];
+		const uint32_t n = n_partials & 0x7fffffffu;
+		for (uint32_t p0 = 0; p0 < n; p0 += 64u) {
+			__syncthreads();
+#pragma unroll
+			for (uint32_t k = 0; k < 64u / DWF_SLICES; ++k) { const uint32_t p = p0 + slice + DWF_SLICES * k; if (p < n) all[slice + DWF_SLICES * k][e] = base[(size_t)p * stride + idx]; }
+			__syncthreads();
+			if (slice == 0) for (uint32_t p = 0; p < min(64u, n - p0); ++p) s = rh(s + all[p][e]); // (the exchange below then adds fifteen zeros to it -- exact)
+		}
+	} else
 	for (uint32_t p = slice; p < n_partials; p += DWF_SLICES) s += base[(size_t)p * stride + idx];
 	__syncthreads();
 	sh[slice][e] = s;
@@ -1532,6 +1669,7 @@ __global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
 	const uint32_t e = threadIdx.x % DWF_PARAMS, slice = threadIdx.x / DWF_PARAMS;
 	const uint32_t n_mlp = a.skip_rgb ? RNB_N_SDF_MLP_PARAMS : RNB_N_SDF_MLP_PARAMS + RNB_N_RGB_MLP_PARAMS;
 	const uint32_t i = blockIdx.x * DWF_PARAMS + e;
+	const uint32_t n_part = a.sliced ? (a.n_partials | 0x80000000u) : a.n_partials;
 	if (blockIdx.x * DWF_PARAMS >= n_mlp) { // last workgroup: the variance gradient (nerf_network.h:327-340)
 		float v = 0.f;
 		for (uint32_t p = threadIdx.x; p < a.n_var_partials; p += DWF_WG) v += a.var_partial[p];
@@ -1551,25 +1689,25 @@ __global__ __launch_bounds__(DWF_WG) void k_dw_finish(const DwFinishArgs a) {
 	// all parameters of a workgroup lie in the same matrix and, for the colour MLP's first matrix, in the same row (matrix sizes and 48 are multiples of 16)
 	float g;
 	if (i < 64 * 32) { // sdf W0
-		g = rh(dw_sum(a.partial[4], 64 * 32, i, a.n_partials, slice, sh, e));
-		g = rh(dw_sum(a.partial[5], 64 * 32, i, a.n_partials, slice, sh, e) + g);
+		g = rh(dw_sum(a.partial[4], 64 * 32, i, n_part, slice, sh, e));
+		g = rh(dw_sum(a.partial[5], 64 * 32, i, n_part, slice, sh, e) + g);
 		if (slice == 0) { if (a.grads16) a.grads16[a.off_sdf + i] = f2h(g); else a.grads[a.off_sdf + i] = g; }
 	} else if (i < RNB_N_SDF_MLP_PARAMS) { // sdf W1
 		const uint32_t j = i - 64 * 32;
-		g = rh(dw_sum(a.partial[3], 16 * 64, j, a.n_partials, slice, sh, e));
-		g = rh(dw_sum(a.partial[6], 16 * 64, j, a.n_partials, slice, sh, e) + g);
+		g = rh(dw_sum(a.partial[3], 16 * 64, j, n_part, slice, sh, e));
+		g = rh(dw_sum(a.partial[6], 16 * 64, j, n_part, slice, sh, e) + g);
 		if (slice == 0) { if (a.grads16) a.grads16[a.off_sdf + i] = f2h(g); else a.grads[a.off_sdf + i] = g; }
 	} else {
 		const uint32_t j = i - RNB_N_SDF_MLP_PARAMS;
 		if (j < 64 * 48) { // rgb W0: compact column c <-> original column (c < 16 ? c : c + 16); the others receive zero input
 			const uint32_t o = j / 48, col = j % 48;
 			const uint32_t cc = col < 16 ? col : (col >= 32 ? col - 16 : 0);
-			const float v = rh(dw_sum(a.partial[2], 64 * 32, o * 32 + cc, a.n_partials, slice, sh, e));
+			const float v = rh(dw_sum(a.partial[2], 64 * 32, o * 32 + cc, n_part, slice, sh, e));
 			g = (col < 16 || col >= 32) ? v : 0.f;
 		} else if (j < 64 * 48 + 64 * 64) {
-			g = rh(dw_sum(a.partial[1], 64 * 64, j - 64 * 48, a.n_partials, slice, sh, e));
+			g = rh(dw_sum(a.partial[1], 64 * 64, j - 64 * 48, n_part, slice, sh, e));
 		} else {
-			g = rh(dw_sum(a.partial[0], 16 * 64, j - 64 * 48 - 64 * 64, a.n_partials, slice, sh, e));
+			g = rh(dw_sum(a.partial[0], 16 * 64, j - 64 * 48 - 64 * 64, n_part, slice, sh, e));
 		}
 		if (slice == 0) { if (a.grads16) a.grads16[a.off_rgb + j] = f2h(g); else a.grads[a.off_rgb + j] = g; }
 	}

@@ -2616,7 +2616,8 @@ __global__ __launch_bounds__(1024) void k_reduce_losses_rollover(const uint32_t 
 // rnb_eval_primitives: the integer / index primitives above, one thread per item (include/rnb_neus2.h); tests/golden/int_fixtures.json
 // holds what the reference's own host-compilable fragments return for the same items.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PRIM_IN_WORDS[19] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1}, PRIM_OUT_WORDS[19] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2};
+constexpr uint32_t PRIM_DW_SAMPLES = 8256; // RNB_PRIM_DW_SLICED: two whole slices and a short one
+constexpr uint32_t PRIM_IN_WORDS[20] = {6, 3, 1, 8, 9, 1, 9, 9, 9, 7, 32, 20, 35, 37, 16, 263, 10, 2, 1, 4 + 8 * PRIM_DW_SAMPLES / 2}, PRIM_OUT_WORDS[20] = {4, 4, 2, 3, 7, 3, 11, 5, 3, 3, 5, 9, 7, 28, 9, 16, 23, 1, 2, 16};
 __global__ void k_prim_bitfield(uint8_t* __restrict__ bitfield, const uint32_t n) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;

@@ -252,6 +252,7 @@ struct rnb_ctx {
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		bool dw_sliced = true; // RNB_DW_SLICED=0 (A/B): the half mode's weight gradients in the training kernel's own tiling (deviation D1', rounds 4-5) instead of the reference's split-K order
 		bool encode_pair = false; // RNB_ENCODE_PAIR=1 (A/B, round 6): when the configuration's first five levels are dense (the default's are: 16^3 ... 71^3), the depth-4 evaluation kernels gather their x-pairs with one 8-byte load
 		                          // (level_issue<true>): bit-identical, 18 % fewer gather instructions -- and SLOWER: 0.5538 vs 0.5500 ms/step over steps 1000-2000, 0.6092 vs 0.6058 at step 6000 (profiles/r06_ab_encode_pair.txt;
 		                          // a 4-byte-aligned 8-byte gather that straddles a 64-byte line costs a second pass, and the coarse levels were L2 hits to begin with). Off.
@@ -906,8 +907,12 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	a.wimg = !c->wimg_valid ? nullptr : (!c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = (a.skip_rgb && !c->knobs.fwd_bwd_generic) || split; // the training kernels leave one weight-gradient partial per workgroup themselves
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
-	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own
-	const size_t slab = sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
+	// half mode, round 6: the weight gradients in the reference's split-K order (k_dw_sliced) -- built for the SDF-only training kernel (--no-albedo, the benchmarked configuration);
+	// the albedo mode's two kernels keep their own tiling (deviation D1'). RNB_DW_SLICED=0: the round-5 form everywhere.
+	const bool sliced = half && sdf_only && !split && c->knobs.dw_sliced;
+	const uint32_t n_slices = (B + DW_SLICE - 1) / DW_SLICE;
+	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own; sliced: one per 4096-sample slice (never more than workgroups)
+	const size_t slab = sliced ? (size_t)n_slices : sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
 	float* p_rgb2; float* p_rgb1; float* p_rgb0; float* p_sdf1; float* p_sdf0; float* p_sdf0b; float* p_sdf1b;
 	{
 		float* p = c->dw_partial.p;
@@ -942,7 +947,8 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// (one workgroup per CU -- no register spills, the two-per-CU instance keeps ~80 values in scratch -- lost: 0.88 vs 0.80 ms/step, half the wavefronts to hide the gathers)
 		if (half) LAUNCH_EV(k_fwd_bwd_sdf_full_h, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
 		else LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
-	} else if (sdf_only && half) LAUNCH_EV(k_fwd_bwd_sdf_h, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+	} else if (sdf_only && half && sliced) LAUNCH_EV(k_fwd_bwd_sdf_hs, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
+	else if (sdf_only && half) LAUNCH_EV(k_fwd_bwd_sdf_h, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else if (sdf_only) LAUNCH_EV(k_fwd_bwd_sdf, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else LAUNCH_EV(k_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_TRAIN, s, ev_fb, c->meta(), c->net(false), a);
 	c->prof.mark(s, P_FWD_BWD);
@@ -968,9 +974,25 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		// the generic kernel's feature-major operands: seven (four with --no-albedo) GEMMs in one launch (0.852 -> 0.831 ms/step); k_fwd_bwd_sdf has
 		// accumulated its weight gradients itself and left one partial per workgroup
 		if (!sdf_only) hipLaunchKernelGGL(k_dw_all, dim3(nwg * d.n), dim3(WG), 0, sd, d);
+		if (sliced) {
+			DwSlicedArgs q;
+			q.n = 0; q.B = B; q.n_slices = n_slices;
+			uint32_t wgs = 0;
+			auto add_sliced = [&](const half_t* yt, const half_t* xt, float* out, uint32_t n_out, uint32_t n_live, uint32_t n_in, uint32_t ones) {
+				q.YT[q.n] = yt; q.XT[q.n] = xt; q.out[q.n] = out; q.n_out[q.n] = n_out; q.n_out_live[q.n] = n_live; q.n_in[q.n] = n_in; q.ones[q.n] = ones;
+				q.first_wg[q.n] = wgs; wgs += n_slices * ((n_out * n_in / 4 + 255) / 256); ++q.n;
+			};
+			add_sliced(T.dz, T.sdfin, p_sdf0, 64, 64, 32, 0);   // dW0 = dz in^T                    (fully_fused_mlp.cu:953-1030)
+			add_sliced(T.dz1, T.ddin, p_sdf0b, 64, 64, 32, 0);  // dW0 += dz1 ddin^T                (:1097-1131, beta = 1)
+			add_sliced(T.dso, T.z1, p_sdf1, 16, 1, 64, 0);      // dW1 = dso z1^T: rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
+			add_sliced(nullptr, T.front, p_sdf1b, 16, 1, 64, 1); // dW1[0, :] += sum front
+			for (uint32_t g = q.n; g < 7; ++g) { q.YT[g] = nullptr; q.XT[g] = nullptr; q.out[g] = nullptr; q.n_out[g] = 0; q.n_out_live[g] = 0; q.n_in[g] = 4; q.ones[g] = 0; }
+			for (uint32_t g = q.n; g < 8; ++g) q.first_wg[g] = wgs;
+			hipLaunchKernelGGL(k_dw_sliced, dim3(wgs), dim3(256), 0, sd, q);
+		}
 		DwFinishArgs f;
 		f.partial[0] = p_rgb2; f.partial[1] = p_rgb1; f.partial[2] = p_rgb0; f.partial[3] = p_sdf1; f.partial[4] = p_sdf0; f.partial[5] = p_sdf0b; f.partial[6] = p_sdf1b;
-		f.n_partials = (uint32_t)slab;
+		f.n_partials = (uint32_t)slab; f.sliced = sliced ? 1u : 0u;
 		f.var_partial = c->var_partial.p; f.n_var_partials = fb_grid * WAVES_PER_WG;
 		f.grads = c->grads.p; f.grads16 = half ? c->grads16.p : nullptr; f.off_sdf = (uint32_t)c->off_sdf; f.off_rgb = (uint32_t)c->off_rgb; f.off_var = (uint32_t)c->off_var; f.skip_rgb = a.skip_rgb;
 		const uint32_t n_fin_blocks = (RNB_N_SDF_MLP_PARAMS + (a.skip_rgb ? 0 : RNB_N_RGB_MLP_PARAMS)) / DWF_PARAMS + 1; // + the variance workgroup
@@ -1510,6 +1532,7 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_hs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_h), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1556,6 +1579,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_DW_SLICED")) k.dw_sliced = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_PAIR")) k.encode_pair = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
 		if (const char* e = getenv("RNB_DEBUG_SCATTER_LEVELS")) { int lo = -1, hi = -1; if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 0 && hi > lo) { k.dbg_scatter_lo = lo; k.dbg_scatter_hi = hi; } }
@@ -2282,7 +2306,7 @@ uint32_t rnb_rays_per_batch(const rnb_ctx* c) { return c ? c->rays_per_batch : 0
 
 int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t n_items, uint32_t* out_host) try {
 	if (!c || (!in_host && n_items) || (!out_host && n_items)) return fail(RNB_ERR_INVALID, "null argument");
-	if (kind < 0 || kind > RNB_PRIM_PREP_DUE) return fail(RNB_ERR_INVALID, "unknown primitive kind");
+	if (kind < 0 || kind > RNB_PRIM_DW_SLICED) return fail(RNB_ERR_INVALID, "unknown primitive kind");
 	if (n_items == 0) return RNB_OK;
 	if (kind == RNB_PRIM_PREP_DUE) { // host logic (Testbed::train, src/testbed.cu:2805-2806): does training step in[i] begin with an occupancy update, and the interval it is due at
 		for (uint32_t i = 0; i < n_items; ++i) { out_host[2 * i] = prep_due(in_host[i]) ? 1u : 0u; out_host[2 * i + 1] = std::min(std::max(in_host[i] / 16u, 1u), 16u); }
@@ -2308,7 +2332,25 @@ int rnb_eval_primitives(rnb_ctx* c, int kind, const uint32_t* in_host, uint32_t 
 	if (rc == RNB_OK && hipMemcpy(in, in_host, n_in * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: copy in failed");
 	if (rc == RNB_OK) {
 		if (bf) hipLaunchKernelGGL(k_prim_bitfield, dim3((uint32_t)((n_bf + 255) / 256)), dim3(256), 0, 0, bf, (uint32_t)n_bf);
-		if (kind == RNB_PRIM_ENCODE) hipLaunchKernelGGL(k_prim_encode, dim3(n_items), dim3(64), 0, 0, in, n_items, out);
+		if (kind == RNB_PRIM_DW_SLICED) { // the half mode's weight-gradient GEMM (k_dw_sliced + the slice sum of k_dw_finish) on the caller's operands, one 4 x 4 GEMM per item
+			const uint32_t S = PRIM_DW_SAMPLES, n_sl = (S + DW_SLICE - 1) / DW_SLICE;
+			float* tmp = nullptr;
+			if (hipMalloc((void**)&tmp, (size_t)n_sl * 16 * 4) != hipSuccess) rc = fail(RNB_ERR_NOMEM, "hipMalloc failed for the primitive self-test");
+			for (uint32_t i = 0; i < n_items && rc == RNB_OK; ++i) {
+				const uint32_t* item = in + (size_t)i * PRIM_IN_WORDS[kind];
+				DwSlicedArgs q;
+				for (uint32_t g = 0; g < 7; ++g) { q.YT[g] = nullptr; q.XT[g] = nullptr; q.out[g] = nullptr; q.n_out[g] = 0; q.n_out_live[g] = 0; q.n_in[g] = 4; q.ones[g] = 0; }
+				const bool ones = (in_host[(size_t)i * PRIM_IN_WORDS[kind]] & 1u) != 0u;
+				q.YT[0] = reinterpret_cast<const half_t*>(item + 4); q.XT[0] = q.YT[0] + (size_t)4 * S; q.out[0] = tmp;
+				q.n_out[0] = 4; q.n_out_live[0] = ones ? 1u : 4u; q.n_in[0] = 4; q.ones[0] = ones ? 1u : 0u;
+				q.n = 1; q.B = S; q.n_slices = n_sl; q.first_wg[0] = 0;
+				for (uint32_t g = 1; g < 8; ++g) q.first_wg[g] = n_sl;
+				hipLaunchKernelGGL(k_dw_sliced, dim3(n_sl), dim3(256), 0, 0, q);
+				hipLaunchKernelGGL(k_prim_dw_sliced_total, dim3(1), dim3(64), 0, 0, tmp, 16u, n_sl, reinterpret_cast<float*>(out + (size_t)i * 16));
+			}
+			(void)hipDeviceSynchronize();
+			if (tmp) (void)hipFree(tmp);
+		} else if (kind == RNB_PRIM_ENCODE) hipLaunchKernelGGL(k_prim_encode, dim3(n_items), dim3(64), 0, 0, in, n_items, out);
 		else hipLaunchKernelGGL(k_primitives, dim3((n_items + 127) / 128), dim3(128), 0, 0, kind, in, n_items, out, bf);
 		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(out_host, out, n_out * 4, hipMemcpyDeviceToHost) != hipSuccess)
 			rc = fail(RNB_ERR_DEVICE, "rnb_eval_primitives: kernel or copy out failed");

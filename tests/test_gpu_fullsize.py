@@ -725,7 +725,7 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
     half (round 5: the product mode `accumulate = RNB_ACCUM_HALF` -- every network kernel with half k-step accumulators, the scatter through
     global_atomic_pk_add_f16 into the half gradient vector): marched set and compaction count identical, the three loss sums within the north star's 1e-4 (the colour sum ray by ray: at most 3 rays of 12 k, whose last
     kept samples sit on a discontinuity of the compositing, may be set aside -- one trained state in three holds such a ray -- and the whole sum stays within 5e-4),
-    SDF-MLP gradient cosine >= 0.99999 and rms deviation <= 5e-3. The hash-grid gradient is the sum of half atomics whose ORDER the reference leaves to the
+    SDF-MLP gradient (round 6: summed in the reference's split-K order, k_dw_sliced) cosine >= 0.999999 and rms deviation <= 2e-3. The hash-grid gradient is the sum of half atomics whose ORDER the reference leaves to the
     hardware: the oracle in a second, seeded order of the same addends (ORC_ATOMIC_ORDER_SEED) gives the distance between two legal outcomes of the reference
     itself, and the HIP result must lie within 1.25 x that floor of the oracle's (it sums a cell run in fp32 before its one atomic: fewer roundings than either).
 
@@ -842,7 +842,9 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             colour_not_met = rel[0] > 1e-4     # the colour sum: checked LAST (below), so that every other statement of this test is asserted first
             assert rel[0] <= 2e-4 and out["colour_sum_rel_dev_of_the_other_rays"] <= 1e-6 and out["rays_set_aside"] <= 1, (rel, out["colour_sum_rel_dev_of_the_other_rays"], out["rays_set_aside"])
             assert D <= 2e-3, D
-            assert out["sdf_mlp"]["cosine"] >= 0.99999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 5e-3, out["sdf_mlp"]
+            # round 6: the weight gradients are summed in the model's (= CUTLASS's split-K) order, bit-identical on the same operands (RNB_PRIM_DW_SLICED); what is left comes from
+            # the operands (dL/d(network output) differs by D). Measured on the pinned state: cosine 0.9999994, rms 1.1e-3, max 6.1e-4 of the scale (round 5: 0.999994, 3.6e-3)
+            assert out["sdf_mlp"]["cosine"] >= 0.999999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 2e-3 and out["sdf_mlp"]["max_dev_over_scale"] <= 1.5e-3, out["sdf_mlp"]
             floor = out["hash_grid_order_floor"]
             # every addend its own half atomic: the whole table within the distance of two legal orders of the reference itself
             pl = out["hash_grid_plain_scatter"]

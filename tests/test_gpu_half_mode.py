@@ -109,7 +109,11 @@ def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo)
             continue
         scale = np.abs(r[lo:hi]).max() + 1e-30
         assert scale > 1e-20, name
-        # the weight gradients keep fp32 accumulators over the samples (the model: 16-sample k-steps rounded to half): a few half ulps of the matrix scale
+        if no_albedo:
+            # round 6: the SDF-only training kernel's weight gradients are summed in the reference's split-K order (k_dw_sliced, bit-identical to the model on the same
+            # operands): what is left is an operand that landed on the neighbouring half in the matrix cores' k-step sums -- at this size none (measured: every half equal)
+            assert np.mean(g[lo:hi] == r[lo:hi]) >= 0.99 and np.abs(g[lo:hi] - r[lo:hi]).max() / scale < 1e-3, (name, np.mean(g[lo:hi] == r[lo:hi]), np.abs(g[lo:hi] - r[lo:hi]).max() / scale)
+        # the albedo mode's weight gradients keep fp32 accumulators over the samples (the model: 16-sample k-steps rounded to half; deviation D1'): a few half ulps of the matrix scale
         assert np.abs(g[lo:hi] - r[lo:hi]).max() / scale < 5e-3, (name, np.abs(g[lo:hi] - r[lo:hi]).max() / scale)
         cos = float(g[lo:hi] @ r[lo:hi] / (np.linalg.norm(g[lo:hi]) * np.linalg.norm(r[lo:hi])))
         assert cos > 0.99999, (name, cos)
@@ -123,6 +127,19 @@ def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo)
     cos = float(gg @ rg / (np.linalg.norm(gg) * np.linalg.norm(rg)))
     assert cos > 0.999995, cos
     assert abs(g[lay["variance"]] - r[lay["variance"]]) <= 2.1e-3 * abs(r[lay["variance"]]) + 1e-7  # the fp32 sum on the device, the fp64 sum in the model, each narrowed to half once
+
+
+def test_sliced_weight_gradients_equal_the_model_bit_for_bit(hpair_no_albedo):
+    """k_dw_sliced + the slice sum of k_dw_finish (the half mode's weight-gradient GEMMs in the reference's split-K order: 4096-sample slices, half accumulators rounded
+    after every 16-sample k-step, slices reduced in half -- tcnn cutlass_matmul.h:83, 315-322) on given operands against the oracle's emulated_dw: the same bits,
+    from sums that are exact in half to an accumulator that overflows. tests/test_oracle_cpu.py holds emulated_dw to an independent numpy statement."""
+    from tests import dw_sliced_cases
+    gpu, cpu = hpair_no_albedo
+    items = dw_sliced_cases.items()
+    out, ref = gpu.eval_primitives("DW_SLICED", items), cpu.eval_primitives("DW_SLICED", items)
+    assert np.array_equal(out, ref), np.argwhere(out != ref)[:8]
+    items2 = dw_sliced_cases.items(seed=7)
+    assert np.array_equal(gpu.eval_primitives("DW_SLICED", items2), cpu.eval_primitives("DW_SLICED", items2))
 
 
 def test_half_mode_optimizer_reads_and_clears_the_half_gradient_vector(hpair):

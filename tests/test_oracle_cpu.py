@@ -392,3 +392,17 @@ def test_deterministic_mode_sums_the_hash_grid_gradients_exactly():
     finally:
         for c in (d0, d1, h1, h2):
             c.close()
+
+
+def test_sliced_weight_gradient_model_against_an_independent_statement():
+    """emulated_dw (the model of tcnn's split-K weight-gradient GEMMs with half accumulators, cutlass_matmul.h:83, 315-322) through RNB_PRIM_DW_SLICED against
+    tests/dw_sliced_cases.py::model: the same slices, k-steps and roundings stated in numpy -- bit for bit, including the accumulator that overflows to infinity."""
+    from tests import dw_sliced_cases
+    items = dw_sliced_cases.items()
+    with oracle_lib.context(target_batch_size=1 << 10, max_rays_per_batch=1 << 10) as c:
+        out = c.eval_primitives("DW_SLICED", items)
+    ref = np.stack([dw_sliced_cases.model(it) for it in items])
+    assert np.array_equal(out, ref), np.argwhere(out != ref)[:8]
+    vals = ref.view(np.float32)
+    assert np.isinf(vals[-1]).all() and np.isfinite(vals[:-1]).all()  # the last item is the overflow case
+    assert not vals[4, 4:].any() and vals[4, :4].all()                  # Y = 1 on row 0 only
