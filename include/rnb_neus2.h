@@ -110,11 +110,9 @@ typedef struct rnb_config {
 	                                     accumulator to half after every 16-wide k-step (WMMA half fragments, fully_fused_mlp.cu:59-68, 198), the hash-grid gradients are summed
 	                                     by atomicAdd(__half2) into a half gradient vector (grid.h:410-430, trainer.h:78-84: RNB_BUF_GRADS_FP16 replaces RNB_BUF_GRADS_FP32).
 	                                     The weight-gradient GEMMs follow tcnn's CUTLASS split-K order (slices of 4096 samples, half accumulators rounded after every 16-sample
-	                                     k-step, the slices reduced in half: cutlass_matmul.h:83, 315-322; RNB_PRIM_DW_SLICED) with --no-albedo (apply_no_albedo = 1, the benchmarked
-	                                     configuration). Fixed at rnb_create. Stated departures from the reference's code in this mode: the default scatter sums a
-	                                     cell run / a workgroup's slice in fp32 before its one packed half atomic (RNB_SCATTER_PLAIN=1 issues the reference's own sequence: every
-	                                     addend its own atomicAdd(__half2)); with the colour MLP live (apply_no_albedo = 0) the weight gradients keep fp32 accumulators in the
-	                                     training kernels' own tiling and round to half once. */
+	                                     k-step, the slices reduced in half: cutlass_matmul.h:83, 315-322; RNB_PRIM_DW_SLICED). Fixed at rnb_create. One stated departure from the
+	                                     reference's code in this mode: the default scatter sums a cell run / a workgroup's slice in fp32 before its one
+	                                     packed half atomic (RNB_SCATTER_PLAIN=1 issues the reference's own sequence: every addend its own atomicAdd(__half2)). */
 	uint32_t deterministic;           /* 0 (default): the hash-grid gradients are summed by floating-point atomics, as in the reference (grid.h:410-430) -- the sum depends on the order
 	                                     the hardware retires them in, so two runs from one state differ in the last bits and a training run is not reproducible (neither is the
 	                                     reference's: src/testbed_nerf.cu:1352, 1557-1561). 1: every addend -- rounded to half first exactly as the reference rounds it (grid.h:415-416),

@@ -924,13 +924,13 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 			return v;
 		};
 		if (SLICED) { // the two input tiles, feature-major in the reference's column order (one 128-byte row segment per store), and dso's row 0
-			static_assert(!SLICED || (EMU && !FULL), "the sliced weight gradients are built for the half mode's SDF-only kernel");
+			static_assert(!SLICED || EMU, "the sliced weight gradients belong to the half mode");
 #pragma unroll
 			for (uint32_t q = 0; q < 32; ++q) {
 				st32(T.sdfin, (uint32_t)fbs_logical_h(q) * B + s, X[lane * S32 + q]);
 				st32(T.ddin, (uint32_t)fbs_logical_h(q) * B + s, D[lane * S32 + q]);
 			}
-			st32(T.dso, s, dout[3]);
+			if (!FULL) st32(T.dso, s, dout[3]); // (FULL: all 16 rows, from their transposed fragments below)
 		}
 		{ // ---- weight gradients of this tile (see the header) ----
 			h8 fso[4];
@@ -960,6 +960,15 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 						for (int r = 0; r < 4; ++r) a_so[ks][4 * h + r] = f2h(t[r]);
 					}
+				if (SLICED) { // dso^T: lane = output row r16, register 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
+#pragma unroll
+					for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+						for (int h = 0; h < 2; ++h) {
+							const uint32_t off = (uint32_t)r16 * B + tile * TILE + 16u * (2 * ks + h) + 4u * hq;
+							st32(reinterpret_cast<h4*>(T.dso), off / 4u, h4{a_so[ks][4 * h], a_so[ks][4 * h + 1], a_so[ks][4 * h + 2], a_so[ks][4 * h + 3]});
+						}
+				}
 			}
 			// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
 			h8 b_in[2][2], b_dd[2][2];
@@ -1024,7 +1033,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 							st32(reinterpret_cast<h4*>(T.front), off / 4u, h4{a_fr[ks][4 * h], a_fr[ks][4 * h + 1], a_fr[ks][4 * h + 2], a_fr[ks][4 * h + 3]});
 						}
 					}
-				if (FULL) {
+				if (FULL && !SLICED) {
 #pragma unroll
 					for (int ks = 0; ks < 2; ++ks) acc_w1f[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_so[ks], b_z1[ks], acc_w1f[nt], 0, 0, 0);
 				}
@@ -1186,6 +1195,11 @@ __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_hs(const GridMeta G, cons
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
 	fwd_bwd_sdf_body<false, true, true>(G, net, a, smem_raw, lm);
 }
+__global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full_hs(const GridMeta G, const NetW net, const TrainArgs a) { // albedo mode's part 2 in the half mode, operands exported for k_dw_sliced
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
+	fwd_bwd_sdf_body<true, true, true>(G, net, a, smem_raw, lm);
+}
 __global__ __launch_bounds__(WG, 2) void k_fwd_bwd_sdf_full_h(const GridMeta G, const NetW net, const TrainArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	__shared__ LevelMeta lm[RNB_MAX_LEVELS];
@@ -1243,6 +1257,7 @@ struct RgbArgs {
 	uint32_t B;
 	const half_t* wimg;       // optional: load_weights_rgb's image prepared by k_prepare_weight_images
 	float *dw_c0, *dw_c1, *dw_c2; // one partial per workgroup: [64][32] compact, [64][64], [16][64]
+	TrainScratch t;               // SLICED: h2, dr, h1, dh2, dh1, cin leave feature-major for k_dw_sliced
 };
 
 // Transpose of chained fragments: in[ms][ks] (lane = sample 16 ms + r16, K slot 8 hq + j = chained position 32 ks + 8 hq + j) ->
@@ -1269,7 +1284,25 @@ __device__ __forceinline__ void transpose_frags(const h8 (&in)[4][KS], h8 (&out)
 	}
 }
 
-template <bool EMU>
+// SLICED: a transposed fragment set (lane = row 16 q + r16 -- a chained position or a natural index --, register 4 h + r <-> sample 32 ks + 16 h + 4 hq + r of the tile) leaves
+// feature-major for k_dw_sliced: four consecutive samples of one row per 8-byte store.
+template <int NQ>
+__device__ __forceinline__ void export_transposed(const h8 (&t)[NQ][2], const int n_q, half_t* __restrict__ dst, const uint32_t B, const uint32_t tile, const int r16, const int hq, const bool chained) {
+#pragma unroll
+	for (int q = 0; q < NQ; ++q) {
+		if (q >= n_q) break;
+		const uint32_t row = chained ? (uint32_t)chain_logical(16 * q + r16) : (uint32_t)(16 * q + r16);
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const uint32_t off = row * B + tile * TILE + 16u * (2 * ks + h) + 4u * hq;
+				st32(reinterpret_cast<h4*>(dst), off / 4u, h4{t[q][ks][4 * h], t[q][ks][4 * h + 1], t[q][ks][4 * h + 2], t[q][ks][4 * h + 3]});
+			}
+	}
+}
+
+template <bool EMU, bool SLICED = false>
 __device__ __forceinline__ void rgb_fwd_bwd_body(const NetW& net, const RgbArgs& a, char* smem_raw) {
 	half_t* wts = reinterpret_cast<half_t*>(smem_raw);
 	if (a.wimg) copy_weight_image(wts, a.wimg, RW_END, threadIdx.x, WG);
@@ -1328,8 +1361,9 @@ __device__ __forceinline__ void rgb_fwd_bwd_body(const NetW& net, const RgbArgs&
 			h8 th2[4][2], tdr[2][2];
 			transpose_frags<2>(bh2, th2, r16, hq);
 			transpose_frags<1>(drf, tdr, r16, hq); // tdr[0]: lane = output row r16; tdr[1] (columns 16..31) is zero
+			if (SLICED) { export_transposed<4>(th2, 4, a.t.h2, a.B, tile, r16, hq, true); export_transposed<2>(tdr, 1, a.t.dr, a.B, tile, r16, hq, false); }
 #pragma unroll
-			for (int qi = 0; qi < 4; ++qi)
+			for (int qi = 0; qi < (SLICED ? 0 : 4); ++qi)
 #pragma unroll
 				for (int ks = 0; ks < 2; ++ks) acc_w2[qi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tdr[0][ks], th2[qi][ks], acc_w2[qi], 0, 0, 0);
 		}
@@ -1352,8 +1386,9 @@ __device__ __forceinline__ void rgb_fwd_bwd_body(const NetW& net, const RgbArgs&
 			h8 th1[4][2], tdh2[4][2];
 			transpose_frags<2>(bh1, th1, r16, hq);
 			transpose_frags<2>(bh2, tdh2, r16, hq);
+			if (SLICED) { export_transposed<4>(th1, 4, a.t.h1, a.B, tile, r16, hq, true); export_transposed<4>(tdh2, 4, a.t.dh2, a.B, tile, r16, hq, true); }
 #pragma unroll
-			for (int qo = 0; qo < 4; ++qo)
+			for (int qo = 0; qo < (SLICED ? 0 : 4); ++qo)
 #pragma unroll
 				for (int qi = 0; qi < 4; ++qi)
 #pragma unroll
@@ -1391,14 +1426,16 @@ __device__ __forceinline__ void rgb_fwd_bwd_body(const NetW& net, const RgbArgs&
 			h8 tdh1[4][2], tc[2][2];
 			transpose_frags<2>(bh1, tdh1, r16, hq);
 			transpose_frags<1>(cf, tc, r16, hq);
+			if (SLICED) { export_transposed<4>(tdh1, 4, a.t.dh1, a.B, tile, r16, hq, true); export_transposed<2>(tc, 2, a.t.cin, a.B, tile, r16, hq, false); }
 #pragma unroll
-			for (int qo = 0; qo < 4; ++qo)
+			for (int qo = 0; qo < (SLICED ? 0 : 4); ++qo)
 #pragma unroll
 				for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
 					for (int ks = 0; ks < 2; ++ks) acc_w0[qo][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tdh1[qo][ks], tc[ni][ks], acc_w0[qo][ni], 0, 0, 0);
 		}
 	}
+	if (SLICED) return; // (k_dw_sliced forms the weight gradients from the exported operands)
 	// The four wavefronts' weight gradients, summed in a fixed order, leave as ONE partial per workgroup in k_dw's layout; the weight image is dead.
 	// D layout of the accumulators: lane r16 = column of the B operand, register r = row 4 hq + r of the A operand, both possibly in chain order.
 	float* red = reinterpret_cast<float*>(smem_raw);
@@ -1447,6 +1484,10 @@ __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd(const NetW net, const Rgb
 __global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd_h(const NetW net, const RgbArgs a) { // rnb_config::accumulate = RNB_ACCUM_HALF
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	rgb_fwd_bwd_body<true>(net, a, smem_raw);
+}
+__global__ __launch_bounds__(WG, 1) void k_rgb_fwd_bwd_hs(const NetW net, const RgbArgs a) { // half mode, weight-gradient operands exported for k_dw_sliced
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	rgb_fwd_bwd_body<true, true>(net, a, smem_raw);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -907,9 +907,9 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	a.wimg = !c->wimg_valid ? nullptr : (!c->knobs.fwd_bwd_generic) ? c->wimg_fbs.p : c->wimg_train.p;
 	const bool sdf_only = (a.skip_rgb && !c->knobs.fwd_bwd_generic) || split; // the training kernels leave one weight-gradient partial per workgroup themselves
 	const uint32_t fb_grid = sdf_only ? std::min<uint32_t>((B / TILE + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * c->knobs.fbs_wg_per_cu) : c->fwd_grid;
-	// half mode, round 6: the weight gradients in the reference's split-K order (k_dw_sliced) -- built for the SDF-only training kernel (--no-albedo, the benchmarked configuration);
-	// the albedo mode's two kernels keep their own tiling (deviation D1'). RNB_DW_SLICED=0: the round-5 form everywhere.
-	const bool sliced = half && sdf_only && !split && c->knobs.dw_sliced;
+	// half mode, round 6: the weight gradients in the reference's split-K order (k_dw_sliced): the training kernels export their GEMM operands feature-major instead of accumulating
+	// in their own tiling (deviation D1' of rounds 4-5; RNB_DW_SLICED=0: that form).
+	const bool sliced = half && sdf_only && c->knobs.dw_sliced; // (sdf_only: the SDF-only training kernel or the albedo mode's two -- not the generic kernel of RNB_FWD_BWD_GENERIC)
 	const uint32_t n_slices = (B + DW_SLICE - 1) / DW_SLICE;
 	// partial weight gradients: one slab per producing workgroup -- k_dw's workgroups (generic kernel) or k_fwd_bwd_sdf's own; sliced: one per 4096-sample slice (never more than workgroups)
 	const size_t slab = sliced ? (size_t)n_slices : sdf_only ? (size_t)fb_grid : (size_t)c->dw_nwg;
@@ -941,11 +941,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 		r.cin = c->cin_eval.p; r.src_slot = flow ? c->src_slot.p : nullptr; r.dout = c->dloss_dout.p; r.dcin = c->dcin.p; r.B = B;
 		r.wimg = c->wimg_valid ? c->wimg_rgb.p : nullptr;
 		r.dw_c0 = p_rgb0; r.dw_c1 = p_rgb1; r.dw_c2 = p_rgb2;
-		if (half) hipLaunchKernelGGL(k_rgb_fwd_bwd_h, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
+		r.t = c->ts;
+		if (half && sliced) hipLaunchKernelGGL(k_rgb_fwd_bwd_hs, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
+		else if (half) hipLaunchKernelGGL(k_rgb_fwd_bwd_h, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
 		else hipLaunchKernelGGL(k_rgb_fwd_bwd, dim3(fb_grid), dim3(WG), LDS_RGB, s, c->net(false), r);
 		a.dcin = c->dcin.p;
 		// (one workgroup per CU -- no register spills, the two-per-CU instance keeps ~80 values in scratch -- lost: 0.88 vs 0.80 ms/step, half the wavefronts to hide the gathers)
-		if (half) LAUNCH_EV(k_fwd_bwd_sdf_full_h, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+		if (half && sliced) LAUNCH_EV(k_fwd_bwd_sdf_full_hs, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
+		else if (half) LAUNCH_EV(k_fwd_bwd_sdf_full_h, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
 		else LAUNCH_EV(k_fwd_bwd_sdf_full, dim3(fb_grid), dim3(WG), LDS_FBS_FULL, s, ev_fb, c->meta(), c->net(false), a);
 	} else if (sdf_only && half && sliced) LAUNCH_EV(k_fwd_bwd_sdf_hs, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
 	else if (sdf_only && half) LAUNCH_EV(k_fwd_bwd_sdf_h, dim3(fb_grid), dim3(WG), LDS_FBS, s, ev_fb, c->meta(), c->net(false), a);
@@ -982,9 +985,14 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 				q.YT[q.n] = yt; q.XT[q.n] = xt; q.out[q.n] = out; q.n_out[q.n] = n_out; q.n_out_live[q.n] = n_live; q.n_in[q.n] = n_in; q.ones[q.n] = ones;
 				q.first_wg[q.n] = wgs; wgs += n_slices * ((n_out * n_in / 4 + 255) / 256); ++q.n;
 			};
+			if (!a.skip_rgb) { // the colour MLP (the largest first)
+				add_sliced(T.dh2, T.h1, p_rgb1, 64, 64, 64, 0);
+				add_sliced(T.dh1, T.cin, p_rgb0, 64, 64, 32, 0);
+				add_sliced(T.dr, T.h2, p_rgb2, 16, 3, 64, 0);    // rows 3..15 of dL/d(colour output) are exact zeros (k_rgb_fwd_bwd)
+			}
 			add_sliced(T.dz, T.sdfin, p_sdf0, 64, 64, 32, 0);   // dW0 = dz in^T                    (fully_fused_mlp.cu:953-1030)
 			add_sliced(T.dz1, T.ddin, p_sdf0b, 64, 64, 32, 0);  // dW0 += dz1 ddin^T                (:1097-1131, beta = 1)
-			add_sliced(T.dso, T.z1, p_sdf1, 16, 1, 64, 0);      // dW1 = dso z1^T: rows 1..15 of dso are exact zeros here (TrainArgs::skip_rgb)
+			add_sliced(T.dso, T.z1, p_sdf1, 16, split ? 16 : 1, 64, 0); // dW1 = dso z1^T: without the colour MLP rows 1..15 of dso are exact zeros (TrainArgs::skip_rgb)
 			add_sliced(nullptr, T.front, p_sdf1b, 16, 1, 64, 1); // dW1[0, :] += sum front
 			for (uint32_t g = q.n; g < 7; ++g) { q.YT[g] = nullptr; q.XT[g] = nullptr; q.out[g] = nullptr; q.n_out[g] = 0; q.n_out_live[g] = 0; q.n_in[g] = 4; q.ones[g] = 0; }
 			for (uint32_t g = q.n; g < 8; ++g) q.first_wg[g] = wgs;
@@ -1533,6 +1541,8 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_hs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_hs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
+	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd_hs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_bwd_sdf_full_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FBS_FULL));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rgb_fwd_bwd_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_RGB));
 	HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds_h), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

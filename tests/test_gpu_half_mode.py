@@ -90,8 +90,8 @@ def test_half_mode_network_evaluation(hpair, step):
 
 @pytest.mark.parametrize("no_albedo", [0, 1])
 def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo):
-    """k_fwd_bwd_sdf_h (--no-albedo) and k_rgb_fwd_bwd_h + k_fwd_bwd_sdf_full_h, the packed-half scatter kernels and k_dw_finish into GRADS_FP16, against
-    the oracle's model from the same loss gradients."""
+    """k_fwd_bwd_sdf_hs (--no-albedo) and k_rgb_fwd_bwd_hs + k_fwd_bwd_sdf_full_hs, k_dw_sliced + k_dw_finish and the packed-half scatter kernels into GRADS_FP16,
+    against the oracle's model from the same loss gradients."""
     gpu, cpu = pair = (hpair_no_albedo if no_albedo else hpair)
     n_rays = 512
     _stage_samples(gpu, cpu, n_rays, step=700)
@@ -109,12 +109,10 @@ def test_half_mode_forward_backward_gradients(hpair, hpair_no_albedo, no_albedo)
             continue
         scale = np.abs(r[lo:hi]).max() + 1e-30
         assert scale > 1e-20, name
-        if no_albedo:
-            # round 6: the SDF-only training kernel's weight gradients are summed in the reference's split-K order (k_dw_sliced, bit-identical to the model on the same
-            # operands): what is left is an operand that landed on the neighbouring half in the matrix cores' k-step sums -- at this size none (measured: every half equal)
-            assert np.mean(g[lo:hi] == r[lo:hi]) >= 0.99 and np.abs(g[lo:hi] - r[lo:hi]).max() / scale < 1e-3, (name, np.mean(g[lo:hi] == r[lo:hi]), np.abs(g[lo:hi] - r[lo:hi]).max() / scale)
-        # the albedo mode's weight gradients keep fp32 accumulators over the samples (the model: 16-sample k-steps rounded to half; deviation D1'): a few half ulps of the matrix scale
-        assert np.abs(g[lo:hi] - r[lo:hi]).max() / scale < 5e-3, (name, np.abs(g[lo:hi] - r[lo:hi]).max() / scale)
+        # round 6: the weight gradients are summed in the reference's split-K order (k_dw_sliced, bit-identical to the model on the same operands): what is left is an
+        # operand that landed on the neighbouring half in the matrix cores' k-step sums -- measured at this size: every half equal without the colour MLP, 99.95 % with it
+        # (the others 7e-7 of the scale apart). Round 5 (fp32 accumulators in the kernels' own tiling, RNB_DW_SLICED=0): 44 % equal, 2.3e-3 of the scale.
+        assert np.mean(g[lo:hi] == r[lo:hi]) >= 0.99 and np.abs(g[lo:hi] - r[lo:hi]).max() / scale < 1e-4, (name, np.mean(g[lo:hi] == r[lo:hi]), np.abs(g[lo:hi] - r[lo:hi]).max() / scale)
         cos = float(g[lo:hi] @ r[lo:hi] / (np.linalg.norm(g[lo:hi]) * np.linalg.norm(r[lo:hi])))
         assert cos > 0.99999, (name, cos)
     gg, rg = g[lay["grid"]:lay["variance"]], r[lay["grid"]:lay["variance"]]
