@@ -506,7 +506,7 @@ __device__ __forceinline__ uint32_t march(const SceneAabb& A, const uint8_t* __r
 }
 
 template <bool SC>
-__global__ __launch_bounds__(128) void k_march_count(const MarchArgs a) {
+__global__ __launch_bounds__(512) void k_march_count(const MarchArgs a) { // (launched with 128 ... 512 threads: RNB_MARCH_NARROW_WGS)
 	if (a.prio == 1u) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2u) __builtin_amdgcn_s_setprio(2); else if (a.prio >= 3u) __builtin_amdgcn_s_setprio(3);
 	extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
 	if (SC) { load_coarse(coarse_lds, a.coarse, a.n_blocks_lds, threadIdx.x, blockDim.x); __syncthreads(); }

@@ -239,6 +239,10 @@ struct rnb_ctx {
 		bool march_skip_narrow = false; // RNB_MARCH_SKIP_NARROW=1: the same skipping in the one-thread-per-ray march of the large batches. Bit-identical (tests, 6100 lockstep steps) and SLOWER: k_march_count 192 -> 221 us
 		                                // at step 2000, window 0.5611 -> 0.5715 ms/step, late 0.6073 -> 0.6204: a wavefront's 64 rays finish with the slowest, and the one ray in 64 that cannot skip keeps the old
 		                                // cost while every lane pays the 64-point scan and the re-entry search (profiles/r06_ab_march_skip_narrow.txt). Off.
+		uint32_t march_narrow_wgs = 128; // RNB_MARCH_NARROW_WGS=64|128|256|512 (A/B, round 6): threads (= rays) per workgroup of the thread-per-ray march. Window / late, ms/step: 64: 0.5512 / 0.6069, 128: 0.5502 / 0.6043,
+		                                 // 256: 0.5589 / 0.6117, 512: 0.5712 / 0.6190 (a workgroup keeps its slots until its slowest ray is through) -- profiles/r06_ab_march_wgs.txt
+		int march_wgs = 1024; // RNB_MARCH_WGS=256|512|1024 (round 6): threads per workgroup of k_march_count_skip. Every workgroup first loads the occupancy's LDS form (~44 KB at step 1000) for its WGS / 16 rays:
+		                      // 64 rays per load instead of 16. Steps 1000-1200 / window: 256: 0.5637 / 0.5502, 512: 0.5608 / 0.5498, 1024: 0.5592 / 0.5492 (bit-identical: the pinned states)
 		int march_skip = 1; // RNB_MARCH_SKIP=0: k_march_count_wide<16> as in rounds 2-5 (every round from box entry to box exit); 1 (round 6): k_march_count_skip; 2: its start-over path forced (tests)
 		bool dw_late = false; // RNB_DW_LATE=1 (A/B)
 		int march_bbox = 1; // RNB_MARCH_BBOX=0: the thread-per-ray march walks from the scene box's entry to its exit (rounds 1-5); 1 (round 6, default): it ends where the ray leaves the occupied region's bounding
@@ -755,7 +759,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u; // (tests: no re-entry cell is accepted -- every ray walks every voxel up to the occupied box's exit)
 			hipLaunchKernelGGL(k_march_count_bbox, dim3(blocks), dim3(128), march_lds, s, a);
 			a.lattice_ok &= 1u;
-		} else if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3(blocks), dim3(128), march_lds, s, a);
+		} else if (sc) hipLaunchKernelGGL(k_march_count<true>, dim3((n_rays + c->knobs.march_narrow_wgs - 1) / c->knobs.march_narrow_wgs), dim3(c->knobs.march_narrow_wgs), march_lds, s, a);
 		else hipLaunchKernelGGL(k_march_count<false>, dim3(blocks), dim3(128), 0, s, a);
 	} else if (sc && n_rays <= c->knobs.march_wave_per_ray_below) {
 		// a batch so small that 16 lanes per ray leave most SIMDs without a wavefront (a rank of a strong-scaling job: 1.8 k rays = 0.4 wavefronts per SIMD): the kernel
@@ -766,7 +770,9 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		if (sc && c->knobs.march_skip && a.lattice_ok) {
 			// round 6: the same rounds, minus the stretches of the ray that cannot hold a sample (kernels_ray.cuh: k_march_count_skip); bit-identical sample set and t
 			if (c->knobs.march_skip == 2) a.lattice_ok |= 2u;
-			hipLaunchKernelGGL((k_march_count_skip<256>), grid, dim3(256), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			if (c->knobs.march_wgs == 512) hipLaunchKernelGGL((k_march_count_skip<512>), dim3((n_rays + 31) / 32), dim3(512), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			else if (c->knobs.march_wgs == 1024) hipLaunchKernelGGL((k_march_count_skip<1024>), dim3((n_rays + 63) / 64), dim3(1024), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
+			else hipLaunchKernelGGL((k_march_count_skip<256>), grid, dim3(256), march_lds + COARSE_WORDS * sizeof(uint32_t), s, a);
 			a.lattice_ok &= 1u;
 		} else if (sc) hipLaunchKernelGGL((k_march_count_wide<16, true>), grid, dim3(256), march_lds, s, a);
 		else hipLaunchKernelGGL((k_march_count_wide<16, false>), grid, dim3(256), 0, s, a);
@@ -1552,6 +1558,8 @@ int rnb_create(const rnb_config* cfg, rnb_ctx** out) try {
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_wide<64, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<256>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<512>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
+		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_skip_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max + (int)(COARSE_WORDS * sizeof(uint32_t))));
 		HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_count_bbox), hipFuncAttributeMaxDynamicSharedMemorySize, march_lds_max));
 	}
@@ -1589,6 +1597,8 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_RAY_CONST_DENSE")) k.ray_const_dense = atoi(e);
 		if (const char* e = getenv("RNB_MARCH_WRITE_SPLIT")) k.march_write_split = atoi(e) != 0 ? 1 : 0;
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
+		if (const char* e = getenv("RNB_MARCH_NARROW_WGS")) { const int w = atoi(e); k.march_narrow_wgs = (w == 64 || w == 256 || w == 512) ? (uint32_t)w : 128u; }
+		if (const char* e = getenv("RNB_MARCH_WGS")) { const int w = atoi(e); k.march_wgs = (w == 256 || w == 512) ? w : 1024; }
 		if (const char* e = getenv("RNB_DW_SLICED")) k.dw_sliced = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_PAIR")) k.encode_pair = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
