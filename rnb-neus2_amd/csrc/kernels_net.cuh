@@ -102,6 +102,7 @@ struct PointArgs {
 	int want_density;          // 0: sdf + bias, 1: density
 	float sdf_bias;
 	const uint32_t* range;     // optional (device): evaluate points range[0] .. range[1] - 1 of xyz / splat_idx instead of 0 .. n - 1 (k_shard_range; n bounds the launch)
+	uint32_t xcd;              // (round 6; RNB_POINT_XCD=0 for the A/B) workgroup b (XCD b % 8) walks the b % 8-th eighth of the tiles: cell-ordered points that are neighbours in space share one L2
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -167,7 +168,10 @@ __device__ __forceinline__ void point_query_chained_body(const GridMeta& G, cons
 	if (a.range) { s_first = a.range[0]; s_end = min(a.range[1], a.n); }
 	const uint32_t n_tiles = (s_end - s_first + TILE - 1) / TILE;
 	const int r16 = lane & 15, hq = lane >> 4;
-	for (uint32_t tile = blockIdx.x * WAVES_PER_WG + wave; tile < n_tiles; tile += gridDim.x * WAVES_PER_WG) {
+	const bool by_xcd = a.xcd != 0u && (gridDim.x & 7u) == 0u;
+	const uint32_t t8 = by_xcd ? (n_tiles + 7u) / 8u : n_tiles, t_base = by_xcd ? (blockIdx.x & 7u) * t8 : 0u, t_stop = min(n_tiles, t_base + t8);
+	const uint32_t t_stride = (by_xcd ? gridDim.x / 8u : gridDim.x) * WAVES_PER_WG;
+	for (uint32_t tile = t_base + (by_xcd ? blockIdx.x / 8u : blockIdx.x) * WAVES_PER_WG + wave; tile < t_stop; tile += t_stride) {
 		const uint32_t s = s_first + tile * TILE + lane;
 		const bool valid = s < s_end;
 		float x = 0.5f, y = 0.5f, z = 0.5f;

@@ -256,6 +256,7 @@ struct rnb_ctx {
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		bool point_xcd = true; // RNB_POINT_XCD=0 (A/B, round 6): PointArgs::xcd -- the occupancy update's cell-ordered points in eight contiguous parts, one per XCD (workgroups go round the XCDs): 286 -> 274 us per update
 		bool dw_sliced = true; // RNB_DW_SLICED=0 (A/B): the half mode's weight gradients in the training kernel's own tiling (deviation D1', rounds 4-5) instead of the reference's split-K order
 		bool encode_pair = false; // RNB_ENCODE_PAIR=1 (A/B, round 6): when the configuration's first five levels are dense (the default's are: 16^3 ... 71^3), the depth-4 evaluation kernels gather their x-pairs with one 8-byte load
 		                          // (level_issue<true>): bit-identical, 18 % fewer gather instructions -- and SLOWER: 0.5538 vs 0.5500 ms/step over steps 1000-2000, 0.6092 vs 0.6058 at step 6000 (profiles/r06_ab_encode_pair.txt;
@@ -479,7 +480,7 @@ int launch_point_query(rnb_ctx* c, hipStream_t s, const float* xyz, uint32_t n, 
 	if (n == 0) return RNB_OK;
 	join_tail_host(c); // (inference launches too: the same side-stream launch writes the MLPs' and the variance's EMA weights)
 	PointArgs a;
-	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range;
+	a.xyz = xyz; a.n = n; a.out = out; a.splat_idx = splat_idx; a.grid_tmp = grid_tmp; a.want_density = want_density; a.sdf_bias = c->cfg.sdf_bias; a.range = range; a.xcd = c->knobs.point_xcd ? 1u : 0u;
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
 	const uint32_t grid = std::min<uint32_t>((n_tiles + WAVES_PER_WG - 1) / WAVES_PER_WG, (uint32_t)c->n_cus * 5); // 86 VGPRs, 28 KB of LDS: five workgroups per CU
 	if (c->half_acc() && c->knobs.encode_depth) hipLaunchKernelGGL(k_point_query_chained_emul_pipe<4>, dim3(grid), dim3(WG), LDS_POINT2, s, c->meta(), c->net(inference), a, (!inference && c->wimg_valid) ? c->wimg_fwd.p : nullptr);
@@ -1599,6 +1600,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_NARROW_WGS")) { const int w = atoi(e); k.march_narrow_wgs = (w == 64 || w == 256 || w == 512) ? (uint32_t)w : 128u; }
 		if (const char* e = getenv("RNB_MARCH_WGS")) { const int w = atoi(e); k.march_wgs = (w == 256 || w == 512) ? w : 1024; }
+		if (const char* e = getenv("RNB_POINT_XCD")) k.point_xcd = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DW_SLICED")) k.dw_sliced = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_PAIR")) k.encode_pair = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_DEPTH")) { const int d = atoi(e); k.encode_depth = (d == 0 || d == 2 || d == 4 || d == 7) ? d : 4; }
