@@ -1446,7 +1446,15 @@ struct ScanChainArgs {
 	unsigned long long* words2; // [n_tiles][4]: ticket << 32 | {kept rays, kept samples, kept first-round samples}: tiles at and behind an overflow of max_samples only
 	uint32_t ticket;
 	uint32_t* error; // mapped host word: a wait gave up
+	uint32_t plain;  // RNB_CHAIN_PLAIN (round 6): the tiles' words travel as agent-scope atomic STORES and LOADS (sc1: served at the memory side, seen by every XCD) instead of read-modify-write
+	                 // atomics, which queue behind the gradient scatter's backlog of atomics there
 };
+__device__ __forceinline__ void chain_put(unsigned long long* p, const unsigned long long v, const bool plain) {
+	if (plain) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else atomicExch(p, v);
+}
+__device__ __forceinline__ unsigned long long chain_get(unsigned long long* p, const bool plain) {
+	return plain ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : atomicAdd(p, 0ull);
+}
 // `bad` (in/out, uniform over the workgroup): a wait of this tile or of a tile in front of it gave up. The HIP programming model does not promise that
 // lower-numbered workgroups are scheduled first (they are on this hardware, one dispatcher per queue handing out workgroups in order), so the
 // spin is bounded; a tile that gives up would otherwise go on with a stale word of an earlier launch. Instead it marks the word it publishes
@@ -1498,14 +1506,14 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 	uint32_t e2 = block_exclusive_scan<SCAN_NW>(f1, lane, wave, wsum, t_f1);
 	// exchange A (wavefront 0: lane q polls tile q < tile)
 	uint32_t fa[3] = {0, 0, 0}, incl_front = 0, flagA = 0; // wavefront 0 keeps the front tiles' sums for exchange B
-	if (tid < 3) atomicExch(a.words + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? total : tid == 1 ? t_pos : t_f1));
+	if (tid < 3) chain_put(a.words + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? total : tid == 1 ? t_pos : t_f1), a.plain != 0u);
 	if (tid < 64) {
 		if (tid < tile) {
 			unsigned long long w0, w1, w2;
 			uint32_t spins = 0;
 			bool got;
 			do {
-				w0 = atomicAdd(a.words + tid * 4 + 0, 0ull); w1 = atomicAdd(a.words + tid * 4 + 1, 0ull); w2 = atomicAdd(a.words + tid * 4 + 2, 0ull);
+				w0 = chain_get(a.words + tid * 4 + 0, a.plain != 0u); w1 = chain_get(a.words + tid * 4 + 1, a.plain != 0u); w2 = chain_get(a.words + tid * 4 + 2, a.plain != 0u);
 				got = (uint32_t)(w0 >> 32) == a.ticket && (uint32_t)(w1 >> 32) == a.ticket && (uint32_t)(w2 >> 32) == a.ticket;
 				if (got) break;
 				__builtin_amdgcn_s_sleep(2);
@@ -1544,7 +1552,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 		e0 = block_exclusive_scan<SCAN_NW>(v[0], lane, wave, wsum, t0);
 		e2 = block_exclusive_scan<SCAN_NW>(v[2], lane, wave, wsum, t2);
 		(void)block_exclusive_scan<SCAN_NW>(v[1], lane, wave, wsum, t1);
-		if (tid < 3) atomicExch(a.words2 + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? (t0 | (bad ? CHAIN_POISON : 0u)) : tid == 1 ? t1 : t2));
+		if (tid < 3) chain_put(a.words2 + tile * 4 + tid, ((unsigned long long)a.ticket << 32) | (tid == 0 ? (t0 | (bad ? CHAIN_POISON : 0u)) : tid == 1 ? t1 : t2), a.plain != 0u);
 		if (tid < 64) {
 			uint32_t fb[3] = {fa[1], fa[0], fa[2]}, fl = 0; // a tile in front of the overflow: all of its rays with samples are kept
 			if (tid < tile && incl_front > a.max_samples) {
@@ -1552,7 +1560,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_rays_chain(const ScanChainArgs
 				uint32_t spins = 0;
 				bool got;
 				do {
-					w0 = atomicAdd(a.words2 + tid * 4 + 0, 0ull); w1 = atomicAdd(a.words2 + tid * 4 + 1, 0ull); w2 = atomicAdd(a.words2 + tid * 4 + 2, 0ull);
+					w0 = chain_get(a.words2 + tid * 4 + 0, a.plain != 0u); w1 = chain_get(a.words2 + tid * 4 + 1, a.plain != 0u); w2 = chain_get(a.words2 + tid * 4 + 2, a.plain != 0u);
 					got = (uint32_t)(w0 >> 32) == a.ticket && (uint32_t)(w1 >> 32) == a.ticket && (uint32_t)(w2 >> 32) == a.ticket;
 					if (got) break;
 					__builtin_amdgcn_s_sleep(2);

@@ -256,6 +256,8 @@ struct rnb_ctx {
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		bool chain_plain = true; // RNB_CHAIN_PLAIN=0 (A/B, round 6): ScanChainArgs::plain -- k_scan_rays_chain's tiles exchange their sums by agent-scope atomic stores / loads instead of read-modify-write atomics (which wait behind
+		                         // the scatter's backlog at the memory side): window 0.5524 -> 0.5512, late 0.6084 -> 0.6066, medians of 4 (profiles/r06_ab_chain_plain.txt)
 		bool point_xcd = true; // RNB_POINT_XCD=0 (A/B, round 6): PointArgs::xcd -- the occupancy update's cell-ordered points in eight contiguous parts, one per XCD (workgroups go round the XCDs): 286 -> 274 us per update
 		bool dw_sliced = true; // RNB_DW_SLICED=0 (A/B): the half mode's weight gradients in the training kernel's own tiling (deviation D1', rounds 4-5) instead of the reference's split-K order
 		bool encode_pair = false; // RNB_ENCODE_PAIR=1 (A/B, round 6): when the configuration's first five levels are dense (the default's are: 16^3 ... 71^3), the depth-4 evaluation kernels gather their x-pairs with one 8-byte load
@@ -784,7 +786,7 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 	if (c->knobs.scan_chain && n_scan_tiles <= 64) { // one launch, one workgroup per 4096-ray tile (k_scan_rays_chain)
 		ScanChainArgs q;
 		q.n = n_rays; q.max_samples = max_samples; q.k1 = a.k1; q.steps = c->ray_steps.p; q.base = c->ray_base.p; q.slot = c->ray_slot.p; q.base1 = c->ray_base1.p;
-		q.counters = c->counters.p; q.fwd_counts = c->fwd_counts.p; q.words = c->scan_words.p; q.words2 = c->scan_words.p + 2 * 64 * 4; q.ticket = ++c->scan_ticket; q.error = c->host_coarse_dev + 5;
+		q.counters = c->counters.p; q.fwd_counts = c->fwd_counts.p; q.words = c->scan_words.p; q.words2 = c->scan_words.p + 2 * 64 * 4; q.ticket = ++c->scan_ticket; q.error = c->host_coarse_dev + 5; q.plain = c->knobs.chain_plain ? 1u : 0u;
 		hipLaunchKernelGGL(k_scan_rays_chain, dim3(n_scan_tiles), dim3(SCAN_WG), 0, s, q);
 	} else if (n_rays >= c->knobs.march_narrow_from) { // one workgroup per 4096-ray tile (<= 64 tiles) instead of one workgroup walking them
 		const uint32_t n_tiles = (n_rays + SCAN_TILE - 1) / SCAN_TILE;
@@ -1600,6 +1602,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_NARROW_WGS")) { const int w = atoi(e); k.march_narrow_wgs = (w == 64 || w == 256 || w == 512) ? (uint32_t)w : 128u; }
 		if (const char* e = getenv("RNB_MARCH_WGS")) { const int w = atoi(e); k.march_wgs = (w == 256 || w == 512) ? w : 1024; }
+		if (const char* e = getenv("RNB_CHAIN_PLAIN")) k.chain_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_POINT_XCD")) k.point_xcd = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DW_SLICED")) k.dw_sliced = atoi(e) != 0;
 		if (const char* e = getenv("RNB_ENCODE_PAIR")) k.encode_pair = atoi(e) != 0;
