@@ -927,14 +927,9 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 			if (hq < 2) v = *reinterpret_cast<const h8*>(SO + (16 * nt + r16) * SO_STRIDE + 8 * hq);
 			return v;
 		};
-		if (SLICED) { // the two input tiles, feature-major in the reference's column order (one 128-byte row segment per store), and dso's row 0
+		if (SLICED) { // dso's row 0 (FULL: all 16 rows, from their transposed fragments below); the two input tiles leave below, as the transposed fragments of the round-3 form
 			static_assert(!SLICED || EMU, "the sliced weight gradients belong to the half mode");
-#pragma unroll
-			for (uint32_t q = 0; q < 32; ++q) {
-				st32(T.sdfin, (uint32_t)fbs_logical_h(q) * B + s, X[lane * S32 + q]);
-				st32(T.ddin, (uint32_t)fbs_logical_h(q) * B + s, D[lane * S32 + q]);
-			}
-			if (!FULL) st32(T.dso, s, dout[3]); // (FULL: all 16 rows, from their transposed fragments below)
+			if (!FULL) st32(T.dso, s, dout[3]);
 		}
 		{ // ---- weight gradients of this tile (see the header) ----
 			h8 fso[4];
@@ -977,7 +972,7 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 			// B operands: lane = input column (tile order), registers j = 4 h + r <-> sample 32 ks + 16 h + 4 hq + r
 			h8 b_in[2][2], b_dd[2][2];
 #pragma unroll
-			for (int n2 = 0; n2 < (SLICED ? 0 : 2); ++n2) {
+			for (int n2 = 0; n2 < 2; ++n2) {
 				h8 idf;
 #pragma unroll
 				for (int j = 0; j < 8; ++j) idf[j] = (8 * hq + j == 16 * n2 + r16) ? (half_t)1.f : (half_t)0.f;
@@ -990,6 +985,20 @@ __device__ __forceinline__ void fwd_bwd_sdf_body(const GridMeta& G, const NetW& 
 #pragma unroll
 						for (int r = 0; r < 4; ++r) { b_in[n2][ks][4 * h + r] = f2h(ti[r]); b_dd[n2][ks][4 * h + r] = f2h(td[r]); }
 					}
+			}
+			if (SLICED) { // the two input tiles, feature-major in the reference's column order: lane = slot 16 n2 + r16 of the tile, four consecutive samples per 8-byte store
+#pragma unroll
+				for (int n2 = 0; n2 < 2; ++n2) {
+					const uint32_t row = (uint32_t)fbs_logical_h(16 * n2 + r16);
+#pragma unroll
+					for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+						for (int h = 0; h < 2; ++h) {
+							const uint32_t off = row * B + tile * TILE + 16u * (2 * ks + h) + 4u * hq;
+							st32(reinterpret_cast<h4*>(T.sdfin), off / 4u, h4{b_in[n2][ks][4 * h], b_in[n2][ks][4 * h + 1], b_in[n2][ks][4 * h + 2], b_in[n2][ks][4 * h + 3]});
+							st32(reinterpret_cast<h4*>(T.ddin), off / 4u, h4{b_dd[n2][ks][4 * h], b_dd[n2][ks][4 * h + 1], b_dd[n2][ks][4 * h + 2], b_dd[n2][ks][4 * h + 3]});
+						}
+				}
 			}
 #pragma unroll
 			for (int nt = 0; nt < 4; ++nt) { // hidden units 16 nt + r16
