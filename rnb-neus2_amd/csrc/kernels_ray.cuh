@@ -1822,12 +1822,13 @@ __device__ __forceinline__ void ray_constants(const LossArgs& a, const uint32_t 
 // LR lanes per ray: 64 while rays are few and long (early training: ~30 marched samples per ray), 16 once the batch has grown
 // to ~100 k rays with ~8 samples each (a wavefront per ray would leave 7 of 8 lanes idle).
 // The per-ray constants of the loss (pixel fetches, two RNG jumps, sRGB, the light triplet: ~2000 instructions) are worked out by
-// ONE thread per ray -- the first MARCH_WRITE_WG / LR threads of the workgroup, one for each of its rays -- and not by every
+// ONE thread per ray -- the first WGS / LR threads of the workgroup, one for each of its rays -- and not by every
 // lane of the ray's group (that was most of this kernel: 65 -> see DESIGN.md section 6).
-constexpr uint32_t MARCH_WRITE_WG = 1024;
-template <int LR>
-__global__ __launch_bounds__(MARCH_WRITE_WG) void k_march_write(const MarchArgs a) {
-	constexpr uint32_t RAYS = MARCH_WRITE_WG / LR;
+// WGS (round 6): 256 threads per workgroup. The 1024 of rounds 2-5 dated from the per-ray constants living here; a 16-wavefront workgroup waits for 16 wave slots to fall free at
+// once beside the gradient scatter's short workgroups -- 13 us of writing took 60-160 us there (profiles/r06_timeline_*), as k_dw_finish had in round 4. No barrier, no LDS: any size gives the same stores.
+template <int LR, int WGS = 256>
+__global__ __launch_bounds__(WGS) void k_march_write(const MarchArgs a) {
+	constexpr uint32_t RAYS = WGS / LR;
 	const bool head = a.part != 2, rest = a.part != 1;
 	if (a.ray_const && rest && threadIdx.x < RAYS) { // thread t: the constants of the workgroup's ray t
 		const uint32_t i = blockIdx.x * RAYS + threadIdx.x;

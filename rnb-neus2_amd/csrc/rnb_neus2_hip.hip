@@ -256,6 +256,7 @@ struct rnb_ctx {
 		int encode_depth = 4; // RNB_ENCODE_DEPTH=0|2|4|7: levels whose gathers k_forward_chained / k_point_query_chained keep in flight (round 5; 0: one level at a time behind branches, rounds 1-4).
 		                      // Interleaved medians, ms/step at steps 1000 / 2000 / 6000: 0: 0.5964 / 0.5884 / 0.6298; 2: 0.5773 / 0.5810 / 0.6209; 4: 0.5775 / 0.5769 / 0.6199; 7: 0.5781 / 0.5776 / 0.6262
 		                      // (profiles/r05_ab_encode_depth.txt). The half mode's evaluation kernels take depth 4 too (254 VGPRs, 4 spilled dwords); the training kernels (rolled level loop, two workgroups per CU: no gain) keep the old form
+		int march_write_wg = 256; // RNB_MARCH_WRITE_WG=1024 (A/B, round 6): threads per workgroup of k_march_write
 		bool chain_plain = true; // RNB_CHAIN_PLAIN=0 (A/B, round 6): ScanChainArgs::plain -- k_scan_rays_chain's tiles exchange their sums by agent-scope atomic stores / loads instead of read-modify-write atomics (which wait behind
 		                         // the scatter's backlog at the memory side): window 0.5524 -> 0.5512, late 0.6084 -> 0.6066, medians of 4 (profiles/r06_ab_chain_plain.txt)
 		bool point_xcd = true; // RNB_POINT_XCD=0 (A/B, round 6): PointArgs::xcd -- the occupancy update's cell-ordered points in eight contiguous parts, one per XCD (workgroups go round the XCDs): 286 -> 274 us per update
@@ -805,8 +806,17 @@ int generate_training_samples(rnb_ctx* c, hipStream_t s, uint32_t n_rays, uint32
 		a.part = part;
 		hipEvent_t ev = part == 2 ? rest_done : done;
 		if (dense_const && part != 1) ev = nullptr; // the constants' launch carries the event
-		if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV(k_march_write<16>, dim3((n_rays + MARCH_WRITE_WG / 16 - 1) / (MARCH_WRITE_WG / 16)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
-		else LAUNCH_EV(k_march_write<64>, dim3((n_rays + MARCH_WRITE_WG / 64 - 1) / (MARCH_WRITE_WG / 64)), dim3(MARCH_WRITE_WG), 0, s, ev, a);
+		if (c->knobs.march_write_wg == 1024) { // RNB_MARCH_WRITE_WG=1024 (A/B): rounds 2-5
+			if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV((k_march_write<16, 1024>), dim3((n_rays + 63) / 64), dim3(1024), 0, s, ev, a);
+			else LAUNCH_EV((k_march_write<64, 1024>), dim3((n_rays + 15) / 16), dim3(1024), 0, s, ev, a);
+		} else if (c->knobs.march_write_wg == 64) {
+			if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV((k_march_write<16, 64>), dim3((n_rays + 3) / 4), dim3(64), 0, s, ev, a);
+			else LAUNCH_EV((k_march_write<64, 64>), dim3(n_rays), dim3(64), 0, s, ev, a);
+		} else if (c->knobs.march_write_wg == 128) {
+			if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV((k_march_write<16, 128>), dim3((n_rays + 7) / 8), dim3(128), 0, s, ev, a);
+			else LAUNCH_EV((k_march_write<64, 128>), dim3((n_rays + 1) / 2), dim3(128), 0, s, ev, a);
+		} else if (n_rays >= c->knobs.march_narrow_from) LAUNCH_EV((k_march_write<16, 256>), dim3((n_rays + 15) / 16), dim3(256), 0, s, ev, a);
+		else LAUNCH_EV((k_march_write<64, 256>), dim3((n_rays + 3) / 4), dim3(256), 0, s, ev, a);
 	}
 	if (dense_const) LAUNCH_EV(k_ray_constants, dim3((n_rays + 63) / 64), dim3(64), 0, s, c->gen_split ? rest_done : done, a, ray_const); // one thread per kept ray
 	c->prof.mark(s, P_MARCH_WRITE);
@@ -1602,6 +1612,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_SCATTER_PLAIN")) k.scatter_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_NARROW_WGS")) { const int w = atoi(e); k.march_narrow_wgs = (w == 64 || w == 256 || w == 512) ? (uint32_t)w : 128u; }
 		if (const char* e = getenv("RNB_MARCH_WGS")) { const int w = atoi(e); k.march_wgs = (w == 256 || w == 512) ? w : 1024; }
+		if (const char* e = getenv("RNB_MARCH_WRITE_WG")) { const int w = atoi(e); k.march_write_wg = (w == 1024 || w == 128 || w == 64) ? w : 256; }
 		if (const char* e = getenv("RNB_CHAIN_PLAIN")) k.chain_plain = atoi(e) != 0;
 		if (const char* e = getenv("RNB_POINT_XCD")) k.point_xcd = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DW_SLICED")) k.dw_sliced = atoi(e) != 0;
