@@ -212,6 +212,8 @@ struct rnb_ctx {
 		uint32_t march_wave_per_ray_below = 4096; // RNB_MARCH_WAVE_PER_RAY_BELOW=n: one wavefront per ray for batches of at most n rays (single-cascade scenes). At an eighth of the batch
 		                                          // (1.8 k rays per step): 0.2985 -> 0.2890 ms/step with 4096 (2560: 0.2887); bit-exact at every size (the full-size tests were run with n = 100 000)
 		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
+		bool join_fold = false; // RNB_JOIN_FOLD=1 (A/B, round 6): rnb_ctx::join_pending -- one event in front of the network evaluation instead of three. SLOWER: window 0.5470 -> 0.5553, late 0.6022 -> 0.6065
+		                        // (the packets whose events are long signalled cost the critical stream little; the folded event arrives two hops later): profiles/r06_ab_join_fold.txt. Off.
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
 		bool poll_loss = true; // RNB_POLL_LOSS=0: the host waits for the completion event of k_reduce_losses_rollover (rounds 1-3) instead of polling the readback's sequence word
 		bool fused_update = true; // RNB_FUSED_UPDATE=0: the occupancy update's grid / bitfield chain as the seven launches of rounds 1-3 (k_ema_grid, k_mean_*, k_grid_to_bitfield, pools, k_coarse_bitfield)
@@ -296,6 +298,13 @@ struct rnb_ctx {
 	// costs the critical stream ~5 us (tools/probe_barriers.hip), so when the next step's march is about to be queued, the wait for ev_tail goes onto ITS stream,
 	// in front of k_march_write (slack there), and the critical stream reaches it through ev_march. tail_pending: nobody has waited for ev_tail yet.
 	bool tail_pending = false;
+	// (round 6) join_pending: the next step's march was already queued when the optimizer was launched, so the weight-gradient stream -- idle behind its weight images -- has taken the
+	// joins: it waits for ev_adam and ev_march and records ev_join, and the critical stream reaches all three side streams through that ONE event at the head of the next step
+	// (three barrier packets: 17-18 us of idle queue in front of every network evaluation, profiles/r06_timeline_*). ev_march_rest (a split k_march_write) stays a wait of its own
+	// behind the first network evaluation. Whoever else consumes what the side streams wrote (join_tail_host) waits for it on the host.
+	// (On the march stream behind k_ray_constants instead, measured: the first evaluation then waits for the second k_march_write too, window 0.5517 -> 0.5748.)
+	bool join_pending = false;
+	hipEvent_t ev_join = nullptr;
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_march_rest = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
 	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
 	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
@@ -337,7 +346,10 @@ static bool prep_due(uint32_t step) { // testbed.cu:2805
 	return step % n_prep_to_skip == 0;
 }
 // Safety net of the deferred join (rnb_ctx::tail_pending) for launches outside the training step's own sequence: wait on the host.
-static void join_tail_host(rnb_ctx* c) { if (c->tail_pending) { (void)hipEventSynchronize(c->ev_tail); c->tail_pending = false; } }
+static void join_tail_host(rnb_ctx* c) {
+	if (c->join_pending) { (void)hipEventSynchronize(c->ev_join); c->join_pending = false; }
+	if (c->tail_pending) { (void)hipEventSynchronize(c->ev_tail); c->tail_pending = false; }
+}
 
 // The one-launch scans (kernels_ray.cuh, chain_prefix) report a wait that gave up through two mapped host words; read after a synchronisation.
 // The launch itself has poisoned its result (zero counters -- the fused scan of k_loss_pass2_rays through k_loss_pass2_samples), so nothing was trained on it.
@@ -1331,6 +1343,14 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			images_done = true;
 			if (!c->sc.c_early) adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			// the join with the side stream: on the next step's march stream if that march is queued after this call (launch_premarch), else here
+			if (c->knobs.join_fold && c->pre.valid) { // the march of the next step is queued already (ev_march is recorded): the weight-gradient stream, idle behind its weight images, takes the joins (rnb_ctx::join_pending)
+				HIP_TRY(hipStreamWaitEvent(sd, c->ev_adam, 0));
+				HIP_TRY(hipStreamWaitEvent(sd, c->ev_march, 0));
+				HIP_TRY(hipEventRecord(c->ev_join, sd));
+				c->join_pending = true;
+				c->sc.dw_joined = true;
+				return optimizer_finish(c, s, images_done);
+			}
 			if (c->knobs.defer_tail && !c->pre.valid && !prep_due(c->cur_step + 1)) c->tail_pending = true;
 			else HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
 			c->sc.dw_joined = true;
@@ -1429,7 +1449,7 @@ int rnb_destroy(rnb_ctx* c) try {
 	c->prof.destroy();
 	if (c->s_march) { (void)hipStreamSynchronize(c->s_march); (void)hipStreamDestroy(c->s_march); }
 	for (hipStream_t st : {c->s_dw, c->s_adam}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-	for (hipEvent_t e : {c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_march_rest, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : {c->ev_join, c->ev_loss, c->ev_march, c->ev_fb, c->ev_dw, c->ev_adam, c->ev_tail, c->ev_march_rest, c->ev_all, c->ev_grid, c->ev_gs, c->ev_sc[0], c->ev_sc[1], c->ev_sc[2], c->ev_sc[3]}) if (e) (void)hipEventDestroy(e);
 	if (c->host_rb) (void)hipHostFree(c->host_rb);
 	if (c->host_coarse) (void)hipHostFree(c->host_coarse);
 	delete c;
@@ -1601,6 +1621,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_FUSED_UPDATE")) k.fused_update = atoi(e) != 0;
 		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
+		if (const char* e = getenv("RNB_JOIN_FOLD")) k.join_fold = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
@@ -1646,7 +1667,7 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 	// without the system-scope fence the queue is spared a cache writeback + invalidate at each of them.
 	HIP_TRY_C(hipEventCreateWithFlags(&c->ev_loss, hipEventDisableTiming));
 	const unsigned dev_flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
-	for (hipEvent_t* e : {&c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_march_rest, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
+	for (hipEvent_t* e : {&c->ev_join, &c->ev_march, &c->ev_fb, &c->ev_dw, &c->ev_adam, &c->ev_tail, &c->ev_march_rest, &c->ev_all, &c->ev_grid, &c->ev_gs, &c->ev_sc[0], &c->ev_sc[1], &c->ev_sc[2], &c->ev_sc[3]}) HIP_TRY_C(hipEventCreateWithFlags(e, dev_flags));
 	HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&c->host_rb), sizeof(*c->host_rb), hipHostMallocMapped));
 	std::memset(c->host_rb, 0, sizeof(*c->host_rb)); // (a recycled pinned block may hold a previous context's sequence word: wait_loss_readback would take it for this context's first step)
 	HIP_TRY_C(hipHostGetDevicePointer(&c->host_rb_dev, c->host_rb, 0));
@@ -1759,7 +1780,7 @@ int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) try {
 		if (rc != RNB_OK) return rc;
 		if (!read_only) c->opt_rec_current = false;
 	}
-	if (id == RNB_BUF_PARAMS_FP16 || id == RNB_BUF_PARAMS_EMA) join_tail_host(c); // both are written by the side stream's optimizer launch (ev_tail)
+	if (c->join_pending || id == RNB_BUF_PARAMS_FP16 || id == RNB_BUF_PARAMS_EMA) join_tail_host(c); // both are written by the side stream's optimizer launch (ev_tail)
 	if (!read_only) { // a possible write before the caller's next call: drop the cached forms now (a kept pointer written later: rnb_params_changed / rnb_bitfield_changed)
 		if (id == RNB_BUF_PARAMS_FP16) c->wimg_valid = false;
 		else if (id == RNB_BUF_DENSITY_BITFIELD) { discard_premarch(c); c->coarse_valid = false; c->gs_pre.valid = false; c->bitfield_foreign = true; }
@@ -2080,6 +2101,8 @@ static uint32_t next_max_inference(rnb_ctx* c) { // testbed_nerf.cu:3891-3896
 // Occupancy update (when due), ray generation + march, network evaluation of all samples, loss + compaction.
 static int step_front(rnb_ctx* c, hipStream_t s) {
 	c->valid_level = compute_valid_level(c->cfg, (int)c->training_step); // testbed.cu:2792
+	const bool joined = c->join_pending; // ev_join: the optimizer's and the weight images' streams of the previous step AND ev_march
+	if (c->join_pending) { HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); c->join_pending = false; }
 	if (c->tail_pending) { HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; } // no march was queued behind the optimizer to take the join
 	c->grid_updated = false;
 	c->prep_ms = 0.f;
@@ -2109,7 +2132,7 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 		c->pre.valid = false;
 		c->cur_k1 = c->pre.k1;
 		join_rest = c->pre.split;
-		HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
+		if (!joined) HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
 	} else {
 		n_rays_total = c->n_rays_total;
 		c->n_rays_total += n_rays * c->cfg.world_size;
