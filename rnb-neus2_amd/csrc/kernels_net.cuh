@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(WG, 2) void k_dw_all(const DwAllArgs a) {
 // and slice, 256 dependent k-steps -- the 16 products of a k-step (exact in fp32) added one after the other in fp32, the half accumulator + that sum rounded to half -- and the slices' results
 // added in half in slice order. This kernel IS that statement: one thread per 4 output elements (o, i0 .. i0 + 3), the samples of its slice in order, the operands read from the feature-major
 // arrays the training kernel exported (TrainScratch; L1 serves a lane's 64-byte line for 32 samples). Plain VALU fp32 adds in the stated order: bit-identical to the model on the same operands
-// (RNB_PRIM_DW_SLICED); an MFMA would add a k-step's products in an order of its own (tools/probe_mfma_arith.hip). Every chain is 4096 samples long whatever the launch: ~70 us beside the scatter.
+// (RNB_PRIM_DW_SLICED); an MFMA would add a k-step's products in an order of its own (tools/probe_mfma_arith.hip). Every chain is 4096 samples long whatever the launch: ~90 us alone, ~235 us beside the scatter (profiles/r06_half_mode_sliced.txt).
 // out[g][slice][n_out * n_in] floats holding half values; k_dw_finish (sliced) adds the slices in half.
 constexpr uint32_t DW_SLICE = 4096; // cutlass_matmul.h:83
 struct DwSlicedArgs {
