@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <new>
 #include <stdexcept>
@@ -212,6 +213,12 @@ struct rnb_ctx {
 		uint32_t march_wave_per_ray_below = 4096; // RNB_MARCH_WAVE_PER_RAY_BELOW=n: one wavefront per ray for batches of at most n rays (single-cascade scenes). At an eighth of the batch
 		                                          // (1.8 k rays per step): 0.2985 -> 0.2890 ms/step with 4096 (2560: 0.2887); bit-exact at every size (the full-size tests were run with n = 100 000)
 		int scatter_order = -1; // RNB_SCATTER_ORDER: 0 = B, A1, A2, C (rounds 1-3); 1 = A1, A2, B, C; 2 = A (one launch), B, C; default: 2 below march_narrow_from rays per step, 0 from there on
+		bool scatter_c_side = false; // RNB_SCATTER_C_SIDE=1 (A/B, round 6): rnb_ctx::sc.c_side -- group C and its optimizer chunk at the end of the weight-gradient stream instead of last on the critical stream. Late 0.6040 -> 0.5991,
+		                             // but steps 1000-1200 0.5617 -> 0.5802, window 0.5483 -> 0.5589: an event that crosses streams costs ~16 us from the producer's end to the consumer's start however idle the
+		                             // consumer's queue has been (C starts 16 us behind group B and takes 62 instead of 37 us beside the optimizer's chunk; the evaluation still starts 16 us behind the last event):
+		                             // profiles/r06_ab_c_side.txt. Off.
+		bool unsafe_skip_joins = false; // RNB_UNSAFE_SKIP_JOINS=1: MEASUREMENT ONLY (the results are then unordered): the critical stream waits for none of the side streams in front of the network evaluation --
+		                                // what the three barrier packets cost
 		bool join_fold = false; // RNB_JOIN_FOLD=1 (A/B, round 6): rnb_ctx::join_pending -- one event in front of the network evaluation instead of three. SLOWER: window 0.5470 -> 0.5553, late 0.6022 -> 0.6065
 		                        // (the packets whose events are long signalled cost the critical stream little; the folded event arrives two hops later): profiles/r06_ab_join_fold.txt. Off.
 		bool defer_tail = true; // RNB_DEFER_TAIL=0: the critical stream itself waits for the side stream's weight images at the end of the optimizer (rounds 1-3)
@@ -308,7 +315,11 @@ struct rnb_ctx {
 	hipEvent_t ev_loss = nullptr, ev_march = nullptr, ev_fb = nullptr, ev_dw = nullptr, ev_adam = nullptr, ev_tail = nullptr, ev_march_rest = nullptr, ev_all = nullptr, ev_sc[4] = {nullptr, nullptr, nullptr, nullptr};
 	// Scatter groups of the queued backward pass: B = middle levels [split1, split0) (final at ev_sc[0]), A = fine levels [split0, off_var) in two
 	// halves (ev_sc[1], ev_sc[3]; the second starts at split_mid), C = coarse levels [off_grid, split1) last; the MLPs + variance follow the dW GEMMs (ev_dw).
-	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true, c_early = false; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0; } sc;
+	struct { bool valid = false, exchanged = false, dp = false, sharded = false, all_final_recorded = false, dw_joined = true, c_early = false; uint64_t split[2] = {0, 0}, split_mid = 0; int order = 0;
+	         // (round 6, RNB_SCATTER_C_SIDE) c_side: group C has NOT been launched by the backward pass: the optimizer launches it (c_launch) with its optimizer chunk at the END of the
+	         // weight-gradient stream, behind the last atomic group (c_after), so that the critical stream falls idle behind its last atomic group and works off the barrier packets of the
+	         // joins while the side streams finish (each costs it ~5 us, tools/probe_barriers.hip -- 16-18 us of idle queue in front of every network evaluation)
+	         bool c_side = false; hipEvent_t c_after = nullptr; std::function<void(hipStream_t, hipEvent_t)> c_launch; } sc;
 	// level groups of the gradient scatter (forward_backward), fixed at creation: C = [0, e_c) LDS, B = [e_c, l_fine) run-length quads, A = [l_fine, L) plain quads
 	struct ScatterGroups { uint32_t e_c = 0, l_fine = 0, Ks[RNB_MAX_LEVELS] = {}; uint64_t k_log2 = 0; } sg;
 	hipStream_t backward_stream = nullptr; // the stream the last backward pass was queued on
@@ -317,7 +328,7 @@ struct rnb_ctx {
 	uint64_t param_capacity = 0; // allocated length of the parameter-shaped arrays: padded so that the data-parallel shards are equal
 	bool dp_order() const { return cfg.world_size > 1 || knobs.dp_order; }
 	struct { bool begun = false, early_done = false; AdamArgs args; } opt; // optimizer state of the running step (it may be applied in two pieces) // scatter groups of the current backward pass (see forward_backward)
-	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; bool split = false; } pre; // samples already generated for the next step
+	struct { bool valid = false, loss_cleared = false; uint32_t n_rays = 0, n_rays_total = 0, max_inference = 0, k1 = 0; bool split = false, march_joined = false; } pre; // samples already generated for the next step
 	struct Readback { double sums[3]; uint32_t counters[4]; uint32_t fwd[2]; uint32_t seq, pad; }* host_rb = nullptr; // pinned, device-mapped; same layout as the device block k_reduce_losses fills; seq: see poll_loss()
 	uint32_t rb_seq = 0;     // sequence number of the last step whose readback was launched in polling mode
 	bool loss_polled = true; // the host has seen that step's readback (or the step publishes through ev_loss instead)
@@ -344,6 +355,12 @@ static void discard_premarch(rnb_ctx* c);
 static bool prep_due(uint32_t step) { // testbed.cu:2805
 	const uint32_t n_prep_to_skip = std::min(std::max(step / 16u, 1u), 16u);
 	return step % n_prep_to_skip == 0;
+}
+// Group C of a training step's scatter was left to the optimizer (sc.c_side) and something else needs the gradients first: launch it on `s` now.
+static void flush_c_side(rnb_ctx* c, hipStream_t s) {
+	if (!c->sc.c_side) return;
+	c->sc.c_side = false;
+	c->sc.c_launch(s, nullptr);
 }
 // Safety net of the deferred join (rnb_ctx::tail_pending) for launches outside the training step's own sequence: wait on the host.
 static void join_tail_host(rnb_ctx* c) {
@@ -931,7 +948,7 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 	const bool half = c->half_acc();
 	if (!c->grads_clean) HIP_TRY(hipMemsetAsync(c->grad_ptr(0), 0, c->n_params * c->grad_elem(), s));
 	c->grads_clean = false;
-	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true; c->sc.c_early = false;
+	c->sc.valid = false; c->sc.exchanged = false; c->sc.sharded = false; c->sc.all_final_recorded = false; c->sc.dw_joined = true; c->sc.c_early = false; c->sc.c_side = false;
 	TrainArgs a;
 	a.coords = c->coords_compacted.p; a.dout = c->dloss_dout.p; a.B = B; a.B_global = B * c->cfg.world_size; a.sdf_bias = c->cfg.sdf_bias; a.t = c->ts; a.skip_rgb = c->cfg.apply_no_albedo ? 1u : 0u;
 	const bool split = c->rgb_split(); // albedo mode: k_rgb_fwd_bwd + k_fwd_bwd_sdf_full instead of the generic kernel and its weight-gradient GEMMs
@@ -1158,8 +1175,26 @@ int forward_backward(rnb_ctx* c, hipStream_t s, bool join_dw = true) {
 			launch_b(s, c->ev_sc[0]);
 		}
 		c->sc.split_mid = c->off_grid + (uint64_t)c->grid.offsets[a_mid] * 2;
+		c->sc.c_side = false;
 		if (c->sc.c_early) HIP_TRY(hipStreamWaitEvent(s, c->ev_sc[2], 0)); // (every gradient is final when `s` is: rnb_gradient_part_wait, stage calls)
-		else if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
+		else if (!c->sc.dp && !join_dw && c->knobs.scatter_c_side && e_c != 0 && !dbg_levels) {
+			// the training step (the optimizer follows): group C is handed to the optimizer's launch (rnb_ctx::sc.c_side); flush_c_side launches it here for whoever asks for the gradients first
+			const ScatterArgs sa_v = sa; const uint32_t e_c_v = e_c, B_v = B; const bool fixed_v = fixed, half_v = half;
+			c->sc.c_launch = [c, sa_v, e_c_v, B_v, fixed_v, half_v](hipStream_t st, hipEvent_t done) {
+				ScatterLdsArgs la; la.a = sa_v; la.n_levels = e_c_v;
+				const uint32_t n_wg = std::max(1u, std::min<uint32_t>(128u, (B_v + 1023) / 1024));
+				la.samples_per_wg = ((B_v + n_wg - 1) / n_wg + 3) / 4 * 4;
+				if (fixed_v) {
+					LAUNCH_EV(k_grid_scatter_lds_fixed, dim3(n_wg, 2), dim3(512), (size_t)c->grid.offsets[e_c_v] * 8, st, nullptr, c->meta(), la);
+					const uint64_t lo = 0, hi = (uint64_t)c->grid.offsets[e_c_v] * 2;
+					const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((hi - lo) / 2 + 255) / 256);
+					LAUNCH_EV(k_fixed_narrow, dim3(blocks), dim3(256), 0, st, done, c->grads_fixed.p, half_v ? nullptr : c->grads.p + c->off_grid, half_v ? c->grads16.p + c->off_grid : nullptr, lo, hi);
+				} else if (half_v) LAUNCH_EV(k_grid_scatter_lds_h, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c_v] * 8, st, done, c->meta(), la);
+				else LAUNCH_EV(k_grid_scatter_lds, dim3(n_wg), dim3(512), (size_t)c->grid.offsets[e_c_v] * 8, st, done, c->meta(), la);
+			};
+			c->sc.c_side = true;
+			c->sc.c_after = c->sc.order == 0 ? c->ev_sc[3] : c->ev_sc[0]; // the last atomic group of the order
+		} else if (!c->sc.dp) launch_c(s, nullptr); // last: its levels hold 32 k parameters, so almost nothing of the optimizer is left after the scatter (-6 % step time vs. first)
 		if (c->sc.dp || join_dw) HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0));
 		c->sc.dw_joined = c->sc.dp || join_dw; // the training step leaves the join to the optimizer, which continues on the side stream (optimizer_step)
 		c->sc.valid = true; // parameter ranges of the groups (grid entries are 2 parameters each)
@@ -1295,6 +1330,7 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 	{ const int rc = optimizer_begin(c); if (rc != RNB_OK) return rc; }
 	c->prof.mark(s, P_NONE);
 	const bool chunked = !c->opt.early_done && c->overlap() && !c->sc.dp && c->sc.valid && !c->sc.exchanged;
+	if (c->sc.c_side && !(chunked && !c->sc.dw_joined)) flush_c_side(c, s); // only the path below that continues on the weight-gradient stream takes group C with it
 	if (!c->sc.dw_joined && !chunked) {
 		HIP_TRY(hipStreamWaitEvent(s, c->ev_dw, 0)); // the paths below step the MLPs on `s`
 		c->sc.dw_joined = true;
@@ -1339,8 +1375,22 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 			hipStream_t sd = c->s_dw;
 			adam_launch(c, sd, 0, c->off_grid);
 			adam_launch(c, sd, c->off_var, c->n_params);
-			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p, c->half_acc() ? 1 : 0);
+			const bool c_side = c->sc.c_side;
+			c->sc.c_side = false;
+			LAUNCH_EV(k_prepare_weight_images, dim3(WIMG_WGS, 4), dim3(WG), 0, sd, c_side ? nullptr : c->ev_tail, c->net(false), c->wimg_fwd.p, c->wimg_fbs.p, c->wimg_train.p, c->wimg_rgb.p, c->half_acc() ? 1 : 0);
 			images_done = true;
+			if (c_side) { // group C + its optimizer chunk end this stream (ev_tail); the critical stream is idle behind its last atomic group
+				HIP_TRY(hipStreamWaitEvent(sd, c->sc.c_after, 0));
+				c->sc.c_launch(sd, nullptr);
+				adam_launch(c, sd, c->off_grid, c->sc.split[1], c->ev_tail);
+				// the joins, in the order the events are expected to fire, so that only the last packet's latency is left when the last of them has: the march (queued already?), then by batch shape
+				// the optimizer's stream and this one
+				if (c->pre.valid) { HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0)); c->pre.march_joined = true; }
+				if (c->sc.order == 2) { HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0)); }
+				else { HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0)); HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); }
+				c->sc.dw_joined = true;
+				return optimizer_finish(c, s, images_done);
+			}
 			if (!c->sc.c_early) adam_launch(c, s, c->off_grid, c->sc.split[1]);
 			// the join with the side stream: on the next step's march stream if that march is queued after this call (launch_premarch), else here
 			if (c->knobs.join_fold && c->pre.valid) { // the march of the next step is queued already (ev_march is recorded): the weight-gradient stream, idle behind its weight images, takes the joins (rnb_ctx::join_pending)
@@ -1352,10 +1402,10 @@ int optimizer_step(rnb_ctx* c, hipStream_t s) {
 				return optimizer_finish(c, s, images_done);
 			}
 			if (c->knobs.defer_tail && !c->pre.valid && !prep_due(c->cur_step + 1)) c->tail_pending = true;
-			else HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
+			else if (!c->knobs.unsafe_skip_joins) HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0));
 			c->sc.dw_joined = true;
 		}
-		HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
+		if (!c->knobs.unsafe_skip_joins) HIP_TRY(hipStreamWaitEvent(s, c->ev_adam, 0));
 	} else {
 		adam_launch(c, s, 0, c->n_params);
 	}
@@ -1622,6 +1672,8 @@ HIP_TRY_C(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_scatter_lds),
 		if (const char* e = getenv("RNB_POLL_LOSS")) k.poll_loss = atoi(e) != 0;
 		if (const char* e = getenv("RNB_DEFER_TAIL")) k.defer_tail = atoi(e) != 0;
 		if (const char* e = getenv("RNB_JOIN_FOLD")) k.join_fold = atoi(e) != 0;
+		if (const char* e = getenv("RNB_SCATTER_C_SIDE")) k.scatter_c_side = atoi(e) != 0;
+		if (const char* e = getenv("RNB_UNSAFE_SKIP_JOINS")) k.unsafe_skip_joins = atoi(e) != 0;
 		if (const char* e = getenv("RNB_MARCH_WAVE_PER_RAY_BELOW")) k.march_wave_per_ray_below = (uint32_t)atoi(e);
 		if (const char* e = getenv("RNB_SCATTER_ORDER")) k.scatter_order = std::max(-1, std::min(2, atoi(e)));
 		if (const char* e = getenv("RNB_SCAN_CHAIN")) k.scan_chain = atoi(e) != 0;
@@ -1771,6 +1823,7 @@ int rnb_set_params(rnb_ctx* c, const float* params) try {
 
 int rnb_buffer(rnb_ctx* c, int id, void** ptr, uint64_t* n_bytes) try {
 	if (!c || !ptr || !n_bytes) return fail(RNB_ERR_INVALID, "null argument");
+	flush_c_side(c, c->backward_stream); // (a gradient vector asked for between a training step's backward pass and its optimizer)
 #define BUF(b) do { *ptr = (void*)(b).p; *n_bytes = (b).bytes(); return RNB_OK; } while (0)
 	const bool read_only = (id & RNB_BUF_READONLY) != 0;
 	id &= ~RNB_BUF_READONLY;
@@ -2084,6 +2137,7 @@ int rnb_optimizer_step(rnb_ctx* c, void* stream) try {
 
 // Drops samples generated ahead of time for a step whose inputs have since changed (controller, flags, bitfield ...).
 static void discard_premarch(rnb_ctx* c) {
+	c->pre.march_joined = false;
 	if (!c->pre.valid) return;
 	(void)hipStreamSynchronize(c->s_march);
 	c->n_rays_total = c->pre.n_rays_total;
@@ -2132,7 +2186,8 @@ static int step_front(rnb_ctx* c, hipStream_t s) {
 		c->pre.valid = false;
 		c->cur_k1 = c->pre.k1;
 		join_rest = c->pre.split;
-		if (!joined) HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
+		if (!joined && !c->pre.march_joined && !c->knobs.unsafe_skip_joins) HIP_TRY(hipStreamWaitEvent(s, c->ev_march, 0));
+		c->pre.march_joined = false;
 	} else {
 		n_rays_total = c->n_rays_total;
 		c->n_rays_total += n_rays * c->cfg.world_size;
@@ -2230,6 +2285,7 @@ static int launch_premarch(rnb_ctx* c) {
 	c->tail_pending = false; // the next step reaches ev_tail through ev_march
 	c->pre.loss_cleared = true;
 	c->n_rays_total += n_rays * c->cfg.world_size;
+	c->pre.march_joined = false;
 	c->pre.valid = true; c->pre.n_rays = n_rays; c->pre.n_rays_total = n_rays_total; c->pre.max_inference = max_inference; c->pre.k1 = c->gen_k1; c->pre.split = c->gen_split;
 	return RNB_OK;
 }
@@ -2444,6 +2500,7 @@ int rnb_set_controller(rnb_ctx* c, uint32_t training_step, uint32_t rays_per_bat
 
 int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) try {
 	if (!c || !ranges || !n_parts) return fail(RNB_ERR_INVALID, "null argument");
+	flush_c_side(c, c->backward_stream); // (a caller that exchanges gradients: group C belongs to the backward pass's stream again)
 	c->sc.exchanged = true; // the caller sums gradients across ranks: the optimizer must not start on a block before its exchange
 	if (c->sc.valid && c->sc.dp) { // scatter order C, B, A1, A2: everything in front of A's levels is final first (ev_sc[0]), then A1 (ev_sc[1])
 		const bool mid = c->sc.split_mid > c->sc.split[0] && c->sc.split_mid < c->off_var;
@@ -2464,11 +2521,13 @@ int rnb_gradient_parts(rnb_ctx* c, uint64_t ranges[3][2], uint32_t* n_parts) try
 
 int rnb_train_step_apply_early(rnb_ctx* c, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	flush_c_side(c, c->backward_stream);
 	return optimizer_step_early(c, as_stream(stream));
 } RNB_GUARD
 
 int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint32_t* n_parts, uint64_t* capacity) try {
 	if (!c || !parts || !n_parts || !capacity) return fail(RNB_ERR_INVALID, "null argument");
+	flush_c_side(c, c->backward_stream);
 	c->sc.exchanged = true;
 	c->sc.sharded = true;
 	shard_layout(c, parts, n_parts);
@@ -2478,6 +2537,7 @@ int rnb_shard_layout(rnb_ctx* c, rnb_shard_part parts[RNB_MAX_SHARD_PARTS], uint
 
 int rnb_train_step_apply_shard(rnb_ctx* c, uint32_t part, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	flush_c_side(c, c->backward_stream);
 	return optimizer_step_shard(c, part, as_stream(stream));
 } RNB_GUARD
 
@@ -2492,6 +2552,7 @@ int rnb_train_step_apply_done(rnb_ctx* c, void* stream) try {
 
 int rnb_gradient_part_wait(rnb_ctx* c, uint32_t part, void* stream) try {
 	if (!c) return fail(RNB_ERR_INVALID, "null ctx");
+	flush_c_side(c, c->backward_stream);
 	// blocks 0 (and, in the data-parallel order, 1 = the first half of the fine levels) of the overlapped schedule have their own events; everything is final at the
 	// end of the backward pass
 	const bool early = part == 0 && c->sc.valid && (c->sc.dp || !c->sc.sharded);
